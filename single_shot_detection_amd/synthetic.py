@@ -1,0 +1,89 @@
+"""Seeded synthetic inputs for the detection hot path.
+
+Everything here is numpy ``default_rng`` (PCG64) so the very same bytes are produced in the
+build container (golden generation against the reference), in the CPU test-suite and on the
+GPU box.  No torch RNG is involved: torch's generators differ between CPU and HIP.
+
+Ground-truth row layout follows the reference dataset contract
+(``bf/datasets/detection_dataset.py:11-17``): ``[x1, y1, x2, y2, class, score]`` fp32.
+"""
+import numpy as np
+
+# (input size, C, levels (Cin, H=W, nb)) -- SURVEY.md §8 table (probed shapes of the reference).
+CONFIGS = {
+    'ssd_mb2_voc': dict(
+        size=300, num_classes=21, score_converter='SOFTMAX',
+        levels=[(96, 19, 4), (1280, 10, 6), (512, 5, 6), (256, 3, 6), (256, 2, 4), (128, 1, 4)],
+        anchor={'type': 'ssd', 'num_scales': 6, 'min_scale': 0.1, 'max_scale': 1.05,
+                'aspect_ratios': [[1.0, 2.0]] + [[1.0, 2.0, 3.0]] * 3 + [[1.0, 2.0]] * 2},
+        matched=0.5, unmatched=0.5, nms_thr=0.45, loss='ce_hnm'),
+    'ssd_300_vgg16_voc': dict(
+        size=300, num_classes=81, score_converter='SOFTMAX',
+        levels=[(512, 37, 4), (512, 18, 6), (512, 9, 6), (256, 5, 6), (256, 3, 4), (256, 2, 4)],
+        anchor={'type': 'ssd', 'num_scales': 6, 'min_scale': 0.15, 'max_scale': 1.05,
+                'aspect_ratios': [[1.0, 2.0]] + [[1.0, 2.0, 3.0]] * 3 + [[1.0, 2.0]] * 2},
+        matched=0.5, unmatched=0.5, nms_thr=0.45, loss='ce_hnm'),
+    'ssd_512_vgg16_coco': dict(
+        size=512, num_classes=81, score_converter='SOFTMAX',
+        levels=[(512, 64, 4), (512, 32, 6), (512, 16, 6), (256, 8, 6), (256, 4, 6), (256, 2, 4), (256, 1, 4)],
+        anchor={'type': 'ssd', 'num_scales': 7, 'min_scale': 0.1, 'max_scale': 1.05,
+                'aspect_ratios': [[1.0, 2.0]] + [[1.0, 2.0, 3.0]] * 4 + [[1.0, 2.0]] * 2},
+        matched=0.5, unmatched=0.5, nms_thr=0.45, loss='ce_hnm'),
+    'retina_rn50_500_coco': dict(
+        size=500, num_classes=80, score_converter='SIGMOID',
+        levels=[(256, 63, 9), (256, 32, 9), (256, 16, 9), (256, 8, 9), (256, 4, 9)],
+        anchor={'type': 'retina_net', 'min_level': 3, 'max_level': 7, 'aspect_ratios': [1.0, 2.0, 0.5],
+                'scale': 4.0, 'scales_per_level': 3},
+        matched=0.5, unmatched=0.4, nms_thr=0.5, loss='focal_naive'),
+    'm2det_512_vgg16_coco': dict(
+        size=512, num_classes=81, score_converter='SOFTMAX',
+        levels=[(1024, 64, 4), (1024, 32, 6), (1024, 16, 6), (1024, 8, 6), (1024, 4, 4), (1024, 2, 4)],
+        anchor={'type': 'ssd', 'num_scales': 6, 'min_scale': 0.07, 'max_scale': 1.05,
+                'aspect_ratios': [[1.0, 2.0]] + [[1.0, 2.0, 3.0]] * 3 + [[1.0, 2.0]] * 2},
+        matched=0.5, unmatched=0.5, nms_thr=0.45, loss='ce_hnm'),
+}
+
+
+def num_anchors(cfg):
+    return sum(h * h * nb for _, h, nb in cfg['levels'])
+
+
+def make_ground_truth(batch, size, num_classes, seed=1, g_min=1, g_max=8, fixed_g=None, background=True):
+    """list[B] of float32 [G_i, 6] rows ``x1,y1,x2,y2,cls,score`` (BASELINE.md §3 'Inputs').
+
+    ``background``: True when class 0 is background (SOFTMAX configs: classes 1..C-1);
+    for SIGMOID configs the reference still uses 1-based class ids (``multibox_loss.py:67``),
+    so classes are 1..C.
+    """
+    rng = np.random.default_rng(seed)
+    out = []
+    hi = num_classes - 1 if background else num_classes
+    for _ in range(batch):
+        g = fixed_g if fixed_g is not None else int(rng.integers(g_min, g_max + 1))
+        xy = rng.uniform(0.0, 0.7 * size, size=(g, 2))
+        wh = rng.uniform(0.05, 0.55, size=(g, 2)) * size
+        x2y2 = np.minimum(xy + wh, size - 1)
+        cls = rng.integers(1, hi + 1, size=(g, 1)).astype(np.float64)
+        score = np.ones((g, 1))
+        out.append(np.concatenate([xy, x2y2, cls, score], axis=1).astype(np.float32))
+    return out
+
+
+def make_logits(batch, anchors, num_classes, seed=2, trained_like=False):
+    """scores ``[B, A*C]`` fp32 N(0,1); ``trained_like`` adds +6 to the background logit."""
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((batch, anchors, num_classes), dtype=np.float32)
+    if trained_like:
+        x[..., 0] += 6.0
+    return x.reshape(batch, anchors * num_classes)
+
+
+def make_locs(batch, anchors, seed=3, scale=1.0):
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal((batch, anchors * 4), dtype=np.float32) * np.float32(scale))
+
+
+def make_feature_maps(batch, levels, seed=23):
+    """list[L] of NCHW fp32 N(0,1) source maps at the §8 shapes (head-only microbench input)."""
+    rng = np.random.default_rng(seed)
+    return [rng.standard_normal((batch, cin, h, h), dtype=np.float32) for cin, h, _ in levels]

@@ -1,0 +1,52 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN = os.path.join(REPO, 'tests', 'golden')
+CONFIG_NAMES = ['ssd_mb2_voc', 'ssd_300_vgg16_voc', 'ssd_512_vgg16_coco', 'retina_rn50_500_coco', 'm2det_512_vgg16_coco']
+GOLDEN_BATCH = {'ssd_mb2_voc': 2, 'ssd_300_vgg16_voc': 4, 'ssd_512_vgg16_coco': 2, 'retina_rn50_500_coco': 2,
+                'm2det_512_vgg16_coco': 2}
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def kats():
+    return np.load(os.path.join(GOLDEN, 'kats.npz'))
+
+
+_cache = {}
+
+
+def load_golden(name):
+    if name not in _cache:
+        _cache[name] = dict(np.load(os.path.join(GOLDEN, f'{name}.npz')))
+    return _cache[name]
+
+
+@pytest.fixture(scope='session')
+def golden():
+    return load_golden
+
+
+def dense_from_rows(rows, vals, shape):
+    out = np.zeros(shape, np.float32)
+    if len(rows):
+        out[rows[:, 0], rows[:, 1]] = vals
+    return out
+
+
+def has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False

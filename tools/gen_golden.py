@@ -1,0 +1,384 @@
+#!/usr/bin/env python3
+"""Generate golden vectors for the detection hot path by RUNNING THE REFERENCE (build container only).
+
+Runs only where ``/root/reference`` exists; the fixtures it writes (``tests/golden/*.npz``) are data --
+seeded inputs (or the seeds that regenerate them) and the reference's outputs -- and travel with the repo.
+No reference source is copied.  Harness-side shims:
+
+  1. empty ``sys.modules`` entries for third-party packages that are not installed in this image and are
+     not on the arithmetic path being recorded (``torchvision``, ``jpeg4py``, ``cv2``);
+  2. ``torch.jit.scope`` (removed in torch 2.x; the reference uses it as a no-op name annotation).
+
+``torchvision.ops.nms`` -- the one third-party kernel ON the path (``bf/utils/box_utils.py:193``) -- is not
+available, so hard-NMS goldens are produced with the documented-contract greedy NMS defined below
+(``_contract_nms``) and are labelled ``nms_contract`` (parity for hard NMS is pinned to that contract, not to
+torchvision's binary).  Soft-NMS goldens use the reference's own ``_soft_nms``.
+
+Usage:  python tools/gen_golden.py [--out tests/golden]
+"""
+import argparse
+import contextlib
+import functools
+import hashlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, '/root/reference')
+
+for _name in ['torchvision', 'torchvision.ops', 'torchvision.models', 'jpeg4py', 'cv2']:
+    sys.modules.setdefault(_name, types.ModuleType(_name))
+sys.modules['torchvision'].ops = sys.modules['torchvision.ops']
+sys.modules['torchvision'].models = sys.modules['torchvision.models']
+sys.modules['jpeg4py'].JPEG = object
+if not hasattr(torch.jit, 'scope'):
+    torch.jit.scope = lambda name: contextlib.nullcontext()
+
+
+def _contract_nms(boxes, scores, iou_threshold):
+    """torchvision.ops.nms documented contract: stable descending score order, keep a box and suppress
+    every later box whose IoU with it is > iou_threshold; IoU = inter / (a + b - inter), no +1."""
+    order = torch.sort(scores, descending=True, stable=True)[1]
+    b = boxes[order]
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    n = b.size(0)
+    dead = torch.zeros(n, dtype=torch.bool)
+    keep = []
+    for i in range(n):
+        if dead[i]:
+            continue
+        keep.append(i)
+        if i + 1 < n:
+            xx1 = torch.maximum(b[i, 0], b[i + 1:, 0])
+            yy1 = torch.maximum(b[i, 1], b[i + 1:, 1])
+            xx2 = torch.minimum(b[i, 2], b[i + 1:, 2])
+            yy2 = torch.minimum(b[i, 3], b[i + 1:, 3])
+            inter = (xx2 - xx1).clamp(min=0) * (yy2 - yy1).clamp(min=0)
+            iou = inter / (area[i] + area[i + 1:] - inter)
+            dead[i + 1:] |= iou > iou_threshold
+    return order[torch.tensor(keep, dtype=torch.long)]
+
+
+sys.modules['torchvision.ops'].nms = _contract_nms
+
+from bf.utils import box_utils                      # noqa: E402
+from detection import matcher, sampler              # noqa: E402
+from detection import detector_builder              # noqa: E402
+from detection.box_coder import BoxCoder            # noqa: E402
+from detection.detector import Predictor            # noqa: E402
+from detection.losses.multibox_loss import MultiboxLoss  # noqa: E402
+from detection.postprocessor import Postprocessor   # noqa: E402
+from detection.target_assigner import TargetAssigner  # noqa: E402
+from detection import anchor_generators as ref_anchor_generators  # noqa: E402
+
+from single_shot_detection_amd import synthetic as syn  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def ref_anchors(cfg):
+    """Reference anchors exactly as ``Detector.generate_anchors`` builds them (detector.py:82-86)."""
+    params = dict(cfg['anchor'])
+    builder = getattr(ref_anchor_generators, params['type']).build_anchor_generators
+    gens = builder(**params)
+    size = cfg['size']
+    img = torch.empty(1, 3, size, size)
+    out = []
+    assert len(gens) == len(cfg['levels'])
+    for gen, (cin, h, nb) in zip(gens, cfg['levels']):
+        assert gen.num_boxes == nb, (gen.num_boxes, nb)
+        fmap = torch.empty(1, 1, h, h)
+        out.append(gen.generate(img, fmap).reshape(-1))
+    return torch.cat(out, dim=0).view(-1, 4)
+
+
+def ref_match(gt_list, anchors, matched, unmatched):
+    """box_idx per image via the reference's iou + matcher (target_assigner.py:46-49), and the target."""
+    corner = box_utils.to_corners(anchors)
+    idx = []
+    for gt in gt_list:
+        gt = torch.from_numpy(gt)
+        if not len(gt):
+            idx.append(torch.full((anchors.size(0),), -2, dtype=torch.long))
+            continue
+        w = box_utils.iou(gt[:, 0:4], corner)
+        idx.append(matcher.match_per_prediction(w, matched, unmatched))
+    target = TargetAssigner(matched, unmatched).encode_ground_truth([torch.from_numpy(g) for g in gt_list], anchors)
+    return torch.stack(idx), target
+
+
+def make_criterion(kind):
+    box_coder = BoxCoder(xy_scale=10.0, wh_scale=5.0)
+    if kind == 'ce_hnm':
+        smp = functools.partial(sampler.hard_negative_mining, negative_per_positive_ratio=3, min_negative_per_image=5)
+        loss_args = {'classification_loss': {'name': 'CrossEntropyLoss'},
+                     'localization_loss': {'name': 'SmoothL1Loss'},
+                     'classification_weight': 1.0, 'localization_weight': 1.0}
+    elif kind == 'focal_naive':
+        smp = sampler.naive_sampler
+        loss_args = {'classification_loss': {'name': 'SigmoidFocalLoss', 'gamma': 2.0, 'alpha': 0.25},
+                     'localization_loss': {'name': 'SmoothL1Loss'},
+                     'classification_weight': 1.0, 'localization_weight': 1.0}
+    else:
+        raise ValueError(kind)
+    return MultiboxLoss(sampler=smp, box_coder=box_coder, **loss_args), box_coder
+
+
+def sparse_rows(x):
+    """[B, A, K] -> (row indices int32 [n,2], values [n,K]) of rows with any nonzero."""
+    nz = (x != 0).any(dim=-1).nonzero()
+    return nz.to(torch.int32).numpy(), x[nz[:, 0], nz[:, 1]].numpy()
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def gen_config(name, out_dir, batch):
+    cfg = syn.CONFIGS[name]
+    C = cfg['num_classes']
+    size = cfg['size']
+    softmax = cfg['score_converter'] == 'SOFTMAX'
+    A = syn.num_anchors(cfg)
+    res = {}
+
+    anchors = ref_anchors(cfg)
+    assert anchors.shape == (A, 4), anchors.shape
+    res['anchors'] = anchors.numpy()
+
+    # ---- T1/T2/T3 ---------------------------------------------------------------------------
+    gt = syn.make_ground_truth(batch, size, C, seed=1, background=softmax)
+    box_idx, target = ref_match(gt, anchors, cfg['matched'], cfg['unmatched'])
+    res['match_box_idx'] = box_idx.to(torch.int16).numpy()
+    res['match_target'] = target.numpy()
+    if name == 'ssd_mb2_voc':
+        res['match_iou_img0'] = box_utils.iou(torch.from_numpy(gt[0])[:, :4], box_utils.to_corners(anchors)).numpy()
+    # stress: G = 32 boxes per image, 2 images
+    gt32 = syn.make_ground_truth(2, size, C, seed=11, fixed_g=32, background=softmax)
+    box_idx32, target32 = ref_match(gt32, anchors, cfg['matched'], cfg['unmatched'])
+    res['match32_box_idx'] = box_idx32.to(torch.int16).numpy()
+    res['match32_target_sha'] = np.array(sha(target32.numpy()))
+    res['match32_num_pos'] = (box_idx32 >= 0).sum(dim=1).numpy()
+
+    # ---- S1 / L1 / L2 / L3 ------------------------------------------------------------------
+    for variant, trained in (('rand', False), ('trained', True)):
+        logits = torch.from_numpy(syn.make_logits(batch, A, C, seed=2, trained_like=trained and softmax))
+        if trained and not softmax:
+            logits = logits - 4.6
+        locs = torch.from_numpy(syn.make_locs(batch, A, seed=3, scale=0.5))
+        logits.requires_grad_(True)
+        locs.requires_grad_(True)
+        criterion, box_coder = make_criterion(cfg['loss'])
+        tgt = target.clone()
+        tcls = tgt[..., 4].long()
+        mask = criterion.sampler(logits.detach().view(batch, A, C), tcls)
+        loss, class_loss, loc_loss = criterion((logits, locs), anchors, tgt)
+        loss.backward()
+        p = f'loss_{variant}_'
+        res[p + 'sampled_bits'] = np.packbits(mask.numpy().astype(np.uint8), axis=1)
+        res[p + 'values'] = np.array([loss.item(), class_loss.item(), loc_loss.item()], dtype=np.float64)
+        res[p + 'cls_reduction'] = np.array(criterion.classification_loss.reduction)
+        gi, gv = sparse_rows(logits.grad.view(batch, A, C))
+        res[p + 'dscores_rows'], res[p + 'dscores_vals'] = gi, gv
+        gi, gv = sparse_rows(locs.grad.view(batch, A, 4))
+        res[p + 'dlocs_rows'], res[p + 'dlocs_vals'] = gi, gv
+        if variant == 'rand':
+            # in-place mutation of target[..., 0:4] (multibox_loss.py:81-82): encoded locs for EVERY anchor
+            enc = tgt[..., 0:4]
+            res['loss_encoded_target_img0_first2k'] = enc[0, :2048].numpy().copy()
+            pos = (tcls > 0)
+            res['loss_encoded_target_pos'] = enc[pos].numpy().copy()
+            res['loss_encoded_target_sum'] = np.array(enc.double().sum().item())
+
+    # ---- P1 / P2 ----------------------------------------------------------------------------
+    pb = 2
+    for variant, trained in (('rand', False), ('trained', True)):
+        logits = torch.from_numpy(syn.make_logits(pb, A, C, seed=5, trained_like=trained and softmax))
+        if trained and not softmax:
+            logits = logits - 4.6
+        locs = torch.from_numpy(syn.make_locs(pb, A, seed=6, scale=0.5))
+        box_coder = BoxCoder(xy_scale=10.0, wh_scale=5.0)
+        for nms_kind, nms_args in (('nms_contract', {}), ('softnms', {'soft': True, 'sigma': 0.5})):
+            if nms_kind == 'softnms' and not (variant == 'trained'):
+                continue  # python soft-nms on 8000 candidates/img is minutes; trained-like is enough to pin it
+            post = Postprocessor(box_coder, score_threshold=0.01,
+                                 nms=dict(max_per_class=100, overlap_threshold=cfg['nms_thr'], **nms_args),
+                                 score_converter=cfg['score_converter'], max_total=200)
+            with torch.no_grad():
+                out = post.postprocess((logits, locs), anchors)
+            key = f'post_{variant}_{nms_kind}_'
+            res[key + 'counts'] = np.array([o.size(0) for o in out], dtype=np.int32)
+            res[key + 'rows'] = torch.cat(out, dim=0).numpy() if len(out) else np.zeros((0, 6), np.float32)
+        if variant == 'rand':
+            with torch.no_grad():
+                s = logits.view(pb, A, C)
+                s = torch.softmax(s, dim=-1) if softmax else torch.sigmoid(s)
+                dec = box_utils.to_corners(box_coder.decode_box(locs.view(pb, A, 4), anchors, inplace=torch.tensor(0)))
+            res['post_probs_img0_first256'] = s[0, :256].numpy()
+            res['post_decoded_img0_first2k'] = dec[0, :2048].numpy()
+            res['post_decoded_sum'] = np.array(dec.double().sum().item())
+
+    path = os.path.join(out_dir, f'{name}.npz')
+    np.savez_compressed(path, **res)
+    print(f'{name}: A={A} -> {path} ({os.path.getsize(path) / 1e6:.2f} MB)')
+
+
+def gen_kats(out_dir):
+    """Quirk known-answer tests."""
+    res = {}
+    # anchors: 4 boxes (centroid form), gts crafted for ties etc.
+    anchors = torch.tensor([[10., 10., 10., 10.], [30., 10., 10., 10.], [50., 10., 10., 10.], [70., 10., 10., 10.]])
+    corner = box_utils.to_corners(anchors)
+    # (1) tie across GTs on one anchor -> first GT on max(dim=0); (2) duplicate force-match -> last GT wins
+    gt = torch.tensor([[5., 5., 15., 15., 1., 1.], [5., 5., 15., 15., 2., 1.], [26., 5., 36., 15., 3., 1.]])
+    w = box_utils.iou(gt[:, :4], corner)
+    res['kat1_gt'] = gt.numpy(); res['kat_anchors'] = anchors.numpy()
+    res['kat1_iou'] = w.numpy()
+    res['kat1_idx_nf'] = matcher.match_per_prediction(w, 0.5, 0.5, force_match_for_each_target=False).numpy()
+    res['kat1_idx'] = matcher.match_per_prediction(w, 0.5, 0.5).numpy()
+    res['kat1_target'] = TargetAssigner(0.5, 0.5).encode_ground_truth([gt], anchors).numpy()
+    # (3) GT with zero IoU everywhere force-matches anchor 0
+    gt = torch.tensor([[200., 200., 210., 210., 4., 1.], [48., 6., 56., 14., 2., 1.]])
+    w = box_utils.iou(gt[:, :4], corner)
+    res['kat3_gt'] = gt.numpy(); res['kat3_iou'] = w.numpy()
+    res['kat3_idx'] = matcher.match_per_prediction(w, 0.5, 0.5).numpy()
+    res['kat3_target'] = TargetAssigner(0.5, 0.5).encode_ground_truth([gt], anchors).numpy()
+    # (4) thresholds .5/.4 -> matched / ignore / unmatched
+    w = torch.tensor([[0.45, 0.6, 0.1]])
+    res['kat4_w'] = w.numpy()
+    res['kat4_idx_nf'] = matcher.match_per_prediction(w, 0.5, 0.4, force_match_for_each_target=False).numpy()
+    res['kat4_idx'] = matcher.match_per_prediction(w, 0.5, 0.4).numpy()
+    # ignore rows in the target: use real boxes with IoU in [0.4, 0.5)
+    gt = torch.tensor([[5., 5., 15., 15., 1., 1.], [24., 5., 34., 15., 2., 1.], [46.5, 5., 56.5, 15., 3., 1.]])
+    w = box_utils.iou(gt[:, :4], corner)
+    res['kat5_gt'] = gt.numpy(); res['kat5_iou'] = w.numpy()
+    res['kat5_idx'] = matcher.match_per_prediction(w, 0.9, 0.3).numpy()
+    res['kat5_idx_nf'] = matcher.match_per_prediction(w, 0.9, 0.3, force_match_for_each_target=False).numpy()
+    res['kat5_target'] = TargetAssigner(0.9, 0.3).encode_ground_truth([gt], anchors).numpy()
+    # (5b) an anchor in the ignore band that is nobody's argmax -> class = score = -1 in the target
+    anchors_b = torch.tensor([[10., 10., 10., 10.], [14., 10., 10., 10.], [50., 10., 10., 10.]])
+    gt = torch.tensor([[5., 5., 15., 15., 7., 0.5]])
+    w = box_utils.iou(gt[:, :4], box_utils.to_corners(anchors_b))
+    res['kat5b_anchors'] = anchors_b.numpy(); res['kat5b_gt'] = gt.numpy(); res['kat5b_iou'] = w.numpy()
+    res['kat5b_idx'] = matcher.match_per_prediction(w, 0.5, 0.4).numpy()
+    res['kat5b_target'] = TargetAssigner(0.5, 0.4).encode_ground_truth([gt], anchors_b).numpy()
+    # (6) degenerate boxes -> NaN IoU
+    a = torch.tensor([[5., 5., 5., 5.]]); b = torch.tensor([[7., 7., 7., 7.], [0., 0., 10., 10.]])
+    res['kat6_iou'] = box_utils.iou(a, b).numpy()
+    # (7) empty GT image in a batch is skipped
+    gt_list = [torch.zeros((0, 6)), torch.tensor([[5., 5., 15., 15., 1., 1.]])]
+    res['kat7_target'] = TargetAssigner(0.5, 0.5).encode_ground_truth(gt_list, anchors).numpy()
+    # (8) HNM: 1 pos, 4 neg, min_neg 5 -> all 4 negatives; 1 ignore
+    rng = np.random.default_rng(7)
+    pred = torch.from_numpy(rng.standard_normal((1, 6, 3), dtype=np.float32))
+    cls = torch.tensor([[2, 0, 0, -1, 0, 0]])
+    res['kat8_pred'] = pred.numpy(); res['kat8_cls'] = cls.numpy()
+    res['kat8_mask'] = sampler.hard_negative_mining(pred, cls, 3, 5).numpy()
+    # (9) HNM ranks: 2 pos, 20 neg, ratio 3, min 5 -> 6 hardest negatives
+    pred = torch.from_numpy(rng.standard_normal((2, 24, 4), dtype=np.float32))
+    cls = torch.zeros((2, 24), dtype=torch.long); cls[0, 3] = 1; cls[0, 17] = 3; cls[1, 0] = 2; cls[0, 5] = -1
+    res['kat9_pred'] = pred.numpy(); res['kat9_cls'] = cls.numpy()
+    res['kat9_mask'] = sampler.hard_negative_mining(pred, cls, 3, 5).numpy()
+    # (10) box coder: in-place encode (eps after divide), out-of-place encode, decode, centroids
+    bc = BoxCoder(10.0, 5.0)
+    pri = torch.from_numpy(rng.uniform(5, 60, size=(16, 4)).astype(np.float32))
+    box = torch.from_numpy(rng.uniform(0, 100, size=(2, 16, 4)).astype(np.float32))
+    box[..., 2:] += box[..., :2]
+    cen = box.clone(); box_utils.to_centroids(cen, inplace=True)
+    res['kat10_priors'] = pri.numpy(); res['kat10_corner_boxes'] = box.numpy()
+    res['kat10_centroids_inplace'] = cen.numpy()
+    res['kat10_centroids'] = box_utils.to_centroids(box).numpy()
+    enc = cen.clone(); bc.encode_box(enc, pri, inplace=True)
+    res['kat10_encode_inplace'] = enc.numpy()
+    res['kat10_encode'] = bc.encode_box(cen, pri).numpy()
+    res['kat10_decode'] = bc.decode_box(enc, pri, inplace=torch.tensor(0)).numpy()
+    res['kat10_to_corners'] = box_utils.to_corners(cen).numpy()
+    # (11) soft-nms and contract nms on a small crafted set
+    b = torch.from_numpy(rng.uniform(0, 50, size=(40, 4)).astype(np.float32)); b[:, 2:] = b[:, :2] + torch.from_numpy(rng.uniform(5, 40, size=(40, 2)).astype(np.float32))
+    s = torch.from_numpy(rng.uniform(0.02, 1, size=(40,)).astype(np.float32))
+    (pb_, ps_), pk = box_utils.nms(b, s, 0.45, 0.01, max_per_class=100)
+    res['kat11_boxes'] = b.numpy(); res['kat11_scores'] = s.numpy(); res['kat11_hard_picked'] = pk.numpy()
+    (pb_, ps_), pk = box_utils.nms(b, s, 0.45, 0.01, max_per_class=100, soft=True, sigma=0.5)
+    res['kat11_soft_picked'] = pk.numpy()
+    # (12) focal loss quirk: reduction attribute after get_ctor/filter_kwargs
+    crit, _ = make_criterion('focal_naive')
+    res['kat12_focal_reduction'] = np.array(crit.classification_loss.reduction)
+    crit, _ = make_criterion('ce_hnm')
+    res['kat12_ce_reduction'] = np.array(crit.classification_loss.reduction)
+    res['kat12_smoothl1_reduction'] = np.array(crit.localization_loss.reduction)
+    path = os.path.join(out_dir, 'kats.npz')
+    np.savez_compressed(path, **res)
+    print(f'kats -> {path} ({os.path.getsize(path) / 1e3:.1f} KB)')
+
+
+class _StubFeatures(torch.nn.Module):
+    """Stands in for the backbone: hands the given source maps to Predictor.forward (detector.py:36-37)."""
+    def __init__(self, sources):
+        super().__init__()
+        self.sources = sources
+
+    def forward(self, img):
+        return list(self.sources), self.sources[-1]
+
+
+def gen_heads(out_dir):
+    """H1 layout golden: reference get_heads + Predictor.forward flatten/cat on small maps, fwd + bwd."""
+    res = {}
+    rng = np.random.default_rng(31)
+    levels = [(16, 5, 4), (32, 3, 6), (8, 1, 4)]
+    C, B = 5, 2
+    heads = detector_builder.get_heads([l[0] for l in levels], [l[2] for l in levels], C, score_head_bias_init=-0.5)
+    srcs = []
+    for i, (cin, h, nb) in enumerate(levels):
+        x = torch.from_numpy(rng.standard_normal((B, cin, h, h), dtype=np.float32)).requires_grad_(True)
+        srcs.append(x)
+        for kind, nout in (('score', nb * C), ('loc', nb * 4)):
+            w = torch.from_numpy((rng.standard_normal((nout, cin, 3, 3), dtype=np.float32) * 0.1))
+            b = torch.from_numpy((rng.standard_normal((nout,), dtype=np.float32) * 0.1))
+            with torch.no_grad():
+                heads[i][kind].weight.copy_(w); heads[i][kind].bias.copy_(b)
+            res[f'w_{kind}_{i}'] = w.numpy(); res[f'b_{kind}_{i}'] = b.numpy()
+        res[f'x_{i}'] = x.detach().numpy()
+    pred = Predictor(_StubFeatures(srcs), torch.nn.ModuleList(), None, heads, C)
+    scores, locs, _ = pred(torch.zeros(B, 3, 8, 8))
+    res['scores'] = scores.detach().numpy(); res['locs'] = locs.detach().numpy()
+    gs = torch.from_numpy(rng.standard_normal(tuple(scores.shape), dtype=np.float32))
+    gl = torch.from_numpy(rng.standard_normal(tuple(locs.shape), dtype=np.float32))
+    res['g_scores'] = gs.numpy(); res['g_locs'] = gl.numpy()
+    (scores * gs).sum().add((locs * gl).sum()).backward()
+    for i in range(len(levels)):
+        res[f'dx_{i}'] = srcs[i].grad.numpy()
+        for kind in ('score', 'loc'):
+            res[f'dw_{kind}_{i}'] = heads[i][kind].weight.grad.numpy()
+            res[f'db_{kind}_{i}'] = heads[i][kind].bias.grad.numpy()
+    res['levels'] = np.array(levels, dtype=np.int32); res['num_classes'] = np.array(C)
+    path = os.path.join(out_dir, 'heads_small.npz')
+    np.savez_compressed(path, **res)
+    print(f'heads -> {path} ({os.path.getsize(path) / 1e3:.1f} KB)')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--out', default=os.path.join(REPO, 'tests', 'golden'))
+    ap.add_argument('--only', default=None)
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    batches = {'ssd_mb2_voc': 2, 'ssd_300_vgg16_voc': 4, 'ssd_512_vgg16_coco': 2,
+               'retina_rn50_500_coco': 2, 'm2det_512_vgg16_coco': 2}
+    if args.only in (None, 'kats'):
+        gen_kats(args.out)
+    if args.only in (None, 'heads'):
+        gen_heads(args.out)
+    for name, b in batches.items():
+        if args.only in (None, name):
+            gen_config(name, args.out, b)
+
+
+if __name__ == '__main__':
+    main()
