@@ -1,0 +1,169 @@
+/*
+ * ssdk.h -- C ABI of libssdk, the MI355X (gfx950) implementation of the single-shot-detection hot path.
+ *
+ * One entry point per reference function on the path; the comment on each declaration cites the
+ * reference interface it replaces (paths relative to the reference repository root).  Rules of the boundary:
+ *   - every pointer marked DEV is device memory owned by the caller (torch); the library never allocates or
+ *     frees device memory on the hot path and keeps no pointer past the call; workspaces are caller-provided,
+ *     sized by the matching *_workspace_bytes() query;
+ *   - every launch goes to the hipStream_t passed as `stream` (void*; NULL = the null stream); no call
+ *     synchronises the device;
+ *   - return value: 0 ok, <0 invalid argument (SSDK_E_*), >0 a hipError_t; no exception crosses the boundary;
+ *     ssdk_last_error_string() gives the thread's last message;
+ *   - fp32 everywhere unless stated; layouts are the reference's: scores [B, A*C] anchor-major/class-minor,
+ *     locs [B, A*4], anchors/priors [A,4] = (cx, cy, w, h) in pixels, target [B, A, 6] =
+ *     (x1, y1, x2, y2, class, score), ground-truth rows (x1, y1, x2, y2, class, score[, difficult]).
+ */
+#ifndef SSDK_H_
+#define SSDK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSDK_VERSION 100
+
+#define SSDK_OK 0
+#define SSDK_E_INVALID (-1)   /* bad argument / shape */
+#define SSDK_E_WORKSPACE (-2) /* workspace missing or too small */
+#define SSDK_E_UNSUPPORTED (-3)
+
+/* detection/matcher.py:4-5 */
+#define SSDK_NOT_MATCHED (-2)
+#define SSDK_IGNORE (-1)
+
+/* classification loss kinds (bf/modules/losses.py) */
+#define SSDK_CLS_CROSS_ENTROPY 0 /* torch.nn.CrossEntropyLoss(reduction='sum', ignore_index=-1), losses.py:4 */
+#define SSDK_CLS_SIGMOID_FOCAL 1 /* SigmoidFocalLoss, losses.py:34-54 */
+
+int ssdk_version(void);
+const char* ssdk_last_error_string(void);
+
+/* ---- anchors ------------------------------------------------------------------------------------------------ */
+
+/*
+ * Host helper: per-level box sizes of detection/anchor_generators/ssd.py:55-104,125-136 (SsdAnchorGenerator with
+ * num_branches = 1, flip = True).  `ratios` are the level's aspect_ratios before flipping; min_scale/max_scale are
+ * the fp32 values scales[i], scales[i+1] of ssd.py:33.  Writes nb x (w, h) to hws (host, capacity hws_cap pairs)
+ * and returns nb (>0) or an error (<0).
+ */
+int ssdk_anchor_sizes_ssd(const double* ratios, int nratio, float min_scale, float max_scale, int img_w, int img_h,
+                          float* hws, int hws_cap);
+
+/* Host helper: detection/anchor_generators/retina_net.py:18-26,40-43 box sizes (scale-major, ratio-minor). */
+int ssdk_anchor_sizes_retina(const double* ratios, int nratio, int level, double scale, int scales_per_level,
+                             float* hws, int hws_cap);
+
+/* Host helper: torch.linspace(start, end, steps) fp32 as used by ssd.py:33 for the scale table. */
+int ssdk_linspace_f32(float start, float end, int steps, float* out);
+
+/*
+ * Device: one level of _generate_anchors (ssd.py:106-151 / retina_net.py:28-54): out DEV [H, W, nb, 4] with
+ * centres linspace((0.5)*step, (0.5 + n - 1)*step, n), step = img / n, and the given (w, h) table (host, nb pairs).
+ */
+int ssdk_anchors_level(float* out, int layer_h, int layer_w, int nb, const float* hws_host, int img_w, int img_h,
+                       void* stream);
+
+/* ---- target assignment (T1 + T2 + T3) ------------------------------------------------------------------------- */
+
+size_t ssdk_encode_ground_truth_workspace_bytes(int batch, int total_gt);
+
+/*
+ * detection/target_assigner.py:22-63 TargetAssigner.encode_ground_truth, with bf/utils/box_utils.py:83-101 (iou)
+ * and detection/matcher.py:33-56 (match_per_prediction, force_match_for_each_target=True) fused.
+ *   gt_rows    DEV [total_gt, gt_stride] rows of all images back to back, gt_stride >= 6
+ *   gt_offsets DEV int32 [batch + 1], image i owns rows gt_offsets[i] .. gt_offsets[i+1]
+ *   anchors    DEV [A, 4] centroid form
+ *   target     DEV [batch, A, 6] (written in full)
+ *   box_idx    DEV int32 [batch, A] or NULL: the matcher's box_idx (-2 not matched, -1 ignore, >= 0 GT index)
+ */
+int ssdk_encode_ground_truth(const float* gt_rows, int gt_stride, const int32_t* gt_offsets, int batch, int total_gt,
+                             const float* anchors, int num_anchors, float matched_threshold,
+                             float unmatched_threshold, float* target, int32_t* box_idx, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
+/* ---- sampler + loss (S1 + L1 + L2 + L3) ----------------------------------------------------------------------- */
+
+size_t ssdk_multibox_loss_workspace_bytes(int batch, int num_anchors, int num_classes);
+
+/*
+ * detection/sampler.py:12-25 hard_negative_mining.  scores DEV [batch, A, C]; target_classes DEV fp32, the class
+ * of anchor r at target_classes[r * class_stride] (class_stride = 6 and pointer = target + 4 reads the class column
+ * of a [batch, A, 6] target in place; 1 = a dense [batch, A] array); sampled DEV uint8 [batch, A] (1 = positive or
+ * selected hard negative).  Leaves the per-anchor log-sum-exp of the scores in the workspace for
+ * ssdk_multibox_loss_fwd to reuse (lse_valid).
+ */
+int ssdk_hard_negative_mining(const float* scores, const float* target_classes, int class_stride, int batch,
+                              int num_anchors, int num_classes, double negative_per_positive_ratio,
+                              int64_t min_negative_per_image, uint8_t* sampled, void* workspace, size_t workspace_bytes,
+                              void* stream);
+
+/* detection/sampler.py:9-10 naive_sampler: positives only. */
+int ssdk_naive_sampler(const float* target_classes, int class_stride, int batch, int num_anchors, uint8_t* sampled,
+                       void* stream);
+
+/*
+ * detection/losses/multibox_loss.py:35-94 MultiboxLoss.forward for a given sampled mask.
+ *   cls_kind SSDK_CLS_CROSS_ENTROPY: sum over sampled rows whose class != -1 of -log_softmax(scores)[class];
+ *            SSDK_CLS_SIGMOID_FOCAL: losses.py:42-54 on the one-hot target of multibox_loss.py:64-67, summed over
+ *            classes; `focal_reduce_mean` != 0 divides by the number of sampled rows (the reference's constructor
+ *            drops reduction='sum' for this class, bf/utils/misc_utils.py:22-29 -- SURVEY.md §8a L1).
+ *   localisation: SmoothL1Loss(sum, beta) over positives on box_coder-encoded targets.
+ *   target DEV [batch, A, 6] is MUTATED like the reference: columns 0..3 become the encoded regression targets
+ *          (to_centroids + encode_box in place, multibox_loss.py:81-82 / box_coder.py:22-30), every anchor.
+ *   out3   DEV float[3] = (loss, class_loss, loc_loss), each already divided by max(1, #positives).
+ *   lse_valid != 0: the workspace already holds this batch's per-anchor log-sum-exp (left there by
+ *          ssdk_hard_negative_mining on the same scores), so the scores are not read again for sampled negatives.
+ * The workspace keeps what ssdk_multibox_loss_bwd needs (divider, per-anchor log-sum-exp); pass the same one.
+ */
+int ssdk_multibox_loss_fwd(int cls_kind, const float* scores, const float* locs, const float* anchors, float* target,
+                           const uint8_t* sampled, int batch, int num_anchors, int num_classes, float focal_gamma,
+                           float focal_alpha, int focal_reduce_mean, float classification_weight,
+                           float localization_weight, float xy_scale, float wh_scale, float eps, float smooth_l1_beta,
+                           int lse_valid, float* out3, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Backward of ssdk_multibox_loss_fwd.  grad_out DEV float[2] = (dL/dclass_loss, dL/dloc_loss).
+ * target is the MUTATED target of the forward call.  dscores DEV [batch, A, C] and dlocs DEV [batch, A, 4] are
+ * written in full (zeros off the sampled / positive rows).
+ */
+int ssdk_multibox_loss_bwd(int cls_kind, const float* scores, const float* locs, const float* target,
+                           const uint8_t* sampled, const float* grad_out, int batch, int num_anchors, int num_classes,
+                           float focal_gamma, float focal_alpha, int focal_reduce_mean, float classification_weight,
+                           float localization_weight, float smooth_l1_beta, float* dscores, float* dlocs,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* detection/box_coder.py:13-34 encode_box (inplace != 0: :22-30, eps after the divide; else :32-34). boxes [n_batch, A, 4]. */
+int ssdk_encode_box(const float* boxes, const float* priors, float* out, int batch, int num_anchors, float xy_scale,
+                    float wh_scale, float eps, int inplace_semantics, void* stream);
+/* detection/box_coder.py:37-57 decode_box -> centroid boxes (inplace_semantics != 0: op order of :45-53, else :55-57). */
+int ssdk_decode_box(const float* locs, const float* priors, float* out, int batch, int num_anchors, float xy_scale,
+                    float wh_scale, int inplace_semantics, void* stream);
+
+/* ---- postprocess (P1 + P2) ----------------------------------------------------------------------------------- */
+
+size_t ssdk_postprocess_workspace_bytes(int batch, int num_anchors, int num_classes, int softmax, int max_per_class,
+                                        int max_total);
+
+/*
+ * detection/postprocessor.py:24-78 Postprocessor.postprocess with bf/utils/box_utils.py:166-194 (nms wrapper:
+ * per-class top max_per_class, then hard NMS per torchvision.ops.nms's contract) fused.
+ *   scores DEV [batch, A, C] logits; locs DEV [batch, A, 4]; priors DEV [A, 4]
+ *   softmax != 0: F.softmax and drop column 0 (classes 1..C-1); else sigmoid (classes 1..C)
+ *   max_per_class in 1..256; max_total <= 0 means None
+ *   out    DEV [batch, out_cap, 6] rows (x1, y1, x2, y2, class, score); counts DEV int32 [batch];
+ *          out_cap >= (max_total > 0 ? max_total : ncls * max_per_class)
+ *   nms_candidates DEV int64 [batch] or NULL: number of boxes that entered NMS per image
+ */
+int ssdk_postprocess(const float* scores, const float* locs, const float* priors, int batch, int num_anchors,
+                     int num_classes, int softmax, float score_threshold, int max_per_class, float nms_threshold,
+                     int max_total, float xy_scale, float wh_scale, float* out, int out_cap, int32_t* counts,
+                     int64_t* nms_candidates, void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSDK_H_ */

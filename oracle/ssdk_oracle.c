@@ -246,7 +246,7 @@ void orc_hard_negative_mining(const float* scores, const float* target, int B, i
         /* :20 min(clamp(P*ratio, min=min_neg), #neg); P*ratio is integer when ratio is */
         double want = (double)npos * ratio;
         if (want < (double)min_neg) want = (double)min_neg;
-        int64_t n = (int64_t)want;
+        int64_t n = (int64_t)ceil(want); /* rank < want: ceil(want) ranks qualify when want is fractional */
         if (n > nneg) n = nneg;
         qsort(kv, (size_t)A, sizeof(orc_kv), cmp_desc_stable); /* rank = argsort(argsort(desc)) ; rank < n */
         for (int64_t r = 0; r < n; ++r) mask[(int64_t)i * A + kv[r].i] = 1;

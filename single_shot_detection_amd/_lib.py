@@ -1,0 +1,134 @@
+"""ctypes binding of libssdk.so (the HIP/gfx950 implementation behind ``include/ssdk.h``).
+
+There is NO fallback: if the shared library is missing or a call fails, an exception is raised.  Tensors are
+handed over as raw device pointers (``Tensor.data_ptr()``) on torch's current HIP stream; torch only owns the
+memory and the stream.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libssdk.so')
+CSRC = os.path.join(_HERE, 'csrc')
+
+_lib = None
+
+
+class SsdkError(RuntimeError):
+    pass
+
+
+def build(jobs=8, force=False):
+    """Compile every HIP source for gfx950 into ``libssdk.so`` (in-tree; hipcc cross-compiles without a GPU)."""
+    args = ['make', '-C', CSRC, f'-j{jobs}']
+    if force:
+        args.append('-B')
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    'ssdk_version': (C.c_int, []),
+    'ssdk_last_error_string': (C.c_char_p, []),
+    'ssdk_anchor_sizes_ssd': (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    'ssdk_anchor_sizes_retina': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_int]),
+    'ssdk_linspace_f32': (C.c_int, [C.c_float, C.c_float, C.c_int, C.c_void_p]),
+    'ssdk_anchors_level': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'ssdk_encode_ground_truth_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int]),
+    'ssdk_encode_ground_truth': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                           C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                           C.c_void_p]),
+    'ssdk_multibox_loss_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'ssdk_hard_negative_mining': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                            C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'ssdk_naive_sampler': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'ssdk_multibox_loss_fwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float,
+                                         C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_size_t, C.c_void_p]),
+    'ssdk_multibox_loss_bwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float,
+                                         C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'ssdk_encode_box': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                  C.c_int, C.c_void_p]),
+    'ssdk_decode_box': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
+                                  C.c_void_p]),
+    'ssdk_postprocess_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'ssdk_postprocess': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                   C.c_int, C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+}
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """The loaded library; raises if it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SsdkError(f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                            f'(or `make -C {CSRC}`); there is no fallback path')
+        _preload_torch_hip_runtime()
+        _lib = _Bound(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def _preload_torch_hip_runtime():
+    """libssdk must share torch's HIP runtime instance (device pointers and streams come from torch).  torch
+    bundles its own libamdhip64.so.7; loading it first makes the dynamic linker resolve libssdk's NEEDED entry of
+    the same SONAME to that instance instead of a second runtime from /opt/rocm."""
+    import torch
+    cand = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so')
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
+class _Bound(object):
+    """Attribute access binds the prototype from _SIGNATURES on first use; unknown or missing symbols raise."""
+
+    def __init__(self, handle):
+        self._handle = handle
+
+    def __getattr__(self, name):
+        if name not in _SIGNATURES:
+            raise AttributeError(f'{name} is not part of the libssdk C ABI (include/ssdk.h)')
+        try:
+            fn = getattr(self._handle, name)
+        except AttributeError:
+            raise SsdkError(f'{LIB_PATH} does not export {name}: stale build, rebuild with `make -C {CSRC}`')
+        fn.restype, fn.argtypes = _SIGNATURES[name]
+        setattr(self, name, fn)
+        return fn
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().ssdk_last_error_string().decode('utf-8', 'replace')
+        if status < 0:
+            raise ValueError(f'{what}: {msg} (status {status})')
+        raise SsdkError(f'{what}: {msg} (hipError {status})')
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device (or host) pointer of a contiguous tensor, or NULL for None."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), 'libssdk takes dense row-major buffers'
+    return C.c_void_p(t.data_ptr())
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise SsdkError('libssdk kernels run on the GPU only; got a tensor on ' + str(t.device) +
+                            ' (there is no CPU fallback)')

@@ -1,0 +1,114 @@
+// common.h -- shared host/device helpers of libssdk (gfx950 only; wave = 64).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/ssdk.h"
+
+namespace ssdk {
+
+constexpr int kWave = 64;
+
+void set_error(const char* fmt, ...);
+
+#define SSDK_REQUIRE(cond, code, ...)     \
+    do {                                  \
+        if (!(cond)) {                    \
+            ::ssdk::set_error(__VA_ARGS__); \
+            return (code);                \
+        }                                 \
+    } while (0)
+
+// Launch check: reports configuration errors of the launch just issued (no device sync).
+#define SSDK_CHECK_LAUNCH(name)                                                        \
+    do {                                                                               \
+        hipError_t e_ = hipGetLastError();                                             \
+        if (e_ != hipSuccess) {                                                        \
+            ::ssdk::set_error("%s: launch failed: %s", name, hipGetErrorString(e_));   \
+            return (int)e_;                                                            \
+        }                                                                              \
+    } while (0)
+
+#define SSDK_CHECK_HIP(expr)                                                             \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            ::ssdk::set_error("%s failed: %s", #expr, hipGetErrorString(e_));            \
+            return (int)e_;                                                              \
+        }                                                                                \
+    } while (0)
+
+__host__ __device__ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Bump allocator over a caller-provided workspace; every carve is 256-byte aligned.
+struct Carver {
+    char* base;
+    size_t off;
+    explicit Carver(void* p) : base(static_cast<char*>(p)), off(0) {}
+    template <typename T>
+    T* take(size_t n) {
+        T* r = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += align_up(n * sizeof(T), 256);
+        return r;
+    }
+};
+
+#ifdef __HIPCC__
+
+// torch.max / torch.min semantics (NaN propagates) -- bf/utils/box_utils.py:61-69 use torch.max/min.
+__device__ __forceinline__ float tmaxf(float a, float b) { return (a > b || a != a) ? a : b; }
+__device__ __forceinline__ float tminf(float a, float b) { return (a < b || a != a) ? a : b; }
+// Tensor.clamp_(0): NaN stays NaN.
+__device__ __forceinline__ float clamp0(float v) { return v < 0.0f ? 0.0f : v; }
+// bf/utils/box_utils.py:38-46 area
+__device__ __forceinline__ float area4(float x1, float y1, float x2, float y2) { return clamp0(x2 - x1) * clamp0(y2 - y1); }
+
+// IoU of two corner boxes, op for op bf/utils/box_utils.py:49-101 (no FMA: this TU is built -ffp-contract=off).
+__device__ __forceinline__ float iou_corner(float4 a, float area_a, float4 b, float area_b) {
+    const float inter = area4(tmaxf(a.x, b.x), tmaxf(a.y, b.y), tminf(a.z, b.z), tminf(a.w, b.w));
+    return inter / (area_a + area_b - inter);
+}
+
+// bf/utils/box_utils.py:16-23 to_corners
+__device__ __forceinline__ float4 to_corners(float4 c) {
+    return make_float4(c.x - c.z / 2.0f, c.y - c.w / 2.0f, c.x + c.z / 2.0f, c.y + c.w / 2.0f);
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+
+// ---- wave-level reductions over 64 lanes (butterfly; every lane ends with the result) ----------------------
+template <typename T, typename Op>
+__device__ __forceinline__ T wave_allreduce(T v, Op op) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = op(v, __shfl_xor(v, m, kWave));
+    return v;
+}
+struct OpAddF { __device__ __forceinline__ float operator()(float a, float b) const { return a + b; } };
+struct OpAddD { __device__ __forceinline__ double operator()(double a, double b) const { return a + b; } };
+struct OpAddI { __device__ __forceinline__ int operator()(int a, int b) const { return a + b; } };
+struct OpMaxF { __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); } };
+struct OpMaxU64 {
+    __device__ __forceinline__ unsigned long long operator()(unsigned long long a, unsigned long long b) const { return a > b ? a : b; }
+};
+
+// Block-wide sum into thread 0 (deterministic for a fixed block size).  `red` = LDS float[blockDim.x / 64].
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* red) {
+    struct Add { __device__ __forceinline__ T operator()(T a, T b) const { return a + b; } };
+    v = wave_allreduce(v, Add());
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane_id() == 0) red[w] = v;
+    __syncthreads();
+    T s = 0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < nw; ++i) s += red[i];
+    return s;
+}
+
+#endif  // __HIPCC__
+
+}  // namespace ssdk

@@ -1,0 +1,605 @@
+// loss.hip -- hard-negative sampler + multibox loss forward/backward + box coder.
+//
+// Reference: detection/sampler.py:9-25, detection/losses/multibox_loss.py:35-94, bf/modules/losses.py:34-54,
+// detection/box_coder.py:13-57, bf/utils/box_utils.py:25-36.  The reference materialises a full log_softmax of
+// [B,A,C], two full argsorts of A per image, boolean-mask gathers and an index_put backward.
+//
+// Kernels (all HBM-bound; the only dense passes over the [B,A,C] logits are ONE read in the forward
+// (hnm_rows_kernel) and ONE write of dscores in the backward -- 8*A*C bytes per image, the algorithmic minimum):
+//   hnm_rows_kernel    streams the logits through a 64-row LDS tile (16-byte coalesced loads, rows of C floats are
+//                      not 16-byte aligned on their own), 4 lanes per row: per-anchor log-sum-exp (kept for the loss
+//                      and its backward) and the background loss -log_softmax[...,0].
+//   hnm_select_kernel  one workgroup per image: exact N-th-largest selection by 4x8-bit radix histograms in LDS
+//                      instead of argsort(argsort()); ties at the threshold go to the lower anchor index.
+//   loss_fwd_kernel    one thread per anchor: target encode in place (to_centroids + encode_box, every anchor, as
+//                      the reference mutates it), smooth-L1 over positives, and the classification term for SAMPLED
+//                      rows only (a gather of x[class] when the log-sum-exp is already there; otherwise the wave
+//                      cooperates on each sampled row).  Partial sums per workgroup, fixed-order final reduce.
+//   loss_bwd_kernel    64-row output tiles: zero-fill, fill the sampled rows, one coalesced write.
+#include <limits.h>
+#include <math.h>
+
+#include "common.h"
+
+namespace ssdk {
+
+constexpr int kTileRows = 64;
+constexpr int kLossThreads = 256;
+constexpr float kMarkPositive = -INFINITY;  // bgloss marker: positive anchor (sampler.py:22 sets -inf for non-negatives)
+constexpr float kMarkIgnore = -1.0f;        // bgloss marker: ignored anchor (class -1)
+
+struct LossState {  // lives in the workspace, written by finalize_kernel, read by the backward
+    float divider;   // max(1, #positives)               multibox_loss.py:88
+    float mean_div;  // #sampled rows for focal 'mean', else 1
+    float out3[3];
+    int npos;
+    int nrows;
+    int pad;
+};
+
+struct LossWs {
+    float* lse;      // [B*A]
+    float* bgloss;   // [B*A]
+    float* partials; // [2 * kMaxPartials]
+    int* counters;   // [4]: npos, nrows
+    LossState* state;
+};
+constexpr int kMaxPartials = 2048;
+
+static LossWs carve_loss_ws(void* ws, size_t n_rows, size_t* total) {
+    Carver c(ws);
+    LossWs w;
+    w.lse = c.take<float>(n_rows);
+    w.bgloss = c.take<float>(n_rows);
+    w.partials = c.take<float>(2 * kMaxPartials);
+    w.counters = c.take<int>(4);
+    w.state = c.take<LossState>(1);
+    if (total) *total = c.off;
+    return w;
+}
+
+// radix key of a negative's background loss: fp32 bits are order-preserving for values >= +0; +1 keeps 0 free
+__device__ __forceinline__ unsigned neg_key(float x) { return x > 0.0f ? __float_as_uint(x) + 1u : 1u; }
+
+__device__ __forceinline__ float quad_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1, kWave));
+    return fmaxf(v, __shfl_xor(v, 2, kWave));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __shfl_xor(v, 1, kWave);
+    return v + __shfl_xor(v, 2, kWave);
+}
+
+// ---- S1: hard negative mining ---------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(kLossThreads) hnm_rows_kernel(const float* __restrict__ scores, const float* __restrict__ target_cls,
+                                                                int cls_stride, long long n_rows, int C, float* __restrict__ lse_out,
+                                                                float* __restrict__ bgloss_out) {
+    extern __shared__ __attribute__((aligned(16))) float s_tile[];  // kTileRows * C floats
+    const long long n_tiles = (n_rows + kTileRows - 1) / kTileRows;
+    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const long long r0 = tile * kTileRows;
+        const int rows = (int)min((long long)kTileRows, n_rows - r0);
+        const int nfloat = rows * C;
+        const float* src = scores + r0 * C;  // 16-byte aligned: r0*C*4 = tile*256*C
+        __syncthreads();
+        for (int t = threadIdx.x; t < (nfloat >> 2); t += kLossThreads)
+            reinterpret_cast<float4*>(s_tile)[t] = reinterpret_cast<const float4*>(src)[t];
+        for (int t = (nfloat & ~3) + threadIdx.x; t < nfloat; t += kLossThreads) s_tile[t] = src[t];
+        __syncthreads();
+        const int row = threadIdx.x >> 2, q = threadIdx.x & 3;
+        const float* x = s_tile + row * C;
+        const bool live = row < rows;
+        float m = -INFINITY;
+        if (live)
+            for (int c = q; c < C; c += 4) m = fmaxf(m, x[c]);
+        m = quad_max(m);
+        float s = 0.0f;
+        if (live)
+            for (int c = q; c < C; c += 4) s += __expf(x[c] - m);
+        s = quad_sum(s);
+        if (live && q == 0) {
+            const float ls = logf(s);
+            const float cls = target_cls[(r0 + row) * cls_stride];
+            const float loss = -((x[0] - m) - ls);  // sampler.py:13 -log_softmax[..., NEGATIVE_CLASS]
+            lse_out[r0 + row] = m + ls;
+            bgloss_out[r0 + row] = cls == 0.0f ? fmaxf(loss, 0.0f) : (cls == -1.0f ? kMarkIgnore : kMarkPositive);
+        }
+    }
+}
+
+// One workgroup per image.  Selects the `n` largest background losses among negatives (sampler.py:17-25).
+__global__ void __launch_bounds__(1024) hnm_select_kernel(const float* __restrict__ bgloss, int A, double ratio,
+                                                          long long min_neg, uint8_t* __restrict__ sampled) {
+    __shared__ unsigned s_hist[256];
+    __shared__ int s_cnt[2];
+    __shared__ unsigned s_prefix, s_need, s_wave_cnt[16], s_run;
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const float* v = bgloss + (size_t)i * A;
+    uint8_t* out = sampled + (size_t)i * A;
+    if (tid < 2) s_cnt[tid] = 0;
+    __syncthreads();
+    int npos = 0, nneg = 0;
+    for (int a = tid; a < A; a += blockDim.x) {
+        const float x = v[a];
+        npos += x == kMarkPositive;
+        nneg += x >= 0.0f;
+    }
+    npos = wave_allreduce(npos, OpAddI());
+    nneg = wave_allreduce(nneg, OpAddI());
+    if (lane_id() == 0) { atomicAdd(&s_cnt[0], npos); atomicAdd(&s_cnt[1], nneg); }
+    __syncthreads();
+    npos = s_cnt[0]; nneg = s_cnt[1];
+    // sampler.py:20  min(clamp(P * ratio, min=min_neg), #neg); `rank < n` with a fractional n keeps ceil(n) ranks
+    long long n;
+    if (ratio == floor(ratio)) {
+        n = (long long)npos * (long long)ratio;
+        if (n < min_neg) n = min_neg;
+    } else {
+        float want = (float)npos * (float)ratio;  // int64 tensor * python float -> float32 tensor
+        if (want < (float)min_neg) want = (float)min_neg;
+        n = (long long)ceilf(want);
+    }
+    if (n > nneg) n = nneg;
+    if (n >= nneg || n <= 0) {  // every negative, or none: no ranking needed
+        const bool all = n > 0;
+        for (int a = tid; a < A; a += blockDim.x) {
+            const float x = v[a];
+            out[a] = (x == kMarkPositive) || (all && x >= 0.0f);
+        }
+        return;
+    }
+    // radix select of the n-th largest key among negatives; key = fp32 bits (losses are >= +0) + 1
+    unsigned prefix = 0, need = (unsigned)n;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int b = tid; b < 256; b += blockDim.x) s_hist[b] = 0;
+        __syncthreads();
+        const unsigned himask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (int a = tid; a < A; a += blockDim.x) {
+            const float x = v[a];
+            if (x >= 0.0f) {
+                const unsigned key = neg_key(x);
+                if ((key & himask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255u], 1u);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned acc = 0;
+            int b = 255;
+            for (; b > 0; --b) {
+                if (acc + s_hist[b] >= need) break;
+                acc += s_hist[b];
+            }
+            s_prefix = prefix | ((unsigned)b << shift);
+            s_need = need - acc;
+        }
+        __syncthreads();
+        prefix = s_prefix; need = s_need;
+        __syncthreads();
+    }
+    // prefix = key of the n-th largest; `need` of the anchors whose key == prefix are taken, lowest index first
+    const unsigned thr = prefix;
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    for (int base = 0; base < A; base += blockDim.x) {
+        const int a = base + tid;
+        float x = kMarkIgnore;
+        if (a < A) x = v[a];
+        const bool neg = x >= 0.0f;
+        const unsigned key = neg ? neg_key(x) : 0u;
+        const bool eq = neg && key == thr;
+        const unsigned long long bal = __ballot(eq);
+        const int w = tid >> 6;
+        if (lane_id() == 0) s_wave_cnt[w] = (unsigned)__popcll(bal);
+        __syncthreads();
+        unsigned before = s_run;
+        for (int k = 0; k < w; ++k) before += s_wave_cnt[k];
+        before += (unsigned)__popcll(bal & ((1ull << lane_id()) - 1ull));
+        if (a < A) out[a] = (x == kMarkPositive) || (neg && key > thr) || (eq && before < need);
+        __syncthreads();
+        if (tid == 0) {
+            unsigned tot = 0;
+            for (int k = 0; k < (int)(blockDim.x >> 6); ++k) tot += s_wave_cnt[k];
+            s_run += tot;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) naive_sampler_kernel(const float* __restrict__ target_cls, int cls_stride, long long n_rows,
+                                                            uint8_t* __restrict__ sampled) {
+    for (long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x; r < n_rows; r += (long long)gridDim.x * blockDim.x) {
+        const float cls = target_cls[r * cls_stride];
+        sampled[r] = cls != 0.0f && cls != -1.0f;  // sampler.py:10
+    }
+}
+
+// ---- L1/L2/L3 forward -----------------------------------------------------------------------------------------
+
+// torch smooth_l1: z < beta ? 0.5 z^2 / beta : z - 0.5 beta
+__device__ __forceinline__ float smooth_l1(float a, float b, float beta) {
+    const float z = fabsf(a - b);
+    return z < beta ? 0.5f * z * z / beta : z - 0.5f * beta;
+}
+__device__ __forceinline__ float smooth_l1_grad(float a, float b, float beta) {
+    const float d = a - b;
+    return d <= -beta ? -1.0f : (d >= beta ? 1.0f : d / beta);
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// bf/modules/losses.py:42-52 for one element; tg = one-hot target value
+__device__ __forceinline__ float focal_elem(float x, float tg, float gamma, float alpha) {
+    const float aw = tg * alpha + (1.0f - tg) * (1.0f - alpha);
+    float pb = sigmoid_f(x);
+    pb = pb * tg + (1.0f - pb) * (1.0f - tg);
+    const float ce = fmaxf(x, 0.0f) - x * tg + log1pf(__expf(-fabsf(x)));
+    return aw * __powf(1.0f - pb, gamma) * ce;
+}
+__device__ __forceinline__ float focal_elem_grad(float x, float tg, float gamma, float alpha) {
+    const float aw = tg * alpha + (1.0f - tg) * (1.0f - alpha);
+    const float s = sigmoid_f(x);
+    const float pb = s * tg + (1.0f - s) * (1.0f - tg);
+    const float ce = fmaxf(x, 0.0f) - x * tg + log1pf(__expf(-fabsf(x)));
+    const float om = 1.0f - pb;
+    const float dpb = s * (1.0f - s) * (2.0f * tg - 1.0f);
+    return aw * (-gamma * __powf(om, gamma - 1.0f) * dpb * ce + __powf(om, gamma) * (s - tg));
+}
+
+struct LossParams {
+    int cls_kind, C, lse_valid;
+    float gamma, alpha, xy_scale, wh_scale, eps, beta;
+};
+
+__global__ void __launch_bounds__(kLossThreads) loss_fwd_kernel(LossParams p, const float* __restrict__ scores,
+                                                                const float4* __restrict__ locs, const float4* __restrict__ anchors,
+                                                                float* __restrict__ target, const uint8_t* __restrict__ sampled,
+                                                                long long n_rows, int A, float* __restrict__ lse,
+                                                                float* __restrict__ partials, int* __restrict__ counters) {
+    __shared__ float s_red[kLossThreads / kWave];
+    __shared__ int s_redi[kLossThreads / kWave];
+    float cls_acc = 0.0f, loc_acc = 0.0f;
+    int npos = 0, nrows = 0;
+    const int lane = lane_id();
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long n_iter = (n_rows + stride - 1) / stride;
+    for (long long it = 0; it < n_iter; ++it) {
+        const long long r = it * stride + blockIdx.x * (long long)blockDim.x + threadIdx.x;
+        const bool live = r < n_rows;
+        int cls = 0;
+        float tscore = 0.0f;
+        bool smp = false, pos = false;
+        if (live) {
+            float2* trow = reinterpret_cast<float2*>(target + r * 6);  // 24-byte rows: 8-byte aligned
+            float2 t01 = trow[0], t23 = trow[1];
+            const float2 t45 = trow[2];
+            cls = (int)t45.x;  // multibox_loss.py:48 .long()
+            tscore = t45.y;
+            pos = cls != 0 && cls != -1;
+            smp = sampled[r] != 0;
+            npos += pos;
+            // box_utils.py:33-34 to_centroids(inplace), then box_coder.py:22-30 encode_box(inplace)
+            const float4 pr = anchors[r % A];
+            t23.x -= t01.x; t23.y -= t01.y;
+            t01.x += t23.x / 2.0f; t01.y += t23.y / 2.0f;
+            t01.x -= pr.x; t01.y -= pr.y;
+            t01.x /= pr.z; t01.y /= pr.w;
+            t01.x *= p.xy_scale; t01.y *= p.xy_scale;
+            t23.x /= pr.z; t23.y /= pr.w;
+            t23.x += p.eps; t23.y += p.eps;
+            t23.x = logf(t23.x); t23.y = logf(t23.y);
+            t23.x *= p.wh_scale; t23.y *= p.wh_scale;
+            trow[0] = t01; trow[1] = t23;
+            if (pos) {  // multibox_loss.py:84-86
+                const float4 l = locs[r];
+                loc_acc += smooth_l1(l.x, t01.x, p.beta) + smooth_l1(l.y, t01.y, p.beta) + smooth_l1(l.z, t23.x, p.beta) +
+                           smooth_l1(l.w, t23.y, p.beta);
+            }
+        }
+        const bool want = p.cls_kind == SSDK_CLS_CROSS_ENTROPY ? (smp && cls != -1) : smp;  // CE: ignore_index = -1
+        nrows += smp;
+        if (p.cls_kind == SSDK_CLS_CROSS_ENTROPY && p.lse_valid) {
+            if (want) cls_acc += lse[r] - scores[r * p.C + cls];
+        } else {
+            unsigned long long todo = __ballot(want);
+            while (todo) {  // the wave cooperates on each sampled row
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const long long rs = __shfl(r, src, kWave);
+                const int cs = __shfl(cls, src, kWave);
+                const float ts = __shfl(tscore, src, kWave);
+                const float* x = scores + rs * p.C;
+                float val;
+                if (p.cls_kind == SSDK_CLS_CROSS_ENTROPY) {
+                    float m = -INFINITY;
+                    for (int c = lane; c < p.C; c += kWave) m = fmaxf(m, x[c]);
+                    m = wave_allreduce(m, OpMaxF());
+                    float s = 0.0f;
+                    for (int c = lane; c < p.C; c += kWave) s += __expf(x[c] - m);
+                    s = wave_allreduce(s, OpAddF());
+                    const float l = m + logf(s);
+                    if (lane == src) lse[rs] = l;
+                    val = l - x[cs];
+                } else {
+                    const bool ps = cs != 0 && cs != -1;
+                    float f = 0.0f;
+                    for (int c = lane; c < p.C; c += kWave)
+                        f += focal_elem(x[c], (ps && c == cs - 1) ? ts : 0.0f, p.gamma, p.alpha);  // multibox_loss.py:64-67
+                    val = wave_allreduce(f, OpAddF());
+                }
+                if (lane == src) cls_acc += val;
+            }
+        }
+    }
+    const float cs_ = block_sum(cls_acc, s_red);
+    const float ls_ = block_sum(loc_acc, s_red);
+    const int np_ = block_sum(npos, s_redi);
+    const int nr_ = block_sum(nrows, s_redi);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = cs_;
+        partials[kMaxPartials + blockIdx.x] = ls_;
+        if (np_) atomicAdd(&counters[0], np_);
+        if (nr_) atomicAdd(&counters[1], nr_);
+    }
+}
+
+__global__ void __launch_bounds__(256) loss_finalize_kernel(const float* __restrict__ partials, int n_part,
+                                                            const int* __restrict__ counters, int cls_kind, int reduce_mean,
+                                                            float cls_w, float loc_w, LossState* __restrict__ state,
+                                                            float* __restrict__ out3) {
+    __shared__ double s_red[4];
+    double c = 0.0, l = 0.0;
+    for (int k = threadIdx.x; k < n_part; k += blockDim.x) { c += (double)partials[k]; l += (double)partials[kMaxPartials + k]; }
+    c = block_sum(c, s_red);
+    l = block_sum(l, s_red);
+    if (threadIdx.x == 0) {
+        const int npos = counters[0], nrows = counters[1];
+        const float divider = (float)(npos < 1 ? 1 : npos);  // multibox_loss.py:88
+        const float mean_div = (cls_kind == SSDK_CLS_SIGMOID_FOCAL && reduce_mean) ? (float)nrows : 1.0f;
+        const float class_loss = (float)c / mean_div * cls_w / divider;  // :90
+        const float loc_loss = (float)l * loc_w / divider;               // :89
+        state->divider = divider; state->mean_div = mean_div; state->npos = npos; state->nrows = nrows;
+        state->out3[0] = class_loss + loc_loss; state->out3[1] = class_loss; state->out3[2] = loc_loss;
+        out3[0] = class_loss + loc_loss; out3[1] = class_loss; out3[2] = loc_loss;
+    }
+}
+
+// ---- backward ------------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(kLossThreads) loss_bwd_kernel(LossParams p, int reduce_mean, float cls_w, float loc_w,
+                                                                const float* __restrict__ scores, const float4* __restrict__ locs,
+                                                                const float* __restrict__ target, const uint8_t* __restrict__ sampled,
+                                                                const float* __restrict__ grad_out, long long n_rows,
+                                                                const float* __restrict__ lse, const LossState* __restrict__ state,
+                                                                float* __restrict__ dscores, float4* __restrict__ dlocs) {
+    extern __shared__ __attribute__((aligned(16))) float s_tile[];  // kTileRows * C floats
+    __shared__ int s_cls[kTileRows];
+    __shared__ float s_tscore[kTileRows];
+    __shared__ int s_any;
+    const float divider = state->divider;
+    const float g_cls = grad_out[0] * cls_w / divider / (reduce_mean ? state->mean_div : 1.0f);
+    const float g_loc = grad_out[1] * loc_w / divider;
+    const long long n_tiles = (n_rows + kTileRows - 1) / kTileRows;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const long long r0 = tile * kTileRows;
+        const int rows = (int)min((long long)kTileRows, n_rows - r0);
+        __syncthreads();
+        if (threadIdx.x == 0) s_any = 0;
+        __syncthreads();
+        if (threadIdx.x < rows) {
+            const long long r = r0 + threadIdx.x;
+            const float2* trow = reinterpret_cast<const float2*>(target + r * 6);
+            const float2 t01 = trow[0], t23 = trow[1], t45 = trow[2];
+            const int cls = (int)t45.x;
+            const bool pos = cls != 0 && cls != -1;
+            const bool smp = sampled[r] != 0;
+            const bool want = p.cls_kind == SSDK_CLS_CROSS_ENTROPY ? (smp && cls != -1) : smp;
+            s_cls[threadIdx.x] = want ? cls : INT_MIN;
+            s_tscore[threadIdx.x] = t45.y;
+            if (want) s_any = 1;
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pos) {
+                const float4 l = locs[r];
+                g = make_float4(smooth_l1_grad(l.x, t01.x, p.beta) * g_loc, smooth_l1_grad(l.y, t01.y, p.beta) * g_loc,
+                                smooth_l1_grad(l.z, t23.x, p.beta) * g_loc, smooth_l1_grad(l.w, t23.y, p.beta) * g_loc);
+            }
+            dlocs[r] = g;
+        }
+        __syncthreads();
+        const int nfloat = rows * p.C;
+        float* dst = dscores + r0 * p.C;
+        if (!s_any) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int t = threadIdx.x; t < (nfloat >> 2); t += kLossThreads) reinterpret_cast<float4*>(dst)[t] = z;
+            for (int t = (nfloat & ~3) + threadIdx.x; t < nfloat; t += kLossThreads) dst[t] = 0.0f;
+            continue;
+        }
+        for (int t = threadIdx.x; t < nfloat; t += kLossThreads) s_tile[t] = 0.0f;
+        __syncthreads();
+        for (int row = wave; row < rows; row += kLossThreads / kWave) {
+            const int cls = s_cls[row];
+            if (cls == INT_MIN) continue;
+            const long long r = r0 + row;
+            const float* x = scores + r * p.C;
+            float* o = s_tile + row * p.C;
+            if (p.cls_kind == SSDK_CLS_CROSS_ENTROPY) {
+                const float l = lse[r];
+                for (int c = lane; c < p.C; c += kWave) o[c] = (__expf(x[c] - l) - (c == cls ? 1.0f : 0.0f)) * g_cls;
+            } else {
+                const bool ps = cls != 0 && cls != -1;
+                const float ts = s_tscore[row];
+                for (int c = lane; c < p.C; c += kWave)
+                    o[c] = focal_elem_grad(x[c], (ps && c == cls - 1) ? ts : 0.0f, p.gamma, p.alpha) * g_cls;
+            }
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < (nfloat >> 2); t += kLossThreads)
+            reinterpret_cast<float4*>(dst)[t] = reinterpret_cast<const float4*>(s_tile)[t];
+        for (int t = (nfloat & ~3) + threadIdx.x; t < nfloat; t += kLossThreads) dst[t] = s_tile[t];
+    }
+}
+
+// ---- box coder (elementwise) ------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) encode_box_kernel(const float4* __restrict__ boxes, const float4* __restrict__ priors,
+                                                         float4* __restrict__ out, long long n, int A, float xy_scale,
+                                                         float wh_scale, float eps, int inplace_semantics) {
+    for (long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x; r < n; r += (long long)gridDim.x * blockDim.x) {
+        const float4 b = boxes[r], p = priors[r % A];
+        float4 o;
+        if (inplace_semantics) {  // box_coder.py:22-30: eps after the divide
+            o.x = (b.x - p.x) / p.z * xy_scale;
+            o.y = (b.y - p.y) / p.w * xy_scale;
+            o.z = logf(b.z / p.z + eps) * wh_scale;
+            o.w = logf(b.w / p.w + eps) * wh_scale;
+        } else {  // box_coder.py:32-34: eps before the divide
+            o.x = (b.x - p.x) / p.z * xy_scale;
+            o.y = (b.y - p.y) / p.w * xy_scale;
+            o.z = logf((b.z + eps) / p.z) * wh_scale;
+            o.w = logf((b.w + eps) / p.w) * wh_scale;
+        }
+        out[r] = o;
+    }
+}
+
+__global__ void __launch_bounds__(256) decode_box_kernel(const float4* __restrict__ locs, const float4* __restrict__ priors,
+                                                         float4* __restrict__ out, long long n, int A, float xy_scale, float wh_scale,
+                                                         int inplace_semantics) {
+    for (long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x; r < n; r += (long long)gridDim.x * blockDim.x) {
+        const float4 t = locs[r], p = priors[r % A];
+        if (inplace_semantics)  // box_coder.py:45-53: /= scale, *= p_wh, += p_xy ; /= scale, exp, *= p_wh
+            out[r] = make_float4(t.x / xy_scale * p.z + p.x, t.y / xy_scale * p.w + p.y, expf(t.z / wh_scale) * p.z,
+                                 expf(t.w / wh_scale) * p.w);
+        else  // box_coder.py:55-57
+            out[r] = make_float4(p.x + p.z * t.x / xy_scale, p.y + p.w * t.y / xy_scale, p.z * expf(t.z / wh_scale),
+                                 p.w * expf(t.w / wh_scale));
+    }
+}
+
+static inline int stream_grid(long long work_items, int per_block) {
+    long long b = (work_items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    return (int)(b > 2048 ? 2048 : b);
+}
+
+}  // namespace ssdk
+
+using namespace ssdk;
+
+extern "C" size_t ssdk_multibox_loss_workspace_bytes(int batch, int num_anchors, int num_classes) {
+    (void)num_classes;
+    size_t total = 0;
+    carve_loss_ws(nullptr, (size_t)batch * (size_t)num_anchors, &total);
+    return total;
+}
+
+static int check_loss_common(const char* fn, const void* scores, int batch, int A, int C, void* ws, size_t ws_bytes) {
+    SSDK_REQUIRE(batch > 0 && A > 0 && C > 0, SSDK_E_INVALID, "%s: batch=%d anchors=%d classes=%d", fn, batch, A, C);
+    SSDK_REQUIRE(scores && ((uintptr_t)scores & 15) == 0, SSDK_E_INVALID, "%s: scores must be non-null and 16-byte aligned", fn);
+    SSDK_REQUIRE((size_t)kTileRows * C * sizeof(float) <= 160 * 1024 - 4096, SSDK_E_UNSUPPORTED, "%s: num_classes=%d too large for an LDS tile", fn, C);
+    SSDK_REQUIRE(ws && ws_bytes >= ssdk_multibox_loss_workspace_bytes(batch, A, C), SSDK_E_WORKSPACE, "%s: workspace too small", fn);
+    return SSDK_OK;
+}
+
+extern "C" int ssdk_hard_negative_mining(const float* scores, const float* target_classes, int class_stride, int batch,
+                                         int num_anchors, int num_classes, double negative_per_positive_ratio,
+                                         int64_t min_negative_per_image, uint8_t* sampled, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+    int rc = check_loss_common("ssdk_hard_negative_mining", scores, batch, num_anchors, num_classes, workspace, workspace_bytes);
+    if (rc) return rc;
+    SSDK_REQUIRE(target_classes && sampled && class_stride >= 1, SSDK_E_INVALID, "ssdk_hard_negative_mining: null pointer / bad stride");
+    SSDK_REQUIRE(negative_per_positive_ratio >= 0, SSDK_E_INVALID, "ssdk_hard_negative_mining: negative ratio");
+    hipStream_t s = (hipStream_t)stream;
+    const long long n_rows = (long long)batch * num_anchors;
+    LossWs w = carve_loss_ws(workspace, (size_t)n_rows, nullptr);
+    const size_t lds = (size_t)kTileRows * num_classes * sizeof(float);
+    if (lds > 48 * 1024)
+        SSDK_CHECK_HIP(hipFuncSetAttribute((const void*)hnm_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(hnm_rows_kernel, dim3(stream_grid(n_rows, kTileRows)), dim3(kLossThreads), lds, s, scores, target_classes, class_stride,
+                       n_rows, num_classes, w.lse, w.bgloss);
+    SSDK_CHECK_LAUNCH("hnm_rows_kernel");
+    hipLaunchKernelGGL(hnm_select_kernel, dim3(batch), dim3(1024), 0, s, w.bgloss, num_anchors, negative_per_positive_ratio,
+                       (long long)min_negative_per_image, sampled);
+    SSDK_CHECK_LAUNCH("hnm_select_kernel");
+    return SSDK_OK;
+}
+
+extern "C" int ssdk_naive_sampler(const float* target_classes, int class_stride, int batch, int num_anchors, uint8_t* sampled,
+                                  void* stream) {
+    SSDK_REQUIRE(target_classes && sampled && batch > 0 && num_anchors > 0 && class_stride >= 1, SSDK_E_INVALID, "ssdk_naive_sampler: bad arguments");
+    const long long n_rows = (long long)batch * num_anchors;
+    hipLaunchKernelGGL(naive_sampler_kernel, dim3(stream_grid(n_rows, 256)), dim3(256), 0, (hipStream_t)stream, target_classes, class_stride, n_rows, sampled);
+    SSDK_CHECK_LAUNCH("naive_sampler_kernel");
+    return SSDK_OK;
+}
+
+extern "C" int ssdk_multibox_loss_fwd(int cls_kind, const float* scores, const float* locs, const float* anchors, float* target,
+                                      const uint8_t* sampled, int batch, int num_anchors, int num_classes, float focal_gamma,
+                                      float focal_alpha, int focal_reduce_mean, float classification_weight,
+                                      float localization_weight, float xy_scale, float wh_scale, float eps, float smooth_l1_beta,
+                                      int lse_valid, float* out3, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_loss_common("ssdk_multibox_loss_fwd", scores, batch, num_anchors, num_classes, workspace, workspace_bytes);
+    if (rc) return rc;
+    SSDK_REQUIRE(cls_kind == SSDK_CLS_CROSS_ENTROPY || cls_kind == SSDK_CLS_SIGMOID_FOCAL, SSDK_E_INVALID, "ssdk_multibox_loss_fwd: cls_kind=%d", cls_kind);
+    SSDK_REQUIRE(locs && anchors && target && sampled && out3, SSDK_E_INVALID, "ssdk_multibox_loss_fwd: null pointer");
+    SSDK_REQUIRE(((uintptr_t)locs & 15) == 0 && ((uintptr_t)anchors & 15) == 0 && ((uintptr_t)target & 7) == 0, SSDK_E_INVALID,
+                 "ssdk_multibox_loss_fwd: locs/anchors need 16-byte and target 8-byte alignment");
+    SSDK_REQUIRE(smooth_l1_beta > 0, SSDK_E_INVALID, "ssdk_multibox_loss_fwd: beta must be > 0");
+    hipStream_t s = (hipStream_t)stream;
+    const long long n_rows = (long long)batch * num_anchors;
+    LossWs w = carve_loss_ws(workspace, (size_t)n_rows, nullptr);
+    SSDK_CHECK_HIP(hipMemsetAsync(w.counters, 0, 4 * sizeof(int), s));
+    LossParams p{cls_kind, num_classes, lse_valid, focal_gamma, focal_alpha, xy_scale, wh_scale, eps, smooth_l1_beta};
+    const int grid = stream_grid(n_rows, kLossThreads);
+    hipLaunchKernelGGL(loss_fwd_kernel, dim3(grid), dim3(kLossThreads), 0, s, p, scores, (const float4*)locs, (const float4*)anchors,
+                       target, sampled, n_rows, num_anchors, w.lse, w.partials, w.counters);
+    SSDK_CHECK_LAUNCH("loss_fwd_kernel");
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, w.partials, grid, w.counters, cls_kind, focal_reduce_mean,
+                       classification_weight, localization_weight, w.state, out3);
+    SSDK_CHECK_LAUNCH("loss_finalize_kernel");
+    return SSDK_OK;
+}
+
+extern "C" int ssdk_multibox_loss_bwd(int cls_kind, const float* scores, const float* locs, const float* target,
+                                      const uint8_t* sampled, const float* grad_out, int batch, int num_anchors, int num_classes,
+                                      float focal_gamma, float focal_alpha, int focal_reduce_mean, float classification_weight,
+                                      float localization_weight, float smooth_l1_beta, float* dscores, float* dlocs, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+    int rc = check_loss_common("ssdk_multibox_loss_bwd", scores, batch, num_anchors, num_classes, workspace, workspace_bytes);
+    if (rc) return rc;
+    SSDK_REQUIRE(locs && target && sampled && grad_out && dscores && dlocs, SSDK_E_INVALID, "ssdk_multibox_loss_bwd: null pointer");
+    SSDK_REQUIRE(((uintptr_t)dscores & 15) == 0 && ((uintptr_t)dlocs & 15) == 0 && ((uintptr_t)locs & 15) == 0, SSDK_E_INVALID,
+                 "ssdk_multibox_loss_bwd: dscores/dlocs/locs must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const long long n_rows = (long long)batch * num_anchors;
+    LossWs w = carve_loss_ws(workspace, (size_t)n_rows, nullptr);
+    LossParams p{cls_kind, num_classes, 1, focal_gamma, focal_alpha, 0.f, 0.f, 0.f, smooth_l1_beta};
+    const size_t lds = (size_t)kTileRows * num_classes * sizeof(float);
+    if (lds > 48 * 1024)
+        SSDK_CHECK_HIP(hipFuncSetAttribute((const void*)loss_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(stream_grid(n_rows, kTileRows)), dim3(kLossThreads), lds, s, p,
+                       cls_kind == SSDK_CLS_SIGMOID_FOCAL ? focal_reduce_mean : 0, classification_weight, localization_weight,
+                       scores, (const float4*)locs, target, sampled, grad_out, n_rows, w.lse, w.state, dscores, (float4*)dlocs);
+    SSDK_CHECK_LAUNCH("loss_bwd_kernel");
+    return SSDK_OK;
+}
+
+extern "C" int ssdk_encode_box(const float* boxes, const float* priors, float* out, int batch, int num_anchors, float xy_scale,
+                               float wh_scale, float eps, int inplace_semantics, void* stream) {
+    SSDK_REQUIRE(boxes && priors && out && batch > 0 && num_anchors > 0, SSDK_E_INVALID, "ssdk_encode_box: bad arguments");
+    const long long n = (long long)batch * num_anchors;
+    hipLaunchKernelGGL(encode_box_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)boxes,
+                       (const float4*)priors, (float4*)out, n, num_anchors, xy_scale, wh_scale, eps, inplace_semantics);
+    SSDK_CHECK_LAUNCH("encode_box_kernel");
+    return SSDK_OK;
+}
+
+extern "C" int ssdk_decode_box(const float* locs, const float* priors, float* out, int batch, int num_anchors, float xy_scale,
+                               float wh_scale, int inplace_semantics, void* stream) {
+    SSDK_REQUIRE(locs && priors && out && batch > 0 && num_anchors > 0, SSDK_E_INVALID, "ssdk_decode_box: bad arguments");
+    const long long n = (long long)batch * num_anchors;
+    hipLaunchKernelGGL(decode_box_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)locs,
+                       (const float4*)priors, (float4*)out, n, num_anchors, xy_scale, wh_scale, inplace_semantics);
+    SSDK_CHECK_LAUNCH("decode_box_kernel");
+    return SSDK_OK;
+}

@@ -1,0 +1,83 @@
+"""TargetAssigner -- mirror of detection/target_assigner.py:17-63 on libssdk (csrc/match.hip)."""
+import numpy as np
+import torch
+
+from .. import _lib
+
+# detection/target_assigner.py:7-14
+LOC_INDEX_START = 0
+LOC_INDEX_END = 4
+CLASS_INDEX = 4
+SCORE_INDEX = 5
+TARGET_SIZE = 6
+
+NEGATIVE_CLASS = 0  # bf/datasets/detection_dataset.py:17
+IGNORE_CLASS = -1
+
+GT_ROW = 6  # x1, y1, x2, y2, class, score (bf/datasets/detection_dataset.py:11-15); extra columns are dropped
+
+
+def pack_ground_truth(ground_truth, device):
+    """list[B] of [G_i, >=6] tensors (any device) -> (rows [sum G, 6] fp32, offsets int32 [B+1]) on ``device``.
+
+    One pinned staging buffer and one async H2D copy per batch (the reference moves each image's tensor
+    separately, target_assigner.py:35)."""
+    counts = [int(g.size(0)) if g.dim() == 2 else 0 for g in ground_truth]
+    total = sum(counts)
+    if all((not g.is_cuda) for g in ground_truth):
+        stage = torch.empty((total * GT_ROW + len(counts) + 1,), dtype=torch.float32)
+        if torch.cuda.is_available():
+            stage = stage.pin_memory()
+        rows = stage[:total * GT_ROW].view(total, GT_ROW)
+        offs = stage[total * GT_ROW:].view(torch.int32)
+        pos = 0
+        offs[0] = 0
+        for i, (g, n) in enumerate(zip(ground_truth, counts)):
+            if n:
+                rows[pos:pos + n] = g[:, :GT_ROW].to(torch.float32)
+            pos += n
+            offs[i + 1] = pos
+        dev = stage.to(device, non_blocking=True)
+        return dev[:total * GT_ROW].view(total, GT_ROW), dev[total * GT_ROW:].view(torch.int32), total
+    rows = torch.cat([g[:, :GT_ROW].to(device=device, dtype=torch.float32) for g, n in zip(ground_truth, counts) if n], dim=0) \
+        if total else torch.zeros((0, GT_ROW), dtype=torch.float32, device=device)
+    offs = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32).to(device, non_blocking=True)
+    return rows.contiguous(), offs, total
+
+
+class TargetAssigner(object):
+    def __init__(self, matched_threshold, unmatched_threshold):
+        self.matched_threshold = matched_threshold
+        self.unmatched_threshold = unmatched_threshold
+        self._ws = None
+
+    def encode_ground_truth(self, ground_truth, anchors, return_box_idx=False):
+        """
+        Args:
+            ground_truth: list(:len Batch) of torch.tensor(:shape [Boxes_i, >=6])
+            anchors: torch.tensor(:shape [AnchorBoxes, 4]) on the GPU
+        Returns:
+            target: torch.tensor(:shape [Batch, AnchorBoxes, 6]) on anchors.device
+            (the reference runs this on the CPU because its anchors live there; here anchors are device-resident
+            and so is the result -- the ``target.to(device)`` of detection/init.py:115 becomes a no-op)
+        """
+        _lib.require_cuda(anchors)
+        lib = _lib.lib()
+        device = anchors.device
+        batch_size = len(ground_truth)
+        num_anchors = anchors.size(0)
+        anchors = anchors.contiguous().float()
+        rows, offs, total = pack_ground_truth(ground_truth, device)
+        target = torch.empty((batch_size, num_anchors, TARGET_SIZE), dtype=torch.float32, device=device)
+        box_idx = torch.empty((batch_size, num_anchors), dtype=torch.int32, device=device) if return_box_idx else None
+        need = lib.ssdk_encode_ground_truth_workspace_bytes(batch_size, total)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = torch.empty((max(need, 4096),), dtype=torch.uint8, device=device)
+        _lib.check(lib.ssdk_encode_ground_truth(_lib.ptr(rows), GT_ROW, _lib.ptr(offs), batch_size, total,
+                                                _lib.ptr(anchors), num_anchors, float(self.matched_threshold),
+                                                float(self.unmatched_threshold), _lib.ptr(target), _lib.ptr(box_idx),
+                                                _lib.ptr(self._ws), self._ws.numel(), _lib.current_stream()),
+                   'ssdk_encode_ground_truth')
+        # keep the staging tensors alive until the stream has consumed them
+        target._ssdk_keepalive = (rows, offs)
+        return (target, box_idx) if return_box_idx else target
