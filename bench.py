@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the detection hot path on MI355X (driver contract: see the task statement).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched under torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the hot path over one batch of synthetic input, inputs resident in HBM:
+    multi-scale heads forward (fused score|loc implicit GEMMs, all levels)          H1
+    -> device-resident anchors (cached)                                             A1
+    -> IoU match + target encode                                                    T1-T3
+    -> hard-negative mining + multibox loss forward                                 S1, L1-L3
+    -> loss backward + heads backward (dgrad, wgrad, dbias)                         L1, H1
+    -> (N > 1) RCCL all-reduce of the flat head-gradient bucket
+    -> SGD step on the head parameters (stock torch optimizer: the runtime's, kept so no training work is skipped)
+Workload: BASELINE.json configs[1] -- ssd_300_vgg16_voc, batch 32 per GPU, 81 classes (the literal of the sample file),
+source maps N(0,1) at the probed shapes.  Weak scaling: per-GPU batch fixed.
+The postprocess (eval) leg is timed separately and reported as nms_boxes_per_sec / postprocess_images_per_sec.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from single_shot_detection_amd import synthetic as syn  # noqa: E402
+
+PEAK_FP32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
+
+
+def head_flops_per_image(levels, C):
+    """sum over levels of 2*H*W*9*Cin*nb*(C+4)."""
+    return sum(2.0 * h * h * 9 * cin * nb * (C + 4) for cin, h, nb in levels)
+
+
+class HotPath(object):
+    def __init__(self, cfg_name, batch, device, seed=23):
+        from single_shot_detection_amd.detection import detector_builder, anchor_generators, sampler
+        from single_shot_detection_amd.detection.box_coder import BoxCoder
+        from single_shot_detection_amd.detection.losses.multibox_loss import MultiboxLoss
+        from single_shot_detection_amd.detection.postprocessor import Postprocessor
+        from single_shot_detection_amd.detection.target_assigner import TargetAssigner
+        import functools
+        self.cfg = cfg = syn.CONFIGS[cfg_name]
+        self.batch, self.device = batch, device
+        self.levels, self.C = cfg['levels'], cfg['num_classes']
+        torch.manual_seed(seed)
+        self.heads = detector_builder.get_heads([l[0] for l in self.levels], [l[2] for l in self.levels], self.C,
+                                                score_head_bias_init=(-4.6 if cfg['loss'] != 'ce_hnm' else 0.0)).to(device)
+        fm = syn.make_feature_maps(batch, self.levels, seed=seed)
+        self.sources = [torch.from_numpy(x).to(device).contiguous(memory_format=torch.channels_last).requires_grad_(True) for x in fm]
+        p = dict(cfg['anchor'])
+        gens = getattr(anchor_generators, p.pop('type')).build_anchor_generators(**p)
+        img = torch.empty((1, 3, cfg['size'], cfg['size']), device=device)
+        self.anchors = torch.cat([g.generate(img, (h, h)).reshape(-1) for g, (_, h, _) in zip(gens, self.levels)]).view(-1, 4)
+        softmax = cfg['score_converter'] == 'SOFTMAX'
+        gt = syn.make_ground_truth(batch, cfg['size'], self.C, seed=1, background=softmax)
+        self.gt_np = gt
+        self.gt = [torch.from_numpy(g).to(device) for g in gt]
+        box_coder = BoxCoder(10.0, 5.0)
+        if cfg['loss'] == 'ce_hnm':
+            smp = functools.partial(sampler.hard_negative_mining, negative_per_positive_ratio=3, min_negative_per_image=5)
+            cl = {'name': 'CrossEntropyLoss'}
+        else:
+            smp = sampler.naive_sampler
+            cl = {'name': 'SigmoidFocalLoss', 'gamma': 2.0, 'alpha': 0.25}
+        self.criterion = MultiboxLoss(sampler=smp, box_coder=box_coder, classification_loss=cl,
+                                      localization_loss={'name': 'SmoothL1Loss'})
+        self.assigner = TargetAssigner(cfg['matched'], cfg['unmatched'])
+        self.post = Postprocessor(box_coder, score_threshold=0.01, nms={'max_per_class': 100, 'overlap_threshold': cfg['nms_thr']},
+                                  score_converter=cfg['score_converter'], max_total=200)
+        self.params = [p for p in self.heads.parameters()]
+        self.opt = torch.optim.SGD(self.params, lr=1e-3, momentum=0.9, weight_decay=5e-4)
+        self.fwd_events = []
+
+    def forward_heads(self, timed=False):
+        from single_shot_detection_amd.detection.modules.heads import multi_level_heads
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        out = multi_level_heads(self.sources, self.sources, self.heads)
+        if timed:
+            e1.record()
+            self.fwd_events.append((e0, e1))
+        return out
+
+    def train_step(self, world=1, timed=False):
+        self.opt.zero_grad(set_to_none=True)
+        for s in self.sources:
+            s.grad = None
+        scores, locs = self.forward_heads(timed)
+        target = self.assigner.encode_ground_truth(self.gt, self.anchors)
+        loss, class_loss, loc_loss = self.criterion((scores, locs), self.anchors, target)
+        loss.backward()
+        if world > 1:
+            import torch.distributed as dist
+            flat = torch.cat([p.grad.reshape(-1) for p in self.params])
+            dist.all_reduce(flat)
+            flat.div_(world)
+            off = 0
+            for p in self.params:
+                n = p.numel()
+                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                off += n
+        self.opt.step()
+        return loss
+
+    def eval_step(self):
+        with torch.no_grad():
+            scores, locs = self.forward_heads()
+            return self.post.postprocess_padded((scores, locs), self.anchors)
+
+
+def cpu_baseline(hp, sample_images=4):
+    """The oracle (CPU restatement, kind 'port') timed on the host cores on a bounded sample of the same workload:
+    C oracle (OpenMP) for match / HNM / loss fwd+bwd over the full batch, torch CPU convolutions for the heads
+    fwd+bwd over `sample_images` images; reported per image."""
+    import oracle
+    import torch.nn.functional as F
+    cfg, C, B = hp.cfg, hp.C, hp.batch
+    A = hp.anchors.shape[0]
+    threads = oracle.max_threads()
+    anchors = hp.anchors.cpu().numpy()
+    logits = syn.make_logits(B, A, C, seed=2)
+    locs = syn.make_locs(B, A, seed=3, scale=0.5)
+    t0 = time.perf_counter()
+    target = oracle.encode_ground_truth(hp.gt_np, anchors, cfg['matched'], cfg['unmatched'])
+    if cfg['loss'] == 'ce_hnm':
+        mask = oracle.hard_negative_mining(logits, target, 3, 5)
+        oracle.multibox_loss(logits, locs, anchors, target, mask, kind='ce')
+    else:
+        mask = oracle.naive_sampler(logits, target)
+        oracle.multibox_loss(logits, locs, anchors, target, mask, kind='focal')
+    t_small = (time.perf_counter() - t0) / B
+    torch.set_num_threads(threads)
+    sb = min(sample_images, B)
+    xs = [s.detach()[:sb].cpu().contiguous().requires_grad_(True) for s in hp.sources]
+    ws = [(h['score'].weight.detach().cpu().contiguous().requires_grad_(True), h['score'].bias.detach().cpu().requires_grad_(True),
+           h['loc'].weight.detach().cpu().contiguous().requires_grad_(True), h['loc'].bias.detach().cpu().requires_grad_(True)) for h in hp.heads]
+    t0 = time.perf_counter()
+    outs = []
+    for x, (w1, b1, w2, b2) in zip(xs, ws):
+        outs.append(F.conv2d(x, w1, b1, padding=1).permute(0, 2, 3, 1).reshape(sb, -1))
+        outs.append(F.conv2d(x, w2, b2, padding=1).permute(0, 2, 3, 1).reshape(sb, -1))
+    torch.cat(outs, 1).sum().backward()
+    t_conv = (time.perf_counter() - t0) / sb
+    per_image = t_small + t_conv
+    return {'value': 1.0 / per_image, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+            'sample': f'oracle match+HNM+loss fwd/bwd on {B} images ({t_small * 1e3:.2f} ms/img) + torch CPU head convs fwd+bwd on {sb} images '
+                      f'({t_conv * 1e3:.1f} ms/img), {threads} threads'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', default='ssd_300_vgg16_voc')
+    ap.add_argument('--batch', type=int, default=32, help='per-GPU batch (weak scaling)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--eval-steps', type=int, default=5)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=device)   # nccl == RCCL on ROCm
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    hp = HotPath(args.config, args.batch, device)
+    for _ in range(args.warmup):
+        hp.train_step(world)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        hp.train_step(world, timed=True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * args.batch * args.steps / dt
+
+    # forward head GEMMs (igemm_fwd_kernel<4,false>, one launch per level) timed with events inside the timed region
+    fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in hp.fwd_events]))
+    flops_step = head_flops_per_image(hp.levels, hp.C) * args.batch
+    achieved = flops_step / (fwd_ms * 1e-3) / 1e12
+
+    # eval leg: heads forward + postprocess (NMS boxes/s = candidates entering NMS per second)
+    for _ in range(2):
+        hp.eval_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.eval_steps):
+        hp.eval_step()
+    barrier()
+    dte = (time.perf_counter() - t0) / args.eval_steps
+    cand = int(hp.post.last_nms_candidates.sum().item())
+    # postprocess alone
+    scores, locs = hp.forward_heads()
+    scores, locs = scores.detach(), locs.detach()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.eval_steps):
+        hp.post.postprocess_padded((scores, locs), hp.anchors)
+    barrier()
+    dtp = (time.perf_counter() - t0) / args.eval_steps
+
+    if rank == 0:
+        A = hp.anchors.shape[0]
+        out = {
+            'metric': 'images/sec (train step) + NMS boxes/sec, SSD-300 VGG16 batch 32 @1/2/4/8 GPU',
+            'value': value, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{args.config}: heads fwd+bwd (fp32 MFMA) + IoU-match + HNM/multibox loss fwd+bwd + SGD on head params; '
+                                   f'source maps N(0,1) NHWC at the probed shapes, C={hp.C}, A={A}, G~U{{1..8}}',
+                       'global_batch': world * args.batch, 'per_gpu_batch': args.batch, 'parallelism': f'dp{world}'},
+            'nms_boxes_per_sec': world * cand / dtp, 'postprocess_images_per_sec': world * args.batch / dtp,
+            'eval_images_per_sec': world * args.batch / dte, 'nms_candidates_per_image': cand / args.batch,
+            'roofline': {'bound': 'mfma', 'kernel': 'igemm_fwd_kernel<4,false> (forward head GEMMs, one launch per pyramid level)',
+                         'achieved': achieved, 'peak': PEAK_FP32_MATRIX_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / PEAK_FP32_MATRIX_TFLOPS, 'traffic': None,
+                         'algorithmic_gflop_per_step': flops_step / 1e9, 'ms_per_step': fwd_ms},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(hp)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -55,6 +55,14 @@ _SIGNATURES = {
                                   C.c_int, C.c_void_p]),
     'ssdk_decode_box': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
                                   C.c_void_p]),
+    'ssdk_head_conv_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p,
+                                     C.c_longlong, C.c_longlong, C.c_void_p]),
+    'ssdk_head_conv_bwd_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'ssdk_head_conv_bwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                     C.c_int, C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p, C.c_longlong,
+                                     C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_size_t, C.c_void_p]),
     'ssdk_postprocess_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'ssdk_postprocess': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                    C.c_int, C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_void_p,
@@ -123,7 +131,9 @@ def ptr(t):
     """Device (or host) pointer of a contiguous tensor, or NULL for None."""
     if t is None:
         return None
-    assert t.is_contiguous(), 'libssdk takes dense row-major buffers'
+    import torch
+    dense = t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+    assert dense, 'libssdk takes dense buffers (row-major, or channels_last for 4-d maps / weights)'
     return C.c_void_p(t.data_ptr())
 
 

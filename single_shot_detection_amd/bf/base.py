@@ -1,0 +1,62 @@
+"""Plain-torch backbone stand-ins with torchvision's module indexing (torchvision is not installed in this image and
+pretrained weights cannot be fetched).  Out of the hot path (north_star: "backbone stays PyTorch-ROCm"); they exist
+so that ``detection.init`` can be driven end to end.  Architectures are the published ones (VGG-16-BN config D;
+ResNet-50 bottlenecks); weights are randomly initialised."""
+import torch.nn as nn
+
+
+class _Vgg16Bn(nn.Module):
+    CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']
+
+    def __init__(self, pretrained=False, **kwargs):
+        super().__init__()
+        layers, c = [], 3
+        for v in self.CFG:
+            if v == 'M':
+                layers.append(nn.MaxPool2d(kernel_size=2, stride=2))  # floor mode: 300 -> 37 -> 18
+            else:
+                layers += [nn.Conv2d(c, v, kernel_size=3, padding=1), nn.BatchNorm2d(v), nn.ReLU(inplace=True)]
+                c = v
+        self.features = nn.Sequential(*layers)  # 44 modules; out_layers (32, 42) are ReLUs after conv4_3 / conv5_3
+
+
+class _Bottleneck(nn.Module):
+    def __init__(self, cin, width, stride):
+        super().__init__()
+        cout = width * 4
+        self.conv1 = nn.Conv2d(cin, width, 1, bias=False); self.bn1 = nn.BatchNorm2d(width)
+        self.conv2 = nn.Conv2d(width, width, 3, stride=stride, padding=1, bias=False); self.bn2 = nn.BatchNorm2d(width)
+        self.conv3 = nn.Conv2d(width, cout, 1, bias=False); self.bn3 = nn.BatchNorm2d(cout)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride, bias=False), nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        x = self.relu(self.bn1(self.conv1(x)))
+        x = self.relu(self.bn2(self.conv2(x)))
+        x = self.bn3(self.conv3(x))
+        return self.relu(x + idt)
+
+
+class _ResNet50(nn.Module):
+    def __init__(self, pretrained=False, **kwargs):
+        super().__init__()
+
+        def stage(cin, width, n, stride):
+            return nn.Sequential(*[_Bottleneck(cin if i == 0 else width * 4, width, stride if i == 0 else 1) for i in range(n)])
+        # the flattened ``features`` of bf/builders/base_builder.py:10-23: conv1, bn1, relu, maxpool, layer1..4
+        self.features = nn.Sequential(nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True),
+                                      nn.MaxPool2d(3, stride=2, padding=1), stage(64, 64, 3, 1), stage(256, 128, 4, 2),
+                                      stage(512, 256, 6, 2), stage(1024, 512, 3, 2))
+
+
+_ZOO = {'torchvision_vgg16_bn': _Vgg16Bn, 'torchvision_resnet50': _ResNet50}
+
+
+def create_base(name, weight=None, **model_args):
+    """bf/builders/base_builder.py:59-86 for the backbones the BASELINE configs name; no remote loaders."""
+    if name not in _ZOO:
+        raise NotImplementedError(f'backbone {name!r} is outside the hot-path scope; available: {sorted(_ZOO)}')
+    return _ZOO[name](**model_args)

@@ -1,0 +1,113 @@
+"""Multi-scale head convolutions on libssdk (csrc/conv.hip) -- the arithmetic of detection/detector.py:50-66.
+
+One autograd function covers every pyramid level: it launches one implicit-GEMM per level that writes directly
+into the concatenated ``scores [B, A*C]`` / ``locs [B, A*4]`` buffers (no permute / contiguous / cat), and its
+backward produces the source-map gradients, the weight gradients and the bias gradients per level.
+"""
+import torch
+
+from ... import _lib
+
+
+def to_nhwc(x):
+    """[B,C,H,W] tensor whose memory is NHWC (zero-copy when the producer already runs channels_last)."""
+    x = x.float()
+    if x.dim() != 4:
+        raise ValueError('source maps must be [Batch, Channels, Height, Width]')
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+def weight_khwc(w):
+    """[N,Cin,3,3] parameter whose memory is [N,3,3,Cin]."""
+    return w.float().contiguous(memory_format=torch.channels_last)
+
+
+class _HeadsFn(torch.autograd.Function):
+    """apply(num_classes, x_0, ws_0, bs_0, wl_0, bl_0, x_1, ...) -> (scores [B, sum HW*nb*C], locs [B, sum HW*nb*4])"""
+
+    @staticmethod
+    def forward(ctx, *args):
+        lib = _lib.lib()
+        L = len(args) // 5
+        levels = []
+        s_off = l_off = 0
+        for i in range(L):
+            x, ws, bs, wl, bl = args[5 * i:5 * i + 5]
+            _lib.require_cuda(x, ws, wl)
+            x, ws, wl = to_nhwc(x), weight_khwc(ws), weight_khwc(wl)
+            B, cin, H, W = x.shape
+            if ws.shape[1:] != (cin, 3, 3) or wl.shape[1:] != (cin, 3, 3):
+                raise ValueError(f'head {i}: weights {tuple(ws.shape)}/{tuple(wl.shape)} do not match Cin={cin}, 3x3')
+            levels.append(dict(x=x, ws=ws, bs=None if bs is None else bs.float().contiguous(), wl=wl,
+                               bl=None if bl is None else bl.float().contiguous(), B=B, cin=cin, H=H, W=W,
+                               ns=ws.shape[0], nl=wl.shape[0], s_off=s_off, l_off=l_off))
+            s_off += H * W * ws.shape[0]
+            l_off += H * W * wl.shape[0]
+        B = levels[0]['B']
+        dev = levels[0]['x'].device
+        scores = torch.empty((B, s_off), dtype=torch.float32, device=dev)
+        locs = torch.empty((B, l_off), dtype=torch.float32, device=dev)
+        stream = _lib.current_stream()
+        for lv in levels:
+            _lib.check(lib.ssdk_head_conv_fwd(_lib.ptr(lv['x']), lv['B'], lv['H'], lv['W'], lv['cin'], _lib.ptr(lv['ws']),
+                                              _lib.ptr(lv['bs']), lv['ns'], _lib.ptr(lv['wl']), _lib.ptr(lv['bl']), lv['nl'],
+                                              _lib.ptr(scores), s_off, lv['s_off'], _lib.ptr(locs), l_off, lv['l_off'],
+                                              stream), 'ssdk_head_conv_fwd')
+        ctx.levels = levels
+        ctx.totals = (s_off, l_off)
+        return scores, locs
+
+    @staticmethod
+    def backward(ctx, dscores, dlocs):
+        lib = _lib.lib()
+        s_tot, l_tot = ctx.totals
+        dscores = dscores.float().contiguous()
+        dlocs = dlocs.float().contiguous()
+        stream = _lib.current_stream()
+        grads = []
+        for i, lv in enumerate(ctx.levels):
+            need_x, need_ws, need_bs, need_wl, need_bl = ctx.needs_input_grad[5 * i:5 * i + 5]
+            x = lv['x']
+            dx = torch.empty_like(x, memory_format=torch.channels_last) if need_x else None
+            need_w = need_ws or need_wl
+            dws = torch.empty_like(lv['ws'], memory_format=torch.channels_last) if need_w else None
+            dwl = torch.empty_like(lv['wl'], memory_format=torch.channels_last) if need_w else None
+            need_b = (need_bs and lv['bs'] is not None) or (need_bl and lv['bl'] is not None)
+            dbs = torch.empty((lv['ns'],), dtype=torch.float32, device=x.device) if need_b else None
+            dbl = torch.empty((lv['nl'],), dtype=torch.float32, device=x.device) if need_b else None
+            need = lib.ssdk_head_conv_bwd_workspace_bytes(lv['cin'], lv['ns'], lv['nl'])
+            ws = torch.empty((need,), dtype=torch.uint8, device=x.device) if need_x else None
+            _lib.check(lib.ssdk_head_conv_bwd(_lib.ptr(x), lv['B'], lv['H'], lv['W'], lv['cin'], _lib.ptr(lv['ws']), lv['ns'],
+                                              _lib.ptr(lv['wl']), lv['nl'], _lib.ptr(dscores), s_tot, lv['s_off'],
+                                              _lib.ptr(dlocs), l_tot, lv['l_off'], _lib.ptr(dx), _lib.ptr(dws), _lib.ptr(dbs),
+                                              _lib.ptr(dwl), _lib.ptr(dbl), _lib.ptr(ws), need if need_x else 0, stream),
+                       'ssdk_head_conv_bwd')
+            grads += [dx, dws if need_ws else None, dbs if (need_bs and lv['bs'] is not None) else None,
+                      dwl if need_wl else None, dbl if (need_bl and lv['bl'] is not None) else None]
+        return tuple(grads)
+
+
+def multi_level_heads(sources_score, sources_loc, heads):
+    """heads: nn.ModuleList of nn.ModuleDict({'score': Conv2d, 'loc': Conv2d}) (detector_builder.py:111-137).
+    When the score and loc towers feed different maps (SharedConvPredictor) the two convs of a level run as two
+    single-head GEMMs; otherwise they are fused along N."""
+    args = []
+    split = []
+    for head, xs, xl in zip(heads, sources_score, sources_loc):
+        if xs is xl:
+            args += [xs, head['score'].weight, head['score'].bias, head['loc'].weight, head['loc'].bias]
+            split.append(False)
+        else:
+            split.append(True)
+    if not any(split):
+        return _HeadsFn.apply(*args)
+    # separate towers: run score heads and loc heads as two passes with an empty partner
+    s_args, l_args = [], []
+    for head, xs, xl in zip(heads, sources_score, sources_loc):
+        empty_w = head['score'].weight.new_zeros((0,) + tuple(head['score'].weight.shape[1:]))
+        empty_w_l = head['loc'].weight.new_zeros((0,) + tuple(head['loc'].weight.shape[1:]))
+        s_args += [xs, head['score'].weight, head['score'].bias, empty_w, None]
+        l_args += [xl, head['loc'].weight, head['loc'].bias, empty_w_l, None]
+    scores, _ = _HeadsFn.apply(*s_args)
+    locs, _ = _HeadsFn.apply(*l_args)
+    return scores, locs

@@ -1,0 +1,114 @@
+"""GPU parity: multi-scale head convolutions (H1) through the C ABI -- layout pinned by the reference's own
+Predictor.forward golden (tests/golden/heads_small.npz), arithmetic against torch's fp32 CPU convolution.
+fp32 MFMA accumulates in a different order than the CPU kernel: tolerances are relative to the K-reduction size."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from single_shot_detection_amd.detection import detector_builder
+from single_shot_detection_amd.detection.modules.heads import multi_level_heads
+from conftest import GOLDEN
+import os
+
+pytestmark = pytest.mark.gpu
+
+
+def build_heads(levels, num_classes, weights, dev='cuda'):
+    heads = detector_builder.get_heads([l[0] for l in levels], [l[2] for l in levels], num_classes)
+    for i, head in enumerate(heads):
+        for kind in ('score', 'loc'):
+            w, b = weights[(kind, i)]
+            with torch.no_grad():
+                head[kind].weight.copy_(torch.from_numpy(w))
+                head[kind].bias.copy_(torch.from_numpy(b))
+    return heads.to(dev)
+
+
+def reference_forward(xs, weights, levels):
+    """detector.py:50-66 with torch CPU convs."""
+    scores, locs = [], []
+    for i, x in enumerate(xs):
+        ws, bs = weights[('score', i)]
+        wl, bl = weights[('loc', i)]
+        s = F.conv2d(x, torch.from_numpy(ws), torch.from_numpy(bs), padding=1)
+        l = F.conv2d(x, torch.from_numpy(wl), torch.from_numpy(bl), padding=1)
+        scores.append(s.permute(0, 2, 3, 1).contiguous().view(x.size(0), -1))
+        locs.append(l.permute(0, 2, 3, 1).contiguous().view(x.size(0), -1))
+    return torch.cat(scores, 1), torch.cat(locs, 1)
+
+
+def test_heads_layout_vs_reference_golden():
+    g = np.load(os.path.join(GOLDEN, 'heads_small.npz'))
+    levels = [tuple(int(v) for v in r) for r in g['levels']]
+    C = int(g['num_classes'])
+    weights = {(k, i): (g[f'w_{k}_{i}'], g[f'b_{k}_{i}']) for i in range(len(levels)) for k in ('score', 'loc')}
+    heads = build_heads(levels, C, weights)
+    xs = [torch.from_numpy(g[f'x_{i}']).cuda().requires_grad_(True) for i in range(len(levels))]
+    scores, locs = multi_level_heads(xs, xs, heads)
+    np.testing.assert_allclose(scores.detach().cpu().numpy(), g['scores'], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(locs.detach().cpu().numpy(), g['locs'], rtol=1e-5, atol=2e-5)
+    (scores * torch.from_numpy(g['g_scores']).cuda()).sum().add((locs * torch.from_numpy(g['g_locs']).cuda()).sum()).backward()
+    for i in range(len(levels)):
+        np.testing.assert_allclose(xs[i].grad.cpu().numpy(), g[f'dx_{i}'], rtol=1e-4, atol=2e-5)
+        for k in ('score', 'loc'):
+            np.testing.assert_allclose(heads[i][k].weight.grad.cpu().numpy(), g[f'dw_{k}_{i}'], rtol=1e-4, atol=5e-5)
+            np.testing.assert_allclose(heads[i][k].bias.grad.cpu().numpy(), g[f'db_{k}_{i}'], rtol=1e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize('levels,C,B', [
+    ([(512, 37, 4), (512, 18, 6), (512, 9, 6), (256, 5, 6), (256, 3, 4), (256, 2, 4)], 81, 2),   # ssd_300_vgg16_voc
+    ([(96, 19, 4), (1280, 10, 6), (512, 5, 6), (256, 3, 6), (256, 2, 4), (128, 1, 4)], 21, 2),   # ssd_mb2_voc
+    ([(24, 7, 3), (40, 5, 5)], 7, 3),                                                            # Cin % 32 != 0, odd N
+    ([(256, 8, 9)], 80, 1),                                                                      # retina level (nb=9, C=80)
+])
+def test_heads_vs_torch_cpu_conv(levels, C, B):
+    rng = np.random.default_rng(17)
+    weights, xs_np = {}, []
+    for i, (cin, h, nb) in enumerate(levels):
+        xs_np.append(rng.standard_normal((B, cin, h, h), dtype=np.float32))
+        for k, nout in (('score', nb * C), ('loc', nb * 4)):
+            weights[(k, i)] = (rng.standard_normal((nout, cin, 3, 3), dtype=np.float32) * np.float32(0.02),
+                               rng.standard_normal((nout,), dtype=np.float32) * np.float32(0.1))
+    xs_cpu = [torch.from_numpy(x).requires_grad_(True) for x in xs_np]
+    ws_cpu = {k: (torch.from_numpy(w).requires_grad_(True), torch.from_numpy(b).requires_grad_(True)) for k, (w, b) in weights.items()}
+    scores_ref, locs_ref = [], []
+    for i, x in enumerate(xs_cpu):
+        s = F.conv2d(x, *ws_cpu[('score', i)], padding=1)
+        l = F.conv2d(x, *ws_cpu[('loc', i)], padding=1)
+        scores_ref.append(s.permute(0, 2, 3, 1).contiguous().view(B, -1))
+        locs_ref.append(l.permute(0, 2, 3, 1).contiguous().view(B, -1))
+    scores_ref, locs_ref = torch.cat(scores_ref, 1), torch.cat(locs_ref, 1)
+    gs = torch.from_numpy(rng.standard_normal(tuple(scores_ref.shape), dtype=np.float32))
+    gl = torch.from_numpy(rng.standard_normal(tuple(locs_ref.shape), dtype=np.float32))
+    # sparse upstream gradient like the real loss: most rows are exactly zero
+    gs[:, (rng.random(gs.shape[1]) < 0.9)] = 0
+    ((scores_ref * gs).sum() + (locs_ref * gl).sum()).backward()
+
+    heads = build_heads(levels, C, weights)
+    xs = [torch.from_numpy(x).cuda().requires_grad_(True) for x in xs_np]
+    scores, locs = multi_level_heads(xs, xs, heads)
+    kmax = 9 * max(l[0] for l in levels)
+    tol = 2e-6 * np.sqrt(kmax)
+    np.testing.assert_allclose(scores.detach().cpu().numpy(), scores_ref.detach().numpy(), rtol=1e-5, atol=tol)
+    np.testing.assert_allclose(locs.detach().cpu().numpy(), locs_ref.detach().numpy(), rtol=1e-5, atol=tol)
+    ((scores * gs.cuda()).sum() + (locs * gl.cuda()).sum()).backward()
+    for i, (cin, h, nb) in enumerate(levels):
+        np.testing.assert_allclose(xs[i].grad.cpu().numpy(), xs_cpu[i].grad.numpy(), rtol=1e-4, atol=1e-4)
+        for k in ('score', 'loc'):
+            wref, bref = ws_cpu[(k, i)]
+            scale = float(wref.grad.abs().max()) + 1e-6
+            np.testing.assert_allclose(heads[i][k].weight.grad.cpu().numpy(), wref.grad.numpy(), rtol=1e-4, atol=2e-5 * scale + 1e-5)
+            np.testing.assert_allclose(heads[i][k].bias.grad.cpu().numpy(), bref.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_heads_accept_nchw_and_channels_last_sources():
+    rng = np.random.default_rng(3)
+    levels, C, B = [(64, 6, 4)], 5, 2
+    weights = {('score', 0): (rng.standard_normal((20, 64, 3, 3), dtype=np.float32) * 0.05, np.zeros(20, np.float32)),
+               ('loc', 0): (rng.standard_normal((16, 64, 3, 3), dtype=np.float32) * 0.05, np.zeros(16, np.float32))}
+    heads = build_heads(levels, C, weights)
+    x = torch.from_numpy(rng.standard_normal((B, 64, 6, 6), dtype=np.float32)).cuda()
+    a = multi_level_heads([x], [x], heads)
+    b = multi_level_heads([x.contiguous(memory_format=torch.channels_last)] * 1, [x.contiguous(memory_format=torch.channels_last)] * 1, heads)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
