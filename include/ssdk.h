@@ -171,29 +171,45 @@ int ssdk_postprocess(const float* scores, const float* locs, const float* priors
  * permute(0,2,3,1).contiguous().view(B,-1), written straight into the concatenated outputs of detector.py:65-66.
  *   x        DEV [batch, H, W, Cin]  NHWC (= torch channels_last memory of the [B,Cin,H,W] source map)
  *   w_score  DEV [n_score, 3, 3, Cin] (= channels_last memory of the [n_score,Cin,3,3] parameter); b_score [n_score] or NULL
- *   w_loc    DEV [n_loc, 3, 3, Cin]; b_loc [n_loc] or NULL
- *   scores   DEV: element (image b, pixel p = y*W+x, channel n) at scores[b*scores_batch_stride + scores_offset + p*n_score + n]
- *            (scores_batch_stride = A*C, scores_offset = C * anchors of the preceding levels); locs alike with 4.
- * fp32 in, fp32 accumulate on the matrix cores (v_mfma_f32_32x32x2_f32).
+ *   w_loc    DEV [n_loc, 3, 3, Cin]; b_loc [n_loc] or NULL (n_loc may be 0)
+ *   scores_offset / locs_offset: this level's first element inside one image's row of scores / locs
+ *            (= C resp. 4 times the anchors of the preceding levels); element (image b, pixel p = y*W+x, channel n) lives at
+ *            scores[b*scores_batch_stride + scores_offset + p*n_score + n], locs alike.
+ *   backward outputs (ssdk_heads_bwd only; NULL = skip): dx DEV [batch,H,W,Cin]; dw_score/dw_loc like the weights
+ *            (both or neither); db_score/db_loc.  All are overwritten, not accumulated.
  */
-int ssdk_head_conv_fwd(const float* x, int batch, int h, int w, int cin, const float* w_score, const float* b_score,
-                       int n_score, const float* w_loc, const float* b_loc, int n_loc, float* scores,
-                       long long scores_batch_stride, long long scores_offset, float* locs,
-                       long long locs_batch_stride, long long locs_offset, void* stream);
-
-size_t ssdk_head_conv_bwd_workspace_bytes(int cin, int n_score, int n_loc);
+typedef struct ssdk_head_level {
+    const float* x;
+    int h, w, cin;
+    const float* w_score;
+    const float* b_score;
+    int n_score;
+    const float* w_loc;
+    const float* b_loc;
+    int n_loc;
+    long long scores_offset;
+    long long locs_offset;
+    float* dx;
+    float* dw_score;
+    float* db_score;
+    float* dw_loc;
+    float* db_loc;
+} ssdk_head_level;
 
 /*
- * Backward of ssdk_head_conv_fwd for one level (what autograd derives for detector.py:50-66).
- *   dscores / dlocs: gradients of the concatenated outputs, addressed like scores / locs above.
- *   dx       DEV [batch, H, W, Cin] or NULL (skip);  dw_score / dw_loc DEV like the weights or NULL (skip both);
- *   db_score / db_loc DEV or NULL.  All outputs are overwritten (not accumulated).
+ * All levels of detector.py:50-66 in one grouped launch (n_levels <= 8): scores DEV [batch, scores_batch_stride],
+ * locs DEV [batch, locs_batch_stride].  fp32 in, fp32 accumulate on the matrix cores (v_mfma_f32_32x32x2_f32).
  */
-int ssdk_head_conv_bwd(const float* x, int batch, int h, int w, int cin, const float* w_score, int n_score,
-                       const float* w_loc, int n_loc, const float* dscores, long long scores_batch_stride,
-                       long long scores_offset, const float* dlocs, long long locs_batch_stride,
-                       long long locs_offset, float* dx, float* dw_score, float* db_score, float* dw_loc,
-                       float* db_loc, void* workspace, size_t workspace_bytes, void* stream);
+int ssdk_heads_fwd(const ssdk_head_level* levels, int n_levels, int batch, float* scores, long long scores_batch_stride,
+                   float* locs, long long locs_batch_stride, void* stream);
+
+size_t ssdk_heads_bwd_workspace_bytes(const ssdk_head_level* levels, int n_levels, int batch);
+
+/* Backward of ssdk_heads_fwd (what autograd derives for detector.py:50-66): dscores / dlocs are the gradients of the
+ * concatenated outputs, addressed like scores / locs. */
+int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int batch, const float* dscores,
+                   long long scores_batch_stride, const float* dlocs, long long locs_batch_stride, void* workspace,
+                   size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -55,19 +55,25 @@ _SIGNATURES = {
                                   C.c_int, C.c_void_p]),
     'ssdk_decode_box': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
                                   C.c_void_p]),
-    'ssdk_head_conv_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
-                                     C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p,
-                                     C.c_longlong, C.c_longlong, C.c_void_p]),
-    'ssdk_head_conv_bwd_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
-    'ssdk_head_conv_bwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
-                                     C.c_int, C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p, C.c_longlong,
-                                     C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                     C.c_void_p, C.c_size_t, C.c_void_p]),
+    'ssdk_heads_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_void_p]),
+    'ssdk_heads_bwd_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    'ssdk_heads_bwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong,
+                                 C.c_void_p, C.c_size_t, C.c_void_p]),
     'ssdk_postprocess_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'ssdk_postprocess': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                    C.c_int, C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }
+
+
+class HeadLevel(C.Structure):
+    """ssdk_head_level (include/ssdk.h)."""
+    _fields_ = [('x', C.c_void_p), ('h', C.c_int), ('w', C.c_int), ('cin', C.c_int),
+                ('w_score', C.c_void_p), ('b_score', C.c_void_p), ('n_score', C.c_int),
+                ('w_loc', C.c_void_p), ('b_loc', C.c_void_p), ('n_loc', C.c_int),
+                ('scores_offset', C.c_longlong), ('locs_offset', C.c_longlong),
+                ('dx', C.c_void_p), ('dw_score', C.c_void_p), ('db_score', C.c_void_p), ('dw_loc', C.c_void_p),
+                ('db_loc', C.c_void_p)]
 
 
 def exported_symbols():

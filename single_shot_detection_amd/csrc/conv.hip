@@ -3,25 +3,30 @@
 // Reference: detection/detector_builder.py:111-137 (get_heads: per level a 3x3/pad-1 score conv with nb*C outputs
 // and a 3x3/pad-1 loc conv with nb*4 outputs, both with bias) applied in detection/detector.py:50-66, each followed
 // by permute(0,2,3,1).contiguous().view(B,-1) and a cat over levels -- 2*L library convolutions plus 2*L
-// permute copies plus 2 concatenations per forward.
+// permute copies plus 2 concatenations per forward, and tail levels (5x5 ... 1x1) that cannot fill the chip.
 //
-// Here each level is ONE GEMM  C[m][n] = sum_k A[m][k] * W[n][k]  with
+// Here every level is ONE GEMM  C[m][n] = sum_k A[m][k] * W[n][k]  with
 //     m = (image, y, x) output pixel, n = output channel of the FUSED score|loc head, k = (tap, input channel),
-// computed with v_mfma_f32_32x32x2_f32 (exact fp32: parity mode -- the loss must match the reference to 1e-4) and
-// an epilogue that adds the bias and stores straight into the concatenated [B, A*C] / [B, A*4] buffers at the
-// level's offset (the NHWC flatten of detector.py:52-63 IS the natural output order of this GEMM, so permute,
-// contiguous and cat disappear).  Activations are NHWC (channels-last) so that a K-slice of an A row is one
+// and ALL levels run in ONE grouped launch (a work list ordered by decreasing work per workgroup), so the small maps
+// fill the gaps of the big ones.  The arithmetic is v_mfma_f32_32x32x2_f32: exact fp32 (parity mode -- the loss must
+// match the reference to 1e-4).  The epilogue adds the bias and stores straight into the concatenated [B, A*C] /
+// [B, A*4] buffers at the level's offset: the NHWC flatten of detector.py:52-63 IS the natural output order of this
+// GEMM, so permute, contiguous and cat disappear.  Activations are NHWC (channels-last): a K-slice of an A row is one
 // contiguous 128-byte line; weights are [n][tap][cin] (= torch channels_last memory of the OIHW parameter).
 //
-// Tiling (wave = 64 lanes): workgroup = 4 waves = 128 output pixels x (32*tn) channels, tn <= 8 chosen per level so
-// that the N tiles are balanced (N = 340 -> 6 + 5 tiles, N = 510 -> 8 + 8); wave w owns pixel rows 32w..32w+31 and
-// all tn column tiles: tn accumulators of 16 VGPRs.  K is walked in slices of 32: the next slice is prefetched
-// global -> registers while the current one is multiplied out of LDS (rows padded to 36 floats: conflict-free
-// ds_read_b128; one b128 read feeds four MFMAs of a tile).  The backward-data pass is the same kernel with the
-// taps mirrored, dY (= the dscores|dlocs slices) as the A operand and the per-tap transposed weights as W.
-// The backward-weights pass (igemm_wgrad_kernel) contracts over pixels instead: both operands are read in their
-// natural row-major form ([pixel][channel]), K = pixels is split across workgroups and partial tiles are
-// accumulated with fp32 atomics shaped as two 128-byte segments per wave instruction.
+// Tiling (wave = 64 lanes): workgroup = 4 waves = 128 output pixels x (32*tn) channels, tn <= 4 balanced per level
+// (N = 340 -> 4+4+3 tiles, N = 510 -> 4+4+4+4); wave w owns pixel rows 32w..32w+31 and all tn column tiles (tn
+// accumulators of 16 registers), ~150 VGPRs and 37 KB of LDS per workgroup -> 3 workgroups per CU, so a SIMD always
+// has another wave's MFMAs to issue while one wave waits on a barrier or an LDS read.  K is walked in slices of 32;
+// the next slice is prefetched global -> registers while the current one is multiplied out of LDS (rows padded to 36
+// floats: conflict-free ds_read_b128, one b128 read feeds four MFMAs of a tile).
+//
+// Backward: pack_dy_kernel gathers each level's slice of dscores|dlocs into 16-byte aligned, zero padded rows
+// [pixel][Npad] (the [B, A*C] rows are only 4/8-byte aligned when nb*C is odd) and sums the bias gradients on the way.
+// Backward-data is the SAME kernel with mirrored taps, A = packed dY, W = per-tap transposed weights.
+// Backward-weights (igemm_wgrad_kernel) contracts over pixels: both operands are read in their natural
+// [pixel][channel] form, K = pixels is split across workgroups and partial tiles are accumulated with fp32 atomics
+// shaped as two 128-byte segments per wave instruction.
 #include "common.h"
 
 namespace ssdk {
@@ -29,37 +34,40 @@ namespace ssdk {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kBM = 128;       // output pixels per workgroup
-constexpr int kBK = 32;        // K slice
-constexpr int kLdsStride = 36; // floats per LDS row (32 + 4 pad)
-constexpr int kMaxTN = 8;      // 32-wide column tiles per workgroup
+constexpr int kBM = 128;        // output pixels per workgroup
+constexpr int kBK = 32;         // K slice
+constexpr int kLdsStride = 36;  // floats per LDS row (32 + 4 pad)
+constexpr int kMaxTN = 4;       // 32-wide column tiles per workgroup
 constexpr int kConvThreads = 256;
+constexpr int kMaxProblems = 8;
 
-struct RowSeg {        // a [pixel][channel] operand made of up to two channel segments (dscores | dlocs)
-    const float* p0;   // segment 0 base (level offset already applied)
-    const float* p1;   // segment 1 base or null
-    long long b0, b1;  // per-image stride in floats
-    int c0, c1;        // channels per segment
-    int s0, s1;        // per-pixel stride in floats
-};
-
-struct GemmFwd {
-    RowSeg a;            // A operand rows: input pixels (Hin x Win per image)
-    int B, Hout, Wout, Hin, Win;
-    int ksize, stride, pad, mirror;  // mirror != 0: backward-data (taps flipped, pad' = ksize-1-pad)
-    const float* w0;     // W rows for n <  n0: [n0][taps*Cc]
-    const float* w1;     // W rows for n >= n0: [n1][taps*Cc]
+struct ConvProblem {
+    // A operand rows [pixel][channel], one segment
+    const float* a;
+    long long a_bstride;  // per-image stride (floats)
+    int a_pstride;        // per-pixel stride (floats)
+    int Cc;               // channels (K per tap)
+    int B, Hout, Wout, Hin, Win, ksize, stride, pad;
+    // W rows: n < n0 -> w0[n][taps*Cc], else w1[n-n0][taps*Cc]
+    const float* w0;
+    const float* w1;
     const float* bias0;
     const float* bias1;
     int n0, n1;
-    float* o0;           // output segment 0: element (image b, pixel p, channel n) at o0 + b*ob0 + p*os0 + n
+    // output: element (image b, pixel p, channel n) at o0 + b*ob0 + p*os0 + n (n < n0) / o1 + b*ob1 + p*os1 + (n-n0)
+    float* o0;
     float* o1;
     long long ob0, ob1;
     int os0, os1;
-    int tiles_n;         // 32-wide column tiles in total
-    int n_blocks;        // workgroups along N
-    int m_tiles;
+    int tiles_n, n_blocks, m_tiles;
+    int block_begin;  // first workgroup of this problem in the grouped grid
     int relu;
+};
+
+struct ConvGroup {
+    int count;
+    int total_blocks;
+    ConvProblem p[kMaxProblems];
 };
 
 template <int VEC>
@@ -67,121 +75,116 @@ struct VecT;
 template <>
 struct VecT<4> { typedef float4 type; };
 template <>
-struct VecT<2> { typedef float2 type; };
-template <>
 struct VecT<1> { typedef float type; };
-
 template <int VEC>
 __device__ __forceinline__ typename VecT<VEC>::type vzero();
 template <>
 __device__ __forceinline__ float4 vzero<4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 template <>
-__device__ __forceinline__ float2 vzero<2>() { return make_float2(0.f, 0.f); }
-template <>
 __device__ __forceinline__ float vzero<1>() { return 0.f; }
-
-// pointer to channel c of pixel row `pix` of image b, or null when c is past the last channel
-__device__ __forceinline__ const float* seg_ptr(const RowSeg& r, int b, long long pix, int c) {
-    if (c < r.c0) return r.p0 + (long long)b * r.b0 + pix * r.s0 + c;
-    c -= r.c0;
-    if (c < r.c1) return r.p1 + (long long)b * r.b1 + pix * r.s1 + c;
-    return nullptr;
-}
 
 // ---- forward / backward-data ------------------------------------------------------------------------------------
 // MIRROR = false: forward convolution; MIRROR = true: backward-data (separate instantiations so that profiles list the
 // forward GEMMs and the dgrad GEMMs as different kernels).
 template <int VEC, bool MIRROR>
-__global__ void __launch_bounds__(kConvThreads) igemm_fwd_kernel(GemmFwd g) {
+__global__ void __launch_bounds__(kConvThreads, 3) igemm_fwd_kernel(ConvGroup grp) {
     typedef typename VecT<VEC>::type vec_t;
-    constexpr int kVecPerRow = kBK / VEC;                 // vector loads per 32-float row slice
+    constexpr int kVecPerRow = kBK / VEC;  // vector loads per 32-float row slice
     constexpr int kRowsPerPass = kConvThreads / kVecPerRow;
     constexpr int kAPasses = kBM / kRowsPerPass;
-    constexpr int kBPassesMax = kMaxTN * 32 / kRowsPerPass;
+    constexpr int kBPasses = kMaxTN * 32 / kRowsPerPass;
 
     __shared__ __attribute__((aligned(16))) float s_a[kBM * kLdsStride];
     __shared__ __attribute__((aligned(16))) float s_b[kMaxTN * 32 * kLdsStride];
 
-    // workgroups that share an M tile get the same blockIdx % 8 (same XCD under round-robin placement: they re-read
-    // the same activation rows from one L2).  Speed only; any placement is correct.
-    const int id = blockIdx.x;
+    int pi = 0;
+#pragma unroll 1
+    for (int i = 1; i < grp.count; ++i)
+        if ((int)blockIdx.x >= grp.p[i].block_begin) pi = i;
+    const ConvProblem& g = grp.p[pi];
+
+    // workgroups that share an M tile get the same (id % 8) inside the problem (same XCD under round-robin placement
+    // when block_begin % 8 == 0: they re-read the same activation rows from one L2).  Speed only.
+    const int id = blockIdx.x - g.block_begin;
     const int per_chunk = 8 * g.n_blocks;
     const int chunk = id / per_chunk, within = id % per_chunk;
     const int m_tile = chunk * 8 + (within & 7);
     const int n_block = within >> 3;
     if (m_tile >= g.m_tiles) return;
 
-    const int Cc = g.a.c0 + g.a.c1;
+    const int Cc = g.Cc;
     const int taps = g.ksize * g.ksize;
     const int chunks = (Cc + kBK - 1) / kBK;
     const int n_slices = taps * chunks;
     const long long K = (long long)taps * Cc;
     const int N = g.n0 + g.n1;
-    const int M = g.B * g.Hout * g.Wout;
+    const int hw = g.Hout * g.Wout;
+    const int M = g.B * hw;
 
-    // balanced split of the column tiles over the n blocks
     const int base_t = g.tiles_n / g.n_blocks, rem_t = g.tiles_n % g.n_blocks;
     const int tn = base_t + (n_block < rem_t ? 1 : 0);
-    const int tile0 = n_block * base_t + min(n_block, rem_t);
-    const int n_begin = tile0 * 32;
+    const int n_begin = (n_block * base_t + min(n_block, rem_t)) * 32;
 
     const int tid = threadIdx.x;
     const int lrow = tid / kVecPerRow, lcol = (tid % kVecPerRow) * VEC;
 
-    // per-thread A rows: pixel coordinates of the rows this thread stages
-    int a_b[kAPasses], a_y[kAPasses], a_x[kAPasses];
+    // per-thread A rows: offset of the centre-tap pixel and a 9-bit validity mask per tap
+    long long a_off[kAPasses];
+    unsigned a_mask[kAPasses];
 #pragma unroll
     for (int p = 0; p < kAPasses; ++p) {
         const int m = m_tile * kBM + lrow + p * kRowsPerPass;
+        a_off[p] = 0;
+        a_mask[p] = 0;
         if (m < M) {
-            const int hw = g.Hout * g.Wout;
-            a_b[p] = m / hw;
-            const int r = m % hw;
-            a_y[p] = r / g.Wout;
-            a_x[p] = r % g.Wout;
-        } else {
-            a_b[p] = -1; a_y[p] = 0; a_x[p] = 0;
+            const int b = m / hw, r = m % hw;
+            const int y = r / g.Wout, x = r % g.Wout;
+            unsigned mask = 0;
+            int by, bx;
+            if (!MIRROR) {  // input pixel = out*stride - pad + k
+                by = y * g.stride - g.pad;
+                bx = x * g.stride - g.pad;
+                for (int t = 0; t < taps; ++t) {
+                    const int iy = by + t / g.ksize, ix = bx + t % g.ksize;
+                    if (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) mask |= 1u << t;
+                }
+            } else {  // backward-data: rows are output-gradient pixels (y + pad - k) / stride; stride 1 only here
+                by = y + g.pad;
+                bx = x + g.pad;
+                for (int t = 0; t < taps; ++t) {
+                    const int iy = by - t / g.ksize, ix = bx - t % g.ksize;
+                    if (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) mask |= 1u << t;
+                }
+            }
+            a_mask[p] = mask;
+            a_off[p] = (long long)b * g.a_bstride + ((long long)by * g.Win + bx) * g.a_pstride;
         }
     }
+    // per-thread W rows
+    const float* w_row[kBPasses];
+#pragma unroll
+    for (int p = 0; p < kBPasses; ++p) {
+        const int rr = lrow + p * kRowsPerPass;
+        const int n = n_begin + rr;
+        w_row[p] = (rr < tn * 32 && n < N) ? (n < g.n0 ? g.w0 + (long long)n * K : g.w1 + (long long)(n - g.n0) * K) : nullptr;
+    }
 
-    vec_t ra[kAPasses], rb[kBPassesMax];
-    const int b_passes = (tn * 32 + kRowsPerPass - 1) / kRowsPerPass;
-
+    vec_t ra[kAPasses], rb[kBPasses];
     auto load_slice = [&](int slice) {
         const int tap = slice / chunks, c = (slice % chunks) * kBK + lcol;
         const int ky = tap / g.ksize, kx = tap % g.ksize;
+        const long long tap_off = MIRROR ? -((long long)ky * g.Win + kx) * g.a_pstride : ((long long)ky * g.Win + kx) * g.a_pstride;
+        const bool c_ok = c < Cc;
 #pragma unroll
         for (int p = 0; p < kAPasses; ++p) {
             vec_t v = vzero<VEC>();
-            if (a_b[p] >= 0) {
-                int iy, ix;
-                bool ok = true;
-                if (!MIRROR) {  // input pixel = out*stride - pad + k
-                    iy = a_y[p] * g.stride - g.pad + ky;
-                    ix = a_x[p] * g.stride - g.pad + kx;
-                } else {          // backward-data: the rows are OUTPUT-gradient pixels, (y + pad - k) / stride
-                    const int ty = a_y[p] + g.pad - ky, tx = a_x[p] + g.pad - kx;
-                    ok = (ty % g.stride == 0) && (tx % g.stride == 0) && ty >= 0 && tx >= 0;
-                    iy = ty / g.stride;
-                    ix = tx / g.stride;
-                }
-                if (ok && iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) {
-                    const float* src = seg_ptr(g.a, a_b[p], (long long)iy * g.Win + ix, c);
-                    if (src) v = *reinterpret_cast<const vec_t*>(src);
-                }
-            }
+            if (c_ok && ((a_mask[p] >> tap) & 1u)) v = *reinterpret_cast<const vec_t*>(g.a + a_off[p] + tap_off + c);
             ra[p] = v;
         }
 #pragma unroll
-        for (int p = 0; p < kBPassesMax; ++p) {
+        for (int p = 0; p < kBPasses; ++p) {
             vec_t v = vzero<VEC>();
-            if (p < b_passes) {
-                const int n = n_begin + lrow + p * kRowsPerPass;
-                if (n < N && c < Cc && lrow + p * kRowsPerPass < tn * 32) {
-                    const float* wrow = n < g.n0 ? g.w0 + (long long)n * K : g.w1 + (long long)(n - g.n0) * K;
-                    v = *reinterpret_cast<const vec_t*>(wrow + (long long)tap * Cc + c);
-                }
-            }
+            if (c_ok && w_row[p]) v = *reinterpret_cast<const vec_t*>(w_row[p] + (long long)tap * Cc + c);
             rb[p] = v;
         }
     };
@@ -190,8 +193,8 @@ __global__ void __launch_bounds__(kConvThreads) igemm_fwd_kernel(GemmFwd g) {
         for (int p = 0; p < kAPasses; ++p)
             *reinterpret_cast<vec_t*>(&s_a[(lrow + p * kRowsPerPass) * kLdsStride + lcol]) = ra[p];
 #pragma unroll
-        for (int p = 0; p < kBPassesMax; ++p)
-            if (p < b_passes) *reinterpret_cast<vec_t*>(&s_b[(lrow + p * kRowsPerPass) * kLdsStride + lcol]) = rb[p];
+        for (int p = 0; p < kBPasses; ++p)
+            *reinterpret_cast<vec_t*>(&s_b[(lrow + p * kRowsPerPass) * kLdsStride + lcol]) = rb[p];
     };
 
     f32x16 acc[kMaxTN];
@@ -212,6 +215,7 @@ __global__ void __launch_bounds__(kConvThreads) igemm_fwd_kernel(GemmFwd g) {
         if (slice + 1 < n_slices) load_slice(slice + 1);  // in flight while the MFMAs below run
 #pragma unroll
         for (int gk = 0; gk < kBK / 8; ++gk) {
+            // lane (r, h) reads k = gk*8 + 4h .. +3 of its row: MFMA kk pairs k = gk*8+kk (h=0) with gk*8+4+kk (h=1)
             const f32x4 av = *reinterpret_cast<const f32x4*>(a_rd + gk * 8);
             f32x4 bv[kMaxTN];
 #pragma unroll
@@ -231,7 +235,6 @@ __global__ void __launch_bounds__(kConvThreads) igemm_fwd_kernel(GemmFwd g) {
     }
 
     // epilogue: C/D map of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
-    const int hw = g.Hout * g.Wout;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int m = m_tile * kBM + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -258,33 +261,38 @@ __global__ void __launch_bounds__(kConvThreads) igemm_fwd_kernel(GemmFwd g) {
 }
 
 // ---- backward-weights ------------------------------------------------------------------------------------------
-struct GemmWgrad {
-    RowSeg dy;           // output-gradient rows [pixel of Hout x Wout][n], n = dy.c0 + dy.c1 channels
-    RowSeg x;            // input rows [pixel of Hin x Win][c]
+struct WgradProblem {
+    const float* dy;  // packed [M][Npad]
+    const float* x;   // [B][Hin*Win][Cc]
+    int Npad, Cc;
     int B, Hout, Wout, Hin, Win, ksize, stride, pad;
-    float* dw0;          // [n0][taps*Cc] (+=)
-    float* dw1;          // [n1][taps*Cc] (+=)
+    float* dw0;       // [n0][taps*Cc] (+=)
+    float* dw1;       // [n1][taps*Cc] (+=)
     int n0, n1;
-    int k_splits;        // workgroups along the pixel (K) dimension
-    int n_tiles;         // 128-row tiles over N
-    int c_tiles32;       // 32-wide tiles over Cc
-    int c_blocks;        // workgroups along Cc
+    int k_splits, n_tiles, c_tiles32, c_blocks;
+    int block_begin;
+};
+struct WgradGroup {
+    int count;
+    int total_blocks;
+    WgradProblem p[kMaxProblems];
 };
 
-// LDS: dY slice [32 pixels][128 n] and X slice [32 pixels][32*tn c]; MFMA A operand = dY^T, B operand = X.
-template <int VEC_DY>
-__global__ void __launch_bounds__(kConvThreads) igemm_wgrad_kernel(GemmWgrad g) {
-    typedef typename VecT<VEC_DY>::type dvec_t;
-    constexpr int kDyVecPerRow = 128 / VEC_DY;
-    constexpr int kDyRowsPerPass = kConvThreads / kDyVecPerRow > 0 ? kConvThreads / kDyVecPerRow : 1;
-    constexpr int kDyPasses = 32 / kDyRowsPerPass;
+// LDS: dY slice [32 pixels][128 n] and X slice [32 pixels][128 c]; MFMA A operand = dY^T, B operand = X.
+__global__ void __launch_bounds__(kConvThreads, 3) igemm_wgrad_kernel(WgradGroup grp) {
     __shared__ __attribute__((aligned(16))) float s_dy[32 * 128];
-    __shared__ __attribute__((aligned(16))) float s_x[32 * kMaxTN * 32];
+    __shared__ __attribute__((aligned(16))) float s_x[32 * 128];
 
-    const int Cc = g.x.c0 + g.x.c1;
+    int pi = 0;
+#pragma unroll 1
+    for (int i = 1; i < grp.count; ++i)
+        if ((int)blockIdx.x >= grp.p[i].block_begin) pi = i;
+    const WgradProblem& g = grp.p[pi];
+
+    const int Cc = g.Cc;
     const int N = g.n0 + g.n1;
     const int taps = g.ksize * g.ksize;
-    int id = blockIdx.x;
+    int id = blockIdx.x - g.block_begin;
     const int ksp = id % g.k_splits; id /= g.k_splits;
     const int cb = id % g.c_blocks; id /= g.c_blocks;
     const int nt = id % g.n_tiles; id /= g.n_tiles;
@@ -301,8 +309,10 @@ __global__ void __launch_bounds__(kConvThreads) igemm_wgrad_kernel(GemmWgrad g) 
     const int slices_total = (M + 31) / 32;
     const int per = (slices_total + g.k_splits - 1) / g.k_splits;
     const int s_begin = ksp * per, s_end = min(slices_total, s_begin + per);
+    if (s_begin >= s_end) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r32 = lane & 31, h = lane >> 5;
+    const bool wave_live = n_begin + wave * 32 < N;
 
     f32x16 acc[kMaxTN];
 #pragma unroll
@@ -310,49 +320,57 @@ __global__ void __launch_bounds__(kConvThreads) igemm_wgrad_kernel(GemmWgrad g) 
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
 
-    // staging maps: dY slice = 32 rows x 128 floats; X slice = 32 rows x (32*tn) floats as float4
-    const int dy_row = tid / kDyVecPerRow, dy_col = (tid % kDyVecPerRow) * VEC_DY;
-    const int x_vec_per_row = tn * 8;  // float4 per row
-
-    for (int s = s_begin; s < s_end; ++s) {
-        __syncthreads();
-        // dY slice
+    // staging: 32 rows x 32 float4 per operand = 1024 float4 -> 4 per thread; thread t: row = t/32 + 8p, col4 = t%32
+    const int srow = tid >> 5, scol = (tid & 31) * 4;
+    float4 rdy[4], rx[4];
+    auto load_slice = [&](int s) {
 #pragma unroll
-        for (int p = 0; p < kDyPasses; ++p) {
-            const int row = dy_row + p * kDyRowsPerPass;
-            const int m = s * 32 + row;
-            dvec_t v = vzero<VEC_DY>();
+        for (int p = 0; p < 4; ++p) {
+            const int m = s * 32 + srow + p * 8;
+            float4 vd = make_float4(0.f, 0.f, 0.f, 0.f), vx = vd;
             if (m < M) {
-                const int b = m / hw, pix = m % hw;
-                const float* src = seg_ptr(g.dy, b, pix, n_begin + dy_col);
-                if (src) v = *reinterpret_cast<const dvec_t*>(src);
-            }
-            *reinterpret_cast<dvec_t*>(&s_dy[row * 128 + dy_col]) = v;
-        }
-        // X slice (shifted by the tap)
-        for (int t = tid; t < 32 * x_vec_per_row; t += kConvThreads) {
-            const int row = t / x_vec_per_row, c = c_begin + (t % x_vec_per_row) * 4;
-            const int m = s * 32 + row;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < M && c < Cc) {
-                const int b = m / hw, pix = m % hw;
-                const int iy = (pix / g.Wout) * g.stride - g.pad + ky, ix = (pix % g.Wout) * g.stride - g.pad + kx;
-                if (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) {
-                    const float* src = seg_ptr(g.x, b, (long long)iy * g.Win + ix, c);
-                    if (src) v = *reinterpret_cast<const float4*>(src);
+                if (n_begin + scol < g.Npad) vd = *reinterpret_cast<const float4*>(g.dy + (long long)m * g.Npad + n_begin + scol);
+                const int c = c_begin + scol;
+                if (scol < tn * 32 && c < Cc) {
+                    const int b = m / hw, pix = m % hw;
+                    const int iy = (pix / g.Wout) * g.stride - g.pad + ky, ix = (pix % g.Wout) * g.stride - g.pad + kx;
+                    if (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win)
+                        vx = *reinterpret_cast<const float4*>(g.x + ((long long)b * g.Hin * g.Win + (long long)iy * g.Win + ix) * Cc + c);
                 }
             }
-            *reinterpret_cast<float4*>(&s_x[row * (kMaxTN * 32) + (t % x_vec_per_row) * 4]) = v;
+            rdy[p] = vd;
+            rx[p] = vx;
+        }
+    };
+    auto store_slice = [&]() {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            *reinterpret_cast<float4*>(&s_dy[(srow + p * 8) * 128 + scol]) = rdy[p];
+            *reinterpret_cast<float4*>(&s_x[(srow + p * 8) * 128 + scol]) = rx[p];
+        }
+    };
+
+    load_slice(s_begin);
+    store_slice();
+    __syncthreads();
+    for (int s = s_begin; s < s_end; ++s) {
+        if (s + 1 < s_end) load_slice(s + 1);
+        if (wave_live) {
+#pragma unroll 4
+            for (int k2 = 0; k2 < 32; k2 += 2) {
+                const float av = s_dy[(k2 + h) * 128 + wave * 32 + r32];
+#pragma unroll
+                for (int j = 0; j < kMaxTN; ++j)
+                    if (j < tn) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s_x[(k2 + h) * 128 + j * 32 + r32], acc[j], 0, 0, 0);
+            }
         }
         __syncthreads();
-#pragma unroll 4
-        for (int k2 = 0; k2 < 32; k2 += 2) {
-            const float av = s_dy[(k2 + h) * 128 + wave * 32 + r32];
-#pragma unroll
-            for (int j = 0; j < kMaxTN; ++j)
-                if (j < tn) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s_x[(k2 + h) * (kMaxTN * 32) + j * 32 + r32], acc[j], 0, 0, 0);
+        if (s + 1 < s_end) {
+            store_slice();
+            __syncthreads();
         }
     }
+    if (!wave_live) return;
     const long long K = (long long)taps * Cc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -368,22 +386,34 @@ __global__ void __launch_bounds__(kConvThreads) igemm_wgrad_kernel(GemmWgrad g) 
     }
 }
 
-// dbias[n] += sum over pixels of dY[pixel][n]
-__global__ void __launch_bounds__(256) colsum_kernel(RowSeg dy, int B, int HW, float* __restrict__ db0, float* __restrict__ db1,
-                                                     int rows_per_block) {
-    const int N = dy.c0 + dy.c1;
+// ---- dY pack (+ bias gradient) --------------------------------------------------------------------------------------
+// out[m][n] (n < Npad) = n < n0 ? ds[b*sb + p*n0 + n] : (n < n0+n1 ? dl[b*lb + p*n1 + n-n0] : 0);  db += column sums
+__global__ void __launch_bounds__(256) pack_dy_kernel(const float* __restrict__ ds, long long sb, const float* __restrict__ dl,
+                                                      long long lb, int n0, int n1, int Npad, int B, int HW,
+                                                      float* __restrict__ out, float* __restrict__ db0, float* __restrict__ db1,
+                                                      int rows_per_block) {
     const long long M = (long long)B * HW;
     const long long m0 = (long long)blockIdx.x * rows_per_block, m1 = min(M, m0 + rows_per_block);
-    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    const int N = n0 + n1;
+    for (int n = threadIdx.x; n < Npad; n += blockDim.x) {
         float s = 0.0f;
-        for (long long m = m0; m < m1; ++m) s += *seg_ptr(dy, (int)(m / HW), m % HW, n);
-        if (n < dy.c0) atomicAdd(db0 + n, s); else atomicAdd(db1 + (n - dy.c0), s);
+        for (long long m = m0; m < m1; ++m) {
+            const int b = (int)(m / HW);
+            const long long p = m % HW;
+            float v = 0.0f;
+            if (n < n0) v = ds[(long long)b * sb + p * n0 + n];
+            else if (n < N) v = dl[(long long)b * lb + p * n1 + (n - n0)];
+            out[m * Npad + n] = v;
+            s += v;
+        }
+        if (n < n0) { if (db0) atomicAdd(db0 + n, s); }
+        else if (n < N) { if (db1) atomicAdd(db1 + (n - n0), s); }
     }
 }
 
-// Wd[c][tap][n] = W[n][tap][c]  (per-tap transpose: the backward-data GEMM wants K = (tap, n) contiguous per c)
+// Wd[c][tap][n] (n < Npad, zero padded) = W[n][tap][c]: the backward-data GEMM wants K = (tap, n) contiguous per c
 __global__ void __launch_bounds__(256) transpose_taps_kernel(const float* __restrict__ w0, const float* __restrict__ w1, int n0, int n1,
-                                                             int taps, int Cc, float* __restrict__ wd) {
+                                                             int Npad, int taps, int Cc, float* __restrict__ wd) {
     __shared__ float tile[32][33];
     const int N = n0 + n1;
     const int tap = blockIdx.z;
@@ -398,150 +428,188 @@ __global__ void __launch_bounds__(256) transpose_taps_kernel(const float* __rest
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         const int c = cb + r, n = nb + tx;
-        if (n < N && c < Cc) wd[((long long)c * taps + tap) * N + n] = tile[tx][r];
+        if (n < Npad && c < Cc) wd[((long long)c * taps + tap) * Npad + n] = tile[tx][r];
     }
-}
-
-static int pick_vec(const RowSeg& r, int also_mult) {
-    auto ok = [&](int v) {
-        if (r.c0 % v || (r.c1 && r.c1 % v) || r.s0 % v || (r.p1 && r.s1 % v) || r.b0 % v || (r.p1 && r.b1 % v)) return false;
-        if (((uintptr_t)r.p0 & (v * 4 - 1)) || (r.p1 && ((uintptr_t)r.p1 & (v * 4 - 1)))) return false;
-        if (also_mult % v) return false;
-        return true;
-    };
-    return ok(4) ? 4 : (ok(2) ? 2 : 1);
 }
 
 }  // namespace ssdk
 
 using namespace ssdk;
 
-static RowSeg make_seg(const float* p0, long long b0, int c0, int s0, const float* p1, long long b1, int c1, int s1) {
-    RowSeg r;
-    r.p0 = p0; r.b0 = b0; r.c0 = c0; r.s0 = s0;
-    r.p1 = p1; r.b1 = b1; r.c1 = p1 ? c1 : 0; r.s1 = s1;
-    return r;
-}
+// ---- host side ---------------------------------------------------------------------------------------------------
 
-static int launch_fwd(GemmFwd& g, int vec_hint_k, hipStream_t s) {
+static void finish_problem(ConvProblem& g) {
     const int N = g.n0 + g.n1;
-    const int M = g.B * g.Hout * g.Wout;
     g.tiles_n = cdiv(N, 32);
     g.n_blocks = cdiv(g.tiles_n, kMaxTN);
-    g.m_tiles = cdiv(M, kBM);
-    const int chunks8 = cdiv(g.m_tiles, 8);
-    const int grid = chunks8 * 8 * g.n_blocks;
-    const int Cc = g.a.c0 + g.a.c1;
-    int vec = pick_vec(g.a, Cc);
-    // weights rows: [n][taps*Cc] -> need Cc % vec == 0 and aligned bases
-    while (vec > 1 && ((((uintptr_t)g.w0) & (vec * 4 - 1)) || (g.w1 && (((uintptr_t)g.w1) & (vec * 4 - 1))) || Cc % vec)) vec >>= 1;
-    (void)vec_hint_k;
-    if (g.mirror) {
-        if (vec == 4) hipLaunchKernelGGL((igemm_fwd_kernel<4, true>), dim3(grid), dim3(kConvThreads), 0, s, g);
-        else if (vec == 2) hipLaunchKernelGGL((igemm_fwd_kernel<2, true>), dim3(grid), dim3(kConvThreads), 0, s, g);
-        else hipLaunchKernelGGL((igemm_fwd_kernel<1, true>), dim3(grid), dim3(kConvThreads), 0, s, g);
+    g.m_tiles = cdiv(g.B * g.Hout * g.Wout, kBM);
+}
+static int problem_blocks(const ConvProblem& g) { return cdiv(g.m_tiles, 8) * 8 * g.n_blocks; }
+static long long problem_block_work(const ConvProblem& g) {
+    const int chunks = cdiv(g.Cc, kBK);
+    return (long long)g.ksize * g.ksize * chunks * cdiv(g.tiles_n, g.n_blocks);
+}
+
+// orders the problems by decreasing work per workgroup (longest first), assigns block ranges, launches
+static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t s) {
+    ConvGroup grp;
+    int order[kMaxProblems];
+    for (int i = 0; i < count; ++i) order[i] = i;
+    for (int i = 0; i < count; ++i)
+        for (int j = i + 1; j < count; ++j)
+            if (problem_block_work(probs[order[j]]) > problem_block_work(probs[order[i]])) { int t = order[i]; order[i] = order[j]; order[j] = t; }
+    int begin = 0;
+    bool vec4 = true;
+    for (int i = 0; i < count; ++i) {
+        ConvProblem& g = probs[order[i]];
+        g.block_begin = begin;
+        begin += problem_blocks(g);
+        if (g.Cc % 4 || g.a_pstride % 4 || g.a_bstride % 4 || ((uintptr_t)g.a & 15) || ((uintptr_t)g.w0 & 15) || (g.w1 && ((uintptr_t)g.w1 & 15))) vec4 = false;
+        grp.p[i] = g;
+    }
+    grp.count = count;
+    grp.total_blocks = begin;
+    if (mirror) {
+        if (vec4) hipLaunchKernelGGL((igemm_fwd_kernel<4, true>), dim3(begin), dim3(kConvThreads), 0, s, grp);
+        else hipLaunchKernelGGL((igemm_fwd_kernel<1, true>), dim3(begin), dim3(kConvThreads), 0, s, grp);
     } else {
-        if (vec == 4) hipLaunchKernelGGL((igemm_fwd_kernel<4, false>), dim3(grid), dim3(kConvThreads), 0, s, g);
-        else if (vec == 2) hipLaunchKernelGGL((igemm_fwd_kernel<2, false>), dim3(grid), dim3(kConvThreads), 0, s, g);
-        else hipLaunchKernelGGL((igemm_fwd_kernel<1, false>), dim3(grid), dim3(kConvThreads), 0, s, g);
+        if (vec4) hipLaunchKernelGGL((igemm_fwd_kernel<4, false>), dim3(begin), dim3(kConvThreads), 0, s, grp);
+        else hipLaunchKernelGGL((igemm_fwd_kernel<1, false>), dim3(begin), dim3(kConvThreads), 0, s, grp);
     }
     SSDK_CHECK_LAUNCH("igemm_fwd_kernel");
     return SSDK_OK;
 }
 
-static int check_conv_geom(const char* fn, int batch, int h, int w, int cin, int n_score, int n_loc) {
-    SSDK_REQUIRE(batch > 0 && h > 0 && w > 0 && cin > 0 && n_score > 0 && n_loc >= 0, SSDK_E_INVALID,
-                 "%s: batch=%d H=%d W=%d Cin=%d n_score=%d n_loc=%d", fn, batch, h, w, cin, n_score, n_loc);
-    SSDK_REQUIRE((long long)batch * h * w < (1LL << 31) - kBM, SSDK_E_INVALID, "%s: too many pixels", fn);
+static int check_level(const char* fn, int batch, const ssdk_head_level& lv) {
+    SSDK_REQUIRE(batch > 0 && lv.h > 0 && lv.w > 0 && lv.cin > 0 && lv.n_score > 0 && lv.n_loc >= 0, SSDK_E_INVALID,
+                 "%s: batch=%d H=%d W=%d Cin=%d n_score=%d n_loc=%d", fn, batch, lv.h, lv.w, lv.cin, lv.n_score, lv.n_loc);
+    SSDK_REQUIRE((long long)batch * lv.h * lv.w < (1LL << 31) - kBM, SSDK_E_INVALID, "%s: too many pixels", fn);
+    SSDK_REQUIRE(lv.x && lv.w_score && (lv.n_loc == 0 || lv.w_loc), SSDK_E_INVALID, "%s: null pointer", fn);
     return SSDK_OK;
 }
 
-extern "C" int ssdk_head_conv_fwd(const float* x, int batch, int h, int w, int cin, const float* w_score, const float* b_score,
-                                  int n_score, const float* w_loc, const float* b_loc, int n_loc, float* scores,
-                                  long long scores_batch_stride, long long scores_offset, float* locs,
-                                  long long locs_batch_stride, long long locs_offset, void* stream) {
-    int rc = check_conv_geom("ssdk_head_conv_fwd", batch, h, w, cin, n_score, n_loc);
-    if (rc) return rc;
-    SSDK_REQUIRE(x && w_score && scores && (n_loc == 0 || (w_loc && locs)), SSDK_E_INVALID, "ssdk_head_conv_fwd: null pointer");
-    GemmFwd g{};
-    g.a = make_seg(x, (long long)h * w * cin, cin, cin, nullptr, 0, 0, 0);
-    g.B = batch; g.Hout = h; g.Wout = w; g.Hin = h; g.Win = w;
-    g.ksize = 3; g.stride = 1; g.pad = 1; g.mirror = 0;
-    g.w0 = w_score; g.w1 = w_loc; g.bias0 = b_score; g.bias1 = b_loc; g.n0 = n_score; g.n1 = n_loc;
-    g.o0 = scores + scores_offset; g.ob0 = scores_batch_stride; g.os0 = n_score;
-    g.o1 = locs ? locs + locs_offset : nullptr; g.ob1 = locs_batch_stride; g.os1 = n_loc;
-    g.relu = 0;
-    return launch_fwd(g, 0, (hipStream_t)stream);
-}
+static inline int npad_of(const ssdk_head_level& lv) { return cdiv(lv.n_score + lv.n_loc, 32) * 32; }
 
-extern "C" size_t ssdk_head_conv_bwd_workspace_bytes(int cin, int n_score, int n_loc) {
-    return align_up((size_t)9 * cin * (size_t)(n_score + n_loc) * sizeof(float), 256);
-}
-
-extern "C" int ssdk_head_conv_bwd(const float* x, int batch, int h, int w, int cin, const float* w_score, int n_score,
-                                  const float* w_loc, int n_loc, const float* dscores, long long scores_batch_stride,
-                                  long long scores_offset, const float* dlocs, long long locs_batch_stride,
-                                  long long locs_offset, float* dx, float* dw_score, float* db_score, float* dw_loc,
-                                  float* db_loc, void* workspace, size_t workspace_bytes, void* stream) {
-    int rc = check_conv_geom("ssdk_head_conv_bwd", batch, h, w, cin, n_score, n_loc);
-    if (rc) return rc;
-    SSDK_REQUIRE(x && w_score && dscores && (n_loc == 0 || (w_loc && dlocs)), SSDK_E_INVALID, "ssdk_head_conv_bwd: null pointer");
-    hipStream_t s = (hipStream_t)stream;
-    const int N = n_score + n_loc;
-    RowSeg dy = make_seg(dscores + scores_offset, scores_batch_stride, n_score, n_score, n_loc ? dlocs + locs_offset : nullptr,
-                         locs_batch_stride, n_loc, n_loc);
-    if (dx) {  // backward-data: dX[m][c] = sum_(tap,n) dY[m + pad - tap][n] * W[n][tap][c]
-        SSDK_REQUIRE(workspace && workspace_bytes >= ssdk_head_conv_bwd_workspace_bytes(cin, n_score, n_loc), SSDK_E_WORKSPACE,
-                     "ssdk_head_conv_bwd: workspace too small");
-        float* wd = (float*)workspace;
-        hipLaunchKernelGGL(transpose_taps_kernel, dim3(cdiv(N, 32), cdiv(cin, 32), 9), dim3(256), 0, s, w_score, w_loc, n_score,
-                           n_loc, 9, cin, wd);
-        SSDK_CHECK_LAUNCH("transpose_taps_kernel");
-        GemmFwd g{};
-        g.a = dy;
-        g.B = batch; g.Hout = h; g.Wout = w; g.Hin = h; g.Win = w;
-        g.ksize = 3; g.stride = 1; g.pad = 1; g.mirror = 1;
-        g.w0 = wd; g.w1 = nullptr; g.bias0 = nullptr; g.bias1 = nullptr; g.n0 = cin; g.n1 = 0;
-        g.o0 = dx; g.ob0 = (long long)h * w * cin; g.os0 = cin; g.o1 = nullptr; g.ob1 = 0; g.os1 = 0;
+extern "C" int ssdk_heads_fwd(const ssdk_head_level* levels, int n_levels, int batch, float* scores,
+                              long long scores_batch_stride, float* locs, long long locs_batch_stride, void* stream) {
+    SSDK_REQUIRE(levels && n_levels > 0 && n_levels <= kMaxProblems, SSDK_E_INVALID, "ssdk_heads_fwd: n_levels=%d (1..%d)", n_levels, kMaxProblems);
+    SSDK_REQUIRE(scores, SSDK_E_INVALID, "ssdk_heads_fwd: null scores");
+    ConvProblem probs[kMaxProblems];
+    for (int i = 0; i < n_levels; ++i) {
+        const ssdk_head_level& lv = levels[i];
+        int rc = check_level("ssdk_heads_fwd", batch, lv);
+        if (rc) return rc;
+        SSDK_REQUIRE(lv.n_loc == 0 || locs, SSDK_E_INVALID, "ssdk_heads_fwd: null locs");
+        ConvProblem g{};
+        g.a = lv.x; g.a_bstride = (long long)lv.h * lv.w * lv.cin; g.a_pstride = lv.cin; g.Cc = lv.cin;
+        g.B = batch; g.Hout = lv.h; g.Wout = lv.w; g.Hin = lv.h; g.Win = lv.w; g.ksize = 3; g.stride = 1; g.pad = 1;
+        g.w0 = lv.w_score; g.w1 = lv.n_loc ? lv.w_loc : nullptr; g.bias0 = lv.b_score; g.bias1 = lv.b_loc; g.n0 = lv.n_score; g.n1 = lv.n_loc;
+        g.o0 = scores + lv.scores_offset; g.ob0 = scores_batch_stride; g.os0 = lv.n_score;
+        g.o1 = lv.n_loc ? locs + lv.locs_offset : nullptr; g.ob1 = locs_batch_stride; g.os1 = lv.n_loc;
         g.relu = 0;
-        rc = launch_fwd(g, 0, s);
+        finish_problem(g);
+        probs[i] = g;
+    }
+    return launch_group(probs, n_levels, false, (hipStream_t)stream);
+}
+
+extern "C" size_t ssdk_heads_bwd_workspace_bytes(const ssdk_head_level* levels, int n_levels, int batch) {
+    size_t total = 0;
+    for (int i = 0; i < n_levels; ++i) {
+        const ssdk_head_level& lv = levels[i];
+        const size_t npad = (size_t)npad_of(lv);
+        total += align_up((size_t)batch * lv.h * lv.w * npad * sizeof(float), 256);  // packed dY
+        total += align_up((size_t)lv.cin * 9 * npad * sizeof(float), 256);           // transposed weights
+    }
+    return total;
+}
+
+extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int batch, const float* dscores,
+                              long long scores_batch_stride, const float* dlocs, long long locs_batch_stride,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    SSDK_REQUIRE(levels && n_levels > 0 && n_levels <= kMaxProblems, SSDK_E_INVALID, "ssdk_heads_bwd: n_levels=%d (1..%d)", n_levels, kMaxProblems);
+    SSDK_REQUIRE(dscores, SSDK_E_INVALID, "ssdk_heads_bwd: null dscores");
+    SSDK_REQUIRE(workspace && workspace_bytes >= ssdk_heads_bwd_workspace_bytes(levels, n_levels, batch), SSDK_E_WORKSPACE,
+                 "ssdk_heads_bwd: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    Carver carve(workspace);
+    ConvProblem dgrad[kMaxProblems];
+    WgradGroup wg;
+    int n_dgrad = 0, n_wgrad = 0;
+    const float* packed[kMaxProblems];
+    for (int i = 0; i < n_levels; ++i) {
+        const ssdk_head_level& lv = levels[i];
+        int rc = check_level("ssdk_heads_bwd", batch, lv);
+        if (rc) return rc;
+        SSDK_REQUIRE(lv.n_loc == 0 || dlocs, SSDK_E_INVALID, "ssdk_heads_bwd: null dlocs");
+        SSDK_REQUIRE(lv.cin % 4 == 0 && ((uintptr_t)lv.x & 15) == 0, SSDK_E_UNSUPPORTED, "ssdk_heads_bwd: Cin %% 4 != 0 or x not 16-byte aligned");
+        const int npad = npad_of(lv), hw = lv.h * lv.w;
+        const long long M = (long long)batch * hw;
+        float* dyp = carve.take<float>((size_t)M * npad);
+        float* wd = carve.take<float>((size_t)lv.cin * 9 * npad);
+        packed[i] = dyp;
+        if (lv.db_score) SSDK_CHECK_HIP(hipMemsetAsync(lv.db_score, 0, sizeof(float) * (size_t)lv.n_score, s));
+        if (lv.db_loc && lv.n_loc) SSDK_CHECK_HIP(hipMemsetAsync(lv.db_loc, 0, sizeof(float) * (size_t)lv.n_loc, s));
+        const int rows_per_block = 64;
+        hipLaunchKernelGGL(pack_dy_kernel, dim3((unsigned)((M + rows_per_block - 1) / rows_per_block)), dim3(256), 0, s,
+                           dscores + lv.scores_offset, scores_batch_stride, lv.n_loc ? dlocs + lv.locs_offset : nullptr, locs_batch_stride,
+                           lv.n_score, lv.n_loc, npad, batch, hw, dyp, lv.db_score, lv.db_loc, rows_per_block);
+        SSDK_CHECK_LAUNCH("pack_dy_kernel");
+        if (lv.dx) {  // backward-data: dX[m][c] = sum_(tap,n) dY[m + pad - tap][n] * W[n][tap][c]
+            hipLaunchKernelGGL(transpose_taps_kernel, dim3(cdiv(npad, 32), cdiv(lv.cin, 32), 9), dim3(256), 0, s, lv.w_score, lv.w_loc,
+                               lv.n_score, lv.n_loc, npad, 9, lv.cin, wd);
+            SSDK_CHECK_LAUNCH("transpose_taps_kernel");
+            ConvProblem g{};
+            g.a = dyp; g.a_bstride = (long long)hw * npad; g.a_pstride = npad; g.Cc = npad;
+            g.B = batch; g.Hout = lv.h; g.Wout = lv.w; g.Hin = lv.h; g.Win = lv.w; g.ksize = 3; g.stride = 1; g.pad = 1;
+            g.w0 = wd; g.w1 = nullptr; g.bias0 = nullptr; g.bias1 = nullptr; g.n0 = lv.cin; g.n1 = 0;
+            g.o0 = lv.dx; g.ob0 = (long long)hw * lv.cin; g.os0 = lv.cin; g.o1 = nullptr; g.ob1 = 0; g.os1 = 0;
+            g.relu = 0;
+            finish_problem(g);
+            dgrad[n_dgrad++] = g;
+        }
+        if (lv.dw_score) {
+            SSDK_REQUIRE(lv.n_loc == 0 || lv.dw_loc, SSDK_E_INVALID, "ssdk_heads_bwd: dw_loc missing");
+            SSDK_CHECK_HIP(hipMemsetAsync(lv.dw_score, 0, sizeof(float) * (size_t)lv.n_score * 9 * lv.cin, s));
+            if (lv.n_loc) SSDK_CHECK_HIP(hipMemsetAsync(lv.dw_loc, 0, sizeof(float) * (size_t)lv.n_loc * 9 * lv.cin, s));
+            WgradProblem g{};
+            g.dy = dyp; g.x = lv.x; g.Npad = npad; g.Cc = lv.cin;
+            g.B = batch; g.Hout = lv.h; g.Wout = lv.w; g.Hin = lv.h; g.Win = lv.w; g.ksize = 3; g.stride = 1; g.pad = 1;
+            g.dw0 = lv.dw_score; g.dw1 = lv.dw_loc; g.n0 = lv.n_score; g.n1 = lv.n_loc;
+            g.n_tiles = cdiv(lv.n_score + lv.n_loc, 128);
+            g.c_tiles32 = cdiv(lv.cin, 32);
+            g.c_blocks = cdiv(g.c_tiles32, kMaxTN);
+            wg.p[n_wgrad++] = g;
+        }
+    }
+    if (n_dgrad) {
+        int rc = launch_group(dgrad, n_dgrad, true, s);
         if (rc) return rc;
     }
-    if (dw_score) {
-        SSDK_REQUIRE(n_loc == 0 || dw_loc, SSDK_E_INVALID, "ssdk_head_conv_bwd: dw_loc missing");
-        SSDK_CHECK_HIP(hipMemsetAsync(dw_score, 0, sizeof(float) * (size_t)n_score * 9 * cin, s));
-        if (n_loc) SSDK_CHECK_HIP(hipMemsetAsync(dw_loc, 0, sizeof(float) * (size_t)n_loc * 9 * cin, s));
-        GemmWgrad g{};
-        g.dy = dy;
-        g.x = make_seg(x, (long long)h * w * cin, cin, cin, nullptr, 0, 0, 0);
-        SSDK_REQUIRE(cin % 4 == 0 && ((uintptr_t)x & 15) == 0, SSDK_E_UNSUPPORTED, "ssdk_head_conv_bwd: Cin must be a multiple of 4 and x 16-byte aligned");
-        g.B = batch; g.Hout = h; g.Wout = w; g.Hin = h; g.Win = w; g.ksize = 3; g.stride = 1; g.pad = 1;
-        g.dw0 = dw_score; g.dw1 = dw_loc; g.n0 = n_score; g.n1 = n_loc;
-        g.n_tiles = cdiv(N, 128);
-        g.c_tiles32 = cdiv(cin, 32);
-        g.c_blocks = cdiv(g.c_tiles32, kMaxTN);
-        const int out_tiles = 9 * g.n_tiles * g.c_blocks;
-        const int slices = cdiv(batch * h * w, 32);
-        int ks = cdiv(2048, out_tiles);
-        if (ks > slices) ks = slices;
-        if (ks < 1) ks = 1;
-        g.k_splits = ks;
-        const int vec = pick_vec(dy, 4) ;
-        const int grid = out_tiles * ks;
-        // the dY slice loader reads 128 consecutive n starting at a multiple of 128: segment boundary must not split a vector
-        if (vec == 4) hipLaunchKernelGGL(igemm_wgrad_kernel<4>, dim3(grid), dim3(kConvThreads), 0, s, g);
-        else if (vec == 2) hipLaunchKernelGGL(igemm_wgrad_kernel<2>, dim3(grid), dim3(kConvThreads), 0, s, g);
-        else hipLaunchKernelGGL(igemm_wgrad_kernel<1>, dim3(grid), dim3(kConvThreads), 0, s, g);
+    if (n_wgrad) {
+        // split K (= pixels) so that the whole group has ~6 workgroups per CU and every split has >= 8 slices
+        long long out_tiles = 0;
+        for (int i = 0; i < n_wgrad; ++i) out_tiles += 9LL * wg.p[i].n_tiles * wg.p[i].c_blocks;
+        long long total_slices = 0;
+        for (int i = 0; i < n_wgrad; ++i) total_slices += 9LL * wg.p[i].n_tiles * wg.p[i].c_blocks * cdiv(wg.p[i].B * wg.p[i].Hout * wg.p[i].Wout, 32);
+        const long long target_blocks = 256 * 6;
+        long long slices_per_block = total_slices / target_blocks;
+        if (slices_per_block < 8) slices_per_block = 8;
+        int begin = 0;
+        for (int i = 0; i < n_wgrad; ++i) {
+            WgradProblem& g = wg.p[i];
+            const int slices = cdiv(g.B * g.Hout * g.Wout, 32);
+            int ks = (int)((slices + slices_per_block - 1) / slices_per_block);
+            if (ks < 1) ks = 1;
+            g.k_splits = ks;
+            g.block_begin = begin;
+            begin += 9 * g.n_tiles * g.c_blocks * ks;
+        }
+        wg.count = n_wgrad;
+        wg.total_blocks = begin;
+        hipLaunchKernelGGL(igemm_wgrad_kernel, dim3(begin), dim3(kConvThreads), 0, s, wg);
         SSDK_CHECK_LAUNCH("igemm_wgrad_kernel");
     }
-    if (db_score) {
-        SSDK_CHECK_HIP(hipMemsetAsync(db_score, 0, sizeof(float) * (size_t)n_score, s));
-        if (n_loc && db_loc) SSDK_CHECK_HIP(hipMemsetAsync(db_loc, 0, sizeof(float) * (size_t)n_loc, s));
-        const int rows_per_block = 64;
-        const long long M = (long long)batch * h * w;
-        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((M + rows_per_block - 1) / rows_per_block)), dim3(256), 0, s, dy, batch, h * w,
-                           db_score, db_loc, rows_per_block);
-        SSDK_CHECK_LAUNCH("colsum_kernel");
-    }
+    (void)packed;
     return SSDK_OK;
 }

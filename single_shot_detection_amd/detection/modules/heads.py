@@ -22,8 +22,27 @@ def weight_khwc(w):
     return w.float().contiguous(memory_format=torch.channels_last)
 
 
+def _dp(t):
+    return None if t is None or t.numel() == 0 else t.data_ptr()
+
+
 class _HeadsFn(torch.autograd.Function):
-    """apply(num_classes, x_0, ws_0, bs_0, wl_0, bl_0, x_1, ...) -> (scores [B, sum HW*nb*C], locs [B, sum HW*nb*4])"""
+    """apply(x_0, ws_0, bs_0, wl_0, bl_0, x_1, ...) -> (scores [B, sum HW*nb*C], locs [B, sum HW*nb*4])"""
+
+    @staticmethod
+    def _level_array(levels, grads=None):
+        arr = (_lib.HeadLevel * len(levels))()
+        for i, lv in enumerate(levels):
+            a = arr[i]
+            a.x, a.h, a.w, a.cin = _dp(lv['x']), lv['H'], lv['W'], lv['cin']
+            a.w_score, a.b_score, a.n_score = _dp(lv['ws']), _dp(lv['bs']), lv['ns']
+            a.w_loc, a.b_loc, a.n_loc = _dp(lv['wl']), _dp(lv['bl']), lv['nl']
+            a.scores_offset, a.locs_offset = lv['s_off'], lv['l_off']
+            if grads is not None:
+                gr = grads[i]
+                a.dx, a.dw_score, a.db_score, a.dw_loc, a.db_loc = (_dp(gr['dx']), _dp(gr['dws']), _dp(gr['dbs']),
+                                                                    _dp(gr['dwl']), _dp(gr['dbl']))
+        return arr
 
     @staticmethod
     def forward(ctx, *args):
@@ -44,15 +63,13 @@ class _HeadsFn(torch.autograd.Function):
             s_off += H * W * ws.shape[0]
             l_off += H * W * wl.shape[0]
         B = levels[0]['B']
+        if any(lv['B'] != B for lv in levels):
+            raise ValueError('all source maps must share the batch size')
         dev = levels[0]['x'].device
         scores = torch.empty((B, s_off), dtype=torch.float32, device=dev)
         locs = torch.empty((B, l_off), dtype=torch.float32, device=dev)
-        stream = _lib.current_stream()
-        for lv in levels:
-            _lib.check(lib.ssdk_head_conv_fwd(_lib.ptr(lv['x']), lv['B'], lv['H'], lv['W'], lv['cin'], _lib.ptr(lv['ws']),
-                                              _lib.ptr(lv['bs']), lv['ns'], _lib.ptr(lv['wl']), _lib.ptr(lv['bl']), lv['nl'],
-                                              _lib.ptr(scores), s_off, lv['s_off'], _lib.ptr(locs), l_off, lv['l_off'],
-                                              stream), 'ssdk_head_conv_fwd')
+        arr = _HeadsFn._level_array(levels)
+        _lib.check(lib.ssdk_heads_fwd(arr, L, B, _dp(scores), s_off, _dp(locs), l_off, _lib.current_stream()), 'ssdk_heads_fwd')
         ctx.levels = levels
         ctx.totals = (s_off, l_off)
         return scores, locs
@@ -61,30 +78,30 @@ class _HeadsFn(torch.autograd.Function):
     def backward(ctx, dscores, dlocs):
         lib = _lib.lib()
         s_tot, l_tot = ctx.totals
+        levels = ctx.levels
+        B = levels[0]['B']
         dscores = dscores.float().contiguous()
         dlocs = dlocs.float().contiguous()
-        stream = _lib.current_stream()
-        grads = []
-        for i, lv in enumerate(ctx.levels):
+        grads, out = [], []
+        for i, lv in enumerate(levels):
             need_x, need_ws, need_bs, need_wl, need_bl = ctx.needs_input_grad[5 * i:5 * i + 5]
             x = lv['x']
-            dx = torch.empty_like(x, memory_format=torch.channels_last) if need_x else None
             need_w = need_ws or need_wl
-            dws = torch.empty_like(lv['ws'], memory_format=torch.channels_last) if need_w else None
-            dwl = torch.empty_like(lv['wl'], memory_format=torch.channels_last) if need_w else None
             need_b = (need_bs and lv['bs'] is not None) or (need_bl and lv['bl'] is not None)
-            dbs = torch.empty((lv['ns'],), dtype=torch.float32, device=x.device) if need_b else None
-            dbl = torch.empty((lv['nl'],), dtype=torch.float32, device=x.device) if need_b else None
-            need = lib.ssdk_head_conv_bwd_workspace_bytes(lv['cin'], lv['ns'], lv['nl'])
-            ws = torch.empty((need,), dtype=torch.uint8, device=x.device) if need_x else None
-            _lib.check(lib.ssdk_head_conv_bwd(_lib.ptr(x), lv['B'], lv['H'], lv['W'], lv['cin'], _lib.ptr(lv['ws']), lv['ns'],
-                                              _lib.ptr(lv['wl']), lv['nl'], _lib.ptr(dscores), s_tot, lv['s_off'],
-                                              _lib.ptr(dlocs), l_tot, lv['l_off'], _lib.ptr(dx), _lib.ptr(dws), _lib.ptr(dbs),
-                                              _lib.ptr(dwl), _lib.ptr(dbl), _lib.ptr(ws), need if need_x else 0, stream),
-                       'ssdk_head_conv_bwd')
-            grads += [dx, dws if need_ws else None, dbs if (need_bs and lv['bs'] is not None) else None,
-                      dwl if need_wl else None, dbl if (need_bl and lv['bl'] is not None) else None]
-        return tuple(grads)
+            gr = dict(dx=torch.empty_like(x, memory_format=torch.channels_last) if need_x else None,
+                      dws=torch.empty_like(lv['ws'], memory_format=torch.channels_last) if need_w else None,
+                      dwl=torch.empty_like(lv['wl'], memory_format=torch.channels_last) if need_w else None,
+                      dbs=torch.empty((lv['ns'],), dtype=torch.float32, device=x.device) if need_b else None,
+                      dbl=torch.empty((lv['nl'],), dtype=torch.float32, device=x.device) if need_b else None)
+            grads.append(gr)
+            out += [gr['dx'], gr['dws'] if need_ws else None, gr['dbs'] if (need_bs and lv['bs'] is not None) else None,
+                    gr['dwl'] if need_wl else None, gr['dbl'] if (need_bl and lv['bl'] is not None) else None]
+        arr = _HeadsFn._level_array(levels, grads)
+        need = lib.ssdk_heads_bwd_workspace_bytes(arr, len(levels), B)
+        ws = torch.empty((need,), dtype=torch.uint8, device=dscores.device)
+        _lib.check(lib.ssdk_heads_bwd(arr, len(levels), B, _dp(dscores), s_tot, _dp(dlocs), l_tot, _dp(ws), need,
+                                      _lib.current_stream()), 'ssdk_heads_bwd')
+        return tuple(out)
 
 
 def multi_level_heads(sources_score, sources_loc, heads):

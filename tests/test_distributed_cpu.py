@@ -1,0 +1,65 @@
+"""CPU, world_size 2, gloo: the exchange step of the N > 1 path (flat head-gradient bucket all-reduce) and sharding."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from single_shot_detection_amd.distributed import GradBucket, shard_batch
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(0)
+    conv_a = torch.nn.Conv2d(8, 12, 3, padding=1)
+    conv_b = torch.nn.Conv2d(8, 4, 3, padding=1)
+    for m in (conv_a, conv_b):   # channels_last parameter memory like the head convs
+        m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+    params = list(conv_a.parameters()) + list(conv_b.parameters())
+    g = torch.Generator().manual_seed(100 + rank)
+    for p in params:
+        grad = torch.randn(p.shape, generator=g)
+        p.grad = grad.contiguous(memory_format=torch.channels_last) if grad.dim() == 4 else grad
+    local = [p.grad.clone() for p in params]
+    bucket = GradBucket(params)
+    bucket.allreduce_()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, [x.numpy() for x in local])
+    for i, p in enumerate(params):
+        want = sum(torch.from_numpy(gathered[r][i]) for r in range(world)) / world
+        assert torch.allclose(p.grad, want, atol=1e-6), (rank, i)
+        assert p.grad.stride() == local[i].stride()
+    np.save(os.path.join(out_dir, f'ok{rank}.npy'), np.array([1]))
+    dist.destroy_process_group()
+
+
+def test_grad_bucket_allreduce_gloo_world2(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f'ok{r}.npy') for r in range(world))
+
+
+def test_shard_batch_covers_everything_once():
+    items = list(range(13))
+    for world in (1, 2, 4, 8):
+        parts = [shard_batch(items, r, world) for r in range(world)]
+        assert sum(parts, []) == items
+
+
+def test_bucket_is_noop_without_process_group():
+    p = torch.nn.Parameter(torch.ones(3))
+    p.grad = torch.full((3,), 2.0)
+    GradBucket([p]).allreduce_()
+    assert torch.equal(p.grad, torch.full((3,), 2.0))
