@@ -211,6 +211,53 @@ int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int batch, const
                    long long scores_batch_stride, const float* dlocs, long long locs_batch_stride, void* workspace,
                    size_t workspace_bytes, void* stream);
 
+/* ---- pyramid tail (H2) and RetinaNet tower (H3): generic NHWC convolution + BatchNorm --------------------------- */
+
+/*
+ * torch.nn.Conv2d(cin, cout, ksize, stride, padding, bias) on NHWC buffers, as used by bf/modules/conv.py:4-36
+ * (Conv2dBn of detection/detector_builder.py:57-109) and detection/modules/predictors.py:28-31,60-66.
+ *   x [batch,hin,win,cin]; w [cout,ksize,ksize,cin] (channels_last memory of the OIHW parameter); bias [cout] or NULL;
+ *   ksize 1 or 3, stride 1 or 2; relu != 0 fuses max(.,0) into the epilogue (the tower's conv -> ReLU);
+ *   y [batch,hout,wout,cout].  Backward fields (ssdk_conv2d_bwd): dy like y (gradient w.r.t. the convolution output,
+ *   i.e. with a fused ReLU already undone by ssdk_relu_bwd); dx like x, dw like w, db [cout]; NULL = skip.
+ */
+typedef struct ssdk_conv_desc {
+    const float* x;
+    int hin, win, cin;
+    const float* w;
+    const float* bias;
+    int cout, ksize, stride, pad, relu;
+    float* y;
+    const float* dy;
+    float* dx;
+    float* dw;
+    float* db;
+} ssdk_conv_desc;
+
+/* n <= 8 convolutions (e.g. the five pyramid levels of one shared tower layer) in one grouped launch. */
+int ssdk_conv2d_fwd(const ssdk_conv_desc* descs, int n, int batch, void* stream);
+size_t ssdk_conv2d_bwd_workspace_bytes(const ssdk_conv_desc* descs, int n, int batch);
+/* accumulate != 0: dw / db are added to (weights shared across the n descriptors); else overwritten. */
+int ssdk_conv2d_bwd(const ssdk_conv_desc* descs, int n, int batch, int accumulate, void* workspace, size_t workspace_bytes,
+                    void* stream);
+/* dx = y > 0 ? dy : 0 (n floats, n % 4 == 0). */
+int ssdk_relu_bwd(const float* y, const float* dy, long long n, float* dx, void* stream);
+
+size_t ssdk_batchnorm_workspace_bytes(int channels);
+/*
+ * torch.nn.BatchNorm2d forward on [rows = batch*H*W][channels] (NHWC), optional fused ReLU after it (conv.py:33-35).
+ * training != 0: batch statistics (biased variance), running_mean / running_var updated with `momentum` (unbiased
+ * variance) when non-NULL; else running statistics.  save_mean / save_rstd [channels] are kept for the backward.
+ */
+int ssdk_batchnorm_fwd(const float* x, long long rows, int channels, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float momentum, float eps, int training, int relu,
+                       float* y, float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
+                       void* stream);
+/* y is the forward output (needed only when relu != 0, for the mask). */
+int ssdk_batchnorm_bwd(const float* x, const float* y, const float* dy, long long rows, int channels, const float* gamma,
+                       const float* save_mean, const float* save_rstd, int relu, int training, float* dx, float* dgamma,
+                       float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,6 +59,17 @@ _SIGNATURES = {
     'ssdk_heads_bwd_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     'ssdk_heads_bwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong,
                                  C.c_void_p, C.c_size_t, C.c_void_p]),
+    'ssdk_conv2d_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'ssdk_conv2d_bwd_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    'ssdk_conv2d_bwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'ssdk_relu_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]),
+    'ssdk_batchnorm_workspace_bytes': (C.c_size_t, [C.c_int]),
+    'ssdk_batchnorm_fwd': (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_size_t, C.c_void_p]),
+    'ssdk_batchnorm_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_size_t, C.c_void_p]),
     'ssdk_postprocess_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'ssdk_postprocess': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                    C.c_int, C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_void_p,
@@ -74,6 +85,14 @@ class HeadLevel(C.Structure):
                 ('scores_offset', C.c_longlong), ('locs_offset', C.c_longlong),
                 ('dx', C.c_void_p), ('dw_score', C.c_void_p), ('db_score', C.c_void_p), ('dw_loc', C.c_void_p),
                 ('db_loc', C.c_void_p)]
+
+
+class ConvDesc(C.Structure):
+    """ssdk_conv_desc (include/ssdk.h)."""
+    _fields_ = [('x', C.c_void_p), ('hin', C.c_int), ('win', C.c_int), ('cin', C.c_int), ('w', C.c_void_p),
+                ('bias', C.c_void_p), ('cout', C.c_int), ('ksize', C.c_int), ('stride', C.c_int), ('pad', C.c_int),
+                ('relu', C.c_int), ('y', C.c_void_p), ('dy', C.c_void_p), ('dx', C.c_void_p), ('dw', C.c_void_p),
+                ('db', C.c_void_p)]
 
 
 def exported_symbols():

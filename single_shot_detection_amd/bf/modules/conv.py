@@ -1,6 +1,9 @@
 """Conv blocks of the pyramid tail -- mirror of bf/modules/conv.py:4-85 (same submodule names, so state_dict keys
 ``conv``/``bn``/``activation`` and ``depthwise_*``/``pointwise_*`` line up with the reference's checkpoints)."""
+import torch
 import torch.nn as nn
+
+from ... import ops
 
 
 class Conv2dBn(nn.Module):
@@ -14,7 +17,22 @@ class Conv2dBn(nn.Module):
         if activation_params is not None:
             self.activation = getattr(nn, activation_params['name'])(**activation_params['args'])
 
+    def _hip_ok(self):
+        c = self.conv
+        act = self._modules.get('activation')
+        return (c.groups == 1 and c.kernel_size in ((1, 1), (3, 3)) and c.stride in ((1, 1), (2, 2)) and c.dilation == (1, 1)
+                and c.padding[0] == c.padding[1] and c.padding_mode == 'zeros' and c.in_channels % 4 == 0 and c.out_channels % 4 == 0
+                and (act is None or isinstance(act, nn.ReLU)))
+
     def forward(self, x):  # conv.py:30-36: conv -> BN -> activation
+        if self._hip_ok():   # libssdk: implicit-GEMM conv (csrc/conv.hip) + BatchNorm/ReLU kernels (csrc/norm.hip)
+            has_bn, has_act = 'bn' in self._modules, 'activation' in self._modules
+            c = self.conv
+            x = ops.conv2d(x, c.weight, c.bias, stride=c.stride[0], padding=c.padding[0], relu=has_act and not has_bn)
+            if has_bn:
+                x = ops.batch_norm(x, self.bn, relu=has_act)
+            return x
+        # grouped / depthwise / exotic variants (neck-side, out of the hot-path scope): stock PyTorch-ROCm modules
         x = self.conv(x)
         if 'bn' in self._modules:
             x = self.bn(x)

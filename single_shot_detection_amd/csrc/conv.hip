@@ -86,7 +86,9 @@ __device__ __forceinline__ float vzero<1>() { return 0.f; }
 // ---- forward / backward-data ------------------------------------------------------------------------------------
 // MIRROR = false: forward convolution; MIRROR = true: backward-data (separate instantiations so that profiles list the
 // forward GEMMs and the dgrad GEMMs as different kernels).
-template <int VEC, bool MIRROR>
+// STRIDED (backward-data of a strided convolution only): the source pixel of a tap is (y + pad - k) / stride when
+// divisible, so the tap offset is no longer uniform over the rows; it is recomputed per row and slice.
+template <int VEC, bool MIRROR, bool STRIDED = false>
 __global__ void __launch_bounds__(kConvThreads, 3) igemm_fwd_kernel(ConvGroup grp) {
     typedef typename VecT<VEC>::type vec_t;
     constexpr int kVecPerRow = kBK / VEC;  // vector loads per 32-float row slice
@@ -131,11 +133,13 @@ __global__ void __launch_bounds__(kConvThreads, 3) igemm_fwd_kernel(ConvGroup gr
     // per-thread A rows: offset of the centre-tap pixel and a 9-bit validity mask per tap
     long long a_off[kAPasses];
     unsigned a_mask[kAPasses];
+    int a_yx[kAPasses];  // STRIDED only: (y + pad) << 16 | (x + pad)
 #pragma unroll
     for (int p = 0; p < kAPasses; ++p) {
         const int m = m_tile * kBM + lrow + p * kRowsPerPass;
         a_off[p] = 0;
         a_mask[p] = 0;
+        a_yx[p] = 0;
         if (m < M) {
             const int b = m / hw, r = m % hw;
             const int y = r / g.Wout, x = r % g.Wout;
@@ -148,16 +152,19 @@ __global__ void __launch_bounds__(kConvThreads, 3) igemm_fwd_kernel(ConvGroup gr
                     const int iy = by + t / g.ksize, ix = bx + t % g.ksize;
                     if (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) mask |= 1u << t;
                 }
-            } else {  // backward-data: rows are output-gradient pixels (y + pad - k) / stride; stride 1 only here
+            } else {  // backward-data: rows are output-gradient pixels (y + pad - k) / stride
                 by = y + g.pad;
                 bx = x + g.pad;
                 for (int t = 0; t < taps; ++t) {
-                    const int iy = by - t / g.ksize, ix = bx - t % g.ksize;
-                    if (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) mask |= 1u << t;
+                    const int ty = by - t / g.ksize, tx = bx - t % g.ksize;
+                    if (ty >= 0 && tx >= 0 && ty % g.stride == 0 && tx % g.stride == 0 && ty / g.stride < g.Hin && tx / g.stride < g.Win)
+                        mask |= 1u << t;
                 }
             }
             a_mask[p] = mask;
-            a_off[p] = (long long)b * g.a_bstride + ((long long)by * g.Win + bx) * g.a_pstride;
+            a_yx[p] = (by << 16) | bx;
+            a_off[p] = STRIDED ? (long long)b * g.a_bstride
+                               : (long long)b * g.a_bstride + ((long long)by * g.Win + bx) * g.a_pstride;
         }
     }
     // per-thread W rows
@@ -178,7 +185,14 @@ __global__ void __launch_bounds__(kConvThreads, 3) igemm_fwd_kernel(ConvGroup gr
 #pragma unroll
         for (int p = 0; p < kAPasses; ++p) {
             vec_t v = vzero<VEC>();
-            if (c_ok && ((a_mask[p] >> tap) & 1u)) v = *reinterpret_cast<const vec_t*>(g.a + a_off[p] + tap_off + c);
+            if (c_ok && ((a_mask[p] >> tap) & 1u)) {
+                if (STRIDED) {
+                    const int iy = ((a_yx[p] >> 16) - ky) / g.stride, ix = ((a_yx[p] & 0xFFFF) - kx) / g.stride;
+                    v = *reinterpret_cast<const vec_t*>(g.a + a_off[p] + ((long long)iy * g.Win + ix) * g.a_pstride + c);
+                } else {
+                    v = *reinterpret_cast<const vec_t*>(g.a + a_off[p] + tap_off + c);
+                }
+            }
             ra[p] = v;
         }
 #pragma unroll
@@ -411,6 +425,17 @@ __global__ void __launch_bounds__(256) pack_dy_kernel(const float* __restrict__ 
     }
 }
 
+// db[n] += sum over rows of dy[row][n]   (dense [M][N] rows)
+__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ dy, long long M, int N, float* __restrict__ db,
+                                                     int rows_per_block) {
+    const long long m0 = (long long)blockIdx.x * rows_per_block, m1 = min(M, m0 + rows_per_block);
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        float s = 0.0f;
+        for (long long m = m0; m < m1; ++m) s += dy[m * N + n];
+        atomicAdd(db + n, s);
+    }
+}
+
 // Wd[c][tap][n] (n < Npad, zero padded) = W[n][tap][c]: the backward-data GEMM wants K = (tap, n) contiguous per c
 __global__ void __launch_bounds__(256) transpose_taps_kernel(const float* __restrict__ w0, const float* __restrict__ w1, int n0, int n1,
                                                              int Npad, int taps, int Cc, float* __restrict__ wd) {
@@ -469,7 +494,12 @@ static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t 
     }
     grp.count = count;
     grp.total_blocks = begin;
-    if (mirror) {
+    bool strided = false;
+    for (int i = 0; i < count; ++i) strided = strided || probs[i].stride != 1;
+    if (mirror && strided) {
+        if (vec4) hipLaunchKernelGGL((igemm_fwd_kernel<4, true, true>), dim3(begin), dim3(kConvThreads), 0, s, grp);
+        else hipLaunchKernelGGL((igemm_fwd_kernel<1, true, true>), dim3(begin), dim3(kConvThreads), 0, s, grp);
+    } else if (mirror) {
         if (vec4) hipLaunchKernelGGL((igemm_fwd_kernel<4, true>), dim3(begin), dim3(kConvThreads), 0, s, grp);
         else hipLaunchKernelGGL((igemm_fwd_kernel<1, true>), dim3(begin), dim3(kConvThreads), 0, s, grp);
     } else {
@@ -611,5 +641,133 @@ extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int b
         SSDK_CHECK_LAUNCH("igemm_wgrad_kernel");
     }
     (void)packed;
+    return SSDK_OK;
+}
+
+// ---- generic NHWC convolution (extras H2, Retina tower H3) on the same kernels --------------------------------------
+
+static int check_conv(const char* fn, int batch, const ssdk_conv_desc& d) {
+    SSDK_REQUIRE(batch > 0 && d.hin > 0 && d.win > 0 && d.cin > 0 && d.cout > 0, SSDK_E_INVALID, "%s: bad shape", fn);
+    SSDK_REQUIRE((d.ksize == 1 || d.ksize == 3) && d.stride >= 1 && d.stride <= 2 && d.pad >= 0 && d.pad < d.ksize, SSDK_E_UNSUPPORTED,
+                 "%s: ksize=%d stride=%d pad=%d (1x1 / 3x3, stride 1..2)", fn, d.ksize, d.stride, d.pad);
+    SSDK_REQUIRE(d.x && d.w, SSDK_E_INVALID, "%s: null pointer", fn);
+    SSDK_REQUIRE((d.hin + 2 * d.pad - d.ksize) / d.stride + 1 > 0 && (d.win + 2 * d.pad - d.ksize) / d.stride + 1 > 0, SSDK_E_INVALID, "%s: empty output", fn);
+    return SSDK_OK;
+}
+static inline int out_dim(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; }
+
+extern "C" int ssdk_conv2d_fwd(const ssdk_conv_desc* descs, int n, int batch, void* stream) {
+    SSDK_REQUIRE(descs && n > 0 && n <= kMaxProblems, SSDK_E_INVALID, "ssdk_conv2d_fwd: n=%d (1..%d)", n, kMaxProblems);
+    ConvProblem probs[kMaxProblems];
+    for (int i = 0; i < n; ++i) {
+        const ssdk_conv_desc& d = descs[i];
+        int rc = check_conv("ssdk_conv2d_fwd", batch, d);
+        if (rc) return rc;
+        SSDK_REQUIRE(d.y, SSDK_E_INVALID, "ssdk_conv2d_fwd: null output");
+        const int ho = out_dim(d.hin, d.ksize, d.stride, d.pad), wo = out_dim(d.win, d.ksize, d.stride, d.pad);
+        ConvProblem g{};
+        g.a = d.x; g.a_bstride = (long long)d.hin * d.win * d.cin; g.a_pstride = d.cin; g.Cc = d.cin;
+        g.B = batch; g.Hout = ho; g.Wout = wo; g.Hin = d.hin; g.Win = d.win; g.ksize = d.ksize; g.stride = d.stride; g.pad = d.pad;
+        g.w0 = d.w; g.w1 = nullptr; g.bias0 = d.bias; g.bias1 = nullptr; g.n0 = d.cout; g.n1 = 0;
+        g.o0 = d.y; g.ob0 = (long long)ho * wo * d.cout; g.os0 = d.cout; g.o1 = nullptr; g.ob1 = 0; g.os1 = 0;
+        g.relu = d.relu;
+        finish_problem(g);
+        probs[i] = g;
+    }
+    return launch_group(probs, n, false, (hipStream_t)stream);
+}
+
+extern "C" size_t ssdk_conv2d_bwd_workspace_bytes(const ssdk_conv_desc* descs, int n, int batch) {
+    (void)batch;
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        const ssdk_conv_desc& d = descs[i];
+        total += align_up((size_t)d.cin * d.ksize * d.ksize * (size_t)d.cout * sizeof(float), 256);
+    }
+    return total;
+}
+
+// dy: gradient w.r.t. the convolution output (AFTER any fused ReLU has been undone by the caller), [batch,hout,wout,cout]
+// with cout % 4 == 0.  dw / db are ACCUMULATED when `accumulate` != 0 (shared weights across levels), else overwritten.
+extern "C" int ssdk_conv2d_bwd(const ssdk_conv_desc* descs, int n, int batch, int accumulate, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+    SSDK_REQUIRE(descs && n > 0 && n <= kMaxProblems, SSDK_E_INVALID, "ssdk_conv2d_bwd: n=%d (1..%d)", n, kMaxProblems);
+    SSDK_REQUIRE(workspace && workspace_bytes >= ssdk_conv2d_bwd_workspace_bytes(descs, n, batch), SSDK_E_WORKSPACE, "ssdk_conv2d_bwd: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    Carver carve(workspace);
+    ConvProblem dgrad[kMaxProblems];
+    WgradGroup wg;
+    int n_dgrad = 0, n_wgrad = 0;
+    for (int i = 0; i < n; ++i) {
+        const ssdk_conv_desc& d = descs[i];
+        int rc = check_conv("ssdk_conv2d_bwd", batch, d);
+        if (rc) return rc;
+        SSDK_REQUIRE(d.dy, SSDK_E_INVALID, "ssdk_conv2d_bwd: null dy");
+        SSDK_REQUIRE(d.cout % 4 == 0 && d.cin % 4 == 0 && ((uintptr_t)d.dy & 15) == 0 && ((uintptr_t)d.x & 15) == 0, SSDK_E_UNSUPPORTED,
+                     "ssdk_conv2d_bwd: channels must be multiples of 4 and buffers 16-byte aligned");
+        const int ho = out_dim(d.hin, d.ksize, d.stride, d.pad), wo = out_dim(d.win, d.ksize, d.stride, d.pad);
+        const int taps = d.ksize * d.ksize;
+        const int npad = d.cout;  // no padding: the A rows are the caller's dy rows of exactly cout floats
+        float* wd = carve.take<float>((size_t)d.cin * taps * npad);
+        if (d.dx) {
+            hipLaunchKernelGGL(transpose_taps_kernel, dim3(cdiv(npad, 32), cdiv(d.cin, 32), taps), dim3(256), 0, s, d.w, (const float*)nullptr,
+                               d.cout, 0, npad, taps, d.cin, wd);
+            SSDK_CHECK_LAUNCH("transpose_taps_kernel");
+            ConvProblem g{};
+            // rows of the dgrad GEMM are INPUT pixels; its A operand is dy [ho*wo][cout], W = wd [cin][taps*cout]
+            g.a = d.dy; g.a_bstride = (long long)ho * wo * d.cout; g.a_pstride = d.cout; g.Cc = d.cout;
+            g.B = batch; g.Hout = d.hin; g.Wout = d.win; g.Hin = ho; g.Win = wo; g.ksize = d.ksize; g.stride = d.stride; g.pad = d.pad;
+            g.w0 = wd; g.w1 = nullptr; g.bias0 = nullptr; g.bias1 = nullptr; g.n0 = d.cin; g.n1 = 0;
+            g.o0 = d.dx; g.ob0 = (long long)d.hin * d.win * d.cin; g.os0 = d.cin; g.o1 = nullptr; g.ob1 = 0; g.os1 = 0;
+            g.relu = 0;
+            finish_problem(g);
+            dgrad[n_dgrad++] = g;
+        }
+        if (d.dw) {
+            if (!accumulate) SSDK_CHECK_HIP(hipMemsetAsync(d.dw, 0, sizeof(float) * (size_t)d.cout * taps * d.cin, s));
+            WgradProblem g{};
+            g.dy = d.dy; g.x = d.x; g.Npad = d.cout; g.Cc = d.cin;
+            g.B = batch; g.Hout = ho; g.Wout = wo; g.Hin = d.hin; g.Win = d.win; g.ksize = d.ksize; g.stride = d.stride; g.pad = d.pad;
+            g.dw0 = d.dw; g.dw1 = nullptr; g.n0 = d.cout; g.n1 = 0;
+            g.n_tiles = cdiv(d.cout, 128);
+            g.c_tiles32 = cdiv(d.cin, 32);
+            g.c_blocks = cdiv(g.c_tiles32, kMaxTN);
+            wg.p[n_wgrad++] = g;
+        }
+        if (d.db) {
+            if (!accumulate) SSDK_CHECK_HIP(hipMemsetAsync(d.db, 0, sizeof(float) * (size_t)d.cout, s));
+            const long long M = (long long)batch * ho * wo;
+            const int rows_per_block = 64;
+            hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((M + rows_per_block - 1) / rows_per_block)), dim3(256), 0, s, d.dy, M, d.cout,
+                               d.db, rows_per_block);
+            SSDK_CHECK_LAUNCH("colsum_kernel");
+        }
+    }
+    if (n_dgrad) {
+        int rc = launch_group(dgrad, n_dgrad, true, s);
+        if (rc) return rc;
+    }
+    if (n_wgrad) {
+        long long total_slices = 0;
+        for (int i = 0; i < n_wgrad; ++i) {
+            const WgradProblem& g = wg.p[i];
+            total_slices += (long long)g.ksize * g.ksize * g.n_tiles * g.c_blocks * cdiv(g.B * g.Hout * g.Wout, 32);
+        }
+        long long slices_per_block = total_slices / (256 * 6);
+        if (slices_per_block < 8) slices_per_block = 8;
+        int begin = 0;
+        for (int i = 0; i < n_wgrad; ++i) {
+            WgradProblem& g = wg.p[i];
+            const int slices = cdiv(g.B * g.Hout * g.Wout, 32);
+            int ks = (int)((slices + slices_per_block - 1) / slices_per_block);
+            g.k_splits = ks < 1 ? 1 : ks;
+            g.block_begin = begin;
+            begin += g.ksize * g.ksize * g.n_tiles * g.c_blocks * g.k_splits;
+        }
+        wg.count = n_wgrad;
+        wg.total_blocks = begin;
+        hipLaunchKernelGGL(igemm_wgrad_kernel, dim3(begin), dim3(kConvThreads), 0, s, wg);
+        SSDK_CHECK_LAUNCH("igemm_wgrad_kernel");
+    }
     return SSDK_OK;
 }

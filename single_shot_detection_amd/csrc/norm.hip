@@ -1,0 +1,180 @@
+// norm.hip -- BatchNorm2d (+ optional ReLU) on NHWC rows, forward and backward.
+//
+// Reference: bf/modules/conv.py:30-36 (Conv2dBn: conv -> BatchNorm2d -> ReLU, the SSD pyramid tail built by
+// detection/detector_builder.py:57-109) and detection/modules/predictors.py:60-76 (RetinaNet tower: conv -> ReLU ->
+// a BatchNorm2d per level).  torch.nn.BatchNorm2d semantics: training mode normalises with the biased batch variance
+// and updates running_mean / running_var (unbiased) with `momentum`; eval mode uses the running statistics.
+//
+// All three kernels are HBM-bound streams over a [rows = B*H*W][C] matrix (channels contiguous, so a wave reads whole
+// lines): bn_reduce_kernel accumulates two per-channel sums (64 rows per workgroup in registers, then one fp64 atomic
+// per channel), bn_finalize_kernel turns them into mean / rstd (and the running-stat update), bn_apply_kernel /
+// bn_bwd_apply_kernel are the elementwise passes with the ReLU fused.
+#include "common.h"
+
+namespace ssdk {
+
+constexpr int kBnRows = 64;
+
+// MODE 0: s0 = sum x, s1 = sum x^2.   MODE 1 (backward): s0 = sum dy', s1 = sum dy' * xhat, dy' = relu ? dy * (y > 0) : dy
+template <int MODE>
+__global__ void __launch_bounds__(256) bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+                                                        long long rows, int C, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        int relu, double* __restrict__ sums) {
+    const long long r0 = (long long)blockIdx.x * kBnRows, r1 = min(rows, r0 + kBnRows);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s0 = 0.0f, s1 = 0.0f;
+        if (MODE == 0) {
+            for (long long r = r0; r < r1; ++r) {
+                const float v = x[r * C + c];
+                s0 += v;
+                s1 += v * v;
+            }
+        } else {
+            const float m = mean[c], rs = rstd[c];
+            for (long long r = r0; r < r1; ++r) {
+                float g = dy[r * C + c];
+                if (relu && !(y[r * C + c] > 0.0f)) g = 0.0f;
+                s0 += g;
+                s1 += g * ((x[r * C + c] - m) * rs);
+            }
+        }
+        atomicAdd(sums + c, (double)s0);
+        atomicAdd(sums + C + c, (double)s1);
+    }
+}
+
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const double* __restrict__ sums, long long rows, int C, float eps, float momentum,
+                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                          float* __restrict__ save_mean, float* __restrict__ save_rstd) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        const double n = (double)rows;
+        const double m = sums[c] / n;
+        double var = sums[C + c] / n - m * m;
+        if (var < 0.0) var = 0.0;
+        save_mean[c] = (float)m;
+        save_rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)m;
+        if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(rows > 1 ? var * n / (n - 1.0) : var);
+    }
+}
+
+// eval mode: mean = running_mean, rstd = 1/sqrt(running_var + eps)
+__global__ void __launch_bounds__(256) bn_eval_stats_kernel(const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                                            int C, float eps, float* __restrict__ save_mean, float* __restrict__ save_rstd) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        save_mean[c] = running_mean[c];
+        save_rstd[c] = 1.0f / sqrtf(running_var[c] + eps);
+    }
+}
+
+__global__ void __launch_bounds__(256) bn_apply_kernel(const float4* __restrict__ x, long long n4, int C4, const float4* __restrict__ mean,
+                                                       const float4* __restrict__ rstd, const float4* __restrict__ gamma,
+                                                       const float4* __restrict__ beta, int relu, float4* __restrict__ y) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        const float4 v = x[i], m = mean[c], rs = rstd[c];
+        const float4 ga = gamma ? gamma[c] : make_float4(1.f, 1.f, 1.f, 1.f), be = beta ? beta[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 o = make_float4((v.x - m.x) * rs.x * ga.x + be.x, (v.y - m.y) * rs.y * ga.y + be.y, (v.z - m.z) * rs.z * ga.z + be.z,
+                               (v.w - m.w) * rs.w * ga.w + be.w);
+        if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+        y[i] = o;
+    }
+}
+
+// dx = gamma * rstd * (dy' - [training] (sum dy')/n - xhat * (sum dy' xhat)/n)
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+                                                           long long rows, int C, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const double* __restrict__ sums, int relu, int training,
+                                                           float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const long long total = rows * C;
+    const double inv_n = 1.0 / (double)rows;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        float g = dy[i];
+        if (relu && !(y[i] > 0.0f)) g = 0.0f;
+        const float rs = rstd[c], xhat = (x[i] - mean[c]) * rs;
+        const float ga = gamma ? gamma[c] : 1.0f;
+        float v = g;
+        if (training) v -= (float)(sums[c] * inv_n) + xhat * (float)(sums[C + c] * inv_n);
+        dx[i] = ga * rs * v;
+    }
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            if (dbeta) dbeta[c] = (float)sums[c];
+            if (dgamma) dgamma[c] = (float)sums[C + c];
+        }
+}
+
+static inline int stream_blocks(long long items, int per_block) {
+    long long b = (items + per_block - 1) / per_block;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace ssdk
+
+using namespace ssdk;
+
+extern "C" size_t ssdk_batchnorm_workspace_bytes(int channels) { return align_up((size_t)2 * channels * sizeof(double), 256); }
+
+extern "C" int ssdk_batchnorm_fwd(const float* x, long long rows, int channels, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, float momentum, float eps, int training, int relu, float* y,
+                                  float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes, void* stream) {
+    SSDK_REQUIRE(x && y && save_mean && save_rstd && rows > 0 && channels > 0, SSDK_E_INVALID, "ssdk_batchnorm_fwd: bad arguments");
+    SSDK_REQUIRE(channels % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, SSDK_E_UNSUPPORTED,
+                 "ssdk_batchnorm_fwd: channels %% 4 != 0 or buffers not 16-byte aligned");
+    SSDK_REQUIRE(training || (running_mean && running_var), SSDK_E_INVALID, "ssdk_batchnorm_fwd: eval mode needs running statistics");
+    hipStream_t s = (hipStream_t)stream;
+    if (training) {
+        SSDK_REQUIRE(workspace && workspace_bytes >= ssdk_batchnorm_workspace_bytes(channels), SSDK_E_WORKSPACE, "ssdk_batchnorm_fwd: workspace too small");
+        double* sums = (double*)workspace;
+        SSDK_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)channels, s));
+        hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3((unsigned)((rows + kBnRows - 1) / kBnRows)), dim3(256), 0, s, x, (const float*)nullptr,
+                           (const float*)nullptr, rows, channels, (const float*)nullptr, (const float*)nullptr, 0, sums);
+        SSDK_CHECK_LAUNCH("bn_reduce_kernel");
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(channels, 256)), dim3(256), 0, s, sums, rows, channels, eps, momentum, running_mean,
+                           running_var, save_mean, save_rstd);
+        SSDK_CHECK_LAUNCH("bn_finalize_kernel");
+    } else {
+        hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(channels, 256)), dim3(256), 0, s, running_mean, running_var, channels, eps, save_mean, save_rstd);
+        SSDK_CHECK_LAUNCH("bn_eval_stats_kernel");
+    }
+    const long long n4 = rows * channels / 4;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_blocks(n4, 256)), dim3(256), 0, s, (const float4*)x, n4, channels / 4, (const float4*)save_mean,
+                       (const float4*)save_rstd, (const float4*)gamma, (const float4*)beta, relu, (float4*)y);
+    SSDK_CHECK_LAUNCH("bn_apply_kernel");
+    return SSDK_OK;
+}
+
+extern "C" int ssdk_batchnorm_bwd(const float* x, const float* y, const float* dy, long long rows, int channels, const float* gamma,
+                                  const float* save_mean, const float* save_rstd, int relu, int training, float* dx, float* dgamma,
+                                  float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
+    SSDK_REQUIRE(x && dy && dx && save_mean && save_rstd && rows > 0 && channels > 0 && (!relu || y), SSDK_E_INVALID, "ssdk_batchnorm_bwd: bad arguments");
+    SSDK_REQUIRE(workspace && workspace_bytes >= ssdk_batchnorm_workspace_bytes(channels), SSDK_E_WORKSPACE, "ssdk_batchnorm_bwd: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    double* sums = (double*)workspace;
+    SSDK_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)channels, s));
+    hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3((unsigned)((rows + kBnRows - 1) / kBnRows)), dim3(256), 0, s, x, y, dy, rows, channels, save_mean,
+                       save_rstd, relu, sums);
+    SSDK_CHECK_LAUNCH("bn_reduce_kernel");
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_blocks(rows * channels, 256)), dim3(256), 0, s, x, y, dy, rows, channels, save_mean,
+                       save_rstd, gamma, sums, relu, training, dx, dgamma, dbeta);
+    SSDK_CHECK_LAUNCH("bn_bwd_apply_kernel");
+    return SSDK_OK;
+}
+
+// dx = (y > 0) ? dy : 0  -- undoes a ReLU that was fused into a convolution epilogue (predictors.py:67-68)
+namespace ssdk {
+__global__ void __launch_bounds__(256) relu_bwd_kernel(const float4* __restrict__ y, const float4* __restrict__ dy, long long n4, float4* __restrict__ dx) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 a = y[i], g = dy[i];
+        dx[i] = make_float4(a.x > 0.f ? g.x : 0.f, a.y > 0.f ? g.y : 0.f, a.z > 0.f ? g.z : 0.f, a.w > 0.f ? g.w : 0.f);
+    }
+}
+}  // namespace ssdk
+
+extern "C" int ssdk_relu_bwd(const float* y, const float* dy, long long n, float* dx, void* stream) {
+    SSDK_REQUIRE(y && dy && dx && n > 0 && n % 4 == 0, SSDK_E_INVALID, "ssdk_relu_bwd: bad arguments (n %% 4 == 0)");
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(stream_blocks(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)y, (const float4*)dy, n / 4, (float4*)dx);
+    SSDK_CHECK_LAUNCH("relu_bwd_kernel");
+    return SSDK_OK;
+}

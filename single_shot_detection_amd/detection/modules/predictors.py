@@ -1,11 +1,13 @@
 """SharedConvPredictor -- mirror of detection/modules/predictors.py:8-76 (RetinaNet tower: per layer one 3x3 conv
 SHARED across levels, then ReLU, then a BatchNorm PER LEVEL; separate score and loc towers).  Module nesting and names
-follow the reference so checkpoints map 1:1.  Round 1 runs the tower on stock PyTorch-ROCm ops; the heads behind it
-run on libssdk."""
+follow the reference so checkpoints map 1:1.  Each tower layer is ONE grouped implicit-GEMM launch over the five
+levels (shared weights, ReLU fused into the epilogue, csrc/conv.hip) followed by the per-level BatchNorm kernels
+(csrc/norm.hip)."""
 import functools
 
 import torch.nn as nn
 
+from ... import ops
 from ...bf.modules import conv
 
 
@@ -39,10 +41,17 @@ class SharedConvPredictor(nn.Module):
                 nn.init.zeros_(layer.bias)
         self.convs.apply(_init_predictor)
 
+    def _layer(self, block, norms, xs):
+        if isinstance(block, conv.Conv2dBn) and isinstance(self.activation, nn.ReLU) and block._hip_ok():
+            c = block.conv
+            ys = ops.conv2d(list(xs), c.weight, c.bias, stride=c.stride[0], padding=c.padding[0], relu=True)
+            return [ops.batch_norm(y, norm) for norm, y in zip(norms, ys)]
+        return [norm(self.activation(block(x))) for norm, x in zip(norms, xs)]   # depthwise towers: stock ops
+
     def forward(self, sources):  # predictors.py:60-76: conv -> activation -> per-level norm
         score_sources = loc_sources = list(sources)
         for score_conv, loc_conv, score_norm, loc_norm in zip(self.convs['score'], self.convs['loc'], self.norms['score'],
                                                               self.norms['loc']):
-            score_sources = [norm(self.activation(score_conv(x))) for norm, x in zip(score_norm, score_sources)]
-            loc_sources = [norm(self.activation(loc_conv(x))) for norm, x in zip(loc_norm, loc_sources)]
+            score_sources = self._layer(score_conv, score_norm, score_sources)
+            loc_sources = self._layer(loc_conv, loc_norm, loc_sources)
         return score_sources, loc_sources

@@ -1,0 +1,140 @@
+"""Autograd wrappers over libssdk's generic NHWC convolution and BatchNorm (csrc/conv.hip, csrc/norm.hip).
+
+Tensors are logical [B,C,H,W] with channels_last memory (= the NHWC buffers the kernels read); weights are logical
+[Cout,Cin,k,k] with channels_last memory (= [Cout][k][k][Cin]).  GPU only -- CPU tensors raise.
+"""
+import torch
+
+from . import _lib
+
+
+def _nhwc(x):
+    return x.float().contiguous(memory_format=torch.channels_last)
+
+
+def _dp(t):
+    return None if t is None or t.numel() == 0 else t.data_ptr()
+
+
+def _out_dim(n, k, s, p):
+    return (n + 2 * p - k) // s + 1
+
+
+class _ConvFn(torch.autograd.Function):
+    """apply(weight, bias, stride, pad, relu, *xs) -> tuple of outputs; the n inputs share `weight` (one grouped launch)."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, stride, pad, relu, *xs):
+        lib = _lib.lib()
+        _lib.require_cuda(weight, *xs)
+        w = weight.float().contiguous(memory_format=torch.channels_last)
+        b = None if bias is None else bias.float().contiguous()
+        cout, cin, k, k2 = w.shape
+        assert k == k2
+        xs = [_nhwc(x) for x in xs]
+        B = xs[0].shape[0]
+        ys = []
+        arr = (_lib.ConvDesc * len(xs))()
+        for i, x in enumerate(xs):
+            assert x.shape[0] == B and x.shape[1] == cin, (tuple(x.shape), cin)
+            ho, wo = _out_dim(x.shape[2], k, stride, pad), _out_dim(x.shape[3], k, stride, pad)
+            y = torch.empty((B, cout, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+            ys.append(y)
+            d = arr[i]
+            d.x, d.hin, d.win, d.cin = _dp(x), x.shape[2], x.shape[3], cin
+            d.w, d.bias, d.cout, d.ksize, d.stride, d.pad, d.relu = _dp(w), _dp(b), cout, k, stride, pad, int(relu)
+            d.y = _dp(y)
+        _lib.check(lib.ssdk_conv2d_fwd(arr, len(xs), B, _lib.current_stream()), 'ssdk_conv2d_fwd')
+        ctx.save_for_backward(w, *xs, *(ys if relu else []))
+        ctx.meta = (stride, pad, bool(relu), len(xs), bias is not None)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        lib = _lib.lib()
+        stride, pad, relu, n, has_bias = ctx.meta
+        saved = ctx.saved_tensors
+        w, xs = saved[0], saved[1:1 + n]
+        ys = saved[1 + n:] if relu else [None] * n
+        cout, cin, k, _ = w.shape
+        B = xs[0].shape[0]
+        stream = _lib.current_stream()
+        need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and has_bias
+        dw = torch.zeros_like(w, memory_format=torch.channels_last) if need_w else None
+        db = torch.zeros((cout,), dtype=torch.float32, device=w.device) if need_b else None
+        arr = (_lib.ConvDesc * n)()
+        dxs, keep = [], []
+        for i in range(n):
+            x = xs[i]
+            dy = _nhwc(dys[i])
+            if relu:  # undo the ReLU fused into the forward epilogue
+                g = torch.empty_like(dy, memory_format=torch.channels_last)
+                _lib.check(lib.ssdk_relu_bwd(_dp(ys[i]), _dp(dy), dy.numel(), _dp(g), stream), 'ssdk_relu_bwd')
+                dy = g
+            keep.append(dy)
+            dx = torch.empty_like(x, memory_format=torch.channels_last) if ctx.needs_input_grad[5 + i] else None
+            dxs.append(dx)
+            d = arr[i]
+            d.x, d.hin, d.win, d.cin = _dp(x), x.shape[2], x.shape[3], cin
+            d.w, d.bias, d.cout, d.ksize, d.stride, d.pad, d.relu = _dp(w), None, cout, k, stride, pad, 0
+            d.dy, d.dx, d.dw, d.db = _dp(dy), _dp(dx), _dp(dw), _dp(db)
+        need = lib.ssdk_conv2d_bwd_workspace_bytes(arr, n, B)
+        ws = torch.empty((max(need, 256),), dtype=torch.uint8, device=w.device)
+        _lib.check(lib.ssdk_conv2d_bwd(arr, n, B, 1, _dp(ws), ws.numel(), stream), 'ssdk_conv2d_bwd')   # dw/db pre-zeroed
+        return (dw, db, None, None, None) + tuple(dxs)
+
+
+def conv2d(xs, weight, bias=None, stride=1, padding=0, relu=False):
+    """Conv2d on a list of maps that share the weights (one grouped GEMM launch); returns a list."""
+    single = isinstance(xs, torch.Tensor)
+    out = _ConvFn.apply(weight, bias, int(stride), int(padding), bool(relu), *([xs] if single else list(xs)))
+    return out[0] if single else list(out)
+
+
+class _BatchNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training, relu):
+        lib = _lib.lib()
+        _lib.require_cuda(x)
+        x = _nhwc(x)
+        B, C, H, W = x.shape
+        rows = B * H * W
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+        mean = torch.empty((C,), dtype=torch.float32, device=x.device)
+        rstd = torch.empty((C,), dtype=torch.float32, device=x.device)
+        ws = torch.empty((lib.ssdk_batchnorm_workspace_bytes(C),), dtype=torch.uint8, device=x.device)
+        g = None if gamma is None else gamma.float().contiguous()
+        b = None if beta is None else beta.float().contiguous()
+        _lib.check(lib.ssdk_batchnorm_fwd(_dp(x), rows, C, _dp(g), _dp(b), _dp(running_mean), _dp(running_var), float(momentum),
+                                          float(eps), int(training), int(relu), _dp(y), _dp(mean), _dp(rstd), _dp(ws), ws.numel(),
+                                          _lib.current_stream()), 'ssdk_batchnorm_fwd')
+        ctx.save_for_backward(x, y if relu else x.new_empty(0), g if g is not None else x.new_empty(0), mean, rstd)
+        ctx.meta = (bool(relu), bool(training), gamma is not None, beta is not None)
+        ctx.mark_non_differentiable(mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.lib()
+        x, y, g, mean, rstd = ctx.saved_tensors
+        relu, training, has_g, has_b = ctx.meta
+        B, C, H, W = x.shape
+        dy = _nhwc(dy)
+        dx = torch.empty_like(x, memory_format=torch.channels_last)
+        dgamma = torch.empty((C,), dtype=torch.float32, device=x.device)
+        dbeta = torch.empty((C,), dtype=torch.float32, device=x.device)
+        ws = torch.empty((lib.ssdk_batchnorm_workspace_bytes(C),), dtype=torch.uint8, device=x.device)
+        _lib.check(lib.ssdk_batchnorm_bwd(_dp(x), _dp(y) if relu else None, _dp(dy), B * H * W, C, _dp(g) if has_g else None, _dp(mean),
+                                          _dp(rstd), int(relu), int(training), _dp(dx), _dp(dgamma), _dp(dbeta), _dp(ws), ws.numel(),
+                                          _lib.current_stream()), 'ssdk_batchnorm_bwd')
+        return dx, dgamma if has_g else None, dbeta if has_b else None, None, None, None, None, None, None
+
+
+def batch_norm(x, bn, relu=False):
+    """``bn`` is a torch.nn.BatchNorm2d (its parameters / buffers are used and updated exactly like torch does)."""
+    if bn.momentum is None or not bn.track_running_stats:
+        raise NotImplementedError('BatchNorm2d with momentum=None / track_running_stats=False is not on the GPU path')
+    training = bn.training
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, training, relu)

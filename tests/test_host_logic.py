@@ -73,9 +73,10 @@ def test_builder_shapes_and_state_dict_keys():
     assert heads[0]['score'].weight.is_contiguous(memory_format=torch.channels_last)
     assert torch.allclose(heads[0]['score'].bias, torch.full((84,), -4.6))
     extras = detector_builder.get_extras([512], layers=(('s', 512), ('s', 256)))
-    x = torch.zeros((1, 512, 18, 18))
-    y = extras[0](x)
-    assert y.shape == (1, 512, 9, 9) and extras[1](y).shape == (1, 256, 5, 5)
+    assert extras[0][0].conv.weight.shape == (256, 512, 1, 1) and extras[0][1].conv.stride == (2, 2)
+    assert extras[1][1].conv.weight.shape == (256, 128, 3, 3)
+    with pytest.raises(_lib.SsdkError):      # the tail runs on libssdk: CPU tensors are refused, there is no fallback
+        extras[0](torch.zeros((1, 512, 18, 18)))
     assert {'0.0.conv.weight', '0.0.bn.weight', '0.1.conv.weight'} <= set(extras.state_dict().keys())
 
 
