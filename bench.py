@@ -4,15 +4,17 @@
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched under torch.distributed.run, one rank per GPU)
 
 A "step" is one pass of the hot path over one batch of synthetic input, inputs resident in HBM:
-    multi-scale heads forward (fused score|loc implicit GEMMs, all levels)          H1
+    pyramid tail: conv-BN-ReLU extras on the last backbone tap (SSD configs)        H2
+    -> multi-scale heads forward (fused score|loc implicit GEMMs, all levels)       H1
     -> device-resident anchors (cached)                                             A1
     -> IoU match + target encode                                                    T1-T3
     -> hard-negative mining + multibox loss forward                                 S1, L1-L3
-    -> loss backward + heads backward (dgrad, wgrad, dbias)                         L1, H1
+    -> loss backward + heads backward (dgrad, wgrad, dbias) + extras backward       L1, H1, H2
     -> (N > 1) RCCL all-reduce of the flat head-gradient bucket
     -> SGD step on the head parameters (stock torch optimizer: the runtime's, kept so no training work is skipped)
-Workload: BASELINE.json configs[1] -- ssd_300_vgg16_voc, batch 32 per GPU, 81 classes (the literal of the sample file),
-source maps N(0,1) at the probed shapes.  Weak scaling: per-GPU batch fixed.
+Workload: BASELINE.json configs[1] -- ssd_300_vgg16_voc, batch 32 per GPU, 81 classes (the literal of the sample file):
+the two backbone taps (512@37x37, 512@18x18) are N(0,1) NHWC tensors (the backbone itself stays PyTorch-ROCm and is not part
+of the path); the four extras blocks derive the remaining levels.  Weak scaling: per-GPU batch fixed.
 The postprocess (eval) leg is timed separately and reported as nms_boxes_per_sec / postprocess_images_per_sec.
 """
 import argparse
@@ -28,6 +30,11 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 from single_shot_detection_amd import synthetic as syn  # noqa: E402
+from single_shot_detection_amd.distributed import GradBucket  # noqa: E402
+
+# extras of the SSD sample files (samples/ssd_300_vgg16_voc.py:16-18, ssd_512_vgg16_coco.py)
+EXTRAS = {'ssd_300_vgg16_voc': (('s', 512), ('s', 256), ('s', 256), ('s', 256)),
+          'ssd_512_vgg16_coco': (('s', 512), ('s', 256), ('s', 256), ('s', 256), ('s', 256))}
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
@@ -52,8 +59,14 @@ class HotPath(object):
         torch.manual_seed(seed)
         self.heads = detector_builder.get_heads([l[0] for l in self.levels], [l[2] for l in self.levels], self.C,
                                                 score_head_bias_init=(-4.6 if cfg['loss'] != 'ce_hnm' else 0.0)).to(device)
-        fm = syn.make_feature_maps(batch, self.levels, seed=seed)
-        self.sources = [torch.from_numpy(x).to(device).contiguous(memory_format=torch.channels_last).requires_grad_(True) for x in fm]
+        # SSD configs: the backbone taps are the inputs, the extras (H2) derive the other levels; otherwise all levels are inputs
+        self.extras = None
+        n_in = len(self.levels)
+        if cfg_name in EXTRAS:
+            n_in = len(self.levels) - len(EXTRAS[cfg_name])
+            self.extras = detector_builder.get_extras([self.levels[n_in - 1][0]], layers=EXTRAS[cfg_name]).to(device)
+        fm = syn.make_feature_maps(batch, self.levels[:n_in], seed=seed)
+        self.inputs = [torch.from_numpy(x).to(device).contiguous(memory_format=torch.channels_last).requires_grad_(True) for x in fm]
         p = dict(cfg['anchor'])
         gens = getattr(anchor_generators, p.pop('type')).build_anchor_generators(**p)
         img = torch.empty((1, 3, cfg['size'], cfg['size']), device=device)
@@ -74,16 +87,28 @@ class HotPath(object):
         self.assigner = TargetAssigner(cfg['matched'], cfg['unmatched'])
         self.post = Postprocessor(box_coder, score_threshold=0.01, nms={'max_per_class': 100, 'overlap_threshold': cfg['nms_thr']},
                                   score_converter=cfg['score_converter'], max_total=200)
-        self.params = [p for p in self.heads.parameters()]
+        self.params = [p for p in self.heads.parameters()] + ([p for p in self.extras.parameters()] if self.extras is not None else [])
         self.opt = torch.optim.SGD(self.params, lr=1e-3, momentum=0.9, weight_decay=5e-4)
+        self.bucket = GradBucket(self.params)
         self.fwd_events = []
+
+    def pyramid(self):
+        sources = list(self.inputs)
+        if self.extras is not None:
+            x = sources[-1]
+            for layer in self.extras:   # detector.py:39-43
+                x = layer(x)
+                sources.append(x)
+        assert [tuple(s.shape[1:3]) for s in sources] == [(c, h) for c, h, _ in self.levels], [tuple(s.shape) for s in sources]
+        return sources
 
     def forward_heads(self, timed=False):
         from single_shot_detection_amd.detection.modules.heads import multi_level_heads
+        sources = self.pyramid()
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        out = multi_level_heads(self.sources, self.sources, self.heads)
+        out = multi_level_heads(sources, sources, self.heads)
         if timed:
             e1.record()
             self.fwd_events.append((e0, e1))
@@ -91,22 +116,14 @@ class HotPath(object):
 
     def train_step(self, world=1, timed=False):
         self.opt.zero_grad(set_to_none=True)
-        for s in self.sources:
+        for s in self.inputs:
             s.grad = None
         scores, locs = self.forward_heads(timed)
         target = self.assigner.encode_ground_truth(self.gt, self.anchors)
         loss, class_loss, loc_loss = self.criterion((scores, locs), self.anchors, target)
         loss.backward()
         if world > 1:
-            import torch.distributed as dist
-            flat = torch.cat([p.grad.reshape(-1) for p in self.params])
-            dist.all_reduce(flat)
-            flat.div_(world)
-            off = 0
-            for p in self.params:
-                n = p.numel()
-                p.grad.copy_(flat[off:off + n].view_as(p.grad))
-                off += n
+            self.bucket.allreduce_()    # one flat fp32 bucket over RCCL/xGMI
         self.opt.step()
         return loss
 
@@ -139,7 +156,9 @@ def cpu_baseline(hp, sample_images=4):
     t_small = (time.perf_counter() - t0) / B
     torch.set_num_threads(threads)
     sb = min(sample_images, B)
-    xs = [s.detach()[:sb].cpu().contiguous().requires_grad_(True) for s in hp.sources]
+    with torch.no_grad():
+        srcs = hp.pyramid()
+    xs = [s.detach()[:sb].cpu().contiguous().requires_grad_(True) for s in srcs]
     ws = [(h['score'].weight.detach().cpu().contiguous().requires_grad_(True), h['score'].bias.detach().cpu().requires_grad_(True),
            h['loc'].weight.detach().cpu().contiguous().requires_grad_(True), h['loc'].bias.detach().cpu().requires_grad_(True)) for h in hp.heads]
     t0 = time.perf_counter()
@@ -230,8 +249,8 @@ def main():
             'value': value, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'{args.config}: heads fwd+bwd (fp32 MFMA) + IoU-match + HNM/multibox loss fwd+bwd + SGD on head params; '
-                                   f'source maps N(0,1) NHWC at the probed shapes, C={hp.C}, A={A}, G~U{{1..8}}',
+            'config': {'workload': f'{args.config}: extras conv-BN-ReLU + heads fwd+bwd (fp32 MFMA) + IoU-match + HNM/multibox loss fwd+bwd + SGD on '
+                                   f'head/extras params; backbone taps N(0,1) NHWC at the probed shapes, C={hp.C}, A={A}, G~U{{1..8}}',
                        'global_batch': world * args.batch, 'per_gpu_batch': args.batch, 'parallelism': f'dp{world}'},
             'nms_boxes_per_sec': world * cand / dtp, 'postprocess_images_per_sec': world * args.batch / dtp,
             'eval_images_per_sec': world * args.batch / dte, 'nms_candidates_per_image': cand / args.batch,

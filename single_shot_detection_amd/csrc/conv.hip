@@ -88,7 +88,7 @@ __device__ __forceinline__ float vzero<1>() { return 0.f; }
 // forward GEMMs and the dgrad GEMMs as different kernels).
 // STRIDED (backward-data of a strided convolution only): the source pixel of a tap is (y + pad - k) / stride when
 // divisible, so the tap offset is no longer uniform over the rows; it is recomputed per row and slice.
-template <int VEC, bool MIRROR, bool STRIDED = false>
+template <int VEC, bool MIRROR, bool STRIDED = false, bool GENERIC = false>
 __global__ void __launch_bounds__(kConvThreads, 3) igemm_fwd_kernel(ConvGroup grp) {
     typedef typename VecT<VEC>::type vec_t;
     constexpr int kVecPerRow = kBK / VEC;  // vector loads per 32-float row slice
@@ -476,7 +476,7 @@ static long long problem_block_work(const ConvProblem& g) {
 }
 
 // orders the problems by decreasing work per workgroup (longest first), assigns block ranges, launches
-static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t s) {
+static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t s, bool generic = false) {
     ConvGroup grp;
     int order[kMaxProblems];
     for (int i = 0; i < count; ++i) order[i] = i;
@@ -502,6 +502,9 @@ static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t 
     } else if (mirror) {
         if (vec4) hipLaunchKernelGGL((igemm_fwd_kernel<4, true>), dim3(begin), dim3(kConvThreads), 0, s, grp);
         else hipLaunchKernelGGL((igemm_fwd_kernel<1, true>), dim3(begin), dim3(kConvThreads), 0, s, grp);
+    } else if (generic) {  // same code, separate instantiation: profiles list the extras/tower convs apart from the heads
+        if (vec4) hipLaunchKernelGGL((igemm_fwd_kernel<4, false, false, true>), dim3(begin), dim3(kConvThreads), 0, s, grp);
+        else hipLaunchKernelGGL((igemm_fwd_kernel<1, false, false, true>), dim3(begin), dim3(kConvThreads), 0, s, grp);
     } else {
         if (vec4) hipLaunchKernelGGL((igemm_fwd_kernel<4, false>), dim3(begin), dim3(kConvThreads), 0, s, grp);
         else hipLaunchKernelGGL((igemm_fwd_kernel<1, false>), dim3(begin), dim3(kConvThreads), 0, s, grp);
@@ -674,7 +677,7 @@ extern "C" int ssdk_conv2d_fwd(const ssdk_conv_desc* descs, int n, int batch, vo
         finish_problem(g);
         probs[i] = g;
     }
-    return launch_group(probs, n, false, (hipStream_t)stream);
+    return launch_group(probs, n, false, (hipStream_t)stream, true);
 }
 
 extern "C" size_t ssdk_conv2d_bwd_workspace_bytes(const ssdk_conv_desc* descs, int n, int batch) {
