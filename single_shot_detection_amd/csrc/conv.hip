@@ -62,6 +62,13 @@ struct ConvProblem {
     int tiles_n, n_blocks, m_tiles;
     int block_begin;  // first workgroup of this problem in the grouped grid
     int relu;
+    // device-side mode switch (sparse backward): the launch is a no-op for this problem unless *mode == want_mode
+    const int* mode;
+    int want_mode;
+    // SCATTER instantiation: rows are the entries of row_list (pixel ids with a non-zero gradient row), *row_count of them
+    const int* row_list;
+    const int* row_count;
+    int sc_cin;  // scatter: output channels per tap (n = tap * sc_cin + c)
 };
 
 struct ConvGroup {
@@ -88,7 +95,7 @@ __device__ __forceinline__ float vzero<1>() { return 0.f; }
 // forward GEMMs and the dgrad GEMMs as different kernels).
 // STRIDED (backward-data of a strided convolution only): the source pixel of a tap is (y + pad - k) / stride when
 // divisible, so the tap offset is no longer uniform over the rows; it is recomputed per row and slice.
-template <int VEC, bool MIRROR, bool STRIDED = false, bool GENERIC = false>
+template <int VEC, bool MIRROR, bool STRIDED = false, bool GENERIC = false, bool SCATTER = false>
 __global__ void __launch_bounds__(kConvThreads, 3) igemm_fwd_kernel(ConvGroup grp) {
     typedef typename VecT<VEC>::type vec_t;
     constexpr int kVecPerRow = kBK / VEC;  // vector loads per 32-float row slice
@@ -107,6 +114,7 @@ __global__ void __launch_bounds__(kConvThreads, 3) igemm_fwd_kernel(ConvGroup gr
 
     // workgroups that share an M tile get the same (id % 8) inside the problem (same XCD under round-robin placement
     // when block_begin % 8 == 0: they re-read the same activation rows from one L2).  Speed only.
+    if (g.mode && *g.mode != g.want_mode) return;
     const int id = blockIdx.x - g.block_begin;
     const int per_chunk = 8 * g.n_blocks;
     const int chunk = id / per_chunk, within = id % per_chunk;
@@ -115,13 +123,14 @@ __global__ void __launch_bounds__(kConvThreads, 3) igemm_fwd_kernel(ConvGroup gr
     if (m_tile >= g.m_tiles) return;
 
     const int Cc = g.Cc;
-    const int taps = g.ksize * g.ksize;
+    const int taps = SCATTER ? 1 : g.ksize * g.ksize;   // scatter: the taps live in N, K is just the channels
     const int chunks = (Cc + kBK - 1) / kBK;
     const int n_slices = taps * chunks;
     const long long K = (long long)taps * Cc;
     const int N = g.n0 + g.n1;
     const int hw = g.Hout * g.Wout;
-    const int M = g.B * hw;
+    const int M = SCATTER ? *g.row_count : g.B * hw;
+    if (SCATTER && m_tile * kBM >= M) return;
 
     const int base_t = g.tiles_n / g.n_blocks, rem_t = g.tiles_n % g.n_blocks;
     const int tn = base_t + (n_block < rem_t ? 1 : 0);
@@ -140,7 +149,12 @@ __global__ void __launch_bounds__(kConvThreads, 3) igemm_fwd_kernel(ConvGroup gr
         a_off[p] = 0;
         a_mask[p] = 0;
         a_yx[p] = 0;
-        if (m < M) {
+        if (SCATTER) {
+            if (m < M) {
+                a_mask[p] = 1u;
+                a_off[p] = (long long)g.row_list[m] * g.a_pstride;
+            }
+        } else if (m < M) {
             const int b = m / hw, r = m % hw;
             const int y = r / g.Wout, x = r % g.Wout;
             unsigned mask = 0;
@@ -249,6 +263,29 @@ __global__ void __launch_bounds__(kConvThreads, 3) igemm_fwd_kernel(ConvGroup gr
     }
 
     // epilogue: C/D map of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+    if (SCATTER) {
+        // row = a pixel with a non-zero output gradient; column n = tap * Cin + c: add the product into the input-gradient
+        // pixel that tap connects it to (yo - pad + ky, xo - pad + kx).  32 consecutive lanes = 32 consecutive c of one tap.
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = m_tile * kBM + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (m >= M) continue;
+            const int pid = g.row_list[m];
+            const int b = pid / hw, r = pid % hw;
+            const int yo = r / g.Wout, xo = r % g.Wout;
+#pragma unroll
+            for (int j = 0; j < kMaxTN; ++j) {
+                if (j >= tn) continue;
+                const int n = n_begin + j * 32 + r32;
+                if (n >= N) continue;
+                const int tap = n / g.sc_cin, c = n % g.sc_cin;
+                const int ty = yo - g.pad + tap / g.ksize, tx = xo - g.pad + tap % g.ksize;
+                if (ty >= 0 && ty < g.Hin && tx >= 0 && tx < g.Win)
+                    atomicAdd(g.o0 + (long long)b * g.ob0 + ((long long)ty * g.Win + tx) * g.os0 + c, acc[j][e]);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int m = m_tile * kBM + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -285,6 +322,10 @@ struct WgradProblem {
     int n0, n1;
     int k_splits, n_tiles, c_tiles32, c_blocks;
     int block_begin;
+    const int* mode;       // no-op unless *mode == want_mode (NULL: always run)
+    int want_mode;
+    const int* row_list;   // sparse: contract only over these pixel ids (*row_count of them)
+    const int* row_count;
 };
 struct WgradGroup {
     int count;
@@ -303,6 +344,7 @@ __global__ void __launch_bounds__(kConvThreads, 3) igemm_wgrad_kernel(WgradGroup
         if ((int)blockIdx.x >= grp.p[i].block_begin) pi = i;
     const WgradProblem& g = grp.p[pi];
 
+    if (g.mode && *g.mode != g.want_mode) return;
     const int Cc = g.Cc;
     const int N = g.n0 + g.n1;
     const int taps = g.ksize * g.ksize;
@@ -319,7 +361,7 @@ __global__ void __launch_bounds__(kConvThreads, 3) igemm_wgrad_kernel(WgradGroup
     const int n_begin = nt * 128;
 
     const int hw = g.Hout * g.Wout;
-    const int M = g.B * hw;
+    const int M = g.row_list ? *g.row_count : g.B * hw;   // rows of the contraction (compacted when sparse)
     const int slices_total = (M + 31) / 32;
     const int per = (slices_total + g.k_splits - 1) / g.k_splits;
     const int s_begin = ksp * per, s_end = min(slices_total, s_begin + per);
@@ -340,9 +382,10 @@ __global__ void __launch_bounds__(kConvThreads, 3) igemm_wgrad_kernel(WgradGroup
     auto load_slice = [&](int s) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const int m = s * 32 + srow + p * 8;
+            const int mi = s * 32 + srow + p * 8;
             float4 vd = make_float4(0.f, 0.f, 0.f, 0.f), vx = vd;
-            if (m < M) {
+            if (mi < M) {
+                const int m = g.row_list ? g.row_list[mi] : mi;
                 if (n_begin + scol < g.Npad) vd = *reinterpret_cast<const float4*>(g.dy + (long long)m * g.Npad + n_begin + scol);
                 const int c = c_begin + scol;
                 if (scol < tn * 32 && c < Cc) {
@@ -402,13 +445,21 @@ __global__ void __launch_bounds__(kConvThreads, 3) igemm_wgrad_kernel(WgradGroup
 
 // ---- dY pack (+ bias gradient) --------------------------------------------------------------------------------------
 // out[m][n] (n < Npad) = n < n0 ? ds[b*sb + p*n0 + n] : (n < n0+n1 ? dl[b*lb + p*n1 + n-n0] : 0);  db += column sums
+// Also appends the ids of the rows that are not entirely zero to row_list (order inside a block preserved, blocks in
+// completion order) and counts them: the loss gradient is non-zero only on sampled anchors, i.e. on a few % of the pixels.
+constexpr int kPackRows = 32;
 __global__ void __launch_bounds__(256) pack_dy_kernel(const float* __restrict__ ds, long long sb, const float* __restrict__ dl,
                                                       long long lb, int n0, int n1, int Npad, int B, int HW,
                                                       float* __restrict__ out, float* __restrict__ db0, float* __restrict__ db1,
-                                                      int rows_per_block) {
+                                                      int* __restrict__ row_list, int* __restrict__ row_count) {
+    __shared__ unsigned s_flag;
+    __shared__ int s_base;
     const long long M = (long long)B * HW;
-    const long long m0 = (long long)blockIdx.x * rows_per_block, m1 = min(M, m0 + rows_per_block);
+    const long long m0 = (long long)blockIdx.x * kPackRows, m1 = min(M, m0 + kPackRows);
     const int N = n0 + n1;
+    if (threadIdx.x == 0) s_flag = 0u;
+    __syncthreads();
+    unsigned mine = 0u;
     for (int n = threadIdx.x; n < Npad; n += blockDim.x) {
         float s = 0.0f;
         for (long long m = m0; m < m1; ++m) {
@@ -419,10 +470,26 @@ __global__ void __launch_bounds__(256) pack_dy_kernel(const float* __restrict__ 
             else if (n < N) v = dl[(long long)b * lb + p * n1 + (n - n0)];
             out[m * Npad + n] = v;
             s += v;
+            if (v != 0.0f) mine |= 1u << (int)(m - m0);
         }
-        if (n < n0) { if (db0) atomicAdd(db0 + n, s); }
-        else if (n < N) { if (db1) atomicAdd(db1 + (n - n0), s); }
+        if (s != 0.0f) {
+            if (n < n0) { if (db0) atomicAdd(db0 + n, s); }
+            else if (n < N) { if (db1) atomicAdd(db1 + (n - n0), s); }
+        }
     }
+    if (mine) atomicOr(&s_flag, mine);
+    __syncthreads();
+    const unsigned flags = s_flag;
+    if (threadIdx.x == 0) s_base = flags ? atomicAdd(row_count, __popc(flags)) : 0;
+    __syncthreads();
+    if (threadIdx.x < kPackRows && ((flags >> threadIdx.x) & 1u))
+        row_list[s_base + __popc(flags & ((1u << threadIdx.x) - 1u))] = (int)(m0 + threadIdx.x);
+}
+
+// mode[i] = 1 (sparse backward) when fewer than 1/4 of the level's pixel rows carry a gradient, else 0 (dense)
+__global__ void decide_sparse_kernel(const int* __restrict__ counts, const int* __restrict__ totals, int n, int* __restrict__ mode) {
+    const int i = threadIdx.x;
+    if (i < n) mode[i] = (counts[i] * 4 < totals[i]) ? 1 : 0;
 }
 
 // db[n] += sum over rows of dy[row][n]   (dense [M][N] rows)
@@ -457,6 +524,27 @@ __global__ void __launch_bounds__(256) transpose_taps_kernel(const float* __rest
     }
 }
 
+// Wt[tap][c][n] (n < Npad, zero padded) = W[n][tap][c]: rows of the scatter GEMM (n' = tap * Cc + c), K = n contiguous
+__global__ void __launch_bounds__(256) transpose_tapmajor_kernel(const float* __restrict__ w0, const float* __restrict__ w1, int n0, int n1,
+                                                                 int Npad, int taps, int Cc, float* __restrict__ wt) {
+    __shared__ float tile[32][33];
+    const int N = n0 + n1;
+    const int tap = blockIdx.z;
+    const int nb = blockIdx.x * 32, cb = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int n = nb + r, c = cb + tx;
+        float v = 0.0f;
+        if (n < N && c < Cc) v = n < n0 ? w0[((long long)n * taps + tap) * Cc + c] : w1[((long long)(n - n0) * taps + tap) * Cc + c];
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = cb + r, n = nb + tx;
+        if (n < Npad && c < Cc) wt[((long long)tap * Cc + c) * Npad + n] = tile[tx][r];
+    }
+}
+
 }  // namespace ssdk
 
 using namespace ssdk;
@@ -476,7 +564,7 @@ static long long problem_block_work(const ConvProblem& g) {
 }
 
 // orders the problems by decreasing work per workgroup (longest first), assigns block ranges, launches
-static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t s, bool generic = false) {
+static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t s, bool generic = false, bool scatter = false) {
     ConvGroup grp;
     int order[kMaxProblems];
     for (int i = 0; i < count; ++i) order[i] = i;
@@ -496,7 +584,10 @@ static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t 
     grp.total_blocks = begin;
     bool strided = false;
     for (int i = 0; i < count; ++i) strided = strided || probs[i].stride != 1;
-    if (mirror && strided) {
+    if (scatter) {
+        SSDK_REQUIRE(vec4, SSDK_E_UNSUPPORTED, "scatter dgrad needs 16-byte aligned rows");
+        hipLaunchKernelGGL((igemm_fwd_kernel<4, false, false, false, true>), dim3(begin), dim3(kConvThreads), 0, s, grp);
+    } else if (mirror && strided) {
         if (vec4) hipLaunchKernelGGL((igemm_fwd_kernel<4, true, true>), dim3(begin), dim3(kConvThreads), 0, s, grp);
         else hipLaunchKernelGGL((igemm_fwd_kernel<1, true, true>), dim3(begin), dim3(kConvThreads), 0, s, grp);
     } else if (mirror) {
@@ -546,15 +637,59 @@ extern "C" int ssdk_heads_fwd(const ssdk_head_level* levels, int n_levels, int b
     return launch_group(probs, n_levels, false, (hipStream_t)stream);
 }
 
-extern "C" size_t ssdk_heads_bwd_workspace_bytes(const ssdk_head_level* levels, int n_levels, int batch) {
-    size_t total = 0;
+struct HeadsBwdWs {
+    float* dyp[kMaxProblems];
+    float* wd[kMaxProblems];
+    float* wt[kMaxProblems];
+    int* row_list[kMaxProblems];
+    int* counts;  // [kMaxProblems] non-zero gradient rows per level
+    int* totals;  // [kMaxProblems] pixel rows per level
+    int* mode;    // [kMaxProblems] 1 = sparse backward, 0 = dense
+};
+
+static HeadsBwdWs carve_heads_bwd(void* ws, const ssdk_head_level* levels, int n_levels, int batch, size_t* total) {
+    Carver c(ws);
+    HeadsBwdWs w{};
+    w.counts = c.take<int>(kMaxProblems);
+    w.totals = c.take<int>(kMaxProblems);
+    w.mode = c.take<int>(kMaxProblems);
     for (int i = 0; i < n_levels; ++i) {
         const ssdk_head_level& lv = levels[i];
-        const size_t npad = (size_t)npad_of(lv);
-        total += align_up((size_t)batch * lv.h * lv.w * npad * sizeof(float), 256);  // packed dY
-        total += align_up((size_t)lv.cin * 9 * npad * sizeof(float), 256);           // transposed weights
+        const size_t npad = (size_t)npad_of(lv), M = (size_t)batch * lv.h * lv.w;
+        w.dyp[i] = c.take<float>(M * npad);
+        w.wd[i] = c.take<float>((size_t)lv.cin * 9 * npad);
+        w.wt[i] = c.take<float>((size_t)lv.cin * 9 * npad);
+        w.row_list[i] = c.take<int>(M);
     }
+    if (total) *total = c.off;
+    return w;
+}
+
+extern "C" size_t ssdk_heads_bwd_workspace_bytes(const ssdk_head_level* levels, int n_levels, int batch) {
+    size_t total = 0;
+    if (levels && n_levels > 0 && n_levels <= kMaxProblems) carve_heads_bwd(nullptr, levels, n_levels, batch, &total);
     return total;
+}
+
+static void size_wgrad_splits(WgradGroup& wg, int n, int density_div) {
+    long long total_slices = 0;
+    for (int i = 0; i < n; ++i) {
+        const WgradProblem& g = wg.p[i];
+        total_slices += (long long)g.ksize * g.ksize * g.n_tiles * g.c_blocks * cdiv(cdiv(g.B * g.Hout * g.Wout, density_div), 32);
+    }
+    long long slices_per_block = total_slices / (256 * 6);
+    if (slices_per_block < 4) slices_per_block = 4;
+    int begin = 0;
+    for (int i = 0; i < n; ++i) {
+        WgradProblem& g = wg.p[i];
+        const int slices = cdiv(cdiv(g.B * g.Hout * g.Wout, density_div), 32);
+        int ks = (int)((slices + slices_per_block - 1) / slices_per_block);
+        g.k_splits = ks < 1 ? 1 : ks;
+        g.block_begin = begin;
+        begin += g.ksize * g.ksize * g.n_tiles * g.c_blocks * g.k_splits;
+    }
+    wg.count = n;
+    wg.total_blocks = begin;
 }
 
 extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int batch, const float* dscores,
@@ -565,85 +700,100 @@ extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int b
     SSDK_REQUIRE(workspace && workspace_bytes >= ssdk_heads_bwd_workspace_bytes(levels, n_levels, batch), SSDK_E_WORKSPACE,
                  "ssdk_heads_bwd: workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    Carver carve(workspace);
-    ConvProblem dgrad[kMaxProblems];
-    WgradGroup wg;
-    int n_dgrad = 0, n_wgrad = 0;
-    const float* packed[kMaxProblems];
+    HeadsBwdWs w = carve_heads_bwd(workspace, levels, n_levels, batch, nullptr);
+    int h_totals[kMaxProblems] = {0};
+    for (int i = 0; i < n_levels; ++i) {
+        int rc = check_level("ssdk_heads_bwd", batch, levels[i]);
+        if (rc) return rc;
+        SSDK_REQUIRE(levels[i].n_loc == 0 || dlocs, SSDK_E_INVALID, "ssdk_heads_bwd: null dlocs");
+        SSDK_REQUIRE(levels[i].cin % 4 == 0 && ((uintptr_t)levels[i].x & 15) == 0, SSDK_E_UNSUPPORTED, "ssdk_heads_bwd: Cin %% 4 != 0 or x not 16-byte aligned");
+        h_totals[i] = batch * levels[i].h * levels[i].w;
+    }
+    SSDK_CHECK_HIP(hipMemsetAsync(w.counts, 0, sizeof(int) * kMaxProblems, s));
+    SSDK_CHECK_HIP(hipMemcpyAsync(w.totals, h_totals, sizeof(int) * kMaxProblems, hipMemcpyHostToDevice, s));
+
+    // 1. pack dY (aligned, zero padded rows), bias gradients, list of rows that carry a gradient
     for (int i = 0; i < n_levels; ++i) {
         const ssdk_head_level& lv = levels[i];
-        int rc = check_level("ssdk_heads_bwd", batch, lv);
-        if (rc) return rc;
-        SSDK_REQUIRE(lv.n_loc == 0 || dlocs, SSDK_E_INVALID, "ssdk_heads_bwd: null dlocs");
-        SSDK_REQUIRE(lv.cin % 4 == 0 && ((uintptr_t)lv.x & 15) == 0, SSDK_E_UNSUPPORTED, "ssdk_heads_bwd: Cin %% 4 != 0 or x not 16-byte aligned");
         const int npad = npad_of(lv), hw = lv.h * lv.w;
         const long long M = (long long)batch * hw;
-        float* dyp = carve.take<float>((size_t)M * npad);
-        float* wd = carve.take<float>((size_t)lv.cin * 9 * npad);
-        packed[i] = dyp;
         if (lv.db_score) SSDK_CHECK_HIP(hipMemsetAsync(lv.db_score, 0, sizeof(float) * (size_t)lv.n_score, s));
         if (lv.db_loc && lv.n_loc) SSDK_CHECK_HIP(hipMemsetAsync(lv.db_loc, 0, sizeof(float) * (size_t)lv.n_loc, s));
-        const int rows_per_block = 64;
-        hipLaunchKernelGGL(pack_dy_kernel, dim3((unsigned)((M + rows_per_block - 1) / rows_per_block)), dim3(256), 0, s,
+        hipLaunchKernelGGL(pack_dy_kernel, dim3((unsigned)((M + kPackRows - 1) / kPackRows)), dim3(256), 0, s,
                            dscores + lv.scores_offset, scores_batch_stride, lv.n_loc ? dlocs + lv.locs_offset : nullptr, locs_batch_stride,
-                           lv.n_score, lv.n_loc, npad, batch, hw, dyp, lv.db_score, lv.db_loc, rows_per_block);
+                           lv.n_score, lv.n_loc, npad, batch, hw, w.dyp[i], lv.db_score, lv.db_loc, w.row_list[i], w.counts + i);
         SSDK_CHECK_LAUNCH("pack_dy_kernel");
-        if (lv.dx) {  // backward-data: dX[m][c] = sum_(tap,n) dY[m + pad - tap][n] * W[n][tap][c]
-            hipLaunchKernelGGL(transpose_taps_kernel, dim3(cdiv(npad, 32), cdiv(lv.cin, 32), 9), dim3(256), 0, s, lv.w_score, lv.w_loc,
-                               lv.n_score, lv.n_loc, npad, 9, lv.cin, wd);
-            SSDK_CHECK_LAUNCH("transpose_taps_kernel");
-            ConvProblem g{};
-            g.a = dyp; g.a_bstride = (long long)hw * npad; g.a_pstride = npad; g.Cc = npad;
-            g.B = batch; g.Hout = lv.h; g.Wout = lv.w; g.Hin = lv.h; g.Win = lv.w; g.ksize = 3; g.stride = 1; g.pad = 1;
-            g.w0 = wd; g.w1 = nullptr; g.bias0 = nullptr; g.bias1 = nullptr; g.n0 = lv.cin; g.n1 = 0;
-            g.o0 = lv.dx; g.ob0 = (long long)hw * lv.cin; g.os0 = lv.cin; g.o1 = nullptr; g.ob1 = 0; g.os1 = 0;
-            g.relu = 0;
-            finish_problem(g);
-            dgrad[n_dgrad++] = g;
-        }
-        if (lv.dw_score) {
-            SSDK_REQUIRE(lv.n_loc == 0 || lv.dw_loc, SSDK_E_INVALID, "ssdk_heads_bwd: dw_loc missing");
-            SSDK_CHECK_HIP(hipMemsetAsync(lv.dw_score, 0, sizeof(float) * (size_t)lv.n_score * 9 * lv.cin, s));
-            if (lv.n_loc) SSDK_CHECK_HIP(hipMemsetAsync(lv.dw_loc, 0, sizeof(float) * (size_t)lv.n_loc * 9 * lv.cin, s));
-            WgradProblem g{};
-            g.dy = dyp; g.x = lv.x; g.Npad = npad; g.Cc = lv.cin;
-            g.B = batch; g.Hout = lv.h; g.Wout = lv.w; g.Hin = lv.h; g.Win = lv.w; g.ksize = 3; g.stride = 1; g.pad = 1;
-            g.dw0 = lv.dw_score; g.dw1 = lv.dw_loc; g.n0 = lv.n_score; g.n1 = lv.n_loc;
-            g.n_tiles = cdiv(lv.n_score + lv.n_loc, 128);
-            g.c_tiles32 = cdiv(lv.cin, 32);
-            g.c_blocks = cdiv(g.c_tiles32, kMaxTN);
-            wg.p[n_wgrad++] = g;
-        }
+    }
+    hipLaunchKernelGGL(decide_sparse_kernel, dim3(1), dim3(64), 0, s, w.counts, w.totals, n_levels, w.mode);
+    SSDK_CHECK_LAUNCH("decide_sparse_kernel");
+
+    // 2. backward-data.  dense: dX[m][c] = sum_(tap,n) dY[m + pad - tap][n] * W[n][tap][c] (output stationary);
+    //    sparse: T[row][tap*Cin + c] = dY[row][:] . W[:, tap, c] for the non-zero rows only, scatter-added into dX.
+    ConvProblem dense[kMaxProblems], sparse[kMaxProblems];
+    int n_dgrad = 0;
+    for (int i = 0; i < n_levels; ++i) {
+        const ssdk_head_level& lv = levels[i];
+        if (!lv.dx) continue;
+        const int npad = npad_of(lv), hw = lv.h * lv.w;
+        hipLaunchKernelGGL(transpose_taps_kernel, dim3(cdiv(npad, 32), cdiv(lv.cin, 32), 9), dim3(256), 0, s, lv.w_score, lv.w_loc,
+                           lv.n_score, lv.n_loc, npad, 9, lv.cin, w.wd[i]);
+        SSDK_CHECK_LAUNCH("transpose_taps_kernel");
+        hipLaunchKernelGGL(transpose_tapmajor_kernel, dim3(cdiv(npad, 32), cdiv(lv.cin, 32), 9), dim3(256), 0, s, lv.w_score, lv.w_loc,
+                           lv.n_score, lv.n_loc, npad, 9, lv.cin, w.wt[i]);
+        SSDK_CHECK_LAUNCH("transpose_tapmajor_kernel");
+        SSDK_CHECK_HIP(hipMemsetAsync(lv.dx, 0, sizeof(float) * (size_t)batch * hw * lv.cin, s));  // the scatter adds into it
+        ConvProblem g{};
+        g.a = w.dyp[i]; g.a_bstride = (long long)hw * npad; g.a_pstride = npad; g.Cc = npad;
+        g.B = batch; g.Hout = lv.h; g.Wout = lv.w; g.Hin = lv.h; g.Win = lv.w; g.ksize = 3; g.stride = 1; g.pad = 1;
+        g.w0 = w.wd[i]; g.n0 = lv.cin; g.n1 = 0;
+        g.o0 = lv.dx; g.ob0 = (long long)hw * lv.cin; g.os0 = lv.cin;
+        g.mode = w.mode + i; g.want_mode = 0;
+        finish_problem(g);
+        dense[n_dgrad] = g;
+        ConvProblem q = g;
+        q.w0 = w.wt[i]; q.n0 = 9 * lv.cin; q.sc_cin = lv.cin;
+        q.row_list = w.row_list[i]; q.row_count = w.counts + i; q.want_mode = 1;
+        finish_problem(q);  // m_tiles for the worst case; workgroups past the real row count exit at once
+        sparse[n_dgrad] = q;
+        ++n_dgrad;
     }
     if (n_dgrad) {
-        int rc = launch_group(dgrad, n_dgrad, true, s);
+        int rc = launch_group(dense, n_dgrad, true, s);
+        if (rc) return rc;
+        rc = launch_group(sparse, n_dgrad, false, s, false, true);
         if (rc) return rc;
     }
+
+    // 3. backward-weights, dense (all pixels) or sparse (only the listed rows)
+    WgradGroup wd_{}, ws_{};
+    int n_wgrad = 0;
+    for (int i = 0; i < n_levels; ++i) {
+        const ssdk_head_level& lv = levels[i];
+        if (!lv.dw_score) continue;
+        SSDK_REQUIRE(lv.n_loc == 0 || lv.dw_loc, SSDK_E_INVALID, "ssdk_heads_bwd: dw_loc missing");
+        SSDK_CHECK_HIP(hipMemsetAsync(lv.dw_score, 0, sizeof(float) * (size_t)lv.n_score * 9 * lv.cin, s));
+        if (lv.n_loc) SSDK_CHECK_HIP(hipMemsetAsync(lv.dw_loc, 0, sizeof(float) * (size_t)lv.n_loc * 9 * lv.cin, s));
+        WgradProblem g{};
+        g.dy = w.dyp[i]; g.x = lv.x; g.Npad = npad_of(lv); g.Cc = lv.cin;
+        g.B = batch; g.Hout = lv.h; g.Wout = lv.w; g.Hin = lv.h; g.Win = lv.w; g.ksize = 3; g.stride = 1; g.pad = 1;
+        g.dw0 = lv.dw_score; g.dw1 = lv.dw_loc; g.n0 = lv.n_score; g.n1 = lv.n_loc;
+        g.n_tiles = cdiv(lv.n_score + lv.n_loc, 128);
+        g.c_tiles32 = cdiv(lv.cin, 32);
+        g.c_blocks = cdiv(g.c_tiles32, kMaxTN);
+        g.mode = w.mode + i; g.want_mode = 0;
+        wd_.p[n_wgrad] = g;
+        g.want_mode = 1; g.row_list = w.row_list[i]; g.row_count = w.counts + i;
+        ws_.p[n_wgrad] = g;
+        ++n_wgrad;
+    }
     if (n_wgrad) {
-        // split K (= pixels) so that the whole group has ~6 workgroups per CU and every split has >= 8 slices
-        long long out_tiles = 0;
-        for (int i = 0; i < n_wgrad; ++i) out_tiles += 9LL * wg.p[i].n_tiles * wg.p[i].c_blocks;
-        long long total_slices = 0;
-        for (int i = 0; i < n_wgrad; ++i) total_slices += 9LL * wg.p[i].n_tiles * wg.p[i].c_blocks * cdiv(wg.p[i].B * wg.p[i].Hout * wg.p[i].Wout, 32);
-        const long long target_blocks = 256 * 6;
-        long long slices_per_block = total_slices / target_blocks;
-        if (slices_per_block < 8) slices_per_block = 8;
-        int begin = 0;
-        for (int i = 0; i < n_wgrad; ++i) {
-            WgradProblem& g = wg.p[i];
-            const int slices = cdiv(g.B * g.Hout * g.Wout, 32);
-            int ks = (int)((slices + slices_per_block - 1) / slices_per_block);
-            if (ks < 1) ks = 1;
-            g.k_splits = ks;
-            g.block_begin = begin;
-            begin += 9 * g.n_tiles * g.c_blocks * ks;
-        }
-        wg.count = n_wgrad;
-        wg.total_blocks = begin;
-        hipLaunchKernelGGL(igemm_wgrad_kernel, dim3(begin), dim3(kConvThreads), 0, s, wg);
+        size_wgrad_splits(wd_, n_wgrad, 1);
+        hipLaunchKernelGGL(igemm_wgrad_kernel, dim3(wd_.total_blocks), dim3(kConvThreads), 0, s, wd_);
+        SSDK_CHECK_LAUNCH("igemm_wgrad_kernel");
+        size_wgrad_splits(ws_, n_wgrad, 4);  // sparse mode means < 1/4 of the rows
+        hipLaunchKernelGGL(igemm_wgrad_kernel, dim3(ws_.total_blocks), dim3(kConvThreads), 0, s, ws_);
         SSDK_CHECK_LAUNCH("igemm_wgrad_kernel");
     }
-    (void)packed;
     return SSDK_OK;
 }
 

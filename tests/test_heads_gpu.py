@@ -62,7 +62,10 @@ def test_heads_layout_vs_reference_golden():
     ([(24, 7, 3), (40, 5, 5)], 7, 3),                                                            # Cin % 32 != 0, odd N
     ([(256, 8, 9)], 80, 1),                                                                      # retina level (nb=9, C=80)
 ])
-def test_heads_vs_torch_cpu_conv(levels, C, B):
+@pytest.mark.parametrize('pixel_density', [1.0, 0.05])
+def test_heads_vs_torch_cpu_conv(levels, C, B, pixel_density):
+    """pixel_density 1.0 exercises the dense backward kernels, 0.05 the sparse ones (compacted wgrad, scatter dgrad):
+    the device picks the path from the fraction of pixel rows that carry a gradient."""
     rng = np.random.default_rng(17)
     weights, xs_np = {}, []
     for i, (cin, h, nb) in enumerate(levels):
@@ -81,8 +84,18 @@ def test_heads_vs_torch_cpu_conv(levels, C, B):
     scores_ref, locs_ref = torch.cat(scores_ref, 1), torch.cat(locs_ref, 1)
     gs = torch.from_numpy(rng.standard_normal(tuple(scores_ref.shape), dtype=np.float32))
     gl = torch.from_numpy(rng.standard_normal(tuple(locs_ref.shape), dtype=np.float32))
-    # sparse upstream gradient like the real loss: most rows are exactly zero
+    # sparse upstream gradient like the real loss: most entries are exactly zero
     gs[:, (rng.random(gs.shape[1]) < 0.9)] = 0
+    if pixel_density < 1.0:   # and whole pixels (all their anchors, scores and locs) carry no gradient at all
+        s_off = l_off = 0
+        for cin, h, nb in levels:
+            keep = torch.from_numpy((rng.random((B, h * h, 1)) < pixel_density).astype(np.float32))
+            keep[:, 0] = 1.0  # at least one row per image so that the list is never empty
+            ns, nl = h * h * nb * C, h * h * nb * 4
+            gs[:, s_off:s_off + ns] = (gs[:, s_off:s_off + ns].view(B, h * h, nb * C) * keep).view(B, -1)
+            gl[:, l_off:l_off + nl] = (gl[:, l_off:l_off + nl].view(B, h * h, nb * 4) * keep).view(B, -1)
+            s_off += ns
+            l_off += nl
     ((scores_ref * gs).sum() + (locs_ref * gl).sum()).backward()
 
     heads = build_heads(levels, C, weights)
