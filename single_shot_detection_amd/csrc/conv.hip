@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(kConvThreads, 3) igemm_fwd_kernel(ConvGroup gr
     const long long K = (long long)taps * Cc;
     const int N = g.n0 + g.n1;
     const int hw = g.Hout * g.Wout;
-    const int M = SCATTER ? *g.row_count : g.B * hw;
+    const int M = (SCATTER && g.row_list) ? *g.row_count : g.B * hw;
     if (SCATTER && m_tile * kBM >= M) return;
 
     const int base_t = g.tiles_n / g.n_blocks, rem_t = g.tiles_n % g.n_blocks;
@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(kConvThreads, 3) igemm_fwd_kernel(ConvGroup gr
         if (SCATTER) {
             if (m < M) {
                 a_mask[p] = 1u;
-                a_off[p] = (long long)g.row_list[m] * g.a_pstride;
+                a_off[p] = (long long)(g.row_list ? g.row_list[m] : m) * g.a_pstride;
             }
         } else if (m < M) {
             const int b = m / hw, r = m % hw;
@@ -270,9 +270,9 @@ __global__ void __launch_bounds__(kConvThreads, 3) igemm_fwd_kernel(ConvGroup gr
         for (int e = 0; e < 16; ++e) {
             const int m = m_tile * kBM + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
             if (m >= M) continue;
-            const int pid = g.row_list[m];
+            const int pid = g.row_list ? g.row_list[m] : m;
             const int b = pid / hw, r = pid % hw;
-            const int yo = r / g.Wout, xo = r % g.Wout;
+            const int yo = (r / g.Wout) * g.stride, xo = (r % g.Wout) * g.stride;
 #pragma unroll
             for (int j = 0; j < kMaxTN; ++j) {
                 if (j >= tn) continue;
@@ -452,32 +452,58 @@ __global__ void __launch_bounds__(256) pack_dy_kernel(const float* __restrict__ 
                                                       long long lb, int n0, int n1, int Npad, int B, int HW,
                                                       float* __restrict__ out, float* __restrict__ db0, float* __restrict__ db1,
                                                       int* __restrict__ row_list, int* __restrict__ row_count) {
+    // wave w packs rows w, w+4, ... of the 32-row block; lane l owns float4 columns l, l+64, ... (64 columns per pass)
     __shared__ unsigned s_flag;
     __shared__ int s_base;
+    __shared__ float4 s_sum[4][64];
     const long long M = (long long)B * HW;
-    const long long m0 = (long long)blockIdx.x * kPackRows, m1 = min(M, m0 + kPackRows);
-    const int N = n0 + n1;
+    const long long m0 = (long long)blockIdx.x * kPackRows;
+    const int N = n0 + n1, n4 = Npad >> 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_flag = 0u;
-    __syncthreads();
     unsigned mine = 0u;
-    for (int n = threadIdx.x; n < Npad; n += blockDim.x) {
-        float s = 0.0f;
-        for (long long m = m0; m < m1; ++m) {
-            const int b = (int)(m / HW);
-            const long long p = m % HW;
-            float v = 0.0f;
-            if (n < n0) v = ds[(long long)b * sb + p * n0 + n];
-            else if (n < N) v = dl[(long long)b * lb + p * n1 + (n - n0)];
-            out[m * Npad + n] = v;
-            s += v;
-            if (v != 0.0f) mine |= 1u << (int)(m - m0);
+    for (int cbase = 0; cbase < n4; cbase += 64) {
+        const int c4 = cbase + lane;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = wave; r < kPackRows; r += 4) {
+            const long long m = m0 + r;
+            if (m >= M) break;
+            bool nz = false;
+            if (c4 < n4) {
+                const int b = (int)(m / HW);
+                const long long p = m % HW;
+                const float* srow = ds + (long long)b * sb + p * n0;
+                const float* lrow = dl ? dl + (long long)b * lb + p * n1 : nullptr;
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int n = c4 * 4 + k;
+                    v[k] = n < n0 ? srow[n] : (n < N ? lrow[n - n0] : 0.0f);
+                }
+                reinterpret_cast<float4*>(out + m * Npad)[c4] = make_float4(v[0], v[1], v[2], v[3]);
+                acc.x += v[0]; acc.y += v[1]; acc.z += v[2]; acc.w += v[3];
+                nz = v[0] != 0.0f || v[1] != 0.0f || v[2] != 0.0f || v[3] != 0.0f;
+            }
+            if (__ballot(nz)) mine |= 1u << r;
         }
-        if (s != 0.0f) {
-            if (n < n0) { if (db0) atomicAdd(db0 + n, s); }
-            else if (n < N) { if (db1) atomicAdd(db1 + (n - n0), s); }
+        __syncthreads();
+        s_sum[wave][lane] = acc;
+        __syncthreads();
+        if (wave == 0 && c4 < n4) {
+            float4 t = s_sum[0][lane];
+            for (int w = 1; w < 4; ++w) { const float4 u = s_sum[w][lane]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+            const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int n = c4 * 4 + k;
+                if (tv[k] != 0.0f) {
+                    if (n < n0) { if (db0) atomicAdd(db0 + n, tv[k]); }
+                    else if (n < N) { if (db1) atomicAdd(db1 + (n - n0), tv[k]); }
+                }
+            }
         }
     }
-    if (mine) atomicOr(&s_flag, mine);
+    if (lane == 0 && mine) atomicOr(&s_flag, mine);
     __syncthreads();
     const unsigned flags = s_flag;
     if (threadIdx.x == 0) s_base = flags ? atomicAdd(row_count, __popc(flags)) : 0;
@@ -487,9 +513,10 @@ __global__ void __launch_bounds__(256) pack_dy_kernel(const float* __restrict__ 
 }
 
 // mode[i] = 1 (sparse backward) when fewer than 1/4 of the level's pixel rows carry a gradient, else 0 (dense)
-__global__ void decide_sparse_kernel(const int* __restrict__ counts, const int* __restrict__ totals, int n, int* __restrict__ mode) {
+struct LevelTotals { int v[kMaxProblems]; };
+__global__ void decide_sparse_kernel(const int* __restrict__ counts, LevelTotals totals, int n, int* __restrict__ mode) {
     const int i = threadIdx.x;
-    if (i < n) mode[i] = (counts[i] * 4 < totals[i]) ? 1 : 0;
+    if (i < n) mode[i] = ((long long)counts[i] * 4 < (long long)totals.v[i]) ? 1 : 0;
 }
 
 // db[n] += sum over rows of dy[row][n]   (dense [M][N] rows)
@@ -545,11 +572,50 @@ __global__ void __launch_bounds__(256) transpose_tapmajor_kernel(const float* __
     }
 }
 
+// zeroes up to 32 buffers in one launch (gradient accumulators that the atomics add into)
+constexpr int kMaxZero = 32;
+struct ZeroArgs {
+    int count;
+    float* ptr[kMaxZero];
+    unsigned long long n[kMaxZero];  // floats, multiples of 4 use the float4 path
+};
+__global__ void __launch_bounds__(256) zero_many_kernel(ZeroArgs a) {
+    for (int i = blockIdx.y; i < a.count; i += gridDim.y) {
+        float* p = a.ptr[i];
+        const unsigned long long n = a.n[i];
+        if ((n & 3ull) == 0 && ((uintptr_t)p & 15) == 0) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (unsigned long long k = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; k < (n >> 2); k += (unsigned long long)gridDim.x * blockDim.x)
+                reinterpret_cast<float4*>(p)[k] = z;
+        } else {
+            for (unsigned long long k = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; k < n; k += (unsigned long long)gridDim.x * blockDim.x) p[k] = 0.0f;
+        }
+    }
+}
+
 }  // namespace ssdk
 
 using namespace ssdk;
 
 // ---- host side ---------------------------------------------------------------------------------------------------
+
+struct ZeroList {
+    ZeroArgs a;
+    ZeroList() { a.count = 0; }
+    void add(float* p, size_t n) {
+        if (!p || !n || a.count >= kMaxZero) return;
+        a.ptr[a.count] = p;
+        a.n[a.count] = n;
+        ++a.count;
+    }
+    int launch(hipStream_t s) {
+        if (!a.count) return SSDK_OK;
+        hipLaunchKernelGGL(zero_many_kernel, dim3(256, a.count), dim3(256), 0, s, a);
+        SSDK_CHECK_LAUNCH("zero_many_kernel");
+        a.count = 0;
+        return SSDK_OK;
+    }
+};
 
 static void finish_problem(ConvProblem& g) {
     const int N = g.n0 + g.n1;
@@ -678,7 +744,7 @@ static void size_wgrad_splits(WgradGroup& wg, int n, int density_div) {
         total_slices += (long long)g.ksize * g.ksize * g.n_tiles * g.c_blocks * cdiv(cdiv(g.B * g.Hout * g.Wout, density_div), 32);
     }
     long long slices_per_block = total_slices / (256 * 6);
-    if (slices_per_block < 4) slices_per_block = 4;
+    if (slices_per_block < 16) slices_per_block = 16;
     int begin = 0;
     for (int i = 0; i < n; ++i) {
         WgradProblem& g = wg.p[i];
@@ -701,30 +767,43 @@ extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int b
                  "ssdk_heads_bwd: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     HeadsBwdWs w = carve_heads_bwd(workspace, levels, n_levels, batch, nullptr);
-    int h_totals[kMaxProblems] = {0};
+    LevelTotals h_totals{};
     for (int i = 0; i < n_levels; ++i) {
         int rc = check_level("ssdk_heads_bwd", batch, levels[i]);
         if (rc) return rc;
         SSDK_REQUIRE(levels[i].n_loc == 0 || dlocs, SSDK_E_INVALID, "ssdk_heads_bwd: null dlocs");
         SSDK_REQUIRE(levels[i].cin % 4 == 0 && ((uintptr_t)levels[i].x & 15) == 0, SSDK_E_UNSUPPORTED, "ssdk_heads_bwd: Cin %% 4 != 0 or x not 16-byte aligned");
-        h_totals[i] = batch * levels[i].h * levels[i].w;
+        h_totals.v[i] = batch * levels[i].h * levels[i].w;
     }
     SSDK_CHECK_HIP(hipMemsetAsync(w.counts, 0, sizeof(int) * kMaxProblems, s));
-    SSDK_CHECK_HIP(hipMemcpyAsync(w.totals, h_totals, sizeof(int) * kMaxProblems, hipMemcpyHostToDevice, s));
 
+    // 0. zero everything the atomics of this call add into, in one launch (two when > 32 buffers)
+    {
+        ZeroList zl;
+        for (int i = 0; i < n_levels; ++i) {
+            const ssdk_head_level& lv = levels[i];
+            const size_t hw = (size_t)lv.h * lv.w;
+            zl.add(lv.db_score, (size_t)lv.n_score);
+            if (lv.n_loc) zl.add(lv.db_loc, (size_t)lv.n_loc);
+            zl.add(lv.dx, (size_t)batch * hw * lv.cin);
+            zl.add(lv.dw_score, (size_t)lv.n_score * 9 * lv.cin);
+            if (lv.n_loc) zl.add(lv.dw_loc, (size_t)lv.n_loc * 9 * lv.cin);
+            if (zl.a.count > kMaxZero - 5) { int rc = zl.launch(s); if (rc) return rc; }
+        }
+        int rc = zl.launch(s);
+        if (rc) return rc;
+    }
     // 1. pack dY (aligned, zero padded rows), bias gradients, list of rows that carry a gradient
     for (int i = 0; i < n_levels; ++i) {
         const ssdk_head_level& lv = levels[i];
         const int npad = npad_of(lv), hw = lv.h * lv.w;
         const long long M = (long long)batch * hw;
-        if (lv.db_score) SSDK_CHECK_HIP(hipMemsetAsync(lv.db_score, 0, sizeof(float) * (size_t)lv.n_score, s));
-        if (lv.db_loc && lv.n_loc) SSDK_CHECK_HIP(hipMemsetAsync(lv.db_loc, 0, sizeof(float) * (size_t)lv.n_loc, s));
         hipLaunchKernelGGL(pack_dy_kernel, dim3((unsigned)((M + kPackRows - 1) / kPackRows)), dim3(256), 0, s,
                            dscores + lv.scores_offset, scores_batch_stride, lv.n_loc ? dlocs + lv.locs_offset : nullptr, locs_batch_stride,
                            lv.n_score, lv.n_loc, npad, batch, hw, w.dyp[i], lv.db_score, lv.db_loc, w.row_list[i], w.counts + i);
         SSDK_CHECK_LAUNCH("pack_dy_kernel");
     }
-    hipLaunchKernelGGL(decide_sparse_kernel, dim3(1), dim3(64), 0, s, w.counts, w.totals, n_levels, w.mode);
+    hipLaunchKernelGGL(decide_sparse_kernel, dim3(1), dim3(64), 0, s, w.counts, h_totals, n_levels, w.mode);
     SSDK_CHECK_LAUNCH("decide_sparse_kernel");
 
     // 2. backward-data.  dense: dX[m][c] = sum_(tap,n) dY[m + pad - tap][n] * W[n][tap][c] (output stationary);
@@ -741,7 +820,6 @@ extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int b
         hipLaunchKernelGGL(transpose_tapmajor_kernel, dim3(cdiv(npad, 32), cdiv(lv.cin, 32), 9), dim3(256), 0, s, lv.w_score, lv.w_loc,
                            lv.n_score, lv.n_loc, npad, 9, lv.cin, w.wt[i]);
         SSDK_CHECK_LAUNCH("transpose_tapmajor_kernel");
-        SSDK_CHECK_HIP(hipMemsetAsync(lv.dx, 0, sizeof(float) * (size_t)batch * hw * lv.cin, s));  // the scatter adds into it
         ConvProblem g{};
         g.a = w.dyp[i]; g.a_bstride = (long long)hw * npad; g.a_pstride = npad; g.Cc = npad;
         g.B = batch; g.Hout = lv.h; g.Wout = lv.w; g.Hin = lv.h; g.Win = lv.w; g.ksize = 3; g.stride = 1; g.pad = 1;
@@ -771,8 +849,6 @@ extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int b
         const ssdk_head_level& lv = levels[i];
         if (!lv.dw_score) continue;
         SSDK_REQUIRE(lv.n_loc == 0 || lv.dw_loc, SSDK_E_INVALID, "ssdk_heads_bwd: dw_loc missing");
-        SSDK_CHECK_HIP(hipMemsetAsync(lv.dw_score, 0, sizeof(float) * (size_t)lv.n_score * 9 * lv.cin, s));
-        if (lv.n_loc) SSDK_CHECK_HIP(hipMemsetAsync(lv.dw_loc, 0, sizeof(float) * (size_t)lv.n_loc * 9 * lv.cin, s));
         WgradProblem g{};
         g.dy = w.dyp[i]; g.x = lv.x; g.Npad = npad_of(lv); g.Cc = lv.cin;
         g.B = batch; g.Hout = lv.h; g.Wout = lv.w; g.Hin = lv.h; g.Win = lv.w; g.ksize = 3; g.stride = 1; g.pad = 1;
@@ -848,9 +924,10 @@ extern "C" int ssdk_conv2d_bwd(const ssdk_conv_desc* descs, int n, int batch, in
     SSDK_REQUIRE(workspace && workspace_bytes >= ssdk_conv2d_bwd_workspace_bytes(descs, n, batch), SSDK_E_WORKSPACE, "ssdk_conv2d_bwd: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     Carver carve(workspace);
-    ConvProblem dgrad[kMaxProblems];
-    WgradGroup wg;
-    int n_dgrad = 0, n_wgrad = 0;
+    ConvProblem dgrad[kMaxProblems], scat[kMaxProblems];
+    WgradGroup wg{};
+    ZeroList zl{};
+    int n_dgrad = 0, n_scat = 0, n_wgrad = 0;
     for (int i = 0; i < n; ++i) {
         const ssdk_conv_desc& d = descs[i];
         int rc = check_conv("ssdk_conv2d_bwd", batch, d);
@@ -860,24 +937,36 @@ extern "C" int ssdk_conv2d_bwd(const ssdk_conv_desc* descs, int n, int batch, in
                      "ssdk_conv2d_bwd: channels must be multiples of 4 and buffers 16-byte aligned");
         const int ho = out_dim(d.hin, d.ksize, d.stride, d.pad), wo = out_dim(d.win, d.ksize, d.stride, d.pad);
         const int taps = d.ksize * d.ksize;
-        const int npad = d.cout;  // no padding: the A rows are the caller's dy rows of exactly cout floats
-        float* wd = carve.take<float>((size_t)d.cin * taps * npad);
-        if (d.dx) {
-            hipLaunchKernelGGL(transpose_taps_kernel, dim3(cdiv(npad, 32), cdiv(d.cin, 32), taps), dim3(256), 0, s, d.w, (const float*)nullptr,
-                               d.cout, 0, npad, taps, d.cin, wd);
+        float* wd = carve.take<float>((size_t)d.cin * taps * d.cout);
+        if (d.dx && d.stride == 1) {
+            // output stationary: rows are INPUT pixels, A = dy [ho*wo][cout] with mirrored taps, W = wd [cin][taps*cout]
+            hipLaunchKernelGGL(transpose_taps_kernel, dim3(cdiv(d.cout, 32), cdiv(d.cin, 32), taps), dim3(256), 0, s, d.w, (const float*)nullptr,
+                               d.cout, 0, d.cout, taps, d.cin, wd);
             SSDK_CHECK_LAUNCH("transpose_taps_kernel");
             ConvProblem g{};
-            // rows of the dgrad GEMM are INPUT pixels; its A operand is dy [ho*wo][cout], W = wd [cin][taps*cout]
             g.a = d.dy; g.a_bstride = (long long)ho * wo * d.cout; g.a_pstride = d.cout; g.Cc = d.cout;
-            g.B = batch; g.Hout = d.hin; g.Wout = d.win; g.Hin = ho; g.Win = wo; g.ksize = d.ksize; g.stride = d.stride; g.pad = d.pad;
-            g.w0 = wd; g.w1 = nullptr; g.bias0 = nullptr; g.bias1 = nullptr; g.n0 = d.cin; g.n1 = 0;
-            g.o0 = d.dx; g.ob0 = (long long)d.hin * d.win * d.cin; g.os0 = d.cin; g.o1 = nullptr; g.ob1 = 0; g.os1 = 0;
-            g.relu = 0;
+            g.B = batch; g.Hout = d.hin; g.Wout = d.win; g.Hin = ho; g.Win = wo; g.ksize = d.ksize; g.stride = 1; g.pad = d.pad;
+            g.w0 = wd; g.n0 = d.cin; g.n1 = 0;
+            g.o0 = d.dx; g.ob0 = (long long)d.hin * d.win * d.cin; g.os0 = d.cin;
             finish_problem(g);
             dgrad[n_dgrad++] = g;
+        } else if (d.dx) {
+            // strided: input stationary.  T[out pixel][tap*cin + c] = dy[out pixel][:] . W[:, tap, c], scatter-added into
+            // dx at (yo*stride - pad + ky, xo*stride - pad + kx): no multiply is spent on (pixel, tap) pairs that do not exist
+            hipLaunchKernelGGL(transpose_tapmajor_kernel, dim3(cdiv(d.cout, 32), cdiv(d.cin, 32), taps), dim3(256), 0, s, d.w, (const float*)nullptr,
+                               d.cout, 0, d.cout, taps, d.cin, wd);
+            SSDK_CHECK_LAUNCH("transpose_tapmajor_kernel");
+            zl.add(d.dx, (size_t)batch * d.hin * d.win * d.cin);
+            ConvProblem g{};
+            g.a = d.dy; g.a_bstride = (long long)ho * wo * d.cout; g.a_pstride = d.cout; g.Cc = d.cout;
+            g.B = batch; g.Hout = ho; g.Wout = wo; g.Hin = d.hin; g.Win = d.win; g.ksize = d.ksize; g.stride = d.stride; g.pad = d.pad;
+            g.w0 = wd; g.n0 = taps * d.cin; g.n1 = 0; g.sc_cin = d.cin;
+            g.o0 = d.dx; g.ob0 = (long long)d.hin * d.win * d.cin; g.os0 = d.cin;
+            finish_problem(g);
+            scat[n_scat++] = g;
         }
         if (d.dw) {
-            if (!accumulate) SSDK_CHECK_HIP(hipMemsetAsync(d.dw, 0, sizeof(float) * (size_t)d.cout * taps * d.cin, s));
+            if (!accumulate) zl.add(d.dw, (size_t)d.cout * taps * d.cin);
             WgradProblem g{};
             g.dy = d.dy; g.x = d.x; g.Npad = d.cout; g.Cc = d.cin;
             g.B = batch; g.Hout = ho; g.Wout = wo; g.Hin = d.hin; g.Win = d.win; g.ksize = d.ksize; g.stride = d.stride; g.pad = d.pad;
@@ -887,39 +976,31 @@ extern "C" int ssdk_conv2d_bwd(const ssdk_conv_desc* descs, int n, int batch, in
             g.c_blocks = cdiv(g.c_tiles32, kMaxTN);
             wg.p[n_wgrad++] = g;
         }
-        if (d.db) {
-            if (!accumulate) SSDK_CHECK_HIP(hipMemsetAsync(d.db, 0, sizeof(float) * (size_t)d.cout, s));
-            const long long M = (long long)batch * ho * wo;
-            const int rows_per_block = 64;
-            hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((M + rows_per_block - 1) / rows_per_block)), dim3(256), 0, s, d.dy, M, d.cout,
-                               d.db, rows_per_block);
-            SSDK_CHECK_LAUNCH("colsum_kernel");
-        }
+        if (d.db && !accumulate) zl.add(d.db, (size_t)d.cout);
+    }
+    int rc = zl.launch(s);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) {
+        const ssdk_conv_desc& d = descs[i];
+        if (!d.db) continue;
+        const int ho = out_dim(d.hin, d.ksize, d.stride, d.pad), wo = out_dim(d.win, d.ksize, d.stride, d.pad);
+        const long long M = (long long)batch * ho * wo;
+        const int rows_per_block = 64;
+        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((M + rows_per_block - 1) / rows_per_block)), dim3(256), 0, s, d.dy, M, d.cout,
+                           d.db, rows_per_block);
+        SSDK_CHECK_LAUNCH("colsum_kernel");
     }
     if (n_dgrad) {
-        int rc = launch_group(dgrad, n_dgrad, true, s);
+        rc = launch_group(dgrad, n_dgrad, true, s);
+        if (rc) return rc;
+    }
+    if (n_scat) {
+        rc = launch_group(scat, n_scat, false, s, false, true);
         if (rc) return rc;
     }
     if (n_wgrad) {
-        long long total_slices = 0;
-        for (int i = 0; i < n_wgrad; ++i) {
-            const WgradProblem& g = wg.p[i];
-            total_slices += (long long)g.ksize * g.ksize * g.n_tiles * g.c_blocks * cdiv(g.B * g.Hout * g.Wout, 32);
-        }
-        long long slices_per_block = total_slices / (256 * 6);
-        if (slices_per_block < 8) slices_per_block = 8;
-        int begin = 0;
-        for (int i = 0; i < n_wgrad; ++i) {
-            WgradProblem& g = wg.p[i];
-            const int slices = cdiv(g.B * g.Hout * g.Wout, 32);
-            int ks = (int)((slices + slices_per_block - 1) / slices_per_block);
-            g.k_splits = ks < 1 ? 1 : ks;
-            g.block_begin = begin;
-            begin += g.ksize * g.ksize * g.n_tiles * g.c_blocks * g.k_splits;
-        }
-        wg.count = n_wgrad;
-        wg.total_blocks = begin;
-        hipLaunchKernelGGL(igemm_wgrad_kernel, dim3(begin), dim3(kConvThreads), 0, s, wg);
+        size_wgrad_splits(wg, n_wgrad, 1);
+        hipLaunchKernelGGL(igemm_wgrad_kernel, dim3(wg.total_blocks), dim3(kConvThreads), 0, s, wg);
         SSDK_CHECK_LAUNCH("igemm_wgrad_kernel");
     }
     return SSDK_OK;

@@ -16,30 +16,51 @@ namespace ssdk {
 constexpr int kBnRows = 64;
 
 // MODE 0: s0 = sum x, s1 = sum x^2.   MODE 1 (backward): s0 = sum dy', s1 = sum dy' * xhat, dy' = relu ? dy * (y > 0) : dy
+// Workgroup = 64 rows; wave w takes rows w, w+4, ...; lane l owns float4 columns l, l+64, ... (whole 1 KB lines per wave).
 template <int MODE>
 __global__ void __launch_bounds__(256) bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
                                                         long long rows, int C, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         int relu, double* __restrict__ sums) {
+    __shared__ float4 s_part[2][4][64];
     const long long r0 = (long long)blockIdx.x * kBnRows, r1 = min(rows, r0 + kBnRows);
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float s0 = 0.0f, s1 = 0.0f;
-        if (MODE == 0) {
-            for (long long r = r0; r < r1; ++r) {
-                const float v = x[r * C + c];
-                s0 += v;
-                s1 += v * v;
-            }
-        } else {
-            const float m = mean[c], rs = rstd[c];
-            for (long long r = r0; r < r1; ++r) {
-                float g = dy[r * C + c];
-                if (relu && !(y[r * C + c] > 0.0f)) g = 0.0f;
-                s0 += g;
-                s1 += g * ((x[r * C + c] - m) * rs);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C4 = C >> 2;
+    for (int cbase = 0; cbase < C4; cbase += 64) {
+        const int c4 = cbase + lane;
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+        if (c4 < C4) {
+            float4 m4 = a0, rs4 = a0;
+            if (MODE == 1) { m4 = reinterpret_cast<const float4*>(mean)[c4]; rs4 = reinterpret_cast<const float4*>(rstd)[c4]; }
+            for (long long r = r0 + wave; r < r1; r += 4) {
+                const float4 xv = reinterpret_cast<const float4*>(x + r * C)[c4];
+                if (MODE == 0) {
+                    a0.x += xv.x; a0.y += xv.y; a0.z += xv.z; a0.w += xv.w;
+                    a1.x += xv.x * xv.x; a1.y += xv.y * xv.y; a1.z += xv.z * xv.z; a1.w += xv.w * xv.w;
+                } else {
+                    float4 g = reinterpret_cast<const float4*>(dy + r * C)[c4];
+                    if (relu) {
+                        const float4 yv = reinterpret_cast<const float4*>(y + r * C)[c4];
+                        if (!(yv.x > 0.f)) g.x = 0.f;
+                        if (!(yv.y > 0.f)) g.y = 0.f;
+                        if (!(yv.z > 0.f)) g.z = 0.f;
+                        if (!(yv.w > 0.f)) g.w = 0.f;
+                    }
+                    a0.x += g.x; a0.y += g.y; a0.z += g.z; a0.w += g.w;
+                    a1.x += g.x * ((xv.x - m4.x) * rs4.x); a1.y += g.y * ((xv.y - m4.y) * rs4.y);
+                    a1.z += g.z * ((xv.z - m4.z) * rs4.z); a1.w += g.w * ((xv.w - m4.w) * rs4.w);
+                }
             }
         }
-        atomicAdd(sums + c, (double)s0);
-        atomicAdd(sums + C + c, (double)s1);
+        __syncthreads();
+        s_part[0][wave][lane] = a0;
+        s_part[1][wave][lane] = a1;
+        __syncthreads();
+        if (wave < 2 && c4 < C4) {  // wave 0 folds the s0 partials, wave 1 the s1 partials
+            float4 t = s_part[wave][0][lane];
+            for (int w = 1; w < 4; ++w) { const float4 u = s_part[wave][w][lane]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+            double* dst = sums + (size_t)wave * C + (size_t)c4 * 4;
+            atomicAdd(dst + 0, (double)t.x); atomicAdd(dst + 1, (double)t.y); atomicAdd(dst + 2, (double)t.z); atomicAdd(dst + 3, (double)t.w);
+        }
     }
 }
 
