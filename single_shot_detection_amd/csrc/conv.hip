@@ -60,6 +60,7 @@ struct ConvProblem {
     long long ob0, ob1;
     int os0, os1;
     int tiles_n, n_blocks, m_tiles;
+    int k_splits;     // > 1: the K slices are divided over k_splits workgroups that atomically add into a zeroed output
     int block_begin;  // first workgroup of this problem in the grouped grid
     int relu;
     // device-side mode switch (sparse backward): the launch is a no-op for this problem unless *mode == want_mode
@@ -115,7 +116,9 @@ __global__ void __launch_bounds__(kConvThreads, 3) igemm_fwd_kernel(ConvGroup gr
     // workgroups that share an M tile get the same (id % 8) inside the problem (same XCD under round-robin placement
     // when block_begin % 8 == 0: they re-read the same activation rows from one L2).  Speed only.
     if (g.mode && *g.mode != g.want_mode) return;
-    const int id = blockIdx.x - g.block_begin;
+    const int id_all = blockIdx.x - g.block_begin;
+    const int ksp = id_all % g.k_splits;
+    const int id = id_all / g.k_splits;
     const int per_chunk = 8 * g.n_blocks;
     const int chunk = id / per_chunk, within = id % per_chunk;
     const int m_tile = chunk * 8 + (within & 7);
@@ -125,7 +128,11 @@ __global__ void __launch_bounds__(kConvThreads, 3) igemm_fwd_kernel(ConvGroup gr
     const int Cc = g.Cc;
     const int taps = SCATTER ? 1 : g.ksize * g.ksize;   // scatter: the taps live in N, K is just the channels
     const int chunks = (Cc + kBK - 1) / kBK;
-    const int n_slices = taps * chunks;
+    const int n_slices_all = taps * chunks;
+    const int per_split = (n_slices_all + g.k_splits - 1) / g.k_splits;
+    const int slice_begin = ksp * per_split;
+    const int n_slices = min(n_slices_all, slice_begin + per_split);   // end of this workgroup's slice range
+    if (slice_begin >= n_slices) return;
     const long long K = (long long)taps * Cc;
     const int N = g.n0 + g.n1;
     const int hw = g.Hout * g.Wout;
@@ -236,10 +243,10 @@ __global__ void __launch_bounds__(kConvThreads, 3) igemm_fwd_kernel(ConvGroup gr
     const float* a_rd = s_a + (wave * 32 + r32) * kLdsStride + 4 * h;
     const float* b_rd = s_b + r32 * kLdsStride + 4 * h;
 
-    load_slice(0);
+    load_slice(slice_begin);
     store_slice();
     __syncthreads();
-    for (int slice = 0; slice < n_slices; ++slice) {
+    for (int slice = slice_begin; slice < n_slices; ++slice) {
         if (slice + 1 < n_slices) load_slice(slice + 1);  // in flight while the MFMAs below run
 #pragma unroll
         for (int gk = 0; gk < kBK / 8; ++gk) {
@@ -298,14 +305,18 @@ __global__ void __launch_bounds__(kConvThreads, 3) igemm_fwd_kernel(ConvGroup gr
             if (n >= N) continue;
             float v = acc[j][e];
             if (n < g.n0) {
-                if (g.bias0) v += g.bias0[n];
+                if (g.bias0 && ksp == 0) v += g.bias0[n];
+                float* dst = g.o0 + (long long)b * g.ob0 + (long long)pix * g.os0 + n;
+                if (g.k_splits > 1) { atomicAdd(dst, v); continue; }
                 if (g.relu) v = fmaxf(v, 0.0f);
-                g.o0[(long long)b * g.ob0 + (long long)pix * g.os0 + n] = v;
+                *dst = v;
             } else {
                 const int n1 = n - g.n0;
-                if (g.bias1) v += g.bias1[n1];
+                if (g.bias1 && ksp == 0) v += g.bias1[n1];
+                float* dst = g.o1 + (long long)b * g.ob1 + (long long)pix * g.os1 + n1;
+                if (g.k_splits > 1) { atomicAdd(dst, v); continue; }
                 if (g.relu) v = fmaxf(v, 0.0f);
-                g.o1[(long long)b * g.ob1 + (long long)pix * g.os1 + n1] = v;
+                *dst = v;
             }
         }
     }
@@ -448,75 +459,73 @@ __global__ void __launch_bounds__(kConvThreads, 3) igemm_wgrad_kernel(WgradGroup
 // Also appends the ids of the rows that are not entirely zero to row_list (order inside a block preserved, blocks in
 // completion order) and counts them: the loss gradient is non-zero only on sampled anchors, i.e. on a few % of the pixels.
 constexpr int kPackRows = 32;
+constexpr int kPackColIters = 12;  // Npad <= 768 (RetinaNet: 9 * (80 + 4) = 756)
 __global__ void __launch_bounds__(256) pack_dy_kernel(const float* __restrict__ ds, long long sb, const float* __restrict__ dl,
                                                       long long lb, int n0, int n1, int Npad, int B, int HW,
                                                       float* __restrict__ out, float* __restrict__ db0, float* __restrict__ db1,
                                                       int* __restrict__ row_list, int* __restrict__ row_count) {
-    // wave w packs rows w, w+4, ... of the 32-row block; lane l owns float4 columns l, l+64, ... (64 columns per pass)
+    // wave w packs rows w, w+4, ... of the 32-row block; lane l owns columns l, l+64, ... : every load and store of a
+    // wave instruction is 256 contiguous bytes
     __shared__ unsigned s_flag;
     __shared__ int s_base;
-    __shared__ float4 s_sum[4][64];
-    const long long M = (long long)B * HW;
-    const long long m0 = (long long)blockIdx.x * kPackRows;
-    const int N = n0 + n1, n4 = Npad >> 2;
+    __shared__ float s_sum[4][kPackColIters * 64];
+    const int M = B * HW;
+    const int m0 = blockIdx.x * kPackRows;
+    const int N = n0 + n1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int iters = (Npad + 63) >> 6;
     if (threadIdx.x == 0) s_flag = 0u;
+    float acc[kPackColIters];
+#pragma unroll
+    for (int k = 0; k < kPackColIters; ++k) acc[k] = 0.0f;
     unsigned mine = 0u;
-    for (int cbase = 0; cbase < n4; cbase += 64) {
-        const int c4 = cbase + lane;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int r = wave; r < kPackRows; r += 4) {
-            const long long m = m0 + r;
-            if (m >= M) break;
-            bool nz = false;
-            if (c4 < n4) {
-                const int b = (int)(m / HW);
-                const long long p = m % HW;
-                const float* srow = ds + (long long)b * sb + p * n0;
-                const float* lrow = dl ? dl + (long long)b * lb + p * n1 : nullptr;
-                float v[4];
+    for (int r = wave; r < kPackRows; r += 4) {
+        const int m = m0 + r;
+        if (m >= M) break;
+        const int b = m / HW, p = m % HW;
+        const float* srow = ds + (long long)b * sb + (long long)p * n0;
+        const float* lrow = dl ? dl + (long long)b * lb + (long long)p * n1 : nullptr;
+        float* orow = out + (long long)m * Npad;
+        bool nz = false;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int n = c4 * 4 + k;
-                    v[k] = n < n0 ? srow[n] : (n < N ? lrow[n - n0] : 0.0f);
-                }
-                reinterpret_cast<float4*>(out + m * Npad)[c4] = make_float4(v[0], v[1], v[2], v[3]);
-                acc.x += v[0]; acc.y += v[1]; acc.z += v[2]; acc.w += v[3];
-                nz = v[0] != 0.0f || v[1] != 0.0f || v[2] != 0.0f || v[3] != 0.0f;
-            }
-            if (__ballot(nz)) mine |= 1u << r;
-        }
-        __syncthreads();
-        s_sum[wave][lane] = acc;
-        __syncthreads();
-        if (wave == 0 && c4 < n4) {
-            float4 t = s_sum[0][lane];
-            for (int w = 1; w < 4; ++w) { const float4 u = s_sum[w][lane]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
-            const float tv[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int n = c4 * 4 + k;
-                if (tv[k] != 0.0f) {
-                    if (n < n0) { if (db0) atomicAdd(db0 + n, tv[k]); }
-                    else if (n < N) { if (db1) atomicAdd(db1 + (n - n0), tv[k]); }
-                }
+        for (int k = 0; k < kPackColIters; ++k) {
+            if (k >= iters) break;
+            const int n = k * 64 + lane;
+            if (n < Npad) {
+                const float v = n < n0 ? srow[n] : (n < N ? lrow[n - n0] : 0.0f);
+                orow[n] = v;
+                acc[k] += v;
+                nz = nz || v != 0.0f;
             }
         }
+        if (__ballot(nz)) mine |= 1u << r;
     }
+#pragma unroll
+    for (int k = 0; k < kPackColIters; ++k)
+        if (k < iters) s_sum[wave][k * 64 + lane] = acc[k];
     if (lane == 0 && mine) atomicOr(&s_flag, mine);
     __syncthreads();
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float t = s_sum[0][n] + s_sum[1][n] + s_sum[2][n] + s_sum[3][n];
+        if (t != 0.0f) {
+            if (n < n0) { if (db0) atomicAdd(db0 + n, t); }
+            else if (db1) atomicAdd(db1 + (n - n0), t);
+        }
+    }
     const unsigned flags = s_flag;
     if (threadIdx.x == 0) s_base = flags ? atomicAdd(row_count, __popc(flags)) : 0;
     __syncthreads();
     if (threadIdx.x < kPackRows && ((flags >> threadIdx.x) & 1u))
-        row_list[s_base + __popc(flags & ((1u << threadIdx.x) - 1u))] = (int)(m0 + threadIdx.x);
+        row_list[s_base + __popc(flags & ((1u << threadIdx.x) - 1u))] = m0 + (int)threadIdx.x;
 }
 
-// mode[i] = 1 (sparse backward) when fewer than 1/4 of the level's pixel rows carry a gradient, else 0 (dense)
+// mode[i] = 1 (sparse backward) when fewer than 70 % of the level's pixel rows carry a gradient, else 0 (dense).
+// The sparse forms never do more multiplies than the dense ones; what they add is the scatter's atomic traffic
+// (rows * 9 * Cin * 4 bytes), which costs about a third of the dense GEMM time at full density.
 struct LevelTotals { int v[kMaxProblems]; };
 __global__ void decide_sparse_kernel(const int* __restrict__ counts, LevelTotals totals, int n, int* __restrict__ mode) {
     const int i = threadIdx.x;
-    if (i < n) mode[i] = ((long long)counts[i] * 4 < (long long)totals.v[i]) ? 1 : 0;
+    if (i < n) mode[i] = ((long long)counts[i] * 10 < (long long)totals.v[i] * 7) ? 1 : 0;
 }
 
 // db[n] += sum over rows of dy[row][n]   (dense [M][N] rows)
@@ -622,11 +631,24 @@ static void finish_problem(ConvProblem& g) {
     g.tiles_n = cdiv(N, 32);
     g.n_blocks = cdiv(g.tiles_n, kMaxTN);
     g.m_tiles = cdiv(g.B * g.Hout * g.Wout, kBM);
+    g.k_splits = 1;
 }
-static int problem_blocks(const ConvProblem& g) { return cdiv(g.m_tiles, 8) * 8 * g.n_blocks; }
+static int problem_blocks(const ConvProblem& g) { return cdiv(g.m_tiles, 8) * 8 * g.n_blocks * g.k_splits; }
 static long long problem_block_work(const ConvProblem& g) {
     const int chunks = cdiv(g.Cc, kBK);
-    return (long long)g.ksize * g.ksize * chunks * cdiv(g.tiles_n, g.n_blocks);
+    return (long long)g.ksize * g.ksize * chunks * cdiv(g.tiles_n, g.n_blocks) / g.k_splits;
+}
+// small GEMMs (pyramid tail): too few output tiles to fill 256 CUs -> split K, add partial tiles atomically (the
+// caller zeroes the output first).  Not with a fused ReLU (needs the complete sum).
+static bool maybe_split_k(ConvProblem& g) {
+    const int blocks = cdiv(g.m_tiles, 8) * 8 * g.n_blocks;
+    const int slices = g.ksize * g.ksize * cdiv(g.Cc, kBK);
+    if (g.relu || blocks >= 256 || slices < 8) return false;
+    int ks = cdiv(512, blocks);
+    if (ks > slices / 4) ks = slices / 4;
+    if (ks < 2) return false;
+    g.k_splits = ks;
+    return true;
 }
 
 // orders the problems by decreasing work per workgroup (longest first), assigns block ranges, launches
@@ -737,22 +759,22 @@ extern "C" size_t ssdk_heads_bwd_workspace_bytes(const ssdk_head_level* levels, 
     return total;
 }
 
+// K (= pixel rows) is split so that every problem contributes >= ~512 workgroups (tiny maps are latency bound at one
+// wave per SIMD: more, shorter workgroups) and no workgroup walks more than 64 slices; each split costs one 64 KB
+// atomic tile, so never fewer than 2 slices per split.
 static void size_wgrad_splits(WgradGroup& wg, int n, int density_div) {
-    long long total_slices = 0;
-    for (int i = 0; i < n; ++i) {
-        const WgradProblem& g = wg.p[i];
-        total_slices += (long long)g.ksize * g.ksize * g.n_tiles * g.c_blocks * cdiv(cdiv(g.B * g.Hout * g.Wout, density_div), 32);
-    }
-    long long slices_per_block = total_slices / (256 * 6);
-    if (slices_per_block < 16) slices_per_block = 16;
     int begin = 0;
     for (int i = 0; i < n; ++i) {
         WgradProblem& g = wg.p[i];
         const int slices = cdiv(cdiv(g.B * g.Hout * g.Wout, density_div), 32);
-        int ks = (int)((slices + slices_per_block - 1) / slices_per_block);
-        g.k_splits = ks < 1 ? 1 : ks;
+        const int tiles = g.ksize * g.ksize * g.n_tiles * g.c_blocks;
+        int ks = cdiv(512, tiles);
+        if (cdiv(slices, 64) > ks) ks = cdiv(slices, 64);
+        if (ks > slices / 2) ks = slices / 2;
+        if (ks < 1) ks = 1;
+        g.k_splits = ks;
         g.block_begin = begin;
-        begin += g.ksize * g.ksize * g.n_tiles * g.c_blocks * g.k_splits;
+        begin += tiles * ks;
     }
     wg.count = n;
     wg.total_blocks = begin;
@@ -773,6 +795,8 @@ extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int b
         if (rc) return rc;
         SSDK_REQUIRE(levels[i].n_loc == 0 || dlocs, SSDK_E_INVALID, "ssdk_heads_bwd: null dlocs");
         SSDK_REQUIRE(levels[i].cin % 4 == 0 && ((uintptr_t)levels[i].x & 15) == 0, SSDK_E_UNSUPPORTED, "ssdk_heads_bwd: Cin %% 4 != 0 or x not 16-byte aligned");
+        SSDK_REQUIRE(npad_of(levels[i]) <= kPackColIters * 64, SSDK_E_UNSUPPORTED, "ssdk_heads_bwd: n_score + n_loc = %d exceeds %d",
+                     levels[i].n_score + levels[i].n_loc, kPackColIters * 64);
         h_totals.v[i] = batch * levels[i].h * levels[i].w;
     }
     SSDK_CHECK_HIP(hipMemsetAsync(w.counts, 0, sizeof(int) * kMaxProblems, s));
@@ -888,6 +912,7 @@ static inline int out_dim(int in, int k, int s, int p) { return (in + 2 * p - k)
 extern "C" int ssdk_conv2d_fwd(const ssdk_conv_desc* descs, int n, int batch, void* stream) {
     SSDK_REQUIRE(descs && n > 0 && n <= kMaxProblems, SSDK_E_INVALID, "ssdk_conv2d_fwd: n=%d (1..%d)", n, kMaxProblems);
     ConvProblem probs[kMaxProblems];
+    ZeroList zl;
     for (int i = 0; i < n; ++i) {
         const ssdk_conv_desc& d = descs[i];
         int rc = check_conv("ssdk_conv2d_fwd", batch, d);
@@ -901,8 +926,11 @@ extern "C" int ssdk_conv2d_fwd(const ssdk_conv_desc* descs, int n, int batch, vo
         g.o0 = d.y; g.ob0 = (long long)ho * wo * d.cout; g.os0 = d.cout; g.o1 = nullptr; g.ob1 = 0; g.os1 = 0;
         g.relu = d.relu;
         finish_problem(g);
+        if (maybe_split_k(g)) zl.add(d.y, (size_t)batch * ho * wo * d.cout);
         probs[i] = g;
     }
+    int rc = zl.launch((hipStream_t)stream);
+    if (rc) return rc;
     return launch_group(probs, n, false, (hipStream_t)stream, true);
 }
 
