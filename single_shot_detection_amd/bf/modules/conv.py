@@ -16,6 +16,8 @@ class Conv2dBn(nn.Module):
             self.bn = nn.BatchNorm2d(out_channels, **batch_norm_params)
         if activation_params is not None:
             self.activation = getattr(nn, activation_params['name'])(**activation_params['args'])
+        # [cout][ky][kx][cin] memory = the rows the implicit GEMM reads (no per-step permute copy); state_dict unchanged
+        self.conv.weight.data = self.conv.weight.data.contiguous(memory_format=torch.channels_last)
 
     def _hip_ok(self):
         c = self.conv

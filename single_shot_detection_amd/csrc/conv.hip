@@ -460,17 +460,41 @@ __global__ void __launch_bounds__(kConvThreads, 3) igemm_wgrad_kernel(WgradGroup
 // completion order) and counts them: the loss gradient is non-zero only on sampled anchors, i.e. on a few % of the pixels.
 constexpr int kPackRows = 32;
 constexpr int kPackColIters = 12;  // Npad <= 768 (RetinaNet: 9 * (80 + 4) = 756)
-__global__ void __launch_bounds__(256) pack_dy_kernel(const float* __restrict__ ds, long long sb, const float* __restrict__ dl,
-                                                      long long lb, int n0, int n1, int Npad, int B, int HW,
-                                                      float* __restrict__ out, float* __restrict__ db0, float* __restrict__ db1,
-                                                      int* __restrict__ row_list, int* __restrict__ row_count) {
+struct PackLevel {
+    const float* ds; const float* dl;
+    int n0, n1, Npad, HW;
+    float* out; float* db0; float* db1;
+    int* row_list; int* row_count;
+    int block_begin;
+};
+struct PackGroup {
+    int count, B;
+    long long sb, lb;
+    PackLevel lv[kMaxProblems];
+};
+__global__ void __launch_bounds__(256) pack_dy_kernel(PackGroup grp) {
+    int pi = 0;
+#pragma unroll 1
+    for (int i = 1; i < grp.count; ++i)
+        if ((int)blockIdx.x >= grp.lv[i].block_begin) pi = i;
+    const PackLevel& L = grp.lv[pi];
+    const float* __restrict__ ds = L.ds;
+    const float* __restrict__ dl = L.dl;
+    const long long sb = grp.sb, lb = grp.lb;
+    const int n0 = L.n0, n1 = L.n1, Npad = L.Npad, B = grp.B, HW = L.HW;
+    float* __restrict__ out = L.out;
+    float* __restrict__ db0 = L.db0;
+    float* __restrict__ db1 = L.db1;
+    int* __restrict__ row_list = L.row_list;
+    int* __restrict__ row_count = L.row_count;
+    const int block = blockIdx.x - L.block_begin;
     // wave w packs rows w, w+4, ... of the 32-row block; lane l owns columns l, l+64, ... : every load and store of a
     // wave instruction is 256 contiguous bytes
     __shared__ unsigned s_flag;
     __shared__ int s_base;
     __shared__ float s_sum[4][kPackColIters * 64];
     const int M = B * HW;
-    const int m0 = blockIdx.x * kPackRows;
+    const int m0 = block * kPackRows;
     const int N = n0 + n1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int iters = (Npad + 63) >> 6;
@@ -817,14 +841,21 @@ extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int b
         int rc = zl.launch(s);
         if (rc) return rc;
     }
-    // 1. pack dY (aligned, zero padded rows), bias gradients, list of rows that carry a gradient
-    for (int i = 0; i < n_levels; ++i) {
-        const ssdk_head_level& lv = levels[i];
-        const int npad = npad_of(lv), hw = lv.h * lv.w;
-        const long long M = (long long)batch * hw;
-        hipLaunchKernelGGL(pack_dy_kernel, dim3((unsigned)((M + kPackRows - 1) / kPackRows)), dim3(256), 0, s,
-                           dscores + lv.scores_offset, scores_batch_stride, lv.n_loc ? dlocs + lv.locs_offset : nullptr, locs_batch_stride,
-                           lv.n_score, lv.n_loc, npad, batch, hw, w.dyp[i], lv.db_score, lv.db_loc, w.row_list[i], w.counts + i);
+    // 1. pack dY (aligned, zero padded rows), bias gradients, list of rows that carry a gradient: all levels, one launch
+    {
+        PackGroup pg{};
+        pg.count = n_levels; pg.B = batch; pg.sb = scores_batch_stride; pg.lb = locs_batch_stride;
+        int begin = 0;
+        for (int i = 0; i < n_levels; ++i) {
+            const ssdk_head_level& lv = levels[i];
+            PackLevel& L = pg.lv[i];
+            L.ds = dscores + lv.scores_offset; L.dl = lv.n_loc ? dlocs + lv.locs_offset : nullptr;
+            L.n0 = lv.n_score; L.n1 = lv.n_loc; L.Npad = npad_of(lv); L.HW = lv.h * lv.w;
+            L.out = w.dyp[i]; L.db0 = lv.db_score; L.db1 = lv.db_loc; L.row_list = w.row_list[i]; L.row_count = w.counts + i;
+            L.block_begin = begin;
+            begin += cdiv(batch * L.HW, kPackRows);
+        }
+        hipLaunchKernelGGL(pack_dy_kernel, dim3(begin), dim3(256), 0, s, pg);
         SSDK_CHECK_LAUNCH("pack_dy_kernel");
     }
     hipLaunchKernelGGL(decide_sparse_kernel, dim3(1), dim3(64), 0, s, w.counts, h_totals, n_levels, w.mode);

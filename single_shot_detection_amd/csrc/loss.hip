@@ -27,6 +27,7 @@ constexpr int kTileRows = 64;
 constexpr int kLossThreads = 256;
 constexpr float kMarkPositive = -INFINITY;  // bgloss marker: positive anchor (sampler.py:22 sets -inf for non-negatives)
 constexpr float kMarkIgnore = -1.0f;        // bgloss marker: ignored anchor (class -1)
+constexpr int kSelCache = 8;                // values per thread that hnm_select_kernel keeps in registers (8 * 1024 anchors)
 
 struct LossState {  // lives in the workspace, written by finalize_kernel, read by the backward
     float divider;   // max(1, #positives)               multibox_loss.py:88
@@ -119,8 +120,17 @@ __global__ void __launch_bounds__(1024) hnm_select_kernel(const float* __restric
     uint8_t* out = sampled + (size_t)i * A;
     if (tid < 2) s_cnt[tid] = 0;
     __syncthreads();
+    // the first kSelCache * 1024 values live in registers for all passes; anything beyond is re-read (L2 resident)
+    float cache[kSelCache];
+#pragma unroll
+    for (int k = 0; k < kSelCache; ++k) {
+        const int a = tid + k * 1024;
+        cache[k] = a < A ? v[a] : kMarkIgnore;
+    }
     int npos = 0, nneg = 0;
-    for (int a = tid; a < A; a += blockDim.x) {
+#pragma unroll
+    for (int k = 0; k < kSelCache; ++k) { npos += cache[k] == kMarkPositive; nneg += cache[k] >= 0.0f; }
+    for (int a = tid + kSelCache * 1024; a < A; a += blockDim.x) {
         const float x = v[a];
         npos += x == kMarkPositive;
         nneg += x >= 0.0f;
@@ -155,7 +165,15 @@ __global__ void __launch_bounds__(1024) hnm_select_kernel(const float* __restric
         for (int b = tid; b < 256; b += blockDim.x) s_hist[b] = 0;
         __syncthreads();
         const unsigned himask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
-        for (int a = tid; a < A; a += blockDim.x) {
+#pragma unroll
+        for (int k = 0; k < kSelCache; ++k) {
+            const float x = cache[k];
+            if (x >= 0.0f) {
+                const unsigned key = neg_key(x);
+                if ((key & himask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255u], 1u);
+            }
+        }
+        for (int a = tid + kSelCache * 1024; a < A; a += blockDim.x) {
             const float x = v[a];
             if (x >= 0.0f) {
                 const unsigned key = neg_key(x);
