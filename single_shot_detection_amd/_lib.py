@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libssdk.so')
+LIB_PATH = os.environ.get('SSDK_LIB') or os.path.join(_HERE, 'libssdk.so')   # SSDK_LIB: A/B builds of the same ABI
 CSRC = os.path.join(_HERE, 'csrc')
 
 _lib = None

@@ -27,6 +27,8 @@
 // Backward-weights (igemm_wgrad_kernel) contracts over pixels: both operands are read in their natural
 // [pixel][channel] form, K = pixels is split across workgroups and partial tiles are accumulated with fp32 atomics
 // shaped as two 128-byte segments per wave instruction.
+#include <type_traits>
+
 #include "common.h"
 
 namespace ssdk {
@@ -40,6 +42,10 @@ constexpr int kLdsStride = 36;  // floats per LDS row (32 + 4 pad)
 constexpr int kMaxTN = 4;       // 32-wide column tiles per workgroup
 constexpr int kConvThreads = 256;
 constexpr int kMaxProblems = 8;
+#ifndef SSDK_CONV_WAVES
+#define SSDK_CONV_WAVES 2  // workgroups per CU the GEMM kernels are register-budgeted for: 2 -> <=256 VGPRs, no spills
+                           // (measured: the 3-workgroup budget of 168 VGPRs spills the prefetch registers and is 10% slower)
+#endif
 
 struct ConvProblem {
     // A operand rows [pixel][channel], one segment
@@ -91,13 +97,21 @@ __device__ __forceinline__ float4 vzero<4>() { return make_float4(0.f, 0.f, 0.f,
 template <>
 __device__ __forceinline__ float vzero<1>() { return 0.f; }
 
+// A pointer that is the same in every lane, pinned into an SGPR pair (so that `base + lane_offset` becomes the
+// saddr + 32-bit voffset addressing form and never a per-lane 64-bit select or a reload from the kernarg segment).
+__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const float*)(((unsigned long long)hi << 32) | lo);
+}
+
 // ---- forward / backward-data ------------------------------------------------------------------------------------
 // MIRROR = false: forward convolution; MIRROR = true: backward-data (separate instantiations so that profiles list the
 // forward GEMMs and the dgrad GEMMs as different kernels).
 // STRIDED (backward-data of a strided convolution only): the source pixel of a tap is (y + pad - k) / stride when
 // divisible, so the tap offset is no longer uniform over the rows; it is recomputed per row and slice.
 template <int VEC, bool MIRROR, bool STRIDED = false, bool GENERIC = false, bool SCATTER = false>
-__global__ void __launch_bounds__(kConvThreads, 3) igemm_fwd_kernel(ConvGroup grp) {
+__global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_fwd_kernel(ConvGroup grp) {
     typedef typename VecT<VEC>::type vec_t;
     constexpr int kVecPerRow = kBK / VEC;  // vector loads per 32-float row slice
     constexpr int kRowsPerPass = kConvThreads / kVecPerRow;
@@ -146,8 +160,8 @@ __global__ void __launch_bounds__(kConvThreads, 3) igemm_fwd_kernel(ConvGroup gr
     const int tid = threadIdx.x;
     const int lrow = tid / kVecPerRow, lcol = (tid % kVecPerRow) * VEC;
 
-    // per-thread A rows: offset of the centre-tap pixel and a 9-bit validity mask per tap
-    long long a_off[kAPasses];
+    // per-thread A rows: 32-bit element offset of the row's base pixel and a 9-bit validity mask per tap
+    int a_off[kAPasses];
     unsigned a_mask[kAPasses];
     int a_yx[kAPasses];  // STRIDED only: (y + pad) << 16 | (x + pad)
 #pragma unroll
@@ -159,7 +173,7 @@ __global__ void __launch_bounds__(kConvThreads, 3) igemm_fwd_kernel(ConvGroup gr
         if (SCATTER) {
             if (m < M) {
                 a_mask[p] = 1u;
-                a_off[p] = (long long)(g.row_list ? g.row_list[m] : m) * g.a_pstride;
+                a_off[p] = (g.row_list ? g.row_list[m] : m) * g.a_pstride;
             }
         } else if (m < M) {
             const int b = m / hw, r = m % hw;
@@ -184,52 +198,65 @@ __global__ void __launch_bounds__(kConvThreads, 3) igemm_fwd_kernel(ConvGroup gr
             }
             a_mask[p] = mask;
             a_yx[p] = (by << 16) | bx;
-            a_off[p] = STRIDED ? (long long)b * g.a_bstride
-                               : (long long)b * g.a_bstride + ((long long)by * g.Win + bx) * g.a_pstride;
+            a_off[p] = STRIDED ? b * (int)g.a_bstride : b * (int)g.a_bstride + (by * g.Win + bx) * g.a_pstride;
         }
     }
-    // per-thread W rows
-    const float* w_row[kBPasses];
+    // per-thread W rows: 32-bit element offset inside the row's segment; bit 30 set = second segment (w1); -1 = no row
+    int w_off[kBPasses];
 #pragma unroll
     for (int p = 0; p < kBPasses; ++p) {
         const int rr = lrow + p * kRowsPerPass;
         const int n = n_begin + rr;
-        w_row[p] = (rr < tn * 32 && n < N) ? (n < g.n0 ? g.w0 + (long long)n * K : g.w1 + (long long)(n - g.n0) * K) : nullptr;
+        w_off[p] = (rr < tn * 32 && n < N) ? (n < g.n0 ? n * (int)K : ((n - g.n0) * (int)K) | (1 << 30)) : -1;
     }
 
+    // Prefetch of one K slice into registers.  Branch-free: a lane whose element does not exist reads element 0 of the
+    // operand instead (always mapped) and the value is replaced by zero when it is written to LDS, so the eight loads
+    // issue back to back and are all in flight during the MFMAs of the current slice.
+    const float* const a_base = uniform_ptr(g.a);
+    const float* const w0_base = uniform_ptr(g.w0);
+    const float* const w1_base = uniform_ptr(g.w1 ? g.w1 : g.w0);
+    const int win_ps = g.Win * g.a_pstride, a_ps = g.a_pstride, ks = g.ksize, strd = g.stride;
     vec_t ra[kAPasses], rb[kBPasses];
+    unsigned live = 0;
     auto load_slice = [&](int slice) {
-        const int tap = slice / chunks, c = (slice % chunks) * kBK + lcol;
-        const int ky = tap / g.ksize, kx = tap % g.ksize;
-        const long long tap_off = MIRROR ? -((long long)ky * g.Win + kx) * g.a_pstride : ((long long)ky * g.Win + kx) * g.a_pstride;
+        // channel chunk outer, tap inner: the nine taps of one chunk re-read (shifted) pixel rows that are still in L1/L2
+        const int tap = slice % taps, c = (slice / taps) * kBK + lcol;
+        const int ky = tap / ks, kx = tap % ks;
+        const int tap_off = MIRROR ? -(ky * win_ps + kx * a_ps) : (ky * win_ps + kx * a_ps);
         const bool c_ok = c < Cc;
+        live = 0;
 #pragma unroll
         for (int p = 0; p < kAPasses; ++p) {
-            vec_t v = vzero<VEC>();
-            if (c_ok && ((a_mask[p] >> tap) & 1u)) {
-                if (STRIDED) {
-                    const int iy = ((a_yx[p] >> 16) - ky) / g.stride, ix = ((a_yx[p] & 0xFFFF) - kx) / g.stride;
-                    v = *reinterpret_cast<const vec_t*>(g.a + a_off[p] + ((long long)iy * g.Win + ix) * g.a_pstride + c);
-                } else {
-                    v = *reinterpret_cast<const vec_t*>(g.a + a_off[p] + tap_off + c);
-                }
+            const bool ok = c_ok && ((a_mask[p] >> tap) & 1u);
+            int off;
+            if (STRIDED) {
+                const int iy = ((a_yx[p] >> 16) - ky) / strd, ix = ((a_yx[p] & 0xFFFF) - kx) / strd;
+                off = a_off[p] + iy * win_ps + ix * a_ps + c;
+            } else {
+                off = a_off[p] + tap_off + c;
             }
-            ra[p] = v;
+            ra[p] = *reinterpret_cast<const vec_t*>(a_base + (size_t)(unsigned)(ok ? off : 0));
+            live |= (ok ? 1u : 0u) << p;
         }
+        const int wk = tap * Cc + c;
 #pragma unroll
         for (int p = 0; p < kBPasses; ++p) {
-            vec_t v = vzero<VEC>();
-            if (c_ok && w_row[p]) v = *reinterpret_cast<const vec_t*>(w_row[p] + (long long)tap * Cc + c);
-            rb[p] = v;
+            const bool ok = c_ok && w_off[p] >= 0;
+            const unsigned off = ok ? (unsigned)((w_off[p] & ~(1 << 30)) + wk) : 0u;
+            // two loads would double the traffic; the segment is a per-row constant, so select the (uniform) base per lane
+            const float* base = (w_off[p] & (1 << 30)) ? w1_base : w0_base;
+            rb[p] = *reinterpret_cast<const vec_t*>(base + (size_t)off);
+            live |= (ok ? 1u : 0u) << (kAPasses + p);
         }
     };
     auto store_slice = [&]() {
 #pragma unroll
         for (int p = 0; p < kAPasses; ++p)
-            *reinterpret_cast<vec_t*>(&s_a[(lrow + p * kRowsPerPass) * kLdsStride + lcol]) = ra[p];
+            *reinterpret_cast<vec_t*>(&s_a[(lrow + p * kRowsPerPass) * kLdsStride + lcol]) = ((live >> p) & 1u) ? ra[p] : vzero<VEC>();
 #pragma unroll
         for (int p = 0; p < kBPasses; ++p)
-            *reinterpret_cast<vec_t*>(&s_b[(lrow + p * kRowsPerPass) * kLdsStride + lcol]) = rb[p];
+            *reinterpret_cast<vec_t*>(&s_b[(lrow + p * kRowsPerPass) * kLdsStride + lcol]) = ((live >> (kAPasses + p)) & 1u) ? rb[p] : vzero<VEC>();
     };
 
     f32x16 acc[kMaxTN];
@@ -246,27 +273,36 @@ __global__ void __launch_bounds__(kConvThreads, 3) igemm_fwd_kernel(ConvGroup gr
     load_slice(slice_begin);
     store_slice();
     __syncthreads();
-    for (int slice = slice_begin; slice < n_slices; ++slice) {
-        if (slice + 1 < n_slices) load_slice(slice + 1);  // in flight while the MFMAs below run
+    // The K loop is specialised on the number of column tiles (dispatched once per workgroup): with a run-time bound
+    // every MFMA would sit behind its own scalar branch.
+    auto k_loop = [&](auto tn_c) {
+        constexpr int TN = decltype(tn_c)::value;
+        for (int slice = slice_begin; slice < n_slices; ++slice) {
+            if (slice + 1 < n_slices) load_slice(slice + 1);  // in flight while the MFMAs below run
 #pragma unroll
-        for (int gk = 0; gk < kBK / 8; ++gk) {
-            // lane (r, h) reads k = gk*8 + 4h .. +3 of its row: MFMA kk pairs k = gk*8+kk (h=0) with gk*8+4+kk (h=1)
-            const f32x4 av = *reinterpret_cast<const f32x4*>(a_rd + gk * 8);
-            f32x4 bv[kMaxTN];
+            for (int gk = 0; gk < kBK / 8; ++gk) {
+                // lane (r, h) reads k = gk*8 + 4h .. +3 of its row: MFMA kk pairs k = gk*8+kk (h=0) with gk*8+4+kk (h=1)
+                const f32x4 av = *reinterpret_cast<const f32x4*>(a_rd + gk * 8);
+                f32x4 bv[TN];
 #pragma unroll
-            for (int j = 0; j < kMaxTN; ++j)
-                if (j < tn) bv[j] = *reinterpret_cast<const f32x4*>(b_rd + j * 32 * kLdsStride + gk * 8);
+                for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const f32x4*>(b_rd + j * 32 * kLdsStride + gk * 8);
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
+                for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                for (int j = 0; j < kMaxTN; ++j)
-                    if (j < tn) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[j][kk], acc[j], 0, 0, 0);
-        }
-        __syncthreads();
-        if (slice + 1 < n_slices) {
-            store_slice();
+                    for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[j][kk], acc[j], 0, 0, 0);
+            }
             __syncthreads();
+            if (slice + 1 < n_slices) {
+                store_slice();
+                __syncthreads();
+            }
         }
+    };
+    switch (tn) {
+        case 4: k_loop(std::integral_constant<int, 4>{}); break;
+        case 3: k_loop(std::integral_constant<int, 3>{}); break;
+        case 2: k_loop(std::integral_constant<int, 2>{}); break;
+        default: k_loop(std::integral_constant<int, 1>{}); break;
     }
 
     // epilogue: C/D map of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
@@ -345,7 +381,7 @@ struct WgradGroup {
 };
 
 // LDS: dY slice [32 pixels][128 n] and X slice [32 pixels][128 c]; MFMA A operand = dY^T, B operand = X.
-__global__ void __launch_bounds__(kConvThreads, 3) igemm_wgrad_kernel(WgradGroup grp) {
+__global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_wgrad_kernel(WgradGroup grp) {
     __shared__ __attribute__((aligned(16))) float s_dy[32 * 128];
     __shared__ __attribute__((aligned(16))) float s_x[32 * 128];
 
@@ -421,22 +457,31 @@ __global__ void __launch_bounds__(kConvThreads, 3) igemm_wgrad_kernel(WgradGroup
     load_slice(s_begin);
     store_slice();
     __syncthreads();
-    for (int s = s_begin; s < s_end; ++s) {
-        if (s + 1 < s_end) load_slice(s + 1);
-        if (wave_live) {
+    auto k_loop = [&](auto tn_c) {   // specialised on the number of column tiles: no branch per MFMA
+        constexpr int TN = decltype(tn_c)::value;
+        for (int s = s_begin; s < s_end; ++s) {
+            if (s + 1 < s_end) load_slice(s + 1);
+            if (wave_live) {
 #pragma unroll 4
-            for (int k2 = 0; k2 < 32; k2 += 2) {
-                const float av = s_dy[(k2 + h) * 128 + wave * 32 + r32];
+                for (int k2 = 0; k2 < 32; k2 += 2) {
+                    const float av = s_dy[(k2 + h) * 128 + wave * 32 + r32];
 #pragma unroll
-                for (int j = 0; j < kMaxTN; ++j)
-                    if (j < tn) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s_x[(k2 + h) * 128 + j * 32 + r32], acc[j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s_x[(k2 + h) * 128 + j * 32 + r32], acc[j], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+            if (s + 1 < s_end) {
+                store_slice();
+                __syncthreads();
             }
         }
-        __syncthreads();
-        if (s + 1 < s_end) {
-            store_slice();
-            __syncthreads();
-        }
+    };
+    switch (tn) {
+        case 4: k_loop(std::integral_constant<int, 4>{}); break;
+        case 3: k_loop(std::integral_constant<int, 3>{}); break;
+        case 2: k_loop(std::integral_constant<int, 2>{}); break;
+        default: k_loop(std::integral_constant<int, 1>{}); break;
     }
     if (!wave_live) return;
     const long long K = (long long)taps * Cc;
