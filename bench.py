@@ -33,11 +33,24 @@ from single_shot_detection_amd import synthetic as syn  # noqa: E402
 from single_shot_detection_amd.distributed import GradBucket  # noqa: E402
 
 # extras of the SSD sample files (samples/ssd_300_vgg16_voc.py:16-18, ssd_512_vgg16_coco.py)
+TOWER = {'retina_rn50_500_coco': dict(num_layers=4, num_channels=256, kernel_size=3)}
 EXTRAS = {'ssd_300_vgg16_voc': (('s', 512), ('s', 256), ('s', 256), ('s', 256)),
           'ssd_512_vgg16_coco': (('s', 512), ('s', 256), ('s', 256), ('s', 256), ('s', 256))}
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
+
+
+def measured_traffic(kernel_key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r01_pmc.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this command; FETCH_SIZE doubled per the gfx950
+    correction in MI355X_MICROARCH.md, both in KiB).  None when the file is absent or was taken on another workload."""
+    path = os.path.join(REPO, 'profiles', 'r01_pmc.json')
+    try:
+        d = json.load(open(path))[kernel_key]
+        return (2.0 * d['FETCH_SIZE_KiB'] + d['WRITE_SIZE_KiB']) * 1024.0
+    except Exception:
+        return None
 
 
 def head_flops_per_image(levels, C):
@@ -65,6 +78,11 @@ class HotPath(object):
         if cfg_name in EXTRAS:
             n_in = len(self.levels) - len(EXTRAS[cfg_name])
             self.extras = detector_builder.get_extras([self.levels[n_in - 1][0]], layers=EXTRAS[cfg_name]).to(device)
+        # RetinaNet: the shared-conv tower (H3) sits between the FPN maps and the heads (retina_rn50_500_coco.py:18-24)
+        self.tower = None
+        if cfg_name in TOWER:
+            from single_shot_detection_amd.detection.modules.predictors import SharedConvPredictor
+            self.tower = SharedConvPredictor([l[0] for l in self.levels], [l[2] for l in self.levels], self.C, False, **TOWER[cfg_name]).to(device)
         fm = syn.make_feature_maps(batch, self.levels[:n_in], seed=seed)
         self.inputs = [torch.from_numpy(x).to(device).contiguous(memory_format=torch.channels_last).requires_grad_(True) for x in fm]
         p = dict(cfg['anchor'])
@@ -87,7 +105,8 @@ class HotPath(object):
         self.assigner = TargetAssigner(cfg['matched'], cfg['unmatched'])
         self.post = Postprocessor(box_coder, score_threshold=0.01, nms={'max_per_class': 100, 'overlap_threshold': cfg['nms_thr']},
                                   score_converter=cfg['score_converter'], max_total=200)
-        self.params = [p for p in self.heads.parameters()] + ([p for p in self.extras.parameters()] if self.extras is not None else [])
+        self.params = [p for p in self.heads.parameters()] + ([p for p in self.extras.parameters()] if self.extras is not None else []) + \
+                      ([p for p in self.tower.parameters()] if self.tower is not None else [])
         self.opt = torch.optim.SGD(self.params, lr=1e-3, momentum=0.9, weight_decay=5e-4)
         self.bucket = GradBucket(self.params)
         self.fwd_events = []
@@ -105,10 +124,13 @@ class HotPath(object):
     def forward_heads(self, timed=False):
         from single_shot_detection_amd.detection.modules.heads import multi_level_heads
         sources = self.pyramid()
+        score_sources = loc_sources = sources
+        if self.tower is not None:
+            score_sources, loc_sources = self.tower(sources)
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        out = multi_level_heads(sources, sources, self.heads)
+        out = multi_level_heads(score_sources, loc_sources, self.heads)
         if timed:
             e1.record()
             self.fwd_events.append((e0, e1))
@@ -256,7 +278,8 @@ def main():
             'eval_images_per_sec': world * args.batch / dte, 'nms_candidates_per_image': cand / args.batch,
             'roofline': {'bound': 'mfma', 'kernel': 'igemm_fwd_kernel<4,false> (forward head GEMMs, all pyramid levels in one grouped launch)',
                          'achieved': achieved, 'peak': PEAK_FP32_MATRIX_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_FP32_MATRIX_TFLOPS, 'traffic': None,
+                         'frac': achieved / PEAK_FP32_MATRIX_TFLOPS,
+                         'traffic': measured_traffic(f'{args.config}:b{args.batch}:igemm_fwd_heads'),
                          'algorithmic_gflop_per_step': flops_step / 1e9, 'ms_per_step': fwd_ms},
         }
         if not args.no_cpu_baseline and world == 1:

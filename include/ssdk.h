@@ -237,7 +237,8 @@ typedef struct ssdk_conv_desc {
 /* n <= 8 convolutions (e.g. the five pyramid levels of one shared tower layer) in one grouped launch. */
 int ssdk_conv2d_fwd(const ssdk_conv_desc* descs, int n, int batch, void* stream);
 size_t ssdk_conv2d_bwd_workspace_bytes(const ssdk_conv_desc* descs, int n, int batch);
-/* accumulate != 0: dw / db are added to (weights shared across the n descriptors); else overwritten. */
+/* accumulate != 0: dw / db are added to what the buffers hold; else they are overwritten (descriptors that name the
+ * same dw / db -- weights shared across levels -- are summed into it). */
 int ssdk_conv2d_bwd(const ssdk_conv_desc* descs, int n, int batch, int accumulate, void* workspace, size_t workspace_bytes,
                     void* stream);
 /* dx = y > 0 ? dy : 0 (n floats, n % 4 == 0). */

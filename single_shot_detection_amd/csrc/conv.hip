@@ -1070,7 +1070,9 @@ extern "C" int ssdk_conv2d_bwd(const ssdk_conv_desc* descs, int n, int batch, in
             scat[n_scat++] = g;
         }
         if (d.dw) {
-            if (!accumulate) zl.add(d.dw, (size_t)d.cout * taps * d.cin);
+            bool seen = false;  // descriptors that share weights share dw: zero it once
+            for (int q = 0; q < i; ++q) seen = seen || descs[q].dw == d.dw;
+            if (!accumulate && !seen) zl.add(d.dw, (size_t)d.cout * taps * d.cin);
             WgradProblem g{};
             g.dy = d.dy; g.x = d.x; g.Npad = d.cout; g.Cc = d.cin;
             g.B = batch; g.Hout = ho; g.Wout = wo; g.Hin = d.hin; g.Win = d.win; g.ksize = d.ksize; g.stride = d.stride; g.pad = d.pad;
@@ -1080,7 +1082,11 @@ extern "C" int ssdk_conv2d_bwd(const ssdk_conv_desc* descs, int n, int batch, in
             g.c_blocks = cdiv(g.c_tiles32, kMaxTN);
             wg.p[n_wgrad++] = g;
         }
-        if (d.db && !accumulate) zl.add(d.db, (size_t)d.cout);
+        if (d.db && !accumulate) {
+            bool seen = false;
+            for (int q = 0; q < i; ++q) seen = seen || descs[q].db == d.db;
+            if (!seen) zl.add(d.db, (size_t)d.cout);
+        }
     }
     int rc = zl.launch(s);
     if (rc) return rc;

@@ -88,12 +88,49 @@ __global__ void __launch_bounds__(256) bn_eval_stats_kernel(const float* __restr
     }
 }
 
+// sums != NULL (training): mean / rstd come straight from the fp64 sums of bn_reduce_kernel<0> (no separate finalize
+// launch); workgroup 0 also publishes save_mean / save_rstd for the backward and updates the running statistics.
+__device__ __forceinline__ void stats_from_sums(const double* sums, long long rows, int C, int c, float eps, float& m, float& rs, float& var_out) {
+    const double n = (double)rows;
+    const double mu = sums[c] / n;
+    double var = sums[C + c] / n - mu * mu;
+    if (var < 0.0) var = 0.0;
+    m = (float)mu;
+    rs = (float)(1.0 / sqrt(var + (double)eps));
+    var_out = (float)(rows > 1 ? var * n / (n - 1.0) : var);
+}
+
 __global__ void __launch_bounds__(256) bn_apply_kernel(const float4* __restrict__ x, long long n4, int C4, const float4* __restrict__ mean,
                                                        const float4* __restrict__ rstd, const float4* __restrict__ gamma,
-                                                       const float4* __restrict__ beta, int relu, float4* __restrict__ y) {
+                                                       const float4* __restrict__ beta, int relu, float4* __restrict__ y,
+                                                       const double* __restrict__ sums, long long rows, float eps, float momentum,
+                                                       float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                       float* __restrict__ save_mean, float* __restrict__ save_rstd) {
+    const int C = C4 * 4;
+    if (sums && blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            float m, rs, uv;
+            stats_from_sums(sums, rows, C, c, eps, m, rs, uv);
+            save_mean[c] = m;
+            save_rstd[c] = rs;
+            if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * m;
+            if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * uv;
+        }
+    }
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4);
-        const float4 v = x[i], m = mean[c], rs = rstd[c];
+        const float4 v = x[i];
+        float4 m, rs;
+        if (sums) {
+            float uv;
+            stats_from_sums(sums, rows, C, 4 * c + 0, eps, m.x, rs.x, uv);
+            stats_from_sums(sums, rows, C, 4 * c + 1, eps, m.y, rs.y, uv);
+            stats_from_sums(sums, rows, C, 4 * c + 2, eps, m.z, rs.z, uv);
+            stats_from_sums(sums, rows, C, 4 * c + 3, eps, m.w, rs.w, uv);
+        } else {
+            m = mean[c];
+            rs = rstd[c];
+        }
         const float4 ga = gamma ? gamma[c] : make_float4(1.f, 1.f, 1.f, 1.f), be = beta ? beta[c] : make_float4(0.f, 0.f, 0.f, 0.f);
         float4 o = make_float4((v.x - m.x) * rs.x * ga.x + be.x, (v.y - m.y) * rs.y * ga.y + be.y, (v.z - m.z) * rs.z * ga.z + be.z,
                                (v.w - m.w) * rs.w * ga.w + be.w);
@@ -152,16 +189,15 @@ extern "C" int ssdk_batchnorm_fwd(const float* x, long long rows, int channels, 
         hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3((unsigned)((rows + kBnRows - 1) / kBnRows)), dim3(256), 0, s, x, (const float*)nullptr,
                            (const float*)nullptr, rows, channels, (const float*)nullptr, (const float*)nullptr, 0, sums);
         SSDK_CHECK_LAUNCH("bn_reduce_kernel");
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(channels, 256)), dim3(256), 0, s, sums, rows, channels, eps, momentum, running_mean,
-                           running_var, save_mean, save_rstd);
-        SSDK_CHECK_LAUNCH("bn_finalize_kernel");
     } else {
         hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(channels, 256)), dim3(256), 0, s, running_mean, running_var, channels, eps, save_mean, save_rstd);
         SSDK_CHECK_LAUNCH("bn_eval_stats_kernel");
     }
     const long long n4 = rows * channels / 4;
     hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_blocks(n4, 256)), dim3(256), 0, s, (const float4*)x, n4, channels / 4, (const float4*)save_mean,
-                       (const float4*)save_rstd, (const float4*)gamma, (const float4*)beta, relu, (float4*)y);
+                       (const float4*)save_rstd, (const float4*)gamma, (const float4*)beta, relu, (float4*)y,
+                       training ? (const double*)workspace : (const double*)nullptr, rows, eps, momentum, running_mean, running_var, save_mean,
+                       save_rstd);
     SSDK_CHECK_LAUNCH("bn_apply_kernel");
     return SSDK_OK;
 }

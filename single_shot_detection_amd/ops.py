@@ -60,8 +60,8 @@ class _ConvFn(torch.autograd.Function):
         B = xs[0].shape[0]
         stream = _lib.current_stream()
         need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and has_bias
-        dw = torch.zeros_like(w, memory_format=torch.channels_last) if need_w else None
-        db = torch.zeros((cout,), dtype=torch.float32, device=w.device) if need_b else None
+        dw = torch.empty_like(w, memory_format=torch.channels_last) if need_w else None   # zeroed by the library
+        db = torch.empty((cout,), dtype=torch.float32, device=w.device) if need_b else None
         arr = (_lib.ConvDesc * n)()
         dxs, keep = [], []
         for i in range(n):
@@ -80,7 +80,7 @@ class _ConvFn(torch.autograd.Function):
             d.dy, d.dx, d.dw, d.db = _dp(dy), _dp(dx), _dp(dw), _dp(db)
         need = lib.ssdk_conv2d_bwd_workspace_bytes(arr, n, B)
         ws = torch.empty((max(need, 256),), dtype=torch.uint8, device=w.device)
-        _lib.check(lib.ssdk_conv2d_bwd(arr, n, B, 1, _dp(ws), ws.numel(), stream), 'ssdk_conv2d_bwd')   # dw/db pre-zeroed
+        _lib.check(lib.ssdk_conv2d_bwd(arr, n, B, 0, _dp(ws), ws.numel(), stream), 'ssdk_conv2d_bwd')
         return (dw, db, None, None, None) + tuple(dxs)
 
 
