@@ -150,7 +150,8 @@ size_t ssdk_postprocess_workspace_bytes(int batch, int num_anchors, int num_clas
 
 /*
  * detection/postprocessor.py:24-78 Postprocessor.postprocess with bf/utils/box_utils.py:166-194 (nms wrapper:
- * per-class top max_per_class, then hard NMS per torchvision.ops.nms's contract) fused.
+ * per-class top max_per_class, then hard NMS per torchvision.ops.nms's contract, or -- soft_nms != 0 -- the gaussian
+ * soft-NMS of box_utils.py:145-163 with sigma = soft_sigma) fused.
  *   scores DEV [batch, A, C] logits; locs DEV [batch, A, 4]; priors DEV [A, 4]
  *   softmax != 0: F.softmax and drop column 0 (classes 1..C-1); else sigmoid (classes 1..C)
  *   max_per_class in 1..256; max_total <= 0 means None
@@ -160,7 +161,8 @@ size_t ssdk_postprocess_workspace_bytes(int batch, int num_anchors, int num_clas
  */
 int ssdk_postprocess(const float* scores, const float* locs, const float* priors, int batch, int num_anchors,
                      int num_classes, int softmax, float score_threshold, int max_per_class, float nms_threshold,
-                     int max_total, float xy_scale, float wh_scale, float* out, int out_cap, int32_t* counts,
+                     int soft_nms, float soft_sigma, int max_total, float xy_scale, float wh_scale, float* out, int out_cap,
+                     int32_t* counts,
                      int64_t* nms_candidates, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- multi-scale heads (H1) ----------------------------------------------------------------------------------- */

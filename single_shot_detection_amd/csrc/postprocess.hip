@@ -132,6 +132,27 @@ __global__ void __launch_bounds__(kPostThreads) post_select_kernel(const float* 
     }
 }
 
+// descending bitonic sort of s_keys[0..m) (LDS); slots m..P-1 are filled with 0 and end up last.  Whole workgroup.
+__device__ void bitonic_sort_desc(u64* s_keys, int m) {
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    int P = 1;
+    while (P < m) P <<= 1;
+    for (int k = m + tid; k < P; k += nthr) s_keys[k] = 0;
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (P >> 1); t += nthr) {
+                const int lo = 2 * t - (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = (lo & size) == 0;
+                const u64 a = s_keys[lo], b = s_keys[hi];
+                if ((a < b) == desc) { s_keys[lo] = b; s_keys[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // ---- exact top-K of distinct non-zero 64-bit keys, result sorted descending in LDS ---------------------------
 // keys: global, n of them.  s_keys: LDS u64[kSortCap].  s_hist: LDS unsigned[256].  s_misc: LDS u64[4].
 // Returns min(n, K); s_keys[0 .. result) holds the K largest keys in descending order.
@@ -182,23 +203,7 @@ __device__ int block_topk_sorted(const u64* __restrict__ keys, int n, int K, u64
     }
     __syncthreads();
     const int m = min(*s_n, kSortCap);
-    int P = 1;
-    while (P < m) P <<= 1;
-    for (int k = m + tid; k < P; k += nthr) s_keys[k] = 0;
-    __syncthreads();
-    // bitonic sort, descending
-    for (int size = 2; size <= P; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = tid; t < (P >> 1); t += nthr) {
-                const int lo = 2 * t - (t & (stride - 1));
-                const int hi = lo + stride;
-                const bool desc = (lo & size) == 0;
-                const u64 a = s_keys[lo], b = s_keys[hi];
-                if ((a < b) == desc) { s_keys[lo] = b; s_keys[hi] = a; }
-            }
-            __syncthreads();
-        }
-    }
+    bitonic_sort_desc(s_keys, m);
     return min(m, K);
 }
 
@@ -210,7 +215,8 @@ __device__ __forceinline__ u64 readlane_u64(u64 v, int lane) {
 
 // ---- P2: per-(image,class) top-k + NMS -----------------------------------------------------------------------
 __global__ void __launch_bounds__(kPostThreads) post_nms_kernel(const float4* __restrict__ locs, const float4* __restrict__ priors,
-                                                                int A, int ncls, int K, float nms_thr, float xy_scale, float wh_scale,
+                                                                int A, int ncls, int K, float nms_thr, int soft, float sigma, float score_thr,
+                                                                float xy_scale, float wh_scale,
                                                                 const u64* __restrict__ cand, const int* __restrict__ cand_count,
                                                                 float* __restrict__ pc_rows, int* __restrict__ pc_count,
                                                                 u64* __restrict__ nms_candidates) {
@@ -232,6 +238,15 @@ __global__ void __launch_bounds__(kPostThreads) post_nms_kernel(const float4* __
     const int m = block_topk_sorted(cand + (size_t)pc * A, n, K, s_keys, s_hist, s_misc);  // box_utils.py:186-188
     const int W = (m + 63) >> 6;
     const int tid = threadIdx.x;
+    if (soft && n <= K) {
+        // no top-k happened: _soft_nms sees the candidates in boxes[mask] order = ascending anchor (its argmax tie rule and
+        // its "sum of live indices" loop test depend on positions) -> re-sort by anchor
+        if (tid < m) { const u64 k = s_keys[tid]; s_keys[tid] = (k << 32) | (k >> 32); }
+        __syncthreads();
+        bitonic_sort_desc(s_keys, m);   // descending ~anchor = ascending anchor
+        if (tid < m) { const u64 k = s_keys[tid]; s_keys[tid] = (k << 32) | (k >> 32); }
+        __syncthreads();
+    }
     if (tid < m) {
         const unsigned a = 0xFFFFFFFFu - (unsigned)(s_keys[tid] & 0xFFFFFFFFull);
         const float4 t = locs[(size_t)i * A + a], p = priors[a];
@@ -240,9 +255,77 @@ __global__ void __launch_bounds__(kPostThreads) post_nms_kernel(const float4* __
                                        p.w * expf(t.w / wh_scale));
         const float4 b = to_corners(cen);
         s_box[tid] = b;
-        s_area[tid] = (b.z - b.x) * (b.w - b.y);
+        s_area[tid] = soft ? area4(b.x, b.y, b.z, b.w) : (b.z - b.x) * (b.w - b.y);
     }
     __syncthreads();
+    if (soft) {
+        // bf/utils/box_utils.py:145-163 _soft_nms on one wave; lane l owns candidates l, l+64, l+128, l+192.
+        __shared__ int s_picked[kMaxPerClass];
+        __shared__ int s_npicked;
+        if (tid < kWave) {
+            float sc[4];
+            unsigned live = 0;  // the mask of :147 / :156 (refreshed AFTER the pick, BEFORE the decay -- tested one iteration late)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = q * 64 + tid;
+                sc[q] = idx < m ? __uint_as_float((unsigned)(s_keys[idx] >> 32)) : 0.0f;
+                if (idx < m && sc[q] > score_thr) live |= 1u << q;
+            }
+            int npicked = 0;
+            for (int it = 0; it < m; ++it) {
+                int idxsum = 0;  // :151 `mask.nonzero().sum()`: the SUM OF INDICES of live candidates
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if ((live >> q) & 1u) idxsum += q * 64 + tid;
+                idxsum = wave_allreduce(idxsum, OpAddI());
+                if (idxsum == 0) break;
+                u64 best = 0;  // :152 argmax, first maximum: (score bits, ~index)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int idx = q * 64 + tid;
+                    if (idx < m) {
+                        const u64 k = ((u64)__float_as_uint(sc[q]) << 32) | (u64)(0xFFFFFFFFu - (unsigned)idx);
+                        best = k > best ? k : best;
+                    }
+                }
+                best = wave_allreduce(best, OpMaxU64());
+                const int bi = (int)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull));
+                if (tid == 0) s_picked[npicked] = bi;
+                ++npicked;
+                const float4 bb = s_box[bi];
+                const float ba = s_area[bi];
+                live = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int idx = q * 64 + tid;
+                    if (idx == bi) sc[q] = 0.0f;  // :153
+                    if (idx < m && sc[q] > score_thr) {  // :156 mask, then :158-160 decay of the masked candidates
+                        live |= 1u << q;
+                        const float4 bj = s_box[idx];
+                        const float inter = area4(tmaxf(bb.x, bj.x), tmaxf(bb.y, bj.y), tminf(bb.z, bj.z), tminf(bb.w, bj.w));
+                        const float iou = inter / (ba + s_area[idx] - inter);
+                        sc[q] = sc[q] * expf(-(iou * iou / sigma));
+                    }
+                }
+            }
+            if (tid == 0) s_npicked = npicked;
+        }
+        __syncthreads();
+        const int np = s_npicked;
+        if (tid < np) {  // rows in pick order, ORIGINAL scores (:163 scores[picked])
+            const int src = s_picked[tid];
+            float* o = pc_rows + ((size_t)pc * K + tid) * 6;
+            const float4 b = s_box[src];
+            o[0] = b.x; o[1] = b.y; o[2] = b.z; o[3] = b.w;
+            o[4] = (float)(c + 1);
+            o[5] = __uint_as_float((unsigned)(s_keys[src] >> 32));
+        }
+        if (tid == 0) {
+            pc_count[pc] = np;
+            if (nms_candidates) atomicAdd(nms_candidates + i, (u64)m);
+        }
+        return;
+    }
     for (int t = tid; t < m * W; t += kPostThreads) {
         const int k = t / W, w = t % W;
         const float4 bk = s_box[k];
@@ -380,7 +463,8 @@ extern "C" size_t ssdk_postprocess_workspace_bytes(int batch, int num_anchors, i
 
 extern "C" int ssdk_postprocess(const float* scores, const float* locs, const float* priors, int batch, int num_anchors,
                                 int num_classes, int softmax, float score_threshold, int max_per_class, float nms_threshold,
-                                int max_total, float xy_scale, float wh_scale, float* out, int out_cap, int32_t* counts,
+                                int soft_nms, float soft_sigma, int max_total, float xy_scale, float wh_scale, float* out, int out_cap,
+                                int32_t* counts,
                                 int64_t* nms_candidates, void* workspace, size_t workspace_bytes, void* stream) {
     SSDK_REQUIRE(batch > 0 && num_anchors > 0 && num_classes > (softmax ? 1 : 0), SSDK_E_INVALID,
                  "ssdk_postprocess: batch=%d anchors=%d classes=%d", batch, num_anchors, num_classes);
@@ -389,6 +473,7 @@ extern "C" int ssdk_postprocess(const float* scores, const float* locs, const fl
     SSDK_REQUIRE(max_per_class >= 1 && max_per_class <= kMaxPerClass, SSDK_E_UNSUPPORTED,
                  "ssdk_postprocess: max_per_class=%d outside 1..%d (None is not supported on the GPU path)", max_per_class, kMaxPerClass);
     SSDK_REQUIRE(max_total <= kSortCap, SSDK_E_UNSUPPORTED, "ssdk_postprocess: max_total=%d > %d", max_total, kSortCap);
+    SSDK_REQUIRE(!soft_nms || soft_sigma > 0.0f, SSDK_E_INVALID, "ssdk_postprocess: soft-NMS sigma must be > 0");
     const int ncls = ncls_of(num_classes, softmax);
     SSDK_REQUIRE(out_cap >= (max_total > 0 ? max_total : 1), SSDK_E_INVALID, "ssdk_postprocess: out_cap=%d too small", out_cap);
     SSDK_REQUIRE(max_total > 0 || (long long)out_cap >= (long long)ncls * max_per_class, SSDK_E_INVALID,
@@ -410,7 +495,8 @@ extern "C" int ssdk_postprocess(const float* scores, const float* locs, const fl
                        score_threshold, tiles, w.cand, w.cand_count);
     SSDK_CHECK_LAUNCH("post_select_kernel");
     hipLaunchKernelGGL(post_nms_kernel, dim3(batch * ncls), dim3(kPostThreads), 0, s, (const float4*)locs, (const float4*)priors,
-                       num_anchors, ncls, max_per_class, nms_threshold, xy_scale, wh_scale, w.cand, w.cand_count, w.pc_rows, w.pc_count,
+                       num_anchors, ncls, max_per_class, nms_threshold, soft_nms, soft_sigma, score_threshold, xy_scale, wh_scale, w.cand,
+                       w.cand_count, w.pc_rows, w.pc_count,
                        (u64*)nms_candidates);
     SSDK_CHECK_LAUNCH("post_nms_kernel");
     hipLaunchKernelGGL(post_merge_kernel, dim3(batch), dim3(kPostThreads), sizeof(int) * (size_t)(ncls + 1), s, ncls, max_per_class,

@@ -13,8 +13,8 @@ class Postprocessor(object):
         self.score_converter = score_converter
         if score_converter not in ('SIGMOID', 'SOFTMAX'):
             raise ValueError(f'Wrong value for score_converter: {score_converter}')
-        if self.nms_args.get('soft', False):
-            raise NotImplementedError('soft-NMS is not on the round-1 GPU path (SURVEY.md §8f2)')
+        self.soft = bool(self.nms_args.get('soft', False))      # box_utils.py:166 `soft`, `sigma`
+        self.sigma = float(self.nms_args.get('sigma', 0.5))
         if self.nms_args.get('max_per_class') is None:
             raise NotImplementedError('max_per_class=None is not supported on the GPU path (1..256)')
         self.last_nms_candidates = None
@@ -57,7 +57,7 @@ class Postprocessor(object):
         cand = torch.empty((batch_size,), dtype=torch.int64, device=dev)
         _lib.check(lib.ssdk_postprocess(_lib.ptr(b_scores), _lib.ptr(b_boxes), _lib.ptr(priors), batch_size, num_priors,
                                         num_classes, softmax, float(self.score_threshold), max_per_class,
-                                        float(self.nms_args['overlap_threshold']), max_total,
+                                        float(self.nms_args['overlap_threshold']), int(self.soft), self.sigma, max_total,
                                         float(self.box_coder.xy_scale), float(self.box_coder.wh_scale), _lib.ptr(out), cap,
                                         _lib.ptr(counts), _lib.ptr(cand), _lib.ptr(ws), ws.numel(), _lib.current_stream()),
                    'ssdk_postprocess')

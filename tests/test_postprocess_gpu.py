@@ -13,10 +13,11 @@ from conftest import CONFIG_NAMES, load_golden
 pytestmark = pytest.mark.gpu
 
 
-def make_post(cfg, max_total=200, max_per_class=100, thr=0.01):
-    return Postprocessor(BoxCoder(10.0, 5.0), score_threshold=thr,
-                         nms={'max_per_class': max_per_class, 'overlap_threshold': cfg['nms_thr']},
-                         score_converter=cfg['score_converter'], max_total=max_total)
+def make_post(cfg, max_total=200, max_per_class=100, thr=0.01, soft=False):
+    nms = {'max_per_class': max_per_class, 'overlap_threshold': cfg['nms_thr']}
+    if soft:
+        nms.update(soft=True, sigma=0.5)
+    return Postprocessor(BoxCoder(10.0, 5.0), score_threshold=thr, nms=nms, score_converter=cfg['score_converter'], max_total=max_total)
 
 
 def compare(out, ref, tol=1e-4):
@@ -83,6 +84,22 @@ def test_postprocess_full_size_vs_oracle(name, batch, variant):
     assert np.array_equal(post.last_nms_candidates.cpu().numpy(), cand)
 
 
+@pytest.mark.parametrize('name', CONFIG_NAMES)
+def test_soft_nms_vs_reference_golden(name):
+    """Soft-NMS is pure torch in the reference (box_utils.py:145-163), so this golden is pinned by the reference itself."""
+    cfg, g, logits, locs, softmax = inputs(name, 'trained')
+    post = make_post(cfg, soft=True)
+    out = post.postprocess((torch.from_numpy(logits).cuda(), torch.from_numpy(locs).cuda()), torch.from_numpy(g['anchors']).cuda())
+    compare(out, split(g['post_trained_softnms_rows'], g['post_trained_softnms_counts']))
+
+
+def test_soft_nms_worst_case_vs_oracle():
+    cfg, g, logits, locs, softmax = inputs('ssd_mb2_voc', 'rand', batch=2, seeds=(51, 52))
+    out = make_post(cfg, soft=True).postprocess((torch.from_numpy(logits).cuda(), torch.from_numpy(locs).cuda()), torch.from_numpy(g['anchors']).cuda())
+    ref = oracle.postprocess(logits, locs, g['anchors'], softmax=softmax, nms_thr=cfg['nms_thr'], soft=True, sigma=0.5)
+    compare(out, ref)
+
+
 def test_postprocess_variants_vs_oracle():
     """max_total=None (class-order concat), small max_per_class, a high threshold that empties most classes."""
     cfg, g, logits, locs, softmax = inputs('ssd_mb2_voc', 'trained', batch=3, seeds=(41, 42))
@@ -110,8 +127,6 @@ def test_postprocess_ties_and_identical_boxes():
 
 
 def test_unsupported_options_raise():
-    with pytest.raises(NotImplementedError):
-        Postprocessor(BoxCoder(10., 5.), 0.01, {'max_per_class': 100, 'overlap_threshold': .45, 'soft': True}, 'SOFTMAX', 200)
     with pytest.raises(ValueError):
         Postprocessor(BoxCoder(10., 5.), 0.01, {'max_per_class': 100, 'overlap_threshold': .45}, 'TANH', 200)
     p = Postprocessor(BoxCoder(10., 5.), 0.01, {'max_per_class': 1000, 'overlap_threshold': .45}, 'SOFTMAX', 200)
