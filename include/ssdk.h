@@ -261,6 +261,15 @@ int ssdk_batchnorm_bwd(const float* x, const float* y, const float* dy, long lon
                        const float* save_mean, const float* save_rstd, int relu, int training, float* dx, float* dgamma,
                        float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- FPN top-down step (next-row f1) -------------------------------------------------------------------------------- */
+
+/* bf/modules/features.py:106-107: out = fine + F.interpolate(coarse, size=(hf, wf), mode='nearest'); NHWC, channels % 4 == 0. */
+int ssdk_upsample_nearest_add_fwd(const float* fine, const float* coarse, int batch, int hf, int wf, int hc, int wc,
+                                  int channels, float* out, void* stream);
+/* gradient w.r.t. coarse: each coarse pixel sums dout over the fine pixels it was copied to (the gradient w.r.t. fine is dout). */
+int ssdk_upsample_nearest_add_bwd(const float* dout, int batch, int hf, int wf, int hc, int wc, int channels,
+                                  float* dcoarse, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2,11 +2,14 @@
 PyTorch-ROCm modules (north_star); this class only hands their intermediate maps to the hot path.  Maps are
 produced in channels_last memory so the head GEMMs read them without a layout copy."""
 import functools
+import itertools
 
 import torch
 import torch.nn as nn
 
+from ... import ops
 from ...utils import filter_kwargs
+from . import conv
 
 
 def _init_layer(layer, initializer_):
@@ -57,3 +60,51 @@ class Features(nn.Module):
             sources, _ = get_multiple_outputs(self.base, dummy, self.out_layers)
         self.train(was_training)
         return [s.size(1) for s in sources]
+
+
+class FeaturePyramid(Features):
+    """FPN neck -- restatement of bf/modules/features.py:52-120 (ref. arXiv:1612.03144), SURVEY.md §8f1.
+
+    Lateral 1x1 convs and the 3x3 output blocks run on libssdk's implicit-GEMM kernels (``ops.conv2d`` / ``Conv2dBn``), the
+    top-down ``features[i] += interpolate(features[i+1], nearest)`` on ``ssdk_upsample_nearest_add``.  Module names
+    (``pyramid_lateral``, ``pyramid_output``) follow the reference so checkpoints map 1:1."""
+
+    def __init__(self, base, out_layers, pyramid_layers, pyramid_channels, interpolation_mode='nearest', use_depthwise=False,
+                 activation={'name': 'ReLU', 'args': {'inplace': True}}, initializer={'name': 'xavier_normal_'}, **kwargs):
+        super(FeaturePyramid, self).__init__(base, out_layers, initializer=initializer, **kwargs)
+        assert pyramid_layers >= len(out_layers)
+        if interpolation_mode != 'nearest':
+            raise NotImplementedError("FeaturePyramid: only interpolation_mode='nearest' is on the GPU path")
+        self.pyramid_layers = pyramid_layers
+        self.pyramid_channels = pyramid_channels
+        self.interpolation_mode = interpolation_mode
+        self.use_depthwise = use_depthwise
+        self.num_outputs = pyramid_layers
+        self.pyramid_lateral = nn.ModuleList()
+        self.pyramid_output = nn.ModuleList()
+        base_out_channels = super(FeaturePyramid, self).get_out_channels()
+        conv_op = functools.partial(conv.Conv2dBn, groups=pyramid_channels) if use_depthwise else conv.Conv2dBn
+        for in_channels in base_out_channels:
+            lateral = nn.Conv2d(in_channels, pyramid_channels, kernel_size=1)
+            self.pyramid_lateral.append(lateral)
+            self.pyramid_output.append(conv_op(pyramid_channels, pyramid_channels, kernel_size=3, padding=1, activation_params=activation))
+        for _ in range(pyramid_layers - len(base_out_channels)):
+            self.pyramid_output.append(conv_op(pyramid_channels, pyramid_channels, kernel_size=3, padding=1, stride=2,
+                                               activation_params=activation))
+        self.pyramid_lateral.apply(self.init_layer)
+        self.pyramid_output.apply(self.init_layer)
+        for m in self.pyramid_output:   # init_layer rewrote the weights: restore the channels_last memory the GEMM reads
+            m.conv.weight.data = m.conv.weight.data.contiguous(memory_format=torch.channels_last)
+
+    def forward(self, x):
+        sources, _ = super(FeaturePyramid, self).forward(x)
+        features = [ops.conv2d(s, lat.weight, lat.bias) for s, lat in zip(sources, self.pyramid_lateral)]   # features.py:104
+        for i in reversed(range(len(features) - 1)):                                                       # :106-107
+            features[i] = ops.upsample_add(features[i], features[i + 1])
+        outputs = []
+        for output_layer, feature in itertools.zip_longest(self.pyramid_output, features):                 # :109-115
+            outputs.append(output_layer(feature if feature is not None else outputs[-1]))
+        return outputs, outputs[-1]
+
+    def get_out_channels(self):
+        return [self.pyramid_channels] * self.pyramid_layers

@@ -235,3 +235,78 @@ extern "C" int ssdk_relu_bwd(const float* y, const float* dy, long long n, float
     SSDK_CHECK_LAUNCH("relu_bwd_kernel");
     return SSDK_OK;
 }
+
+// ---- FPN top-down step: out = fine + nearest_upsample(coarse) -------------------------------------
+// Reference: bf/modules/features.py:106-107  features[i] += F.interpolate(features[i+1], size=features[i].size()[2:],
+// mode='nearest').  torch 'nearest': src = min(floor(dst * (float)in / out), in - 1).
+namespace ssdk {
+__device__ __forceinline__ int nearest_src(int dst, float scale, int in) {
+    const int s = (int)floorf((float)dst * scale);
+    return s < in - 1 ? s : in - 1;
+}
+
+__global__ void __launch_bounds__(256) upsample_add_kernel(const float4* __restrict__ fine, const float4* __restrict__ coarse, int B, int Hf,
+                                                           int Wf, int Hc, int Wc, int C4, float4* __restrict__ out) {
+    const long long total = (long long)B * Hf * Wf * C4;
+    const float sh = (float)Hc / (float)Hf, sw = (float)Wc / (float)Wf;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long long p = i / C4;
+        const int x = (int)(p % Wf); p /= Wf;
+        const int y = (int)(p % Hf);
+        const int b = (int)(p / Hf);
+        const float4 a = fine[i];
+        const float4 u = coarse[(((long long)b * Hc + nearest_src(y, sh, Hc)) * Wc + nearest_src(x, sw, Wc)) * C4 + c];
+        out[i] = make_float4(a.x + u.x, a.y + u.y, a.z + u.z, a.w + u.w);
+    }
+}
+
+// dcoarse[yc][xc] = sum of dout over the fine pixels whose nearest source is (yc, xc)  (gather form: deterministic)
+__global__ void __launch_bounds__(256) upsample_add_bwd_kernel(const float4* __restrict__ dout, int B, int Hf, int Wf, int Hc, int Wc, int C4,
+                                                               float4* __restrict__ dcoarse) {
+    const long long total = (long long)B * Hc * Wc * C4;
+    const float sh = (float)Hc / (float)Hf, sw = (float)Wc / (float)Wf;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long long p = i / C4;
+        const int xc = (int)(p % Wc); p /= Wc;
+        const int yc = (int)(p % Hc);
+        const int b = (int)(p / Hc);
+        // candidate fine rows/cols: around yc / sh
+        const int y0 = max(0, (int)floorf((float)yc / sh) - 2), y1 = min(Hf - 1, (int)ceilf((float)(yc + 1) / sh) + 2);
+        const int x0 = max(0, (int)floorf((float)xc / sw) - 2), x1 = min(Wf - 1, (int)ceilf((float)(xc + 1) / sw) + 2);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int y = y0; y <= y1; ++y) {
+            if (nearest_src(y, sh, Hc) != yc) continue;
+            for (int x = x0; x <= x1; ++x) {
+                if (nearest_src(x, sw, Wc) != xc) continue;
+                const float4 g = dout[(((long long)b * Hf + y) * Wf + x) * C4 + c];
+                s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+            }
+        }
+        dcoarse[i] = s;
+    }
+}
+}  // namespace ssdk
+
+extern "C" int ssdk_upsample_nearest_add_fwd(const float* fine, const float* coarse, int batch, int hf, int wf, int hc, int wc, int channels,
+                                             float* out, void* stream) {
+    SSDK_REQUIRE(fine && coarse && out && batch > 0 && hf > 0 && wf > 0 && hc > 0 && wc > 0 && channels > 0 && channels % 4 == 0, SSDK_E_INVALID,
+                 "ssdk_upsample_nearest_add_fwd: bad arguments (channels %% 4 == 0)");
+    const long long n4 = (long long)batch * hf * wf * channels / 4;
+    hipLaunchKernelGGL(upsample_add_kernel, dim3(stream_blocks(n4, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)fine, (const float4*)coarse,
+                       batch, hf, wf, hc, wc, channels / 4, (float4*)out);
+    SSDK_CHECK_LAUNCH("upsample_add_kernel");
+    return SSDK_OK;
+}
+
+extern "C" int ssdk_upsample_nearest_add_bwd(const float* dout, int batch, int hf, int wf, int hc, int wc, int channels, float* dcoarse,
+                                             void* stream) {
+    SSDK_REQUIRE(dout && dcoarse && batch > 0 && hf > 0 && wf > 0 && hc > 0 && wc > 0 && channels > 0 && channels % 4 == 0, SSDK_E_INVALID,
+                 "ssdk_upsample_nearest_add_bwd: bad arguments (channels %% 4 == 0)");
+    const long long n4 = (long long)batch * hc * wc * channels / 4;
+    hipLaunchKernelGGL(upsample_add_bwd_kernel, dim3(stream_blocks(n4, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)dout, batch, hf, wf,
+                       hc, wc, channels / 4, (float4*)dcoarse);
+    SSDK_CHECK_LAUNCH("upsample_add_bwd_kernel");
+    return SSDK_OK;
+}

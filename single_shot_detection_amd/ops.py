@@ -138,3 +138,34 @@ def batch_norm(x, bn, relu=False):
     if training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     return _BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, training, relu)
+
+
+class _UpsampleAddFn(torch.autograd.Function):
+    """out = fine + nearest_upsample(coarse, size of fine)   (FPN top-down step, bf/modules/features.py:106-107)"""
+
+    @staticmethod
+    def forward(ctx, fine, coarse):
+        _lib.require_cuda(fine, coarse)
+        fine, coarse = _nhwc(fine), _nhwc(coarse)
+        B, C, Hf, Wf = fine.shape
+        assert coarse.shape[0] == B and coarse.shape[1] == C
+        out = torch.empty_like(fine, memory_format=torch.channels_last)
+        _lib.check(_lib.lib().ssdk_upsample_nearest_add_fwd(_dp(fine), _dp(coarse), B, Hf, Wf, coarse.shape[2], coarse.shape[3], C, _dp(out),
+                                                            _lib.current_stream()), 'ssdk_upsample_nearest_add_fwd')
+        ctx.shapes = (B, C, Hf, Wf, coarse.shape[2], coarse.shape[3])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, C, Hf, Wf, Hc, Wc = ctx.shapes
+        dout = _nhwc(dout)
+        dcoarse = None
+        if ctx.needs_input_grad[1]:
+            dcoarse = torch.empty((B, C, Hc, Wc), dtype=torch.float32, device=dout.device, memory_format=torch.channels_last)
+            _lib.check(_lib.lib().ssdk_upsample_nearest_add_bwd(_dp(dout), B, Hf, Wf, Hc, Wc, C, _dp(dcoarse), _lib.current_stream()),
+                       'ssdk_upsample_nearest_add_bwd')
+        return (dout if ctx.needs_input_grad[0] else None), dcoarse
+
+
+def upsample_add(fine, coarse):
+    return _UpsampleAddFn.apply(fine, coarse)

@@ -119,3 +119,50 @@ def test_retina_tower_vs_torch(train):
     for (n1, p1), (n2, p2) in zip(sorted(tower.named_parameters()), sorted(ref.named_parameters())):
         scale = float(p2.grad.abs().max()) + 1e-6
         np.testing.assert_allclose(p1.grad.cpu().numpy(), p2.grad.numpy(), rtol=2e-3, atol=2e-3 * scale + 1e-5, err_msg=n1)
+
+
+def test_fpn_neck_vs_torch():
+    """FeaturePyramid (bf/modules/features.py:52-120) on libssdk vs the same graph on stock torch CPU ops."""
+    import torch.nn.functional as F
+    from single_shot_detection_amd.bf.modules.features import FeaturePyramid
+
+    class _Base(nn.Module):   # three taps at strides 1, 2, 4 with odd sizes (31 -> 16 -> 8) like ResNet's 63 -> 32 -> 16
+        def __init__(self):
+            super().__init__()
+            self.features = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.Conv2d(8, 16, 3, stride=2, padding=1), nn.Conv2d(16, 32, 3, stride=2, padding=1))
+
+    rng = np.random.default_rng(5)
+    torch.manual_seed(0)
+    fpn = FeaturePyramid(_Base(), out_layers=(0, 1, 2), pyramid_layers=5, pyramid_channels=16)
+    _randomize(fpn.pyramid_lateral, rng); _randomize(fpn.pyramid_output, rng)
+    ref = copy.deepcopy(fpn)
+    fpn = fpn.cuda()
+    x_np = rng.standard_normal((2, 3, 31, 31), dtype=np.float32)
+
+    def ref_forward(x):
+        srcs, cur = [], x
+        for layer in ref.base:
+            cur = layer(cur); srcs.append(cur)
+        feats = [lat(s) for s, lat in zip(srcs, ref.pyramid_lateral)]
+        for i in reversed(range(len(feats) - 1)):
+            feats[i] = feats[i] + F.interpolate(feats[i + 1], size=feats[i].shape[2:], mode='nearest')
+        outs = []
+        for k, blk in enumerate(ref.pyramid_output):
+            src = feats[k] if k < len(feats) else outs[-1]
+            outs.append(torch.relu(blk.bn(blk.conv(src))))
+        return outs
+
+    xr = torch.from_numpy(x_np).requires_grad_(True)
+    xg = torch.from_numpy(x_np).cuda().requires_grad_(True)
+    outs_r = ref_forward(xr)
+    outs_g, last = fpn(xg)
+    assert [tuple(o.shape[2:]) for o in outs_g] == [(31, 31), (16, 16), (8, 8), (4, 4), (2, 2)] and last is outs_g[-1]
+    gws = [torch.from_numpy(rng.standard_normal(tuple(o.shape), dtype=np.float32)) for o in outs_r]
+    for a, b in zip(outs_g, outs_r):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().numpy(), rtol=1e-3, atol=1e-3)
+    sum((a * g).sum() for a, g in zip(outs_r, gws)).backward()
+    sum((a * g.cuda()).sum() for a, g in zip(outs_g, gws)).backward()
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=2e-3, atol=2e-3 * (1 + float(xr.grad.abs().max())))
+    for (n1, p1), (n2, p2) in zip(sorted(fpn.named_parameters()), sorted(ref.named_parameters())):
+        scale = float(p2.grad.abs().max()) + 1e-6
+        np.testing.assert_allclose(p1.grad.cpu().numpy(), p2.grad.numpy(), rtol=2e-3, atol=2e-3 * scale + 1e-5, err_msg=n1)

@@ -107,3 +107,61 @@ def test_ssd300_step_fn_train_and_eval():
     wrapper.preprocess = None
     res = wrapper.predict_single(imgs[0])
     assert res.dim() == 2 and res.shape[1] == 6
+
+
+RETINA = {
+    'base': {'name': 'torchvision_resnet50', 'pretrained': False},
+    'detector': {'num_classes': 80, 'use_depthwise': False,
+                 'features': {'name': 'FeaturePyramid', 'out_layers': (5, 6, 7), 'pyramid_layers': 5, 'pyramid_channels': 256,
+                              'initializer': {'name': 'normal_', 'args': {'mean': 0, 'std': 0.03}}},
+                 'predictor': {'num_layers': 4, 'num_channels': 256, 'kernel_size': 3,
+                               'activation': {'name': 'ReLU', 'args': {'inplace': True}},
+                               'initializer': {'name': 'normal_', 'args': {'mean': 0, 'std': 0.01}}},
+                 'heads': {'initializer': {'name': 'normal_', 'args': {'mean': 0, 'std': 0.01}}, 'score_head_bias_init': -4.6}},
+    'anchor_generator': {'type': 'retina_net', 'min_level': 3, 'max_level': 7, 'aspect_ratios': [1.0, 2.0, 0.5], 'scale': 4.0,
+                         'scales_per_level': 3},
+}
+
+
+def test_retina500_step_fn_train_and_eval():
+    """samples/retina_rn50_500_coco.py wiring: FPN neck + shared-conv tower + focal loss (naive sampler, the reference's
+    reduction='mean' constructor quirk) + SIGMOID postprocess; A = 47 961."""
+    torch.manual_seed(5)
+    dev = torch.device('cuda:0')
+    wrapper, init_state, step_fn = det_init.init(
+        dev, RETINA, {'xy_scale': 10.0, 'wh_scale': 5.0},
+        {'score_threshold': .01, 'max_total': 200, 'nms': {'max_per_class': 100, 'overlap_threshold': .5}, 'score_converter': 'SIGMOID'},
+        {'classification_loss': {'name': 'SigmoidFocalLoss', 'gamma': 2.0, 'alpha': 0.25}, 'localization_loss': {'name': 'SmoothL1Loss'},
+         'classification_weight': 1.0, 'localization_weight': 1.0},
+        {'name': 'naive_sampler'}, {'matched_threshold': 0.5, 'unmatched_threshold': 0.4})
+    detector = wrapper.model
+    detector.train()
+    B = 2
+    imgs = torch.from_numpy(np.random.default_rng(23).standard_normal((B, 3, 500, 500), dtype=np.float32))
+    gt_np = syn.make_ground_truth(B, 500, 80, seed=1, background=False)
+    gt = [torch.from_numpy(g) for g in gt_np]
+    state = init_state()
+    loss, prediction, state = step_fn(0, 'train', (imgs, gt), state)
+    scores, locs = prediction
+    assert scores.shape == (B, 47961 * 80) and locs.shape == (B, 47961 * 4)
+    cfg = syn.CONFIGS['retina_rn50_500_coco']
+    anchors = oracle.anchors(cfg['anchor'], 500, cfg['levels'])
+    target = oracle.encode_ground_truth(gt_np, anchors, 0.5, 0.4)
+    s_np, l_np = scores.cpu().numpy(), locs.cpu().numpy()
+    mask = oracle.naive_sampler(s_np, target)
+    vals, _, _ = oracle.multibox_loss(s_np, l_np, anchors, target, mask, kind='focal', reduce_mean=True, grads=False)
+    assert abs(loss.item() - vals[0]) <= 1e-4 + 1e-5 * abs(vals[0]), (loss.item(), vals)
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in detector.parameters() if p.requires_grad)
+
+    detector.eval()
+    with torch.no_grad():
+        _, dets, state = step_fn(1, 'eval', (imgs, gt), state)
+        s_e, l_e, pri = detector(imgs.to(dev))
+    assert np.array_equal(pri.cpu().numpy().view(np.uint32), anchors.view(np.uint32))
+    ref = oracle.postprocess(s_e.cpu().numpy(), l_e.cpu().numpy(), anchors, softmax=False, nms_thr=0.5)
+    for d, r in zip(dets, ref):
+        assert d.shape[1] == 6 and abs(d.shape[0] - r.shape[0]) <= 1
+        n = min(d.shape[0], r.shape[0])
+        if n:
+            np.testing.assert_allclose(np.sort(d.cpu().numpy()[:n, 5]), np.sort(r[:n, 5]), rtol=1e-4, atol=1e-6)
