@@ -172,6 +172,30 @@ def multibox_loss(scores, locs, anchors, target, sampled, kind='ce', gamma=2.0, 
     return out3, ds, dl
 
 
+CLS_KINDS = {'ce': 0, 'focal': 1, 'softmax_focal': 2, 'ce_soft': 3, 'bce_soft': 4}
+LOC_KINDS = {'smooth_l1': 0, 'giou': 1}
+
+
+def multibox_loss_ex(scores, locs, anchors, target, sampled, cls_kind='ce', loc_kind='smooth_l1', gamma=2.0, alpha=-1.0, epsilon=0.0,
+                     reduce_mean=True, cls_w=1.0, loc_w=1.0, xy_scale=10.0, wh_scale=5.0, eps=1e-8, beta=1.0, grads=True):
+    """The remaining selectable losses (SoftmaxFocal, soft-target CE / BCE, GIoU).  alpha < 0 means None.  MUTATES target
+    unless loc_kind == 'giou'."""
+    assert target.dtype == np.float32 and target.flags.c_contiguous
+    B, A = target.shape[:2]
+    scores = _f32(scores).reshape(B, A, -1)
+    locs = _f32(locs).reshape(B, A, 4)
+    anchors = _f32(anchors)
+    smp = np.ascontiguousarray(sampled, dtype=np.uint8)
+    out3 = np.zeros(3, np.float64)
+    ds = np.empty_like(scores) if grads else None
+    dl = np.empty_like(locs) if grads else None
+    lib().orc_multibox_loss_ex(_p(scores), _p(locs), _p(anchors), _p(target), _p(smp), C.c_int(B), C.c_int64(A), C.c_int(scores.shape[2]),
+                               C.c_int(CLS_KINDS[cls_kind]), C.c_int(LOC_KINDS[loc_kind]), C.c_float(gamma), C.c_float(alpha),
+                               C.c_float(epsilon), C.c_int(int(reduce_mean)), C.c_float(cls_w), C.c_float(loc_w), C.c_float(xy_scale),
+                               C.c_float(wh_scale), C.c_float(eps), C.c_float(beta), _p(out3), _p(ds), _p(dl))
+    return out3, ds, dl
+
+
 def nms_hard(boxes, scores, thr):
     boxes, scores = _f32(boxes), _f32(scores)
     picked = np.empty(max(1, scores.shape[0]), np.int32)

@@ -651,3 +651,199 @@ int orc_anchors_retina_level(const double* ratios, int nratio, int level, double
     free(xs); free(ys);
     return nb;
 }
+
+/* ---- the other selectable losses ------------------------------------------------------------------- */
+
+/* bf/modules/losses.py:13-18 _Loss._soften for a target row with ONE positive entry of value s at column pos (or none):
+ * positive -> s (1 - eps), every other entry -> eps * s / (C - 1).  Row sums are preserved. */
+static inline float soft_t(int c, int pos, float s, int C, float eps) {
+    if (pos < 0) return 0.0f;
+    if (eps == 0.0f) return c == pos ? s : 0.0f;
+    return c == pos ? s - eps * s : eps * s / (float)(C - 1);
+}
+
+/* bf/utils/box_utils.py:104-143 generalized_iou (cartesian=False) for one pair of corner boxes */
+static inline float giou_pair(const float* a, const float* b) {
+    const float inter = area4(tmaxf(a[0], b[0]), tmaxf(a[1], b[1]), tminf(a[2], b[2]), tminf(a[3], b[3]));
+    const float uni = area4(a[0], a[1], a[2], a[3]) + area4(b[0], b[1], b[2], b[3]) - inter;
+    const float enc = area4(tminf(a[0], b[0]), tminf(a[1], b[1]), tmaxf(a[2], b[2]), tmaxf(a[3], b[3]));
+    return inter / uni - (enc - uni) / enc;
+}
+
+/*
+ * MultiboxLoss.forward (detection/losses/multibox_loss.py:35-94) for the remaining loss classes of bf/modules/losses.py:
+ *   cls_kind 2  SoftmaxFocalLoss :56-78 (alpha < 0 means None); class target = integer class, ignore_index = -1;
+ *               reduce_mean != 0: mean over ALL sampled rows (the constructor quirk drops reduction='sum' here too)
+ *   cls_kind 3  CrossEntropyWithSoftTargetsLoss :80-93 on the soft target of multibox_loss.py:68-71
+ *               (class_target[row, cls] = target score for cls != -1), epsilon smoothing, reduction 'sum'
+ *   cls_kind 4  BinaryCrossEntropyWithSoftTargetsLoss :95-106 on the multiclass target of multibox_loss.py:64-67
+ *               (class_target[row, cls - 1] = target score for positives), reduction 'sum'
+ *   cls_kind 0  CrossEntropyLoss (as orc_multibox_loss_ce)
+ *   loc_kind 0  SmoothL1Loss on encoded targets (mutates target[..., 0:4]);
+ *   loc_kind 1  GeneralizedIoULoss :109-114 on decoded corner boxes vs the RAW corner target (multibox_loss.py:77-79;
+ *               target is NOT mutated).
+ * Gradients are finite-difference-free analytic derivatives of exactly these expressions.
+ */
+void orc_multibox_loss_ex(const float* scores, const float* locs, const float* anchors, float* target, const uint8_t* sampled, int B,
+                          int64_t A, int C, int cls_kind, int loc_kind, float gamma, float alpha, float epsilon, int reduce_mean,
+                          float cls_w, float loc_w, float xy_scale, float wh_scale, float eps, float beta, double* out3, float* dscores,
+                          float* dlocs) {
+    const int64_t N = (int64_t)B * A;
+    double cls_sum = 0.0, loc_sum = 0.0, tsum = 0.0;
+    int64_t npos = 0, nrows = 0, nposrows = 0;
+    for (int64_t r = 0; r < N; ++r) {
+        const int64_t j = r % A;
+        float* t = target + r * 6;
+        const int64_t cls = (int64_t)t[4];
+        const float ts = t[5];
+        const int pos = cls != 0 && cls != -1;
+        npos += pos;
+        if (sampled[r]) {
+            nrows += 1;
+            const float* x = scores + r * C;
+            float m, ls;
+            row_lse(x, C, &m, &ls);
+            if (cls_kind == 0) {
+                if (cls != -1) cls_sum += (double)(-((x[cls] - m) - ls));
+            } else if (cls_kind == 2) {
+                if (cls != -1) {
+                    const float logpb = (x[cls] - m) - ls, pb = expf(logpb);
+                    float l = -1.0f * powf(1.0f - pb, gamma) * logpb;
+                    if (alpha >= 0.0f) l *= (cls == 0 ? 1.0f - alpha : alpha);
+                    cls_sum += (double)l;
+                }
+            } else if (cls_kind == 3) {
+                const int p_ = cls != -1 ? (int)cls : -1;
+                float row = 0.0f, rs = 0.0f;
+                for (int c = 0; c < C; ++c) {
+                    const float tc = soft_t(c, p_, ts, C, epsilon);
+                    row += ((x[c] - m) - ls) * tc;
+                    rs += tc;
+                }
+                cls_sum += (double)(-row);
+                tsum += (double)rs;
+            } else if (cls_kind == 4) {
+                const int p_ = pos ? (int)cls - 1 : -1;
+                float row = 0.0f, rs = 0.0f;
+                for (int c = 0; c < C; ++c) {
+                    const float tc = soft_t(c, p_, ts, C, epsilon);
+                    row += fmaxf(x[c], 0.0f) - x[c] * tc + log1pf(expf(-fabsf(x[c])));
+                    rs += tc;
+                }
+                cls_sum += (double)row;
+                tsum += (double)(rs / (float)C);
+                nposrows += rs / (float)C > 0.0f;
+            }
+        }
+        if (loc_kind == 0) {
+            orc_to_centroids_inplace(t, 1);
+            encode_inplace(t, anchors + 4 * j, xy_scale, wh_scale, eps);
+            if (pos) for (int k = 0; k < 4; ++k) loc_sum += (double)smooth_l1(locs[r * 4 + k], t[k], beta);
+        } else if (pos) {
+            float cen[4], cor[4];
+            decode_one(locs + r * 4, anchors + 4 * j, xy_scale, wh_scale, cen);
+            orc_to_corners(cen, cor, 1);
+            loc_sum += (double)(1.0f - giou_pair(cor, t));
+        }
+    }
+    const float divider = (float)(npos < 1 ? 1 : npos);
+    float scale = 1.0f;
+    if (cls_kind == 3) scale = 1.0f / ((float)tsum / (float)nrows);                 /* target.sum(-1).mean() ** -1 */
+    if (cls_kind == 4) scale = 1.0f / ((float)tsum / (float)nposrows);              /* scale.sum() / (scale > 0).sum() ** -1 */
+    const float mean_div = (cls_kind == 2 && reduce_mean) ? (float)nrows : 1.0f;
+    const float class_loss = scale * (float)cls_sum / mean_div * cls_w / divider;
+    const float loc_loss = (float)loc_sum * loc_w / divider;
+    out3[0] = (double)(class_loss + loc_loss); out3[1] = class_loss; out3[2] = loc_loss;
+    if (!dscores && !dlocs) return;
+    for (int64_t r = 0; r < N; ++r) {
+        const int64_t j = r % A;
+        const float* t = target + r * 6;
+        const int64_t cls = (int64_t)t[4];
+        const float ts = t[5];
+        const int pos = cls != 0 && cls != -1;
+        if (dscores) {
+            float* g = dscores + r * C;
+            memset(g, 0, sizeof(float) * C);
+            if (sampled[r]) {
+                const float* x = scores + r * C;
+                float m, ls;
+                row_lse(x, C, &m, &ls);
+                const float gs = scale / mean_div * cls_w / divider;
+                if ((cls_kind == 0 || cls_kind == 2) && cls != -1) {
+                    float coef = 1.0f;   /* dL/dx_c = coef * (p_c - onehot) */
+                    if (cls_kind == 2) {
+                        const float logpb = (x[cls] - m) - ls, pb = expf(logpb), om = 1.0f - pb;
+                        /* L = -(1-p)^g ln p ;  dL/dx_c = [g (1-p)^(g-1) p ln p - (1-p)^g] (onehot - p_c) */
+                        coef = -(gamma * powf(om, gamma - 1.0f) * pb * logpb - powf(om, gamma));
+                        if (alpha >= 0.0f) coef *= (cls == 0 ? 1.0f - alpha : alpha);
+                    }
+                    for (int c = 0; c < C; ++c) g[c] = coef * (expf((x[c] - m) - ls) - (c == cls ? 1.0f : 0.0f)) * gs;
+                } else if (cls_kind == 3) {
+                    const int p_ = cls != -1 ? (int)cls : -1;
+                    float rs = 0.0f;
+                    for (int c = 0; c < C; ++c) rs += soft_t(c, p_, ts, C, epsilon);
+                    for (int c = 0; c < C; ++c) g[c] = (expf((x[c] - m) - ls) * rs - soft_t(c, p_, ts, C, epsilon)) * gs;
+                } else if (cls_kind == 4) {
+                    const int p_ = pos ? (int)cls - 1 : -1;
+                    for (int c = 0; c < C; ++c) g[c] = (sigmoidf_(x[c]) - soft_t(c, p_, ts, C, epsilon)) * gs;
+                }
+            }
+        }
+        if (dlocs) {
+            float* g = dlocs + r * 4;
+            g[0] = g[1] = g[2] = g[3] = 0.0f;
+            if (!pos) continue;
+            const float gl = loc_w / divider;
+            if (loc_kind == 0) {
+                for (int k = 0; k < 4; ++k) g[k] = smooth_l1_grad(locs[r * 4 + k], t[k], beta) * gl;
+            } else {
+                const float* pr = anchors + 4 * j;
+                const float* l = locs + r * 4;
+                float cen[4], P[4];
+                decode_one(l, pr, xy_scale, wh_scale, cen);
+                orc_to_corners(cen, P, 1);
+                /* loss = 2 - inter/uni - uni/enc */
+                const float pw = P[2] - P[0], ph = P[3] - P[1], cw = clamp0(pw), ch = clamp0(ph);
+                const float area_p = cw * ch, area_t = area4(t[0], t[1], t[2], t[3]);
+                const float ix1 = tmaxf(P[0], t[0]), iy1 = tmaxf(P[1], t[1]), ix2 = tminf(P[2], t[2]), iy2 = tminf(P[3], t[3]);
+                const float iw = clamp0(ix2 - ix1), ih = clamp0(iy2 - iy1), inter = iw * ih;
+                const float uni = area_p + area_t - inter;
+                const float ex1 = tminf(P[0], t[0]), ey1 = tminf(P[1], t[1]), ex2 = tmaxf(P[2], t[2]), ey2 = tmaxf(P[3], t[3]);
+                const float ew = clamp0(ex2 - ex1), eh = clamp0(ey2 - ey1), enc = ew * eh;
+                const float d_inter = -1.0f / uni, d_uni = inter / (uni * uni) - 1.0f / enc, d_enc = uni / (enc * enc);
+                const float c_inter = d_inter - d_uni, c_area = d_uni;   /* uni = area_p + area_t - inter */
+                float dP[4] = {0.f, 0.f, 0.f, 0.f};
+                /* area_p = clamp(x2-x1) clamp(y2-y1) (clamp passes the gradient where its argument is >= 0) */
+                if (pw >= 0.0f) { dP[2] += c_area * ch; dP[0] -= c_area * ch; }
+                if (ph >= 0.0f) { dP[3] += c_area * cw; dP[1] -= c_area * cw; }
+                /* inter = clamp(ix2-ix1) clamp(iy2-iy1); max/min route the gradient to the selected argument (ties: half) */
+                if (ix2 - ix1 >= 0.0f) {
+                    const float gq = c_inter * ih;
+                    dP[2] += gq * (P[2] < t[2] ? 1.0f : (P[2] == t[2] ? 0.5f : 0.0f));
+                    dP[0] -= gq * (P[0] > t[0] ? 1.0f : (P[0] == t[0] ? 0.5f : 0.0f));
+                }
+                if (iy2 - iy1 >= 0.0f) {
+                    const float gq = c_inter * iw;
+                    dP[3] += gq * (P[3] < t[3] ? 1.0f : (P[3] == t[3] ? 0.5f : 0.0f));
+                    dP[1] -= gq * (P[1] > t[1] ? 1.0f : (P[1] == t[1] ? 0.5f : 0.0f));
+                }
+                if (ex2 - ex1 >= 0.0f) {
+                    const float gq = d_enc * eh;
+                    dP[2] += gq * (P[2] > t[2] ? 1.0f : (P[2] == t[2] ? 0.5f : 0.0f));
+                    dP[0] -= gq * (P[0] < t[0] ? 1.0f : (P[0] == t[0] ? 0.5f : 0.0f));
+                }
+                if (ey2 - ey1 >= 0.0f) {
+                    const float gq = d_enc * ew;
+                    dP[3] += gq * (P[3] > t[3] ? 1.0f : (P[3] == t[3] ? 0.5f : 0.0f));
+                    dP[1] -= gq * (P[1] < t[1] ? 1.0f : (P[1] == t[1] ? 0.5f : 0.0f));
+                }
+                /* corners = c -+ wh/2 ; c = p_xy + p_wh t_xy / xy_scale ; wh = p_wh exp(t_wh / wh_scale) */
+                const float dcx = dP[0] + dP[2], dcy = dP[1] + dP[3], dw = (dP[2] - dP[0]) * 0.5f, dh = (dP[3] - dP[1]) * 0.5f;
+                g[0] = dcx * pr[2] / xy_scale * gl;
+                g[1] = dcy * pr[3] / xy_scale * gl;
+                g[2] = dw * cen[2] / wh_scale * gl;
+                g[3] = dh * cen[3] / wh_scale * gl;
+            }
+        }
+    }
+}

@@ -214,3 +214,33 @@ def test_decode_matches_reference(name):
     dec = oracle.to_corners(oracle.decode_box(locs.reshape(2, A, 4), g['anchors']))
     np.testing.assert_allclose(dec[0, :2048], g['post_decoded_img0_first2k'], rtol=1e-5, atol=1e-4)
     assert abs(dec.astype(np.float64).sum() - float(g['post_decoded_sum'])) <= 1e-6 * abs(float(g['post_decoded_sum'])) + 1e-2
+
+
+# ---- the other selectable losses, pinned by tests/golden/losses_extra.npz ---------------------------------
+EXTRA_LOSSES = {   # tag: (cls_kind, loc_kind, kwargs, classes)
+    'softmax_focal': ('softmax_focal', 'smooth_l1', dict(gamma=2.0, alpha=0.25, reduce_mean=True), 21),
+    'softmax_focal_noalpha': ('softmax_focal', 'smooth_l1', dict(gamma=1.5, alpha=-1.0, reduce_mean=True), 21),
+    'ce_soft': ('ce_soft', 'smooth_l1', dict(), 21),
+    'ce_soft_eps': ('ce_soft', 'smooth_l1', dict(epsilon=0.1), 21),
+    'bce_soft': ('bce_soft', 'smooth_l1', dict(), 20),
+    'giou': ('ce', 'giou', dict(), 21),
+}
+
+
+@pytest.mark.parametrize('tag', sorted(EXTRA_LOSSES))
+def test_extra_losses_match_reference(tag):
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, 'losses_extra.npz'))
+    cls_kind, loc_kind, kw, nc = EXTRA_LOSSES[tag]
+    anchors = load_golden('ssd_mb2_voc')['anchors']
+    B, A = 2, anchors.shape[0]
+    logits = syn.make_logits(B, A, nc, seed=2)
+    locs = syn.make_locs(B, A, seed=3, scale=0.5)
+    target = g['target'].copy()
+    mask = np.unpackbits(g[tag + '_sampled_bits'], axis=1)[:, :A].astype(bool)
+    vals, ds, dl = oracle.multibox_loss_ex(logits, locs, anchors, target, mask, cls_kind=cls_kind, loc_kind=loc_kind, **kw)
+    np.testing.assert_allclose(vals, g[tag + '_values'], rtol=2e-6, atol=1e-4)
+    np.testing.assert_allclose(ds, dense_from_rows(g[tag + '_dscores_rows'], g[tag + '_dscores_vals'], (B, A, nc)), rtol=2e-4, atol=2e-7)
+    np.testing.assert_allclose(dl, dense_from_rows(g[tag + '_dlocs_rows'], g[tag + '_dlocs_vals'], (B, A, 4)), rtol=2e-4, atol=2e-7)
+    assert bool(g[tag + '_target_mutated']) == (not np.array_equal(target, g['target']))

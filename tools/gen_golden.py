@@ -363,6 +363,52 @@ def gen_heads(out_dir):
     print(f'heads -> {path} ({os.path.getsize(path) / 1e3:.1f} KB)')
 
 
+def gen_losses_extra(out_dir):
+    """The other losses a config can select by name: SoftmaxFocalLoss, CrossEntropyWithSoftTargetsLoss,
+    BinaryCrossEntropyWithSoftTargetsLoss (soft targets = mixup scores in target[..., 5]) and GeneralizedIoULoss."""
+    res = {}
+    name = 'ssd_mb2_voc'
+    cfg = syn.CONFIGS[name]
+    C, B = cfg['num_classes'], 2
+    anchors = ref_anchors(cfg)
+    A = anchors.shape[0]
+    gt = syn.make_ground_truth(B, cfg['size'], C, seed=1)
+    rng = np.random.default_rng(77)
+    for g in gt:   # mixup-style soft scores
+        g[:, 5] = rng.uniform(0.3, 1.0, size=g.shape[0]).astype(np.float32)
+    res['gt_scores'] = np.concatenate([g[:, 5] for g in gt])
+    _, target = ref_match(gt, anchors, 0.5, 0.5)
+    res['target'] = target.numpy()
+    hnm = functools.partial(sampler.hard_negative_mining, negative_per_positive_ratio=3, min_negative_per_image=5)
+    variants = {
+        'softmax_focal': (hnm, {'name': 'SoftmaxFocalLoss', 'gamma': 2.0, 'alpha': 0.25}, {'name': 'SmoothL1Loss'}, C),
+        'softmax_focal_noalpha': (hnm, {'name': 'SoftmaxFocalLoss', 'gamma': 1.5}, {'name': 'SmoothL1Loss'}, C),
+        'ce_soft': (hnm, {'name': 'CrossEntropyWithSoftTargetsLoss'}, {'name': 'SmoothL1Loss'}, C),
+        'ce_soft_eps': (hnm, {'name': 'CrossEntropyWithSoftTargetsLoss', 'epsilon': 0.1}, {'name': 'SmoothL1Loss'}, C),
+        'bce_soft': (sampler.naive_sampler, {'name': 'BinaryCrossEntropyWithSoftTargetsLoss'}, {'name': 'SmoothL1Loss'}, C - 1),
+        'giou': (hnm, {'name': 'CrossEntropyLoss'}, {'name': 'GeneralizedIoULoss'}, C),
+    }
+    for tag, (smp, cl, ll, nc) in variants.items():
+        logits = torch.from_numpy(syn.make_logits(B, A, nc, seed=2)).requires_grad_(True)
+        locs = torch.from_numpy(syn.make_locs(B, A, seed=3, scale=0.5)).requires_grad_(True)
+        crit = MultiboxLoss(sampler=smp, box_coder=BoxCoder(10.0, 5.0), classification_loss=cl, localization_loss=ll,
+                            classification_weight=1.0, localization_weight=1.0)
+        tgt = target.clone()
+        mask = crit.sampler(logits.detach().view(B, A, nc), tgt[..., 4].long())
+        loss, cl_, ll_ = crit((logits, locs), anchors, tgt)
+        loss.backward()
+        res[tag + '_values'] = np.array([loss.item(), cl_.item(), ll_.item()], dtype=np.float64)
+        res[tag + '_sampled_bits'] = np.packbits(mask.numpy().astype(np.uint8), axis=1)
+        gi, gv = sparse_rows(logits.grad.view(B, A, nc)); res[tag + '_dscores_rows'], res[tag + '_dscores_vals'] = gi, gv
+        gi, gv = sparse_rows(locs.grad.view(B, A, 4)); res[tag + '_dlocs_rows'], res[tag + '_dlocs_vals'] = gi, gv
+        res[tag + '_cls_reduction'] = np.array(getattr(crit.classification_loss, 'reduction', 'n/a'))
+        res[tag + '_loc_reduction'] = np.array(getattr(crit.localization_loss, 'reduction', 'n/a'))
+        res[tag + '_target_mutated'] = np.array(not torch.equal(tgt, target))
+    path = os.path.join(out_dir, 'losses_extra.npz')
+    np.savez_compressed(path, **res)
+    print(f'losses_extra -> {path} ({os.path.getsize(path) / 1e3:.1f} KB)')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(REPO, 'tests', 'golden'))
@@ -375,6 +421,8 @@ def main():
         gen_kats(args.out)
     if args.only in (None, 'heads'):
         gen_heads(args.out)
+    if args.only in (None, 'losses_extra'):
+        gen_losses_extra(args.out)
     for name, b in batches.items():
         if args.only in (None, name):
             gen_config(name, args.out, b)
