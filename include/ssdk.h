@@ -38,6 +38,12 @@ extern "C" {
 /* classification loss kinds (bf/modules/losses.py) */
 #define SSDK_CLS_CROSS_ENTROPY 0 /* torch.nn.CrossEntropyLoss(reduction='sum', ignore_index=-1), losses.py:4 */
 #define SSDK_CLS_SIGMOID_FOCAL 1 /* SigmoidFocalLoss, losses.py:34-54 */
+#define SSDK_CLS_SOFTMAX_FOCAL 2 /* SoftmaxFocalLoss, losses.py:56-78 */
+#define SSDK_CLS_CE_SOFT 3       /* CrossEntropyWithSoftTargetsLoss, losses.py:80-93 (target of multibox_loss.py:68-71) */
+#define SSDK_CLS_BCE_SOFT 4      /* BinaryCrossEntropyWithSoftTargetsLoss, losses.py:95-106 (target of multibox_loss.py:64-67) */
+/* localisation loss kinds */
+#define SSDK_LOC_SMOOTH_L1 0 /* torch.nn.SmoothL1Loss(reduction='sum') on box_coder-encoded targets, multibox_loss.py:81-86 */
+#define SSDK_LOC_GIOU 1      /* GeneralizedIoULoss, losses.py:109-114, on decoded corners (multibox_loss.py:77-79) */
 
 int ssdk_version(void);
 const char* ssdk_last_error_string(void);
@@ -106,35 +112,49 @@ int ssdk_naive_sampler(const float* target_classes, int class_stride, int batch,
                        void* stream);
 
 /*
+ * Loss configuration of detection/losses/multibox_loss.py:11-33 (what the constructed loss objects carry).
+ *   focal_alpha < 0 means None (SoftmaxFocalLoss only).  reduce_mean != 0: the focal losses divide by the number of
+ *   sampled rows -- the reference's constructor drops reduction='sum' for classes whose __init__ takes **kwargs
+ *   (bf/utils/misc_utils.py:22-29).  soft_epsilon: label smoothing of the soft-target losses.
+ */
+typedef struct ssdk_loss_params {
+    int cls_kind;  /* SSDK_CLS_* */
+    int loc_kind;  /* SSDK_LOC_* */
+    float focal_gamma;
+    float focal_alpha;
+    int reduce_mean;
+    float soft_epsilon;
+    float classification_weight;
+    float localization_weight;
+    float xy_scale, wh_scale, eps; /* BoxCoder */
+    float smooth_l1_beta;
+} ssdk_loss_params;
+
+/*
  * detection/losses/multibox_loss.py:35-94 MultiboxLoss.forward for a given sampled mask.
- *   cls_kind SSDK_CLS_CROSS_ENTROPY: sum over sampled rows whose class != -1 of -log_softmax(scores)[class];
- *            SSDK_CLS_SIGMOID_FOCAL: losses.py:42-54 on the one-hot target of multibox_loss.py:64-67, summed over
- *            classes; `focal_reduce_mean` != 0 divides by the number of sampled rows (the reference's constructor
- *            drops reduction='sum' for this class, bf/utils/misc_utils.py:22-29 -- SURVEY.md §8a L1).
- *   localisation: SmoothL1Loss(sum, beta) over positives on box_coder-encoded targets.
- *   target DEV [batch, A, 6] is MUTATED like the reference: columns 0..3 become the encoded regression targets
- *          (to_centroids + encode_box in place, multibox_loss.py:81-82 / box_coder.py:22-30), every anchor.
+ *   classification: sum over the sampled rows of the loss selected by cls_kind (ignore_index = -1 for the hard-label
+ *   kinds), localisation: loc_kind over the positives.
+ *   target DEV [batch, A, 6]: with SSDK_LOC_SMOOTH_L1 it is MUTATED like the reference -- columns 0..3 become the
+ *          encoded regression targets (to_centroids + encode_box in place, multibox_loss.py:81-82 / box_coder.py:22-30),
+ *          every anchor; with SSDK_LOC_GIOU it is left alone (multibox_loss.py:77-79).
  *   out3   DEV float[3] = (loss, class_loss, loc_loss), each already divided by max(1, #positives).
  *   lse_valid != 0: the workspace already holds this batch's per-anchor log-sum-exp (left there by
  *          ssdk_hard_negative_mining on the same scores), so the scores are not read again for sampled negatives.
- * The workspace keeps what ssdk_multibox_loss_bwd needs (divider, per-anchor log-sum-exp); pass the same one.
+ * The workspace keeps what ssdk_multibox_loss_bwd needs (divider, scale, per-anchor log-sum-exp); pass the same one.
  */
-int ssdk_multibox_loss_fwd(int cls_kind, const float* scores, const float* locs, const float* anchors, float* target,
-                           const uint8_t* sampled, int batch, int num_anchors, int num_classes, float focal_gamma,
-                           float focal_alpha, int focal_reduce_mean, float classification_weight,
-                           float localization_weight, float xy_scale, float wh_scale, float eps, float smooth_l1_beta,
-                           int lse_valid, float* out3, void* workspace, size_t workspace_bytes, void* stream);
+int ssdk_multibox_loss_fwd(const ssdk_loss_params* params, const float* scores, const float* locs, const float* anchors,
+                           float* target, const uint8_t* sampled, int batch, int num_anchors, int num_classes, int lse_valid,
+                           float* out3, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Backward of ssdk_multibox_loss_fwd.  grad_out DEV float[2] = (dL/dclass_loss, dL/dloc_loss).
- * target is the MUTATED target of the forward call.  dscores DEV [batch, A, C] and dlocs DEV [batch, A, 4] are
+ * target is the target as the forward call left it.  dscores DEV [batch, A, C] and dlocs DEV [batch, A, 4] are
  * written in full (zeros off the sampled / positive rows).
  */
-int ssdk_multibox_loss_bwd(int cls_kind, const float* scores, const float* locs, const float* target,
-                           const uint8_t* sampled, const float* grad_out, int batch, int num_anchors, int num_classes,
-                           float focal_gamma, float focal_alpha, int focal_reduce_mean, float classification_weight,
-                           float localization_weight, float smooth_l1_beta, float* dscores, float* dlocs,
-                           void* workspace, size_t workspace_bytes, void* stream);
+int ssdk_multibox_loss_bwd(const ssdk_loss_params* params, const float* scores, const float* locs, const float* anchors,
+                           const float* target, const uint8_t* sampled, const float* grad_out, int batch, int num_anchors,
+                           int num_classes, float* dscores, float* dlocs, void* workspace, size_t workspace_bytes,
+                           void* stream);
 
 /* detection/box_coder.py:13-34 encode_box (inplace != 0: :22-30, eps after the divide; else :32-34). boxes [n_batch, A, 4]. */
 int ssdk_encode_box(const float* boxes, const float* priors, float* out, int batch, int num_anchors, float xy_scale,

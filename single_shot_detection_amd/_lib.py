@@ -44,13 +44,10 @@ _SIGNATURES = {
     'ssdk_hard_negative_mining': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                             C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'ssdk_naive_sampler': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
-    'ssdk_multibox_loss_fwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                         C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float,
-                                         C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
-                                         C.c_size_t, C.c_void_p]),
-    'ssdk_multibox_loss_bwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                         C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float,
-                                         C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'ssdk_multibox_loss_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'ssdk_multibox_loss_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'ssdk_encode_box': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
                                   C.c_int, C.c_void_p]),
     'ssdk_decode_box': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
@@ -89,6 +86,14 @@ class HeadLevel(C.Structure):
                 ('scores_offset', C.c_longlong), ('locs_offset', C.c_longlong),
                 ('dx', C.c_void_p), ('dw_score', C.c_void_p), ('db_score', C.c_void_p), ('dw_loc', C.c_void_p),
                 ('db_loc', C.c_void_p)]
+
+
+class LossParams(C.Structure):
+    """ssdk_loss_params (include/ssdk.h)."""
+    _fields_ = [('cls_kind', C.c_int), ('loc_kind', C.c_int), ('focal_gamma', C.c_float), ('focal_alpha', C.c_float),
+                ('reduce_mean', C.c_int), ('soft_epsilon', C.c_float), ('classification_weight', C.c_float),
+                ('localization_weight', C.c_float), ('xy_scale', C.c_float), ('wh_scale', C.c_float), ('eps', C.c_float),
+                ('smooth_l1_beta', C.c_float)]
 
 
 class ConvDesc(C.Structure):

@@ -31,16 +31,22 @@ class SigmoidFocalLoss(_Loss):
         raise RuntimeError('SigmoidFocalLoss is evaluated inside ssdk_multibox_loss_fwd (csrc/loss.hip)')
 
 
-def _not_yet(name):
-    class _Unsupported(_Loss):
-        def __init__(self, *args, **kwargs):
-            raise NotImplementedError(f'{name} is not on the round-1 GPU path (SURVEY.md §8f2); '
-                                      f'CrossEntropyLoss, SigmoidFocalLoss and SmoothL1Loss are')
-    _Unsupported.__name__ = name
-    return _Unsupported
+class SoftmaxFocalLoss(_Loss):
+    def __init__(self, gamma=0.0, alpha=None, ignore_index=-100, **kwargs):  # losses.py:57-61
+        super(SoftmaxFocalLoss, self).__init__(**kwargs)
+        self.gamma = gamma
+        self.alpha = alpha
+        self.ignore_index = ignore_index
 
 
-SoftmaxFocalLoss = _not_yet('SoftmaxFocalLoss')
-CrossEntropyWithSoftTargetsLoss = _not_yet('CrossEntropyWithSoftTargetsLoss')
-BinaryCrossEntropyWithSoftTargetsLoss = _not_yet('BinaryCrossEntropyWithSoftTargetsLoss')
-GeneralizedIoULoss = _not_yet('GeneralizedIoULoss')
+class CrossEntropyWithSoftTargetsLoss(_Loss):  # losses.py:80-93
+    SOFT_TARGET = True
+
+
+class BinaryCrossEntropyWithSoftTargetsLoss(_Loss):  # losses.py:95-106
+    SOFT_TARGET = True
+    MULTICLASS = True
+
+
+class GeneralizedIoULoss(_Loss):  # losses.py:109-114
+    IOU_LOSS = True

@@ -32,6 +32,7 @@ constexpr int kSelCache = 8;                // values per thread that hnm_select
 struct LossState {  // lives in the workspace, written by finalize_kernel, read by the backward
     float divider;   // max(1, #positives)               multibox_loss.py:88
     float mean_div;  // #sampled rows for focal 'mean', else 1
+    float scale;     // soft-target losses: 1 / mean target mass (losses.py:89, :102-103), else 1
     float out3[3];
     int npos;
     int nrows;
@@ -52,7 +53,7 @@ static LossWs carve_loss_ws(void* ws, size_t n_rows, size_t* total) {
     LossWs w;
     w.lse = c.take<float>(n_rows);
     w.bgloss = c.take<float>(n_rows);
-    w.partials = c.take<float>(2 * kMaxPartials);
+    w.partials = c.take<float>(3 * kMaxPartials);
     w.counters = c.take<int>(4);
     w.state = c.take<LossState>(1);
     if (total) *total = c.off;
@@ -266,7 +267,53 @@ __device__ __forceinline__ float focal_elem_grad(float x, float tg, float gamma,
 struct LossParams {
     int cls_kind, C, lse_valid;
     float gamma, alpha, xy_scale, wh_scale, eps, beta;
+    int loc_kind;
+    float epsilon;  // label smoothing of the soft-target losses (losses.py:13-18)
 };
+
+// losses.py:13-18 _soften for a target row with one positive entry of value s at column pos (pos < 0: all-zero row)
+__device__ __forceinline__ float soft_t(int c, int pos, float s, int C, float eps) {
+    if (pos < 0) return 0.0f;
+    if (eps == 0.0f) return c == pos ? s : 0.0f;
+    return c == pos ? s - eps * s : eps * s / (float)(C - 1);
+}
+
+// decoded corner box of a prediction (box_coder.py:55-57 + box_utils.py:16-23); cen returns the centroid form
+__device__ __forceinline__ float4 decode_corners(float4 t, float4 p, float xy_scale, float wh_scale, float4& cen) {
+    cen = make_float4(p.x + p.z * t.x / xy_scale, p.y + p.w * t.y / xy_scale, p.z * expf(t.z / wh_scale), p.w * expf(t.w / wh_scale));
+    return to_corners(cen);
+}
+
+// 1 - generalized_iou (box_utils.py:104-143, cartesian=False) of predicted corners P against target corners T
+__device__ __forceinline__ float giou_loss(float4 P, float4 T) {
+    const float inter = area4(tmaxf(P.x, T.x), tmaxf(P.y, T.y), tminf(P.z, T.z), tminf(P.w, T.w));
+    const float uni = area4(P.x, P.y, P.z, P.w) + area4(T.x, T.y, T.z, T.w) - inter;
+    const float enc = area4(tminf(P.x, T.x), tminf(P.y, T.y), tmaxf(P.z, T.z), tmaxf(P.w, T.w));
+    return 1.0f - (inter / uni - (enc - uni) / enc);
+}
+
+// d(giou_loss)/dP: loss = 2 - inter/uni - uni/enc; max/min route the gradient to the selected argument (ties: half),
+// clamp(0) passes it where its argument is >= 0 (what autograd does for box_utils.py:104-143)
+__device__ __forceinline__ float4 giou_loss_grad(float4 P, float4 T) {
+    const float pw = P.z - P.x, ph = P.w - P.y, cw = clamp0(pw), ch = clamp0(ph);
+    const float area_p = cw * ch, area_t = area4(T.x, T.y, T.z, T.w);
+    const float ix1 = tmaxf(P.x, T.x), iy1 = tmaxf(P.y, T.y), ix2 = tminf(P.z, T.z), iy2 = tminf(P.w, T.w);
+    const float iw = clamp0(ix2 - ix1), ih = clamp0(iy2 - iy1), inter = iw * ih;
+    const float uni = area_p + area_t - inter;
+    const float ex1 = tminf(P.x, T.x), ey1 = tminf(P.y, T.y), ex2 = tmaxf(P.z, T.z), ey2 = tmaxf(P.w, T.w);
+    const float ew = clamp0(ex2 - ex1), eh = clamp0(ey2 - ey1), enc = ew * eh;
+    const float d_uni = inter / (uni * uni) - 1.0f / enc, d_enc = uni / (enc * enc);
+    const float c_inter = -1.0f / uni - d_uni, c_area = d_uni;
+    float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto sel = [](float a, float b, bool greater) { return greater ? (a > b ? 1.0f : (a == b ? 0.5f : 0.0f)) : (a < b ? 1.0f : (a == b ? 0.5f : 0.0f)); };
+    if (pw >= 0.0f) { d.z += c_area * ch; d.x -= c_area * ch; }
+    if (ph >= 0.0f) { d.w += c_area * cw; d.y -= c_area * cw; }
+    if (ix2 - ix1 >= 0.0f) { const float g = c_inter * ih; d.z += g * sel(P.z, T.z, false); d.x -= g * sel(P.x, T.x, true); }
+    if (iy2 - iy1 >= 0.0f) { const float g = c_inter * iw; d.w += g * sel(P.w, T.w, false); d.y -= g * sel(P.y, T.y, true); }
+    if (ex2 - ex1 >= 0.0f) { const float g = d_enc * eh; d.z += g * sel(P.z, T.z, true); d.x -= g * sel(P.x, T.x, false); }
+    if (ey2 - ey1 >= 0.0f) { const float g = d_enc * ew; d.w += g * sel(P.w, T.w, true); d.y -= g * sel(P.y, T.y, false); }
+    return d;
+}
 
 __global__ void __launch_bounds__(kLossThreads) loss_fwd_kernel(LossParams p, const float* __restrict__ scores,
                                                                 const float4* __restrict__ locs, const float4* __restrict__ anchors,
@@ -275,8 +322,8 @@ __global__ void __launch_bounds__(kLossThreads) loss_fwd_kernel(LossParams p, co
                                                                 float* __restrict__ partials, int* __restrict__ counters) {
     __shared__ float s_red[kLossThreads / kWave];
     __shared__ int s_redi[kLossThreads / kWave];
-    float cls_acc = 0.0f, loc_acc = 0.0f;
-    int npos = 0, nrows = 0;
+    float cls_acc = 0.0f, loc_acc = 0.0f, t_acc = 0.0f;
+    int npos = 0, nrows = 0, nposrows = 0;
     const int lane = lane_id();
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long n_iter = (n_rows + stride - 1) / stride;
@@ -295,8 +342,14 @@ __global__ void __launch_bounds__(kLossThreads) loss_fwd_kernel(LossParams p, co
             pos = cls != 0 && cls != -1;
             smp = sampled[r] != 0;
             npos += pos;
-            // box_utils.py:33-34 to_centroids(inplace), then box_coder.py:22-30 encode_box(inplace)
             const float4 pr = anchors[r % A];
+            if (p.loc_kind == SSDK_LOC_GIOU) {  // multibox_loss.py:77-79: decoded corners vs the RAW target, no mutation
+                if (pos) {
+                    float4 cen;
+                    loc_acc += giou_loss(decode_corners(locs[r], pr, p.xy_scale, p.wh_scale, cen), make_float4(t01.x, t01.y, t23.x, t23.y));
+                }
+            } else {
+            // box_utils.py:33-34 to_centroids(inplace), then box_coder.py:22-30 encode_box(inplace)
             t23.x -= t01.x; t23.y -= t01.y;
             t01.x += t23.x / 2.0f; t01.y += t23.y / 2.0f;
             t01.x -= pr.x; t01.y -= pr.y;
@@ -312,11 +365,22 @@ __global__ void __launch_bounds__(kLossThreads) loss_fwd_kernel(LossParams p, co
                 loc_acc += smooth_l1(l.x, t01.x, p.beta) + smooth_l1(l.y, t01.y, p.beta) + smooth_l1(l.z, t23.x, p.beta) +
                            smooth_l1(l.w, t23.y, p.beta);
             }
+            }
         }
-        const bool want = p.cls_kind == SSDK_CLS_CROSS_ENTROPY ? (smp && cls != -1) : smp;  // CE: ignore_index = -1
+        const bool hard_label = p.cls_kind == SSDK_CLS_CROSS_ENTROPY || p.cls_kind == SSDK_CLS_SOFTMAX_FOCAL;
+        const bool want = hard_label ? (smp && cls != -1) : smp;  // CE / softmax focal: ignore_index = -1
         nrows += smp;
-        if (p.cls_kind == SSDK_CLS_CROSS_ENTROPY && p.lse_valid) {
-            if (want) cls_acc += lse[r] - scores[r * p.C + cls];
+        if (hard_label && p.lse_valid) {
+            if (want) {
+                const float nlogpb = lse[r] - scores[r * p.C + cls];
+                if (p.cls_kind == SSDK_CLS_CROSS_ENTROPY) {
+                    cls_acc += nlogpb;
+                } else {  // losses.py:56-78
+                    float l = __powf(1.0f - __expf(-nlogpb), p.gamma) * nlogpb;
+                    if (p.alpha >= 0.0f) l *= (cls == 0 ? 1.0f - p.alpha : p.alpha);
+                    cls_acc += l;
+                }
+            }
         } else {
             unsigned long long todo = __ballot(want);
             while (todo) {  // the wave cooperates on each sampled row
@@ -327,7 +391,7 @@ __global__ void __launch_bounds__(kLossThreads) loss_fwd_kernel(LossParams p, co
                 const float ts = __shfl(tscore, src, kWave);
                 const float* x = scores + rs * p.C;
                 float val;
-                if (p.cls_kind == SSDK_CLS_CROSS_ENTROPY) {
+                if (p.cls_kind != SSDK_CLS_SIGMOID_FOCAL && p.cls_kind != SSDK_CLS_BCE_SOFT) {  // softmax family: needs the row's log-sum-exp
                     float m = -INFINITY;
                     for (int c = lane; c < p.C; c += kWave) m = fmaxf(m, x[c]);
                     m = wave_allreduce(m, OpMaxF());
@@ -336,7 +400,36 @@ __global__ void __launch_bounds__(kLossThreads) loss_fwd_kernel(LossParams p, co
                     s = wave_allreduce(s, OpAddF());
                     const float l = m + logf(s);
                     if (lane == src) lse[rs] = l;
-                    val = l - x[cs];
+                    if (p.cls_kind == SSDK_CLS_CROSS_ENTROPY) {
+                        val = l - x[cs];
+                    } else if (p.cls_kind == SSDK_CLS_SOFTMAX_FOCAL) {
+                        const float nlogpb = l - x[cs];
+                        val = __powf(1.0f - __expf(-nlogpb), p.gamma) * nlogpb;
+                        if (p.alpha >= 0.0f) val *= (cs == 0 ? 1.0f - p.alpha : p.alpha);
+                    } else {  // SSDK_CLS_CE_SOFT, losses.py:80-93 on the target of multibox_loss.py:68-71
+                        const int pos_c = cs != -1 ? cs : -1;
+                        float f = 0.0f, rsum = 0.0f;
+                        for (int c = lane; c < p.C; c += kWave) {
+                            const float tc = soft_t(c, pos_c, ts, p.C, p.epsilon);
+                            f += (x[c] - l) * tc;
+                            rsum += tc;
+                        }
+                        val = -wave_allreduce(f, OpAddF());
+                        rsum = wave_allreduce(rsum, OpAddF());
+                        if (lane == src) t_acc += rsum;
+                    }
+                } else if (p.cls_kind == SSDK_CLS_BCE_SOFT) {  // losses.py:95-106 on the target of multibox_loss.py:64-67
+                    const bool ps = cs != 0 && cs != -1;
+                    const int pos_c = ps ? cs - 1 : -1;
+                    float f = 0.0f, rsum = 0.0f;
+                    for (int c = lane; c < p.C; c += kWave) {
+                        const float tc = soft_t(c, pos_c, ts, p.C, p.epsilon);
+                        f += fmaxf(x[c], 0.0f) - x[c] * tc + log1pf(__expf(-fabsf(x[c])));
+                        rsum += tc;
+                    }
+                    val = wave_allreduce(f, OpAddF());
+                    rsum = wave_allreduce(rsum, OpAddF()) / (float)p.C;
+                    if (lane == src) { t_acc += rsum; nposrows += rsum > 0.0f; }
                 } else {
                     const bool ps = cs != 0 && cs != -1;
                     float f = 0.0f;
@@ -350,13 +443,17 @@ __global__ void __launch_bounds__(kLossThreads) loss_fwd_kernel(LossParams p, co
     }
     const float cs_ = block_sum(cls_acc, s_red);
     const float ls_ = block_sum(loc_acc, s_red);
+    const float ts_ = block_sum(t_acc, s_red);
     const int np_ = block_sum(npos, s_redi);
     const int nr_ = block_sum(nrows, s_redi);
+    const int npr_ = block_sum(nposrows, s_redi);
     if (threadIdx.x == 0) {
         partials[blockIdx.x] = cs_;
         partials[kMaxPartials + blockIdx.x] = ls_;
+        partials[2 * kMaxPartials + blockIdx.x] = ts_;
         if (np_) atomicAdd(&counters[0], np_);
         if (nr_) atomicAdd(&counters[1], nr_);
+        if (npr_) atomicAdd(&counters[2], npr_);
     }
 }
 
@@ -365,16 +462,24 @@ __global__ void __launch_bounds__(256) loss_finalize_kernel(const float* __restr
                                                             float cls_w, float loc_w, LossState* __restrict__ state,
                                                             float* __restrict__ out3) {
     __shared__ double s_red[4];
-    double c = 0.0, l = 0.0;
-    for (int k = threadIdx.x; k < n_part; k += blockDim.x) { c += (double)partials[k]; l += (double)partials[kMaxPartials + k]; }
+    double c = 0.0, l = 0.0, t = 0.0;
+    for (int k = threadIdx.x; k < n_part; k += blockDim.x) {
+        c += (double)partials[k]; l += (double)partials[kMaxPartials + k]; t += (double)partials[2 * kMaxPartials + k];
+    }
     c = block_sum(c, s_red);
     l = block_sum(l, s_red);
+    t = block_sum(t, s_red);
     if (threadIdx.x == 0) {
-        const int npos = counters[0], nrows = counters[1];
+        const int npos = counters[0], nrows = counters[1], nposrows = counters[2];
         const float divider = (float)(npos < 1 ? 1 : npos);  // multibox_loss.py:88
-        const float mean_div = (cls_kind == SSDK_CLS_SIGMOID_FOCAL && reduce_mean) ? (float)nrows : 1.0f;
-        const float class_loss = (float)c / mean_div * cls_w / divider;  // :90
+        const bool focal = cls_kind == SSDK_CLS_SIGMOID_FOCAL || cls_kind == SSDK_CLS_SOFTMAX_FOCAL;
+        const float mean_div = (focal && reduce_mean) ? (float)nrows : 1.0f;
+        float scale = 1.0f;
+        if (cls_kind == SSDK_CLS_CE_SOFT) scale = 1.0f / ((float)t / (float)nrows);       // losses.py:89 target.sum(-1).mean() ** -1
+        if (cls_kind == SSDK_CLS_BCE_SOFT) scale = 1.0f / ((float)t / (float)nposrows);   // losses.py:102-103
+        const float class_loss = scale * (float)c / mean_div * cls_w / divider;  // :90
         const float loc_loss = (float)l * loc_w / divider;               // :89
+        state->scale = scale;
         state->divider = divider; state->mean_div = mean_div; state->npos = npos; state->nrows = nrows;
         state->out3[0] = class_loss + loc_loss; state->out3[1] = class_loss; state->out3[2] = loc_loss;
         out3[0] = class_loss + loc_loss; out3[1] = class_loss; out3[2] = loc_loss;
@@ -385,6 +490,7 @@ __global__ void __launch_bounds__(256) loss_finalize_kernel(const float* __restr
 
 __global__ void __launch_bounds__(kLossThreads) loss_bwd_kernel(LossParams p, int reduce_mean, float cls_w, float loc_w,
                                                                 const float* __restrict__ scores, const float4* __restrict__ locs,
+                                                                const float4* __restrict__ anchors, int A,
                                                                 const float* __restrict__ target, const uint8_t* __restrict__ sampled,
                                                                 const float* __restrict__ grad_out, long long n_rows,
                                                                 const float* __restrict__ lse, const LossState* __restrict__ state,
@@ -394,7 +500,7 @@ __global__ void __launch_bounds__(kLossThreads) loss_bwd_kernel(LossParams p, in
     __shared__ float s_tscore[kTileRows];
     __shared__ int s_any;
     const float divider = state->divider;
-    const float g_cls = grad_out[0] * cls_w / divider / (reduce_mean ? state->mean_div : 1.0f);
+    const float g_cls = grad_out[0] * state->scale * cls_w / divider / (reduce_mean ? state->mean_div : 1.0f);
     const float g_loc = grad_out[1] * loc_w / divider;
     const long long n_tiles = (n_rows + kTileRows - 1) / kTileRows;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -411,15 +517,26 @@ __global__ void __launch_bounds__(kLossThreads) loss_bwd_kernel(LossParams p, in
             const int cls = (int)t45.x;
             const bool pos = cls != 0 && cls != -1;
             const bool smp = sampled[r] != 0;
-            const bool want = p.cls_kind == SSDK_CLS_CROSS_ENTROPY ? (smp && cls != -1) : smp;
+            const bool hard_label = p.cls_kind == SSDK_CLS_CROSS_ENTROPY || p.cls_kind == SSDK_CLS_SOFTMAX_FOCAL;
+            const bool want = hard_label ? (smp && cls != -1) : smp;
             s_cls[threadIdx.x] = want ? cls : INT_MIN;
             s_tscore[threadIdx.x] = t45.y;
             if (want) s_any = 1;
             float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
             if (pos) {
                 const float4 l = locs[r];
-                g = make_float4(smooth_l1_grad(l.x, t01.x, p.beta) * g_loc, smooth_l1_grad(l.y, t01.y, p.beta) * g_loc,
-                                smooth_l1_grad(l.z, t23.x, p.beta) * g_loc, smooth_l1_grad(l.w, t23.y, p.beta) * g_loc);
+                if (p.loc_kind == SSDK_LOC_GIOU) {
+                    const float4 pr = anchors[r % A];
+                    float4 cen;
+                    const float4 P = decode_corners(l, pr, p.xy_scale, p.wh_scale, cen);
+                    const float4 d = giou_loss_grad(P, make_float4(t01.x, t01.y, t23.x, t23.y));
+                    // corners = c -+ wh/2 ; c = p_xy + p_wh t / xy_scale ; wh = p_wh exp(t / wh_scale)
+                    g = make_float4((d.x + d.z) * pr.z / p.xy_scale * g_loc, (d.y + d.w) * pr.w / p.xy_scale * g_loc,
+                                    (d.z - d.x) * 0.5f * cen.z / p.wh_scale * g_loc, (d.w - d.y) * 0.5f * cen.w / p.wh_scale * g_loc);
+                } else {
+                    g = make_float4(smooth_l1_grad(l.x, t01.x, p.beta) * g_loc, smooth_l1_grad(l.y, t01.y, p.beta) * g_loc,
+                                    smooth_l1_grad(l.z, t23.x, p.beta) * g_loc, smooth_l1_grad(l.w, t23.y, p.beta) * g_loc);
+                }
             }
             dlocs[r] = g;
         }
@@ -440,9 +557,27 @@ __global__ void __launch_bounds__(kLossThreads) loss_bwd_kernel(LossParams p, in
             const long long r = r0 + row;
             const float* x = scores + r * p.C;
             float* o = s_tile + row * p.C;
-            if (p.cls_kind == SSDK_CLS_CROSS_ENTROPY) {
+            if (p.cls_kind == SSDK_CLS_CROSS_ENTROPY || p.cls_kind == SSDK_CLS_SOFTMAX_FOCAL) {
                 const float l = lse[r];
-                for (int c = lane; c < p.C; c += kWave) o[c] = (__expf(x[c] - l) - (c == cls ? 1.0f : 0.0f)) * g_cls;
+                float coef = 1.0f;  // dL/dx_c = coef * (p_c - onehot_c)
+                if (p.cls_kind == SSDK_CLS_SOFTMAX_FOCAL) {
+                    const float logpb = x[cls] - l, pb = __expf(logpb), om = 1.0f - pb;
+                    coef = -(p.gamma * __powf(om, p.gamma - 1.0f) * pb * logpb - __powf(om, p.gamma));
+                    if (p.alpha >= 0.0f) coef *= (cls == 0 ? 1.0f - p.alpha : p.alpha);
+                }
+                for (int c = lane; c < p.C; c += kWave) o[c] = coef * (__expf(x[c] - l) - (c == cls ? 1.0f : 0.0f)) * g_cls;
+            } else if (p.cls_kind == SSDK_CLS_CE_SOFT) {
+                const float l = lse[r], ts = s_tscore[row];
+                const int pos_c = cls != -1 ? cls : -1;
+                float rsum = 0.0f;
+                for (int c = lane; c < p.C; c += kWave) rsum += soft_t(c, pos_c, ts, p.C, p.epsilon);
+                rsum = wave_allreduce(rsum, OpAddF());
+                for (int c = lane; c < p.C; c += kWave) o[c] = (__expf(x[c] - l) * rsum - soft_t(c, pos_c, ts, p.C, p.epsilon)) * g_cls;
+            } else if (p.cls_kind == SSDK_CLS_BCE_SOFT) {
+                const bool ps = cls != 0 && cls != -1;
+                const int pos_c = ps ? cls - 1 : -1;
+                const float ts = s_tscore[row];
+                for (int c = lane; c < p.C; c += kWave) o[c] = (sigmoid_f(x[c]) - soft_t(c, pos_c, ts, p.C, p.epsilon)) * g_cls;
             } else {
                 const bool ps = cls != 0 && cls != -1;
                 const float ts = s_tscore[row];
@@ -551,53 +686,69 @@ extern "C" int ssdk_naive_sampler(const float* target_classes, int class_stride,
     return SSDK_OK;
 }
 
-extern "C" int ssdk_multibox_loss_fwd(int cls_kind, const float* scores, const float* locs, const float* anchors, float* target,
-                                      const uint8_t* sampled, int batch, int num_anchors, int num_classes, float focal_gamma,
-                                      float focal_alpha, int focal_reduce_mean, float classification_weight,
-                                      float localization_weight, float xy_scale, float wh_scale, float eps, float smooth_l1_beta,
-                                      int lse_valid, float* out3, void* workspace, size_t workspace_bytes, void* stream) {
+static int check_loss_params(const char* fn, const ssdk_loss_params* q) {
+    SSDK_REQUIRE(q, SSDK_E_INVALID, "%s: null params", fn);
+    SSDK_REQUIRE(q->cls_kind >= SSDK_CLS_CROSS_ENTROPY && q->cls_kind <= SSDK_CLS_BCE_SOFT, SSDK_E_INVALID, "%s: cls_kind=%d", fn, q->cls_kind);
+    SSDK_REQUIRE(q->loc_kind == SSDK_LOC_SMOOTH_L1 || q->loc_kind == SSDK_LOC_GIOU, SSDK_E_INVALID, "%s: loc_kind=%d", fn, q->loc_kind);
+    SSDK_REQUIRE(q->smooth_l1_beta > 0, SSDK_E_INVALID, "%s: beta must be > 0", fn);
+    SSDK_REQUIRE(q->soft_epsilon >= 0.0f && q->soft_epsilon < 1.0f, SSDK_E_INVALID, "%s: epsilon outside [0, 1) (losses.py:15)", fn);
+    return SSDK_OK;
+}
+
+static LossParams to_device_params(const ssdk_loss_params* q, int C, int lse_valid) {
+    LossParams p{};
+    p.cls_kind = q->cls_kind; p.C = C; p.lse_valid = lse_valid;
+    p.gamma = q->focal_gamma; p.alpha = q->focal_alpha; p.xy_scale = q->xy_scale; p.wh_scale = q->wh_scale; p.eps = q->eps;
+    p.beta = q->smooth_l1_beta; p.loc_kind = q->loc_kind; p.epsilon = q->soft_epsilon;
+    return p;
+}
+
+extern "C" int ssdk_multibox_loss_fwd(const ssdk_loss_params* params, const float* scores, const float* locs, const float* anchors,
+                                      float* target, const uint8_t* sampled, int batch, int num_anchors, int num_classes, int lse_valid,
+                                      float* out3, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = check_loss_common("ssdk_multibox_loss_fwd", scores, batch, num_anchors, num_classes, workspace, workspace_bytes);
     if (rc) return rc;
-    SSDK_REQUIRE(cls_kind == SSDK_CLS_CROSS_ENTROPY || cls_kind == SSDK_CLS_SIGMOID_FOCAL, SSDK_E_INVALID, "ssdk_multibox_loss_fwd: cls_kind=%d", cls_kind);
+    rc = check_loss_params("ssdk_multibox_loss_fwd", params);
+    if (rc) return rc;
     SSDK_REQUIRE(locs && anchors && target && sampled && out3, SSDK_E_INVALID, "ssdk_multibox_loss_fwd: null pointer");
     SSDK_REQUIRE(((uintptr_t)locs & 15) == 0 && ((uintptr_t)anchors & 15) == 0 && ((uintptr_t)target & 7) == 0, SSDK_E_INVALID,
                  "ssdk_multibox_loss_fwd: locs/anchors need 16-byte and target 8-byte alignment");
-    SSDK_REQUIRE(smooth_l1_beta > 0, SSDK_E_INVALID, "ssdk_multibox_loss_fwd: beta must be > 0");
     hipStream_t s = (hipStream_t)stream;
     const long long n_rows = (long long)batch * num_anchors;
     LossWs w = carve_loss_ws(workspace, (size_t)n_rows, nullptr);
     SSDK_CHECK_HIP(hipMemsetAsync(w.counters, 0, 4 * sizeof(int), s));
-    LossParams p{cls_kind, num_classes, lse_valid, focal_gamma, focal_alpha, xy_scale, wh_scale, eps, smooth_l1_beta};
+    LossParams p = to_device_params(params, num_classes, lse_valid);
     const int grid = stream_grid(n_rows, kLossThreads);
     hipLaunchKernelGGL(loss_fwd_kernel, dim3(grid), dim3(kLossThreads), 0, s, p, scores, (const float4*)locs, (const float4*)anchors,
                        target, sampled, n_rows, num_anchors, w.lse, w.partials, w.counters);
     SSDK_CHECK_LAUNCH("loss_fwd_kernel");
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, w.partials, grid, w.counters, cls_kind, focal_reduce_mean,
-                       classification_weight, localization_weight, w.state, out3);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, w.partials, grid, w.counters, params->cls_kind, params->reduce_mean,
+                       params->classification_weight, params->localization_weight, w.state, out3);
     SSDK_CHECK_LAUNCH("loss_finalize_kernel");
     return SSDK_OK;
 }
 
-extern "C" int ssdk_multibox_loss_bwd(int cls_kind, const float* scores, const float* locs, const float* target,
-                                      const uint8_t* sampled, const float* grad_out, int batch, int num_anchors, int num_classes,
-                                      float focal_gamma, float focal_alpha, int focal_reduce_mean, float classification_weight,
-                                      float localization_weight, float smooth_l1_beta, float* dscores, float* dlocs, void* workspace,
-                                      size_t workspace_bytes, void* stream) {
+extern "C" int ssdk_multibox_loss_bwd(const ssdk_loss_params* params, const float* scores, const float* locs, const float* anchors,
+                                      const float* target, const uint8_t* sampled, const float* grad_out, int batch, int num_anchors,
+                                      int num_classes, float* dscores, float* dlocs, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = check_loss_common("ssdk_multibox_loss_bwd", scores, batch, num_anchors, num_classes, workspace, workspace_bytes);
     if (rc) return rc;
-    SSDK_REQUIRE(locs && target && sampled && grad_out && dscores && dlocs, SSDK_E_INVALID, "ssdk_multibox_loss_bwd: null pointer");
-    SSDK_REQUIRE(((uintptr_t)dscores & 15) == 0 && ((uintptr_t)dlocs & 15) == 0 && ((uintptr_t)locs & 15) == 0, SSDK_E_INVALID,
-                 "ssdk_multibox_loss_bwd: dscores/dlocs/locs must be 16-byte aligned");
+    rc = check_loss_params("ssdk_multibox_loss_bwd", params);
+    if (rc) return rc;
+    SSDK_REQUIRE(locs && anchors && target && sampled && grad_out && dscores && dlocs, SSDK_E_INVALID, "ssdk_multibox_loss_bwd: null pointer");
+    SSDK_REQUIRE(((uintptr_t)dscores & 15) == 0 && ((uintptr_t)dlocs & 15) == 0 && ((uintptr_t)locs & 15) == 0 && ((uintptr_t)anchors & 15) == 0,
+                 SSDK_E_INVALID, "ssdk_multibox_loss_bwd: dscores/dlocs/locs/anchors must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const long long n_rows = (long long)batch * num_anchors;
     LossWs w = carve_loss_ws(workspace, (size_t)n_rows, nullptr);
-    LossParams p{cls_kind, num_classes, 1, focal_gamma, focal_alpha, 0.f, 0.f, 0.f, smooth_l1_beta};
+    LossParams p = to_device_params(params, num_classes, 1);
     const size_t lds = (size_t)kTileRows * num_classes * sizeof(float);
     if (lds > 48 * 1024)
         SSDK_CHECK_HIP(hipFuncSetAttribute((const void*)loss_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(loss_bwd_kernel, dim3(stream_grid(n_rows, kTileRows)), dim3(kLossThreads), lds, s, p,
-                       cls_kind == SSDK_CLS_SIGMOID_FOCAL ? focal_reduce_mean : 0, classification_weight, localization_weight,
-                       scores, (const float4*)locs, target, sampled, grad_out, n_rows, w.lse, w.state, dscores, (float4*)dlocs);
+    const bool focal = params->cls_kind == SSDK_CLS_SIGMOID_FOCAL || params->cls_kind == SSDK_CLS_SOFTMAX_FOCAL;
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(stream_grid(n_rows, kTileRows)), dim3(kLossThreads), lds, s, p, focal ? params->reduce_mean : 0,
+                       params->classification_weight, params->localization_weight, scores, (const float4*)locs, (const float4*)anchors,
+                       num_anchors, target, sampled, grad_out, n_rows, w.lse, w.state, dscores, (float4*)dlocs);
     SSDK_CHECK_LAUNCH("loss_bwd_kernel");
     return SSDK_OK;
 }

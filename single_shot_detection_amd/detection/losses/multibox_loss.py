@@ -1,4 +1,5 @@
 """MultiboxLoss -- mirror of detection/losses/multibox_loss.py:10-94 on libssdk (csrc/loss.hip)."""
+import ctypes
 import functools
 
 import torch
@@ -12,6 +13,11 @@ from ..target_assigner import LOC_INDEX_START, LOC_INDEX_END, CLASS_INDEX, SCORE
 
 SSDK_CLS_CROSS_ENTROPY = 0
 SSDK_CLS_SIGMOID_FOCAL = 1
+SSDK_CLS_SOFTMAX_FOCAL = 2
+SSDK_CLS_CE_SOFT = 3
+SSDK_CLS_BCE_SOFT = 4
+SSDK_LOC_SMOOTH_L1 = 0
+SSDK_LOC_GIOU = 1
 
 
 def _unwrap_sampler(fn):
@@ -44,7 +50,7 @@ class _MultiboxLossFn(torch.autograd.Function):
                                                      float(kw['negative_per_positive_ratio']),
                                                      int(kw['min_negative_per_image']), _lib.ptr(mask), _lib.ptr(ws),
                                                      ws.numel(), _lib.current_stream()), 'ssdk_hard_negative_mining')
-            lse_valid = 1 if module.cls_kind == SSDK_CLS_CROSS_ENTROPY else 0
+            lse_valid = 1 if module.cls_kind in (SSDK_CLS_CROSS_ENTROPY, SSDK_CLS_SOFTMAX_FOCAL) else 0
         elif fn is _sampler.naive_sampler:
             mask = torch.empty((B, A), dtype=torch.uint8, device=dev)
             _lib.check(lib.ssdk_naive_sampler(cls_col.data_ptr(), 6, B, A, _lib.ptr(mask), _lib.current_stream()),
@@ -52,15 +58,11 @@ class _MultiboxLossFn(torch.autograd.Function):
         else:  # any user sampler with the reference's signature (multibox_loss.py:58)
             mask = module.sampler(scores.view(B, A, C), cls_col.long()).to(torch.uint8).contiguous()
         out3 = torch.empty((3,), dtype=torch.float32, device=dev)
-        _lib.check(lib.ssdk_multibox_loss_fwd(module.cls_kind, _lib.ptr(scores), _lib.ptr(locs), _lib.ptr(anchors),
-                                              _lib.ptr(target), _lib.ptr(mask), B, A, C, module.focal_gamma,
-                                              module.focal_alpha, module.focal_reduce_mean,
-                                              float(module.classification_weight), float(module.localization_weight),
-                                              float(module.box_coder.xy_scale), float(module.box_coder.wh_scale),
-                                              float(module.box_coder.eps), module.smooth_l1_beta, lse_valid,
-                                              _lib.ptr(out3), _lib.ptr(ws), ws.numel(), _lib.current_stream()),
-                   'ssdk_multibox_loss_fwd')
-        ctx.save_for_backward(scores, locs, target, mask, ws)
+        params = module.loss_params()
+        _lib.check(lib.ssdk_multibox_loss_fwd(ctypes.byref(params), _lib.ptr(scores), _lib.ptr(locs), _lib.ptr(anchors),
+                                              _lib.ptr(target), _lib.ptr(mask), B, A, C, lse_valid, _lib.ptr(out3), _lib.ptr(ws),
+                                              ws.numel(), _lib.current_stream()), 'ssdk_multibox_loss_fwd')
+        ctx.save_for_backward(scores, locs, anchors, target, mask, ws)
         ctx.module = module
         ctx.shape = (B, A, C)
         ctx.mark_non_differentiable(mask)
@@ -68,19 +70,17 @@ class _MultiboxLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_class, g_loc, _g_mask):
-        scores, locs, target, mask, ws = ctx.saved_tensors
+        scores, locs, anchors, target, mask, ws = ctx.saved_tensors
         module = ctx.module
         B, A, C = ctx.shape
         grad_out = torch.stack([g_class.float().reshape(()), g_loc.float().reshape(())]).contiguous()
         dscores = torch.empty_like(scores)
         dlocs = torch.empty_like(locs)
-        _lib.check(_lib.lib().ssdk_multibox_loss_bwd(module.cls_kind, _lib.ptr(scores), _lib.ptr(locs), _lib.ptr(target),
-                                                     _lib.ptr(mask), _lib.ptr(grad_out), B, A, C, module.focal_gamma,
-                                                     module.focal_alpha, module.focal_reduce_mean,
-                                                     float(module.classification_weight),
-                                                     float(module.localization_weight), module.smooth_l1_beta,
-                                                     _lib.ptr(dscores), _lib.ptr(dlocs), _lib.ptr(ws), ws.numel(),
-                                                     _lib.current_stream()), 'ssdk_multibox_loss_bwd')
+        params = module.loss_params()
+        _lib.check(_lib.lib().ssdk_multibox_loss_bwd(ctypes.byref(params), _lib.ptr(scores), _lib.ptr(locs), _lib.ptr(anchors),
+                                                     _lib.ptr(target), _lib.ptr(mask), _lib.ptr(grad_out), B, A, C, _lib.ptr(dscores),
+                                                     _lib.ptr(dlocs), _lib.ptr(ws), ws.numel(), _lib.current_stream()),
+                   'ssdk_multibox_loss_bwd')
         return dscores, dlocs, None, None, None
 
 
@@ -109,7 +109,7 @@ class MultiboxLoss(nn.Module):
         self.localization_weight = localization_weight
 
         cl = self.classification_loss
-        self.focal_gamma, self.focal_alpha, self.focal_reduce_mean = 2.0, 0.25, 0
+        self.focal_gamma, self.focal_alpha, self.focal_reduce_mean, self.soft_epsilon = 2.0, 0.25, 0, 0.0
         if isinstance(cl, losses.CrossEntropyLoss):
             if cl.reduction != 'sum' or cl.ignore_index != IGNORE_CLASS or cl.weight is not None or \
                     getattr(cl, 'label_smoothing', 0.0) != 0.0:
@@ -121,13 +121,36 @@ class MultiboxLoss(nn.Module):
             self.cls_kind = SSDK_CLS_SIGMOID_FOCAL
             self.focal_gamma, self.focal_alpha = float(cl.gamma), float(cl.alpha)
             self.focal_reduce_mean = 1 if cl.reduction == 'mean' else 0
+        elif isinstance(cl, losses.SoftmaxFocalLoss):
+            if cl.reduction not in ('mean', 'sum') or cl.ignore_index != IGNORE_CLASS:
+                raise NotImplementedError("SoftmaxFocalLoss: reduction must be 'mean' or 'sum' and ignore_index -1")
+            self.cls_kind = SSDK_CLS_SOFTMAX_FOCAL
+            self.focal_gamma = float(cl.gamma)
+            self.focal_alpha = -1.0 if cl.alpha is None else float(cl.alpha)
+            self.focal_reduce_mean = 1 if cl.reduction == 'mean' else 0
+        elif isinstance(cl, (losses.CrossEntropyWithSoftTargetsLoss, losses.BinaryCrossEntropyWithSoftTargetsLoss)):
+            if cl.reduction != 'sum':
+                raise NotImplementedError(f'{type(cl).__name__}: only reduction=sum')
+            self.cls_kind = SSDK_CLS_BCE_SOFT if self.multiclass else SSDK_CLS_CE_SOFT   # multibox_loss.py:64 tests multiclass first
+            self.soft_epsilon = float(cl.epsilon)
         else:
             raise NotImplementedError(f'classification loss {type(cl).__name__} is not on the GPU path')
         ll = self.localization_loss
-        if not isinstance(ll, losses.SmoothL1Loss) or ll.reduction != 'sum':
+        self.smooth_l1_beta = 1.0
+        if isinstance(ll, losses.SmoothL1Loss) and ll.reduction == 'sum':
+            self.loc_kind = SSDK_LOC_SMOOTH_L1
+            self.smooth_l1_beta = float(getattr(ll, 'beta', 1.0))
+        elif isinstance(ll, losses.GeneralizedIoULoss) and ll.reduction == 'sum':
+            self.loc_kind = SSDK_LOC_GIOU
+        else:
             raise NotImplementedError(f'localization loss {type(ll).__name__}(reduction={ll.reduction}) is not on the GPU path')
-        self.smooth_l1_beta = float(getattr(ll, 'beta', 1.0))
         self.last_sampled_mask = None
+
+    def loss_params(self):
+        return _lib.LossParams(self.cls_kind, self.loc_kind, self.focal_gamma, self.focal_alpha, self.focal_reduce_mean,
+                               self.soft_epsilon, float(self.classification_weight), float(self.localization_weight),
+                               float(self.box_coder.xy_scale), float(self.box_coder.wh_scale), float(self.box_coder.eps),
+                               self.smooth_l1_beta)
 
     def forward(self, pred, anchors, target):
         """

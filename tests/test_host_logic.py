@@ -38,10 +38,14 @@ def test_multibox_loss_constructor_surface():
     assert fo.cls_kind == 1 and fo.focal_reduce_mean == 1 and fo.multiclass
     fn, kw = _unwrap_sampler(smp)
     assert fn is sampler.hard_negative_mining and kw == {'negative_per_positive_ratio': 3, 'min_negative_per_image': 5}
-    with pytest.raises(NotImplementedError):
-        MultiboxLoss(smp, bc, {'name': 'SoftmaxFocalLoss'}, {'name': 'SmoothL1Loss'})
-    with pytest.raises(NotImplementedError):
-        MultiboxLoss(smp, bc, {'name': 'CrossEntropyLoss'}, {'name': 'GeneralizedIoULoss'})
+    sf = MultiboxLoss(smp, bc, {'name': 'SoftmaxFocalLoss', 'gamma': 1.5}, {'name': 'SmoothL1Loss'})
+    assert sf.cls_kind == 2 and sf.focal_alpha == -1.0 and sf.focal_reduce_mean == 1     # reduction='sum' dropped here too
+    assert MultiboxLoss(smp, bc, {'name': 'CrossEntropyWithSoftTargetsLoss', 'epsilon': 0.1}, {'name': 'SmoothL1Loss'}).cls_kind == 3
+    assert MultiboxLoss(smp, bc, {'name': 'BinaryCrossEntropyWithSoftTargetsLoss'}, {'name': 'SmoothL1Loss'}).cls_kind == 4
+    gi = MultiboxLoss(smp, bc, {'name': 'CrossEntropyLoss'}, {'name': 'GeneralizedIoULoss'})
+    assert gi.loc_kind == 1 and gi.iou_loss
+    with pytest.raises(AttributeError):
+        MultiboxLoss(smp, bc, {'name': 'NoSuchLoss'}, {'name': 'SmoothL1Loss'})
 
 
 def test_postprocessor_constructor_surface():

@@ -225,3 +225,44 @@ def test_no_positives_divider_is_one():
     vals, _, _ = oracle.multibox_loss(logits, locs, anchors, target.copy(), mask, kind='ce', grads=False)
     np.testing.assert_allclose([loss.item(), cl.item(), ll.item()], vals, rtol=1e-5, atol=1e-5)
     assert ll.item() == 0.0
+
+
+# ---- the other selectable losses on the GPU, against the reference's goldens -------------------------------
+EXTRA = {   # tag: (sampler, classification_loss, localization_loss, classes)
+    'softmax_focal': ('hnm', {'name': 'SoftmaxFocalLoss', 'gamma': 2.0, 'alpha': 0.25}, {'name': 'SmoothL1Loss'}, 21),
+    'softmax_focal_noalpha': ('hnm', {'name': 'SoftmaxFocalLoss', 'gamma': 1.5}, {'name': 'SmoothL1Loss'}, 21),
+    'ce_soft': ('hnm', {'name': 'CrossEntropyWithSoftTargetsLoss'}, {'name': 'SmoothL1Loss'}, 21),
+    'ce_soft_eps': ('hnm', {'name': 'CrossEntropyWithSoftTargetsLoss', 'epsilon': 0.1}, {'name': 'SmoothL1Loss'}, 21),
+    'bce_soft': ('naive', {'name': 'BinaryCrossEntropyWithSoftTargetsLoss'}, {'name': 'SmoothL1Loss'}, 20),
+    'giou': ('hnm', {'name': 'CrossEntropyLoss'}, {'name': 'GeneralizedIoULoss'}, 21),
+}
+
+
+@pytest.mark.parametrize('tag', sorted(EXTRA))
+def test_extra_losses_vs_reference_golden(tag):
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, 'losses_extra.npz'))
+    smp_name, cl, ll, nc = EXTRA[tag]
+    anchors_np = load_golden('ssd_mb2_voc')['anchors']
+    B, A = 2, anchors_np.shape[0]
+    logits = syn.make_logits(B, A, nc, seed=2)
+    locs = syn.make_locs(B, A, seed=3, scale=0.5)
+    smp = functools.partial(sampler.hard_negative_mining, negative_per_positive_ratio=3, min_negative_per_image=5) if smp_name == 'hnm' \
+        else sampler.naive_sampler
+    crit = MultiboxLoss(sampler=smp, box_coder=BoxCoder(10.0, 5.0), classification_loss=cl, localization_loss=ll)
+    s_t = torch.from_numpy(logits).cuda().requires_grad_(True)
+    l_t = torch.from_numpy(locs).cuda().requires_grad_(True)
+    target = torch.from_numpy(g['target'].copy()).cuda()
+    loss, class_loss, loc_loss = crit((s_t, l_t), torch.from_numpy(anchors_np).cuda(), target)
+    loss.backward()
+    ref_mask = np.unpackbits(g[tag + '_sampled_bits'], axis=1)[:, :A].astype(bool)
+    mask = crit.last_sampled_mask.cpu().numpy().astype(bool)
+    check_mask(mask, ref_mask)
+    np.testing.assert_allclose([loss.item(), class_loss.item(), loc_loss.item()], g[tag + '_values'], rtol=3e-6, atol=1e-4)
+    same = mask == ref_mask
+    ds = s_t.grad.view(B, A, nc).cpu().numpy()
+    np.testing.assert_allclose(ds[same], dense_from_rows(g[tag + '_dscores_rows'], g[tag + '_dscores_vals'], (B, A, nc))[same], rtol=3e-4, atol=3e-7)
+    np.testing.assert_allclose(l_t.grad.view(B, A, 4).cpu().numpy(), dense_from_rows(g[tag + '_dlocs_rows'], g[tag + '_dlocs_vals'], (B, A, 4)),
+                               rtol=3e-4, atol=3e-7)
+    assert bool(g[tag + '_target_mutated']) == (not np.array_equal(target.cpu().numpy(), g['target']))
