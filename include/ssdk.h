@@ -283,12 +283,23 @@ int ssdk_batchnorm_bwd(const float* x, const float* y, const float* dy, long lon
 
 /* ---- FPN top-down step (next-row f1) -------------------------------------------------------------------------------- */
 
-/* bf/modules/features.py:106-107: out = fine + F.interpolate(coarse, size=(hf, wf), mode='nearest'); NHWC, channels % 4 == 0. */
+/* bf/modules/features.py:106-107: out = fine + F.interpolate(coarse, size=(hf, wf), mode='nearest'); NHWC, channels % 4 == 0.
+ * fine == NULL: plain nearest upsampling (features.py:371, M2Det base features). */
 int ssdk_upsample_nearest_add_fwd(const float* fine, const float* coarse, int batch, int hf, int wf, int hc, int wc,
                                   int channels, float* out, void* stream);
 /* gradient w.r.t. coarse: each coarse pixel sums dout over the fine pixels it was copied to (the gradient w.r.t. fine is dout). */
 int ssdk_upsample_nearest_add_bwd(const float* dout, int batch, int hf, int wf, int hc, int wc, int channels,
                                   float* dcoarse, void* stream);
+
+/* ---- M2Det scale-wise feature aggregation (next-row f1), bf/modules/features.py:273-300 ----------------------------- */
+
+/* F.adaptive_avg_pool2d(x, 1): x [batch, hw, channels] (NHWC) -> out [batch, channels]; and its backward. */
+int ssdk_global_avgpool_fwd(const float* x, int batch, int hw, int channels, float* out, void* stream);
+int ssdk_global_avgpool_bwd(const float* dout, int batch, int hw, int channels, float* dx, void* stream);
+/* out = x * sigmoid(z), z [batch, channels] broadcast over the pixels (features.py:296-298); backward gives dx and dz. */
+int ssdk_sigmoid_gate_fwd(const float* x, const float* z, int batch, int hw, int channels, float* out, void* stream);
+int ssdk_sigmoid_gate_bwd(const float* x, const float* z, const float* dout, int batch, int hw, int channels, float* dx,
+                          float* dz, void* stream);
 
 #ifdef __cplusplus
 }

@@ -71,6 +71,11 @@ _SIGNATURES = {
                                                 C.c_void_p, C.c_void_p]),
     'ssdk_upsample_nearest_add_bwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                                 C.c_void_p]),
+    'ssdk_global_avgpool_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'ssdk_global_avgpool_bwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'ssdk_sigmoid_gate_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'ssdk_sigmoid_gate_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
     'ssdk_postprocess_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'ssdk_postprocess': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                    C.c_int, C.c_float, C.c_int, C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_void_p,

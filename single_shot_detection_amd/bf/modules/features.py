@@ -108,3 +108,122 @@ class FeaturePyramid(Features):
 
     def get_out_channels(self):
         return [self.pyramid_channels] * self.pyramid_layers
+
+
+def update_existing(dict1, dict2):
+    """bf/utils/misc_utils.py:31-34: fill in keys that are missing."""
+    for k, v in dict2.items():
+        if k not in dict1:
+            dict1[k] = v
+
+
+class ThinnedUshapeModule(nn.Module):
+    """M2Det TUM -- restatement of bf/modules/features.py:215-270 (encoder of stride-2 3x3 blocks, decoder of 1x1 blocks with
+    nearest upsample + skip add, 1x1 smoothing of every decoder stage).  Conv2dBn blocks and the upsample-add run on libssdk."""
+
+    def __init__(self, in_channels, inner_channels, out_channels, num_scales, interpolation_mode='nearest', use_depthwise=False,
+                 activation={'name': 'ReLU', 'args': {'inplace': True}}, initializer={'name': 'xavier_normal_'}):
+        super(ThinnedUshapeModule, self).__init__()
+        if interpolation_mode != 'nearest':
+            raise NotImplementedError("ThinnedUshapeModule: only interpolation_mode='nearest' is on the GPU path")
+        self.interpolation_mode = interpolation_mode
+        self.down_layers = nn.ModuleList()
+        self.up_layers = nn.ModuleList()
+        self.smooth_layers = nn.ModuleList()
+        conv_op = conv.DepthwiseConv2dBn if use_depthwise else conv.Conv2dBn
+        for i in range(num_scales):
+            if i > 0:
+                self.down_layers.append(conv_op(in_channels if i == 1 else inner_channels, inner_channels, kernel_size=3, stride=2,
+                                                padding=1, activation_params=activation))
+                self.up_layers.append(conv_op(inner_channels, in_channels if i == 1 else inner_channels, kernel_size=1,
+                                              activation_params=activation))
+            self.smooth_layers.append(conv_op(in_channels if i == 0 else inner_channels, out_channels, kernel_size=1,
+                                              activation_params=activation))
+
+    def forward(self, x):
+        down_path = [x]
+        for layer in self.down_layers:
+            x = layer(x)
+            down_path.append(x)
+        up_path = [x]
+        for down_x, layer in zip(reversed(down_path[:-1]), reversed(self.up_layers)):
+            x = ops.upsample_add(down_x, layer(x))   # features.py:263-265: interpolate to the skip's size, add the skip
+            up_path.append(x)
+        return [layer(x) for layer, x in zip(reversed(self.smooth_layers), up_path)]
+
+
+class ScalewiseFeatureAggregationModule(nn.Module):
+    """M2Det SFAM -- restatement of bf/modules/features.py:273-300 (a squeeze-excite gate per scale)."""
+
+    def __init__(self, num_channels, num_scales, reduction_ratio=16):
+        super(ScalewiseFeatureAggregationModule, self).__init__()
+        self.fc1 = nn.ModuleList()
+        self.fc2 = nn.ModuleList()
+        for _ in range(num_scales):
+            self.fc1.append(nn.Conv2d(num_channels, num_channels // reduction_ratio, kernel_size=1))
+            self.fc2.append(nn.Conv2d(num_channels // reduction_ratio, num_channels, kernel_size=1))
+
+    def forward(self, features):
+        assert len(features) == len(self.fc1)
+        result = []
+        for feature, fc1, fc2 in zip(features, self.fc1, self.fc2):
+            x = ops.global_avg_pool(feature)
+            x = ops.conv2d(x, fc1.weight, fc1.bias, relu=True)     # fc1 + F.relu
+            x = ops.conv2d(x, fc2.weight, fc2.bias)
+            result.append(ops.sigmoid_gate(feature, x))             # feature * sigmoid(x)
+        return result
+
+
+class MultilevelFeaturePyramid(Features):
+    """M2Det MLFPN neck -- restatement of bf/modules/features.py:303-393."""
+
+    def __init__(self, base, out_layers, num_scales, num_tums, base_reduced_channels=[256, 512], reduced_channels=128,
+                 interpolation_mode='nearest', use_depthwise=False, activation={'name': 'ReLU', 'args': {'inplace': True}},
+                 initializer={'name': 'xavier_normal_'}, tum={'inner_channels': 256, 'out_channels': 128},
+                 sfam={'reduction_ratio': 16}, **kwargs):
+        super(MultilevelFeaturePyramid, self).__init__(base, out_layers, initializer=initializer, **kwargs)
+        assert len(out_layers) == len(base_reduced_channels)
+        assert num_tums > 0
+        self.num_outputs = num_scales
+        self.num_tums = num_tums
+        self.interpolation_mode = interpolation_mode
+        self.base_reducers = nn.ModuleList()
+        base_out_channels = super(MultilevelFeaturePyramid, self).get_out_channels()
+        for in_channels, out_channels in zip(base_out_channels, base_reduced_channels):
+            self.base_reducers.append(conv.Conv2dBn(in_channels, out_channels, kernel_size=1, activation_params=activation))
+        tum = dict(tum)
+        tum.update({'num_scales': num_scales})
+        update_existing(tum, {'interpolation_mode': interpolation_mode, 'use_depthwise': use_depthwise, 'activation': activation})
+        self.tum_out_channels = tum['out_channels']
+        self.tums = nn.ModuleList()
+        self.reducers = nn.ModuleList()
+        self.tums.append(ThinnedUshapeModule(in_channels=sum(base_reduced_channels), **tum))
+        for _ in range(1, num_tums):
+            self.tums.append(ThinnedUshapeModule(in_channels=reduced_channels + self.tum_out_channels, **tum))
+            self.reducers.append(conv.Conv2dBn(sum(base_reduced_channels), reduced_channels, kernel_size=1, activation_params=activation))
+        sfam = dict(sfam)
+        sfam.update({'num_channels': self.tum_out_channels * self.num_tums, 'num_scales': num_scales})
+        self.sfam = ScalewiseFeatureAggregationModule(**sfam)
+        for group in (self.base_reducers, self.tums, self.reducers, self.sfam):
+            group.apply(self.init_layer)
+        for m in self.modules():   # init rewrote the weights: restore the channels_last memory the GEMM kernels read
+            if isinstance(m, conv.Conv2dBn):
+                m.conv.weight.data = m.conv.weight.data.contiguous(memory_format=torch.channels_last)
+
+    def forward(self, x):
+        sources, _ = super(MultilevelFeaturePyramid, self).forward(x)
+        base_reduced = [reducer(source) for reducer, source in zip(self.base_reducers, sources)]
+        size = base_reduced[0].shape[2:]
+        upscaled = [base_reduced[0]] + [ops.upsample_nearest(f, size) for f in base_reduced[1:]]   # features.py:369-371
+        base_features = torch.cat(upscaled, dim=1)
+        features = [[f] for f in self.tums[0](base_features)]
+        for tum, reducer in zip(self.tums[1:], self.reducers):
+            x = torch.cat([features[-1][-1], reducer(base_features)], dim=1)                     # :378-380
+            for i, feature in enumerate(tum(x)):
+                features[i].append(feature)
+        features = [torch.cat(f, dim=1) for f in reversed(features)]                              # :385
+        features = self.sfam(features)
+        return features, features[-1]
+
+    def get_out_channels(self):
+        return [self.tum_out_channels * self.num_tums] * self.num_outputs

@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(256) upsample_add_kernel(const float4* __restr
         const int x = (int)(p % Wf); p /= Wf;
         const int y = (int)(p % Hf);
         const int b = (int)(p / Hf);
-        const float4 a = fine[i];
+        const float4 a = fine ? fine[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 u = coarse[(((long long)b * Hc + nearest_src(y, sh, Hc)) * Wc + nearest_src(x, sw, Wc)) * C4 + c];
         out[i] = make_float4(a.x + u.x, a.y + u.y, a.z + u.z, a.w + u.w);
     }
@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(256) upsample_add_bwd_kernel(const float4* __r
 
 extern "C" int ssdk_upsample_nearest_add_fwd(const float* fine, const float* coarse, int batch, int hf, int wf, int hc, int wc, int channels,
                                              float* out, void* stream) {
-    SSDK_REQUIRE(fine && coarse && out && batch > 0 && hf > 0 && wf > 0 && hc > 0 && wc > 0 && channels > 0 && channels % 4 == 0, SSDK_E_INVALID,
+    SSDK_REQUIRE(coarse && out && batch > 0 && hf > 0 && wf > 0 && hc > 0 && wc > 0 && channels > 0 && channels % 4 == 0, SSDK_E_INVALID,
                  "ssdk_upsample_nearest_add_fwd: bad arguments (channels %% 4 == 0)");
     const long long n4 = (long long)batch * hf * wf * channels / 4;
     hipLaunchKernelGGL(upsample_add_kernel, dim3(stream_blocks(n4, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)fine, (const float4*)coarse,
@@ -308,5 +308,121 @@ extern "C" int ssdk_upsample_nearest_add_bwd(const float* dout, int batch, int h
     hipLaunchKernelGGL(upsample_add_bwd_kernel, dim3(stream_blocks(n4, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)dout, batch, hf, wf,
                        hc, wc, channels / 4, (float4*)dcoarse);
     SSDK_CHECK_LAUNCH("upsample_add_bwd_kernel");
+    return SSDK_OK;
+}
+
+
+// ---- SFAM (M2Det scale-wise feature aggregation): squeeze-excite gate ---------------------------------
+// Reference: bf/modules/features.py:286-298  x = adaptive_avg_pool2d(f, 1); x = fc2(relu(fc1(x))); out = f * sigmoid(x).
+// The two 1x1 "fc" convolutions run on the GEMM kernels; these are the pool and the gate (with their backward).
+namespace ssdk {
+// mean over the HW pixels of each image: x [B][HW][C] -> out [B][C]; one workgroup per (image, 64-float4 column block)
+__global__ void __launch_bounds__(256) avgpool_kernel(const float4* __restrict__ x, int HW, int C4, float4* __restrict__ out) {
+    __shared__ float4 s_part[4][64];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c4 = blockIdx.x * 64 + lane;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < C4)
+        for (int p = wave; p < HW; p += 4) {
+            const float4 v = x[((long long)b * HW + p) * C4 + c4];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    s_part[wave][lane] = a;
+    __syncthreads();
+    if (wave == 0 && c4 < C4) {
+        float4 t = s_part[0][lane];
+        for (int w = 1; w < 4; ++w) { const float4 u = s_part[w][lane]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        const float inv = 1.0f / (float)HW;
+        out[(long long)b * C4 + c4] = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+    }
+}
+__global__ void __launch_bounds__(256) avgpool_bwd_kernel(const float4* __restrict__ dout, int B, int HW, int C4, float4* __restrict__ dx) {
+    const long long total = (long long)B * HW * C4;
+    const float inv = 1.0f / (float)HW;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        const int b = (int)(i / ((long long)HW * C4));
+        const float4 g = dout[(long long)b * C4 + c];
+        dx[i] = make_float4(g.x * inv, g.y * inv, g.z * inv, g.w * inv);
+    }
+}
+__device__ __forceinline__ float sigm(float v) { return 1.0f / (1.0f + __expf(-v)); }
+// out = x * sigmoid(z[b][c])
+__global__ void __launch_bounds__(256) gate_kernel(const float4* __restrict__ x, const float4* __restrict__ z, int B, int HW, int C4,
+                                                   float4* __restrict__ out) {
+    const long long total = (long long)B * HW * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        const int b = (int)(i / ((long long)HW * C4));
+        const float4 v = x[i], q = z[(long long)b * C4 + c];
+        out[i] = make_float4(v.x * sigm(q.x), v.y * sigm(q.y), v.z * sigm(q.z), v.w * sigm(q.w));
+    }
+}
+// dx = dout * sigmoid(z);  dz[b][c] = sigmoid'(z) * sum_hw dout * x   (one workgroup per (image, column block))
+__global__ void __launch_bounds__(256) gate_bwd_kernel(const float4* __restrict__ x, const float4* __restrict__ z, const float4* __restrict__ dout,
+                                                       int HW, int C4, float4* __restrict__ dx, float4* __restrict__ dz) {
+    __shared__ float4 s_part[4][64];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c4 = blockIdx.x * 64 + lane;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), sg = a;
+    if (c4 < C4) {
+        const float4 q = z[(long long)b * C4 + c4];
+        sg = make_float4(sigm(q.x), sigm(q.y), sigm(q.z), sigm(q.w));
+        for (int p = wave; p < HW; p += 4) {
+            const long long i = ((long long)b * HW + p) * C4 + c4;
+            const float4 g = dout[i], v = x[i];
+            dx[i] = make_float4(g.x * sg.x, g.y * sg.y, g.z * sg.z, g.w * sg.w);
+            a.x += g.x * v.x; a.y += g.y * v.y; a.z += g.z * v.z; a.w += g.w * v.w;
+        }
+    }
+    s_part[wave][lane] = a;
+    __syncthreads();
+    if (wave == 0 && c4 < C4) {
+        float4 t = s_part[0][lane];
+        for (int w = 1; w < 4; ++w) { const float4 u = s_part[w][lane]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        dz[(long long)b * C4 + c4] = make_float4(t.x * sg.x * (1.f - sg.x), t.y * sg.y * (1.f - sg.y), t.z * sg.z * (1.f - sg.z), t.w * sg.w * (1.f - sg.w));
+    }
+}
+}  // namespace ssdk
+
+static int check_bhwc(const char* fn, int batch, int hw, int channels) {
+    SSDK_REQUIRE(batch > 0 && batch <= 65535 && hw > 0 && channels > 0 && channels % 4 == 0, SSDK_E_INVALID, "%s: batch=%d hw=%d channels=%d (%% 4 == 0)", fn, batch, hw, channels);
+    return SSDK_OK;
+}
+
+extern "C" int ssdk_global_avgpool_fwd(const float* x, int batch, int hw, int channels, float* out, void* stream) {
+    int rc = check_bhwc("ssdk_global_avgpool_fwd", batch, hw, channels);
+    if (rc) return rc;
+    SSDK_REQUIRE(x && out, SSDK_E_INVALID, "ssdk_global_avgpool_fwd: null pointer");
+    hipLaunchKernelGGL(avgpool_kernel, dim3(cdiv(channels / 4, 64), batch), dim3(256), 0, (hipStream_t)stream, (const float4*)x, hw, channels / 4, (float4*)out);
+    SSDK_CHECK_LAUNCH("avgpool_kernel");
+    return SSDK_OK;
+}
+extern "C" int ssdk_global_avgpool_bwd(const float* dout, int batch, int hw, int channels, float* dx, void* stream) {
+    int rc = check_bhwc("ssdk_global_avgpool_bwd", batch, hw, channels);
+    if (rc) return rc;
+    SSDK_REQUIRE(dout && dx, SSDK_E_INVALID, "ssdk_global_avgpool_bwd: null pointer");
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(stream_blocks((long long)batch * hw * channels / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)dout, batch, hw, channels / 4, (float4*)dx);
+    SSDK_CHECK_LAUNCH("avgpool_bwd_kernel");
+    return SSDK_OK;
+}
+extern "C" int ssdk_sigmoid_gate_fwd(const float* x, const float* z, int batch, int hw, int channels, float* out, void* stream) {
+    int rc = check_bhwc("ssdk_sigmoid_gate_fwd", batch, hw, channels);
+    if (rc) return rc;
+    SSDK_REQUIRE(x && z && out, SSDK_E_INVALID, "ssdk_sigmoid_gate_fwd: null pointer");
+    hipLaunchKernelGGL(gate_kernel, dim3(stream_blocks((long long)batch * hw * channels / 4, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
+                       (const float4*)z, batch, hw, channels / 4, (float4*)out);
+    SSDK_CHECK_LAUNCH("gate_kernel");
+    return SSDK_OK;
+}
+extern "C" int ssdk_sigmoid_gate_bwd(const float* x, const float* z, const float* dout, int batch, int hw, int channels, float* dx, float* dz,
+                                     void* stream) {
+    int rc = check_bhwc("ssdk_sigmoid_gate_bwd", batch, hw, channels);
+    if (rc) return rc;
+    SSDK_REQUIRE(x && z && dout && dx && dz, SSDK_E_INVALID, "ssdk_sigmoid_gate_bwd: null pointer");
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(cdiv(channels / 4, 64), batch), dim3(256), 0, (hipStream_t)stream, (const float4*)x, (const float4*)z,
+                       (const float4*)dout, hw, channels / 4, (float4*)dx, (float4*)dz);
+    SSDK_CHECK_LAUNCH("gate_bwd_kernel");
     return SSDK_OK;
 }

@@ -169,3 +169,87 @@ class _UpsampleAddFn(torch.autograd.Function):
 
 def upsample_add(fine, coarse):
     return _UpsampleAddFn.apply(fine, coarse)
+
+
+class _UpsampleFn(torch.autograd.Function):
+    """F.interpolate(x, size=(h, w), mode='nearest') (bf/modules/features.py:371)."""
+
+    @staticmethod
+    def forward(ctx, coarse, hf, wf):
+        _lib.require_cuda(coarse)
+        coarse = _nhwc(coarse)
+        B, C, Hc, Wc = coarse.shape
+        out = torch.empty((B, C, hf, wf), dtype=torch.float32, device=coarse.device, memory_format=torch.channels_last)
+        _lib.check(_lib.lib().ssdk_upsample_nearest_add_fwd(None, _dp(coarse), B, hf, wf, Hc, Wc, C, _dp(out), _lib.current_stream()),
+                   'ssdk_upsample_nearest_add_fwd')
+        ctx.shapes = (B, C, hf, wf, Hc, Wc)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, C, Hf, Wf, Hc, Wc = ctx.shapes
+        dout = _nhwc(dout)
+        dcoarse = torch.empty((B, C, Hc, Wc), dtype=torch.float32, device=dout.device, memory_format=torch.channels_last)
+        _lib.check(_lib.lib().ssdk_upsample_nearest_add_bwd(_dp(dout), B, Hf, Wf, Hc, Wc, C, _dp(dcoarse), _lib.current_stream()),
+                   'ssdk_upsample_nearest_add_bwd')
+        return dcoarse, None, None
+
+
+def upsample_nearest(x, size):
+    return _UpsampleFn.apply(x, int(size[0]), int(size[1]))
+
+
+class _AvgPoolFn(torch.autograd.Function):
+    """F.adaptive_avg_pool2d(x, 1) -> [B, C, 1, 1]"""
+
+    @staticmethod
+    def forward(ctx, x):
+        _lib.require_cuda(x)
+        x = _nhwc(x)
+        B, C, H, W = x.shape
+        out = torch.empty((B, C, 1, 1), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().ssdk_global_avgpool_fwd(_dp(x), B, H * W, C, _dp(out), _lib.current_stream()), 'ssdk_global_avgpool_fwd')
+        ctx.shape = (B, C, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, C, H, W = ctx.shape
+        dout = dout.float().contiguous()
+        dx = torch.empty((B, C, H, W), dtype=torch.float32, device=dout.device, memory_format=torch.channels_last)
+        _lib.check(_lib.lib().ssdk_global_avgpool_bwd(_dp(dout), B, H * W, C, _dp(dx), _lib.current_stream()), 'ssdk_global_avgpool_bwd')
+        return dx
+
+
+def global_avg_pool(x):
+    return _AvgPoolFn.apply(x)
+
+
+class _GateFn(torch.autograd.Function):
+    """x * sigmoid(z), z [B, C, 1, 1] (bf/modules/features.py:296-298)"""
+
+    @staticmethod
+    def forward(ctx, x, z):
+        _lib.require_cuda(x, z)
+        x = _nhwc(x)
+        z = z.float().contiguous()
+        B, C, H, W = x.shape
+        out = torch.empty_like(x, memory_format=torch.channels_last)
+        _lib.check(_lib.lib().ssdk_sigmoid_gate_fwd(_dp(x), _dp(z), B, H * W, C, _dp(out), _lib.current_stream()), 'ssdk_sigmoid_gate_fwd')
+        ctx.save_for_backward(x, z)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, z = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dout = _nhwc(dout)
+        dx = torch.empty_like(x, memory_format=torch.channels_last)
+        dz = torch.empty_like(z)
+        _lib.check(_lib.lib().ssdk_sigmoid_gate_bwd(_dp(x), _dp(z), _dp(dout), B, H * W, C, _dp(dx), _dp(dz), _lib.current_stream()),
+                   'ssdk_sigmoid_gate_bwd')
+        return dx, dz
+
+
+def sigmoid_gate(x, z):
+    return _GateFn.apply(x, z)

@@ -166,3 +166,71 @@ def test_fpn_neck_vs_torch():
     for (n1, p1), (n2, p2) in zip(sorted(fpn.named_parameters()), sorted(ref.named_parameters())):
         scale = float(p2.grad.abs().max()) + 1e-6
         np.testing.assert_allclose(p1.grad.cpu().numpy(), p2.grad.numpy(), rtol=2e-3, atol=2e-3 * scale + 1e-5, err_msg=n1)
+
+
+def test_m2det_neck_vs_torch():
+    """MultilevelFeaturePyramid (TUM + SFAM, bf/modules/features.py:215-393) on libssdk vs the same graph on stock torch CPU ops."""
+    import torch.nn.functional as F
+    from single_shot_detection_amd.bf.modules.features import MultilevelFeaturePyramid
+
+    class _Base(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.features = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.Conv2d(8, 16, 3, stride=2, padding=1))
+
+    rng = np.random.default_rng(9)
+    torch.manual_seed(0)
+    neck = MultilevelFeaturePyramid(_Base(), out_layers=(0, 1), num_scales=3, num_tums=2, base_reduced_channels=[16, 8], reduced_channels=8,
+                                    tum={'inner_channels': 16, 'out_channels': 8}, sfam={'reduction_ratio': 4})
+    for grp in (neck.base_reducers, neck.tums, neck.reducers, neck.sfam):
+        _randomize(grp, rng)
+    ref = copy.deepcopy(neck)
+    neck = neck.cuda()
+    x_np = rng.standard_normal((4, 3, 21, 21), dtype=np.float32)
+
+    def blk(b, x):   # Conv2dBn with stock ops
+        return torch.relu(b.bn(b.conv(x)))
+
+    def tum_ref(t, x):
+        down = [x]
+        for l in t.down_layers:
+            x = blk(l, x); down.append(x)
+        up = [x]
+        for dx, l in zip(reversed(down[:-1]), reversed(t.up_layers)):
+            x = F.interpolate(blk(l, x), size=dx.shape[2:], mode='nearest') + dx
+            up.append(x)
+        return [blk(l, u) for l, u in zip(reversed(t.smooth_layers), up)]
+
+    def ref_forward(x):
+        srcs, cur = [], x
+        for layer in ref.base:
+            cur = layer(cur); srcs.append(cur)
+        br = [blk(r, s) for r, s in zip(ref.base_reducers, srcs)]
+        base = torch.cat([br[0]] + [F.interpolate(f, size=br[0].shape[2:], mode='nearest') for f in br[1:]], dim=1)
+        feats = [[f] for f in tum_ref(ref.tums[0], base)]
+        for t, r in zip(ref.tums[1:], ref.reducers):
+            xx = torch.cat([feats[-1][-1], blk(r, base)], dim=1)
+            for i, f in enumerate(tum_ref(t, xx)):
+                feats[i].append(f)
+        feats = [torch.cat(f, dim=1) for f in reversed(feats)]
+        out = []
+        for f, fc1, fc2 in zip(feats, ref.sfam.fc1, ref.sfam.fc2):
+            z = fc2(torch.relu(fc1(F.adaptive_avg_pool2d(f, 1))))
+            out.append(f * torch.sigmoid(z))
+        return out
+
+    xr = torch.from_numpy(x_np).requires_grad_(True)
+    xg = torch.from_numpy(x_np).cuda().requires_grad_(True)
+    outs_r = ref_forward(xr)
+    outs_g, _ = neck(xg)
+    assert [tuple(o.shape) for o in outs_g] == [tuple(o.shape) for o in outs_r]
+    for a, b in zip(outs_g, outs_r):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().numpy(), rtol=2e-3, atol=2e-3)
+    gws = [torch.from_numpy(rng.standard_normal(tuple(o.shape), dtype=np.float32)) for o in outs_r]
+    sum((a * g).sum() for a, g in zip(outs_r, gws)).backward()
+    sum((a * g.cuda()).sum() for a, g in zip(outs_g, gws)).backward()
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=5e-3, atol=5e-3 * (1 + float(xr.grad.abs().max())))
+    for (n1, p1), (n2, p2) in zip(sorted(neck.named_parameters()), sorted(ref.named_parameters())):
+        scale = float(p2.grad.abs().max()) + 1e-6
+        # biases feeding a BatchNorm have an analytically zero gradient: what is left is rounding noise, hence the absolute floor
+        np.testing.assert_allclose(p1.grad.cpu().numpy(), p2.grad.numpy(), rtol=5e-3, atol=5e-3 * scale + 2e-4, err_msg=n1)

@@ -165,3 +165,47 @@ def test_retina500_step_fn_train_and_eval():
         n = min(d.shape[0], r.shape[0])
         if n:
             np.testing.assert_allclose(np.sort(d.cpu().numpy()[:n, 5]), np.sort(r[:n, 5]), rtol=1e-4, atol=1e-6)
+
+
+M2DET = {
+    'base': {'name': 'torchvision_vgg16_bn', 'pretrained': False},
+    'detector': {'num_classes': 81,
+                 'features': {'name': 'MultilevelFeaturePyramid', 'out_layers': (32, 42), 'last_feature_layer': 42, 'num_scales': 6,
+                              'num_tums': 8, 'base_reduced_channels': [512, 256]}},
+    'anchor_generator': {'type': 'ssd', 'num_scales': 6, 'min_scale': 0.07, 'max_scale': 1.05,
+                         'aspect_ratios': [[1.0, 2.0]] + [[1.0, 2.0, 3.0]] * 3 + [[1.0, 2.0]] * 2},
+}
+
+
+def test_m2det512_step_fn_train():
+    """samples/m2det_512_vgg16_coco.py wiring: MLFPN neck (8 TUMs x 6 scales + SFAM) -> 1024-channel heads; A = 24 528."""
+    torch.manual_seed(7)
+    dev = torch.device('cuda:0')
+    wrapper, init_state, step_fn = det_init.init(
+        dev, M2DET, {'xy_scale': 10.0, 'wh_scale': 5.0},
+        {'score_threshold': .01, 'max_total': 200, 'nms': {'max_per_class': 100, 'overlap_threshold': .45}, 'score_converter': 'SOFTMAX'},
+        {'classification_loss': {'name': 'CrossEntropyLoss'}, 'localization_loss': {'name': 'SmoothL1Loss'},
+         'classification_weight': 1.0, 'localization_weight': 1.0},
+        {'name': 'hard_negative_mining', 'negative_per_positive_ratio': 3, 'min_negative_per_image': 5},
+        {'matched_threshold': 0.5, 'unmatched_threshold': 0.5})
+    detector = wrapper.model
+    detector.train()
+    B = 2
+    imgs = torch.from_numpy(np.random.default_rng(29).standard_normal((B, 3, 512, 512), dtype=np.float32))
+    gt_np = syn.make_ground_truth(B, 512, 81, seed=2)
+    gt = [torch.from_numpy(g) for g in gt_np]
+    loss, (scores, locs), state = step_fn(0, 'train', (imgs, gt), init_state())
+    assert scores.shape == (B, 24528 * 81) and locs.shape == (B, 24528 * 4)
+    cfg = syn.CONFIGS['m2det_512_vgg16_coco']
+    anchors = oracle.anchors(cfg['anchor'], 512, cfg['levels'])
+    target = oracle.encode_ground_truth(gt_np, anchors, 0.5, 0.5)
+    s_np, l_np = scores.detach().cpu().numpy(), locs.detach().cpu().numpy()
+    mask = oracle.hard_negative_mining(s_np, target, 3, 5)
+    vals, _, _ = oracle.multibox_loss(s_np, l_np, anchors, target, mask, kind='ce', grads=False)
+    assert abs(loss.item() - vals[0]) <= 1e-4 + 1e-5 * abs(vals[0]), (loss.item(), vals)
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in detector.parameters() if p.requires_grad)
+    detector.eval()
+    with torch.no_grad():
+        _, dets, _ = step_fn(1, 'eval', (imgs, gt), state)
+    assert len(dets) == B and all(d.shape[1] == 6 for d in dets)
