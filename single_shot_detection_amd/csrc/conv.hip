@@ -87,23 +87,33 @@ struct ConvGroup {
 template <int VEC>
 struct VecT;
 template <>
-struct VecT<4> { typedef float4 type; };
+struct VecT<4> { typedef f32x4 type; };
 template <>
 struct VecT<1> { typedef float type; };
 template <int VEC>
 __device__ __forceinline__ typename VecT<VEC>::type vzero();
 template <>
-__device__ __forceinline__ float4 vzero<4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ f32x4 vzero<4>() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 template <>
 __device__ __forceinline__ float vzero<1>() { return 0.f; }
 
 // A pointer that is the same in every lane, pinned into an SGPR pair (so that `base + lane_offset` becomes the
 // saddr + 32-bit voffset addressing form and never a per-lane 64-bit select or a reload from the kernarg segment).
-__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+// The result is typed as a GLOBAL (address space 1) pointer: a generic pointer rebuilt from integers compiles to
+// flat_load, which counts against lgkmcnt as well as vmcnt, so every `s_waitcnt lgkmcnt(0)` in front of the MFMAs (meant
+// for the LDS reads) would also wait for the slice prefetch that was just issued.
+typedef const float __attribute__((address_space(1))) * gptr_t;
+__device__ __forceinline__ gptr_t uniform_ptr(const float* p) {
     const unsigned long long v = (unsigned long long)p;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return (const float*)(((unsigned long long)hi << 32) | lo);
+    return (gptr_t)(((unsigned long long)hi << 32) | lo);
 }
+template <int VEC>
+struct GVecT;
+template <>
+struct GVecT<4> { typedef const f32x4 __attribute__((address_space(1))) * type; };
+template <>
+struct GVecT<1> { typedef const float __attribute__((address_space(1))) * type; };
 
 // ---- forward / backward-data ------------------------------------------------------------------------------------
 // MIRROR = false: forward convolution; MIRROR = true: backward-data (separate instantiations so that profiles list the
@@ -118,8 +128,9 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_fwd_kerne
     constexpr int kAPasses = kBM / kRowsPerPass;
     constexpr int kBPasses = kMaxTN * 32 / kRowsPerPass;
 
-    __shared__ __attribute__((aligned(16))) float s_a[kBM * kLdsStride];
-    __shared__ __attribute__((aligned(16))) float s_b[kMaxTN * 32 * kLdsStride];
+    // two LDS stages of the A and W slices (72 KB per workgroup, two workgroups per CU fit the 160 KB)
+    __shared__ __attribute__((aligned(16))) float s_a[2][kBM * kLdsStride];
+    __shared__ __attribute__((aligned(16))) float s_b[2][kMaxTN * 32 * kLdsStride];
 
     int pi = 0;
 #pragma unroll 1
@@ -213,16 +224,20 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_fwd_kerne
     // Prefetch of one K slice into registers.  Branch-free: a lane whose element does not exist reads element 0 of the
     // operand instead (always mapped) and the value is replaced by zero when it is written to LDS, so the eight loads
     // issue back to back and are all in flight during the MFMAs of the current slice.
-    const float* const a_base = uniform_ptr(g.a);
-    const float* const w0_base = uniform_ptr(g.w0);
-    const float* const w1_base = uniform_ptr(g.w1 ? g.w1 : g.w0);
+    typedef typename GVecT<VEC>::type gvec_t;
+    const gptr_t a_base = uniform_ptr(g.a);
+    const gptr_t w0_base = uniform_ptr(g.w0);
+    const gptr_t w1_base = uniform_ptr(g.w1 ? g.w1 : g.w0);
     const int win_ps = g.Win * g.a_pstride, a_ps = g.a_pstride, ks = g.ksize, strd = g.stride;
     vec_t ra[kAPasses], rb[kBPasses];
     unsigned live = 0;
-    auto load_slice = [&](int slice) {
-        // channel chunk outer, tap inner: the nine taps of one chunk re-read (shifted) pixel rows that are still in L1/L2
-        const int tap = slice % taps, c = (slice / taps) * kBK + lcol;
-        const int ky = tap / ks, kx = tap % ks;
+    // slice -> (channel chunk, tap): chunk outer, tap inner -- the nine taps of one chunk re-read (shifted) pixel rows that
+    // are still in L1/L2.  The position of the NEXT slice to load is kept in scalar counters (no divisions in the loop).
+    int ld_tap = slice_begin % taps, ld_chunk = slice_begin / taps;
+    int ld_ky = ld_tap / ks, ld_kx = ld_tap % ks;
+    auto load_slice = [&]() {
+        const int tap = ld_tap, c = ld_chunk * kBK + lcol;
+        const int ky = ld_ky, kx = ld_kx;
         const int tap_off = MIRROR ? -(ky * win_ps + kx * a_ps) : (ky * win_ps + kx * a_ps);
         const bool c_ok = c < Cc;
         live = 0;
@@ -236,7 +251,7 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_fwd_kerne
             } else {
                 off = a_off[p] + tap_off + c;
             }
-            ra[p] = *reinterpret_cast<const vec_t*>(a_base + (size_t)(unsigned)(ok ? off : 0));
+            ra[p] = *(gvec_t)(a_base + (size_t)(unsigned)(ok ? off : 0));
             live |= (ok ? 1u : 0u) << p;
         }
         const int wk = tap * Cc + c;
@@ -245,18 +260,27 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_fwd_kerne
             const bool ok = c_ok && w_off[p] >= 0;
             const unsigned off = ok ? (unsigned)((w_off[p] & ~(1 << 30)) + wk) : 0u;
             // two loads would double the traffic; the segment is a per-row constant, so select the (uniform) base per lane
-            const float* base = (w_off[p] & (1 << 30)) ? w1_base : w0_base;
-            rb[p] = *reinterpret_cast<const vec_t*>(base + (size_t)off);
+            const gptr_t base = (w_off[p] & (1 << 30)) ? w1_base : w0_base;
+            rb[p] = *(gvec_t)(base + (size_t)off);
             live |= (ok ? 1u : 0u) << (kAPasses + p);
         }
+        // advance to the next slice
+        // (selects, not branches: the K loop body must stay one basic block)
+        ++ld_tap;
+        ++ld_kx;
+        const bool wrap_x = ld_kx == ks, wrap_t = ld_tap == taps;
+        ld_kx = (wrap_x || wrap_t) ? 0 : ld_kx;   // (scatter form: taps == 1 although ksize > 1)
+        ld_ky = wrap_t ? 0 : ld_ky + (wrap_x ? 1 : 0);
+        ld_tap = wrap_t ? 0 : ld_tap;
+        ld_chunk += wrap_t ? 1 : 0;
     };
-    auto store_slice = [&]() {
+    auto store_slice = [&](int stage) {
 #pragma unroll
         for (int p = 0; p < kAPasses; ++p)
-            *reinterpret_cast<vec_t*>(&s_a[(lrow + p * kRowsPerPass) * kLdsStride + lcol]) = ((live >> p) & 1u) ? ra[p] : vzero<VEC>();
+            *reinterpret_cast<vec_t*>(&s_a[stage][(lrow + p * kRowsPerPass) * kLdsStride + lcol]) = ((live >> p) & 1u) ? ra[p] : vzero<VEC>();
 #pragma unroll
         for (int p = 0; p < kBPasses; ++p)
-            *reinterpret_cast<vec_t*>(&s_b[(lrow + p * kRowsPerPass) * kLdsStride + lcol]) = ((live >> (kAPasses + p)) & 1u) ? rb[p] : vzero<VEC>();
+            *reinterpret_cast<vec_t*>(&s_b[stage][(lrow + p * kRowsPerPass) * kLdsStride + lcol]) = ((live >> (kAPasses + p)) & 1u) ? rb[p] : vzero<VEC>();
     };
 
     f32x16 acc[kMaxTN];
@@ -267,35 +291,47 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_fwd_kerne
 
     const int lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, h = lane >> 5;
-    const float* a_rd = s_a + (wave * 32 + r32) * kLdsStride + 4 * h;
-    const float* b_rd = s_b + r32 * kLdsStride + 4 * h;
+    const float* a_rd = &s_a[0][0] + (wave * 32 + r32) * kLdsStride + 4 * h;
+    const float* b_rd = &s_b[0][0] + r32 * kLdsStride + 4 * h;
 
-    load_slice(slice_begin);
-    store_slice();
+    // Pipeline (one barrier per slice): while slice s is multiplied out of LDS stage s&1, the registers holding slice s+1
+    // (loaded during slice s-1) are written to the other stage and re-issued for slice s+2 -- the LDS writes, the address
+    // arithmetic and the global loads all sit between MFMAs instead of in a bubble between two barriers.
+    load_slice();
+    store_slice(0);
+    load_slice();
     __syncthreads();
     // The K loop is specialised on the number of column tiles (dispatched once per workgroup): with a run-time bound
     // every MFMA would sit behind its own scalar branch.
     auto k_loop = [&](auto tn_c) {
         constexpr int TN = decltype(tn_c)::value;
+        int stage = 0;
         for (int slice = slice_begin; slice < n_slices; ++slice) {
-            if (slice + 1 < n_slices) load_slice(slice + 1);  // in flight while the MFMAs below run
+            const float* a_cur = a_rd + stage * (kBM * kLdsStride);
+            const float* b_cur = b_rd + stage * (kMaxTN * 32 * kLdsStride);
 #pragma unroll
             for (int gk = 0; gk < kBK / 8; ++gk) {
                 // lane (r, h) reads k = gk*8 + 4h .. +3 of its row: MFMA kk pairs k = gk*8+kk (h=0) with gk*8+4+kk (h=1)
-                const f32x4 av = *reinterpret_cast<const f32x4*>(a_rd + gk * 8);
+                const f32x4 av = *reinterpret_cast<const f32x4*>(a_cur + gk * 8);
                 f32x4 bv[TN];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const f32x4*>(b_rd + j * 32 * kLdsStride + gk * 8);
+                for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const f32x4*>(b_cur + j * 32 * kLdsStride + gk * 8);
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[j][kk], acc[j], 0, 0, 0);
+                // unconditional (straight-line code the scheduler can spread between the MFMAs): past the last slice the
+                // loads degenerate to element 0 of the operands (c >= Cc) and the stage written is never read
+                if (gk == 0) store_slice(stage ^ 1);
+                if (gk == 1) {
+                    load_slice();
+                    // keep the prefetch HERE: left alone the scheduler sinks the loads to the end of the slice (it reuses the
+                    // staging registers for fragment reads), which exposes their latency at the top of the next slice
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             __syncthreads();
-            if (slice + 1 < n_slices) {
-                store_slice();
-                __syncthreads();
-            }
+            stage ^= 1;
         }
     };
     switch (tn) {
