@@ -27,6 +27,8 @@
 // Backward-weights (igemm_wgrad_kernel) contracts over pixels: both operands are read in their natural
 // [pixel][channel] form, K = pixels is split across workgroups and partial tiles are accumulated with fp32 atomics
 // shaped as two 128-byte segments per wave instruction.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -66,6 +68,7 @@ struct ConvProblem {
     long long ob0, ob1;
     int os0, os1;
     int tiles_n, n_blocks, m_tiles;
+    int m_tiles256;   // M tiles of the 8-wave (256-pixel) tiling
     int k_splits;     // > 1: the K slices are divided over k_splits workgroups that atomically add into a zeroed output
     int block_begin;  // first workgroup of this problem in the grouped grid
     int relu;
@@ -76,6 +79,10 @@ struct ConvProblem {
     const int* row_list;
     const int* row_count;
     int sc_cin;  // scatter: output channels per tap (n = tap * sc_cin + c)
+    // column index space: [0, n0) = rows of w0, [n0, n0_pad) unused, [n0_pad, n0_pad + n1) = rows of w1.  n0_pad = n0 except for
+    // the LDS-DMA kernel, which rounds it up to 8 so that every 8-row DMA piece reads ONE weight tensor (one descriptor)
+    int n0_pad;
+    unsigned w0_bytes, w1_bytes;   // LDS-DMA kernel: sizes of the two weight tensors (buffer descriptors)
 };
 
 struct ConvGroup {
@@ -114,6 +121,325 @@ template <>
 struct GVecT<4> { typedef const f32x4 __attribute__((address_space(1))) * type; };
 template <>
 struct GVecT<1> { typedef const float __attribute__((address_space(1))) * type; };
+
+
+// Epilogue shared by the GEMM kernels: bias, optional ReLU, store (or atomic add for split-K / scatter).
+template <bool SCATTER>
+__device__ __forceinline__ void conv_epilogue(const ConvProblem& g, const f32x16 (&acc)[kMaxTN], int m_base, int wave, int r32, int h, int tn,
+                                              int n_begin, int M, int N, int hw, int ksp) {
+    // epilogue: C/D map of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+    if (SCATTER) {
+        // row = a pixel with a non-zero output gradient; column n = tap * Cin + c: add the product into the input-gradient
+        // pixel that tap connects it to (yo - pad + ky, xo - pad + kx).  32 consecutive lanes = 32 consecutive c of one tap.
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = m_base + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (m >= M) continue;
+            const int pid = g.row_list ? g.row_list[m] : m;
+            const int b = pid / hw, r = pid % hw;
+            const int yo = (r / g.Wout) * g.stride, xo = (r % g.Wout) * g.stride;
+#pragma unroll
+            for (int j = 0; j < kMaxTN; ++j) {
+                if (j >= tn) continue;
+                const int n = n_begin + j * 32 + r32;
+                if (n >= N) continue;
+                const int tap = n / g.sc_cin, c = n % g.sc_cin;
+                const int ty = yo - g.pad + tap / g.ksize, tx = xo - g.pad + tap % g.ksize;
+                if (ty >= 0 && ty < g.Hin && tx >= 0 && tx < g.Win)
+                    atomicAdd(g.o0 + (long long)b * g.ob0 + ((long long)ty * g.Win + tx) * g.os0 + c, acc[j][e]);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int m = m_base + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (m >= M) continue;
+        const int b = m / hw, pix = m % hw;
+#pragma unroll
+        for (int j = 0; j < kMaxTN; ++j) {
+            if (j >= tn) continue;
+            const int n = n_begin + j * 32 + r32;
+            if (n >= N) continue;
+            float v = acc[j][e];
+            if (n < g.n0) {
+                if (g.bias0 && ksp == 0) v += g.bias0[n];
+                float* dst = g.o0 + (long long)b * g.ob0 + (long long)pix * g.os0 + n;
+                if (g.k_splits > 1) { atomicAdd(dst, v); continue; }
+                if (g.relu) v = fmaxf(v, 0.0f);
+                *dst = v;
+            } else {
+                if (n < g.n0_pad) continue;   // padding columns between the two heads
+                const int n1 = n - g.n0_pad;
+                if (g.bias1 && ksp == 0) v += g.bias1[n1];
+                float* dst = g.o1 + (long long)b * g.ob1 + (long long)pix * g.os1 + n1;
+                if (g.k_splits > 1) { atomicAdd(dst, v); continue; }
+                if (g.relu) v = fmaxf(v, 0.0f);
+                *dst = v;
+            }
+        }
+    }
+}
+
+#ifdef SSDK_CONV_TRACE
+// experiment only: per-slice timestamps of a few waves (never built into the shipped library)
+__device__ unsigned long long g_trace[32 * 4 * 64 * 8];
+extern "C" int ssdk_debug_read_trace(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * n);
+}
+#define TRACE(slot)                                                                                              \
+    if (trace_on && (tid & 63) == 0 && slice - slice_begin < 64)                                                   \
+    {                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        g_trace[((trace_blk * 4 + wave) * 64 + (slice - slice_begin)) * 8 + (slot)] = __builtin_readcyclecounter(); \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+    }
+#else
+#define TRACE(slot)
+#endif
+
+// ---- forward / backward-data, LDS-DMA staging (the hot instantiations) -----------------------------------------------
+// Same GEMM, same tiling and the same epilogue as igemm_fwd_kernel below, but the K slices travel global -> LDS directly
+// (buffer_load_dwordx4 ... lds), with no staging registers, no ds_write pass and almost no per-slice vector arithmetic:
+//   * measured on the register-staged kernel (in-kernel cycle stamps): of the two waves that share a SIMD
+//     the one in wave slot 1 loses vector-issue arbitration to its partner's MFMA stream, and the ~100 VALU instructions
+//     per slice of address arithmetic / zero-fill selects cost it ~4,000 cycles per slice (12-14k cycles per slice
+//     against 8-9k for the slot-0 wave).  Here a slice costs 8 VALU + 8 DMA issues.
+//   * a DMA piece is one wave instruction = 64 lanes x 16 B = 8 rows x 128 B, written lane-linearly into LDS.  Rows
+//     cannot be padded, so bank conflicts are avoided by an XOR swizzle on the SOURCE side: LDS chunk position q of row
+//     r holds source chunk q ^ ((r >> 1) & 7); the fragment reads apply the same XOR (conflict-free ds_read_b128).
+//   * padding taps, rows past M / N: the lane's voffset gets bit 31 set -> out of range of the buffer -> the DMA
+//     writes zeros (checked on the device: tools/lds_dma_test.hip).  The host only selects this kernel when every valid
+//     byte offset is below 2^31 and Cc % 32 == 0.
+//   * wave w stages the A rows it multiplies itself (32w..32w+31) and W rows 32w..32w+31 for everybody; one barrier
+//     per slice publishes slice s+1 and retires the reads of slice s (two LDS stages of 32 KB).
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr unsigned kOobBit = 0x80000000u;
+
+// WAVES = 4: 128-pixel tiles, two workgroups per CU.  WAVES = 8: 256-pixel tiles, ONE workgroup per CU whose waves w and
+// w + 4 share a SIMD: the barrier keeps the two in step, so the slot-1 wave cannot fall behind its partner the way it
+// does between two independent workgroups (cycle stamps: 12.0k vs 8.7k cycles per slice), and the W slice is staged once
+// for 256 pixels.  The host picks WAVES = 8 when the 256-pixel tiling still fills the chip.
+template <bool MIRROR, bool GENERIC, bool SCATTER, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? SSDK_CONV_WAVES : 1) igemm_dma_kernel(ConvGroup grp) {
+    constexpr int BM = 32 * WAVES;              // output pixels per workgroup
+    constexpr int kWPieces = 16 / WAVES;        // W pieces (8 rows) each wave stages per slice
+    // FOUR separate LDS objects (two stages x two operands), not one array: the compiler orders a ds_read behind an
+    // in-flight LDS-DMA (s_waitcnt vmcnt(0) in front of the read) unless alias scopes prove they touch different objects,
+    // and only distinct __shared__ variables get such scopes.
+    __shared__ __attribute__((aligned(1024))) float s_a0[BM * kBK];
+    __shared__ __attribute__((aligned(1024))) float s_a1[BM * kBK];
+    __shared__ __attribute__((aligned(1024))) float s_b0[kMaxTN * 32 * kBK];
+    __shared__ __attribute__((aligned(1024))) float s_b1[kMaxTN * 32 * kBK];
+
+    int pi = 0;
+#pragma unroll 1
+    for (int i = 1; i < grp.count; ++i)
+        if ((int)blockIdx.x >= grp.p[i].block_begin) pi = i;
+    const ConvProblem& g = grp.p[pi];
+
+    if (g.mode && *g.mode != g.want_mode) return;
+    const int id_all = blockIdx.x - g.block_begin;
+    const int ksp = id_all % g.k_splits;
+    const int id = id_all / g.k_splits;
+    const int per_chunk = 8 * g.n_blocks;   // (both tilings pad the M tiles to a multiple of 8)
+    const int chunk = id / per_chunk, within = id % per_chunk;
+    const int m_tile = chunk * 8 + (within & 7);
+    const int n_block = within >> 3;
+    if (m_tile >= (WAVES == 4 ? g.m_tiles : g.m_tiles256)) return;
+
+    const int Cc = g.Cc;
+    const int ks = g.ksize;
+    const int taps = SCATTER ? 1 : ks * ks;
+    const int chunks = Cc / kBK;
+    const int n_slices_all = taps * chunks;
+    const int per_split = (n_slices_all + g.k_splits - 1) / g.k_splits;
+    const int slice_begin = ksp * per_split;
+    const int n_slices = min(n_slices_all, slice_begin + per_split);
+    if (slice_begin >= n_slices) return;
+    const int K = taps * Cc;
+    const int N = g.n0_pad + g.n1;
+    const int hw = g.Hout * g.Wout;
+    const int M = (SCATTER && g.row_list) ? *g.row_count : g.B * hw;
+    if (SCATTER && m_tile * BM >= M) return;
+
+    const int base_t = g.tiles_n / g.n_blocks, rem_t = g.tiles_n % g.n_blocks;
+    const int tn = base_t + (n_block < rem_t ? 1 : 0);
+    const int n_begin = (n_block * base_t + min(n_block, rem_t)) * 32;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32 = lane & 31, h = lane >> 5;
+
+    // ---- DMA source offsets (per lane, constant over the K loop) ---------------------------------------------------
+    // element offsets are taken relative to a shifted base so that every part is non-negative:
+    //   forward:  pixel part starts at (y*stride - pad, x*stride - pad) >= -pad*(Win+1) pixels;  tap part (ky*Win + kx) >= 0
+    //   mirror:   pixel part (y + pad, x + pad) >= 0;  tap part -(ky*Win + kx) >= -((ks-1)*(Win+1))
+    const int a_ps = g.a_pstride, win_ps = g.Win * a_ps;
+    const int shift = SCATTER ? 0 : (MIRROR ? -(ks - 1) * (win_ps + a_ps) : -g.pad * (win_ps + a_ps));   // elements, <= 0
+    unsigned a_vo[4], a_nmask[4], w_vo[4];   // (w_vo: 16 / WAVES entries used)
+    bool w_seg1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 8 * i + (lane >> 3);                       // row inside the wave's 32
+        const int src_chunk = (lane & 7) ^ ((row >> 1) & 7);       // swizzle (row + 32*wave has the same bits 1..3)
+        const int m = m_tile * BM + wave * 32 + row;
+        a_vo[i] = kOobBit;
+        a_nmask[i] = 0;
+        if (m < M) {
+            if (SCATTER) {
+                a_vo[i] = (unsigned)((g.row_list ? g.row_list[m] : m) * a_ps + src_chunk * 4) * 4u;
+            } else {
+                const int b = m / hw, r = m % hw;
+                const int y = r / g.Wout, x = r % g.Wout;
+                unsigned mask = 0;
+                int by, bx;
+                if (!MIRROR) {
+                    by = y * g.stride - g.pad;
+                    bx = x * g.stride - g.pad;
+                    for (int t = 0; t < taps; ++t) {
+                        const int iy = by + t / ks, ix = bx + t % ks;
+                        if (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) mask |= 1u << t;
+                    }
+                    by += g.pad;   // relative to the shifted base
+                    bx += g.pad;
+                } else {
+                    by = y + g.pad;
+                    bx = x + g.pad;
+                    for (int t = 0; t < taps; ++t) {
+                        const int ty = by - t / ks, tx = bx - t % ks;
+                        if (ty >= 0 && tx >= 0 && ty < g.Hin && tx < g.Win) mask |= 1u << t;   // stride 1 only
+                    }
+                }
+                a_vo[i] = (unsigned)(b * (int)g.a_bstride + by * win_ps + bx * a_ps + src_chunk * 4) * 4u;
+                a_nmask[i] = ~mask;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kWPieces; ++i) {
+        const int wrow = (wave * kWPieces + i) * 8 + (lane >> 3);   // row of the 128-row W slice
+        const int src_chunk = (lane & 7) ^ ((wrow >> 1) & 7);
+        const int n = n_begin + wrow;
+        // (n0_pad is a multiple of 8 and pieces start at multiples of 8: a piece never mixes the two weight tensors)
+        w_vo[i] = (wrow < tn * 32 && n < N && !(n >= g.n0 && n < g.n0_pad))
+                      ? (unsigned)((n < g.n0 ? n : n - g.n0_pad) * K) * 4u + (unsigned)src_chunk * 16u
+                      : kOobBit;
+        w_seg1[i] = n_begin + (wave * kWPieces + i) * 8 >= g.n0_pad;   // uniform: which tensor this piece reads
+    }
+
+    // buffer descriptors (wave-uniform): A window starts `shift` elements before the tensor, W window spans both segments
+    const long long a_records = ((long long)g.B * g.a_bstride - shift) * 4;
+    const __amdgpu_buffer_rsrc_t rsrc_a =
+        __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(g.a + shift), 0, (int)(a_records > 0x7FFFFFFFLL ? 0x7FFFFFFFLL : a_records), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w0 = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(g.w0), 0, (int)g.w0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w1 = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(g.w1 ? g.w1 : g.w0), 0, (int)(g.w1 ? g.w1_bytes : 0), 0x00020000);
+
+    // position of the next slice to stage: channel chunk outer, tap inner (the taps of a chunk re-read rows still in L1/L2)
+    int ld_tap = slice_begin % taps, ld_chunk = slice_begin / taps;
+    int ld_ky = ld_tap / ks, ld_kx = ld_tap % ks;
+    // staging of one slice = 4 A pieces + 4 W pieces per wave; slice_offsets() fixes the (uniform) source offsets of the
+    // slice at the counters and advances them, stage_piece() issues piece i.  The pieces are issued one A + one W per
+    // 16-MFMA group rather than back to back: a DMA instruction costs its wave 60-185 cycles of issue, and eight in a
+    // row at the top of the slice is a ~1,500-cycle hole in that wave's MFMA stream (measured with cycle stamps).
+    unsigned so_a = 0, so_w = 0, tap_bit = 0;
+    auto slice_offsets = [&](bool advance) {
+        const int tap_off = MIRROR ? (ks - 1 - ld_ky) * win_ps + (ks - 1 - ld_kx) * a_ps : ld_ky * win_ps + ld_kx * a_ps;
+        so_a = (unsigned)(tap_off + ld_chunk * kBK) * 4u;
+        so_w = (unsigned)(ld_tap * Cc + ld_chunk * kBK) * 4u;
+        tap_bit = (unsigned)ld_tap;
+        const int inc = advance ? 1 : 0;   // past the last slice: stage the same slice again (into the stage nobody reads)
+        ld_tap += inc;
+        ld_kx += inc;
+        const bool wrap_x = ld_kx == ks, wrap_t = ld_tap == taps;
+        ld_kx = (wrap_x || wrap_t) ? 0 : ld_kx;
+        ld_ky = wrap_t ? 0 : ld_ky + (wrap_x ? 1 : 0);
+        ld_tap = wrap_t ? 0 : ld_tap;
+        ld_chunk += wrap_t ? 1 : 0;
+    };
+    auto stage_piece = [&](int DST, int i) {   // DST is a literal at every call site (folds after inlining)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)((DST ? s_a1 : s_a0) + (wave * 32 + 8 * i) * kBK), 16,
+                                                 a_vo[i] | ((a_nmask[i] >> tap_bit) << 31), so_a, 0, 0);
+    };
+    auto stage_w_piece = [&](int DST, int i) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_seg1[i] ? rsrc_w1 : rsrc_w0, (lds_ptr_t)((DST ? s_b1 : s_b0) + ((wave * (16 / WAVES) + i) * 8) * kBK), 16, w_vo[i],
+                                                 so_w, 0, 0);
+    };
+
+    f32x16 acc[kMaxTN];
+#pragma unroll
+    for (int j = 0; j < kMaxTN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
+
+    // fragment reads: lane (r, h) reads source chunk 2*gk + h of its row, stored at position (2*gk + h) ^ ((r >> 1) & 7)
+    const int pos0 = h ^ ((r32 >> 1) & 7);
+    const int a_row = (wave * 32 + r32) * kBK, b_row = r32 * kBK;
+
+    slice_offsets(true);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stage_piece(0, i);
+#pragma unroll
+    for (int i = 0; i < kWPieces; ++i) stage_w_piece(0, i);
+    __syncthreads();   // (waits for the DMA: it is a pending LDS write of this wave)
+
+    auto k_loop = [&](auto tn_c) {
+        constexpr int TN = decltype(tn_c)::value;
+#ifdef SSDK_CONV_TRACE
+        const bool trace_on = pi == 0 && (blockIdx.x % 31) == 0 && blockIdx.x / 31 < 32;
+        const int trace_blk = blockIdx.x / 31;
+        if (trace_on && lane == 0)
+            g_trace[((trace_blk * 4 + wave) * 64) * 8 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg((15 << 11) | 4) |
+                                                             ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) |
+                                                             ((unsigned long long)TN << 40) | ((unsigned long long)m_tile << 44);
+#endif
+        auto body = [&](auto st_c, int slice) {
+            constexpr int ST = decltype(st_c)::value;
+            TRACE(0)
+            slice_offsets(slice + 2 < n_slices);   // the slice staged now is slice + 1
+            // fragments of group gk + 1 are read, and DMA piece gk is issued, BEFORE the 16 MFMAs of group gk (pinned with a
+            // scheduling barrier: left alone the scheduler sinks the DMAs to the end of the slice, right in front of the wait)
+            f32x4 av[2], bv[2][TN];
+            auto read_frags = [&](int buf, int gk) {
+                const int pos = (pos0 ^ (2 * gk)) * 4;
+                av[buf] = *reinterpret_cast<const f32x4*>(&(ST ? s_a1 : s_a0)[a_row + pos]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bv[buf][j] = *reinterpret_cast<const f32x4*>(&(ST ? s_b1 : s_b0)[b_row + j * 32 * kBK + pos]);
+            };
+            read_frags(0, 0);
+#pragma unroll
+            for (int gk = 0; gk < kBK / 8; ++gk) {
+                if (gk + 1 < kBK / 8) read_frags((gk + 1) & 1, gk + 1);
+                stage_piece(ST ^ 1, gk);
+                if (gk < kWPieces) stage_w_piece(ST ^ 1, gk);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[gk & 1][kk], bv[gk & 1][j][kk], acc[j], 0, 0, 0);
+#ifdef SSDK_CONV_TRACE
+                if (gk == 0) { TRACE(1) }
+                if (gk == 1) { TRACE(2) }
+                if (gk == 2) { TRACE(3) }
+                if (gk == 3) { TRACE(4) }
+#endif
+            }
+            __syncthreads();
+            TRACE(5)
+        };
+        for (int slice = slice_begin; slice < n_slices; slice += 2) {
+            body(std::integral_constant<int, 0>{}, slice);
+            if (slice + 1 < n_slices) body(std::integral_constant<int, 1>{}, slice + 1);
+        }
+    };
+    switch (tn) {
+        case 4: k_loop(std::integral_constant<int, 4>{}); break;
+        case 3: k_loop(std::integral_constant<int, 3>{}); break;
+        case 2: k_loop(std::integral_constant<int, 2>{}); break;
+        default: k_loop(std::integral_constant<int, 1>{}); break;
+    }
+    conv_epilogue<SCATTER>(g, acc, m_tile * BM, wave, r32, h, tn, n_begin, M, N, hw, ksp);
+}
 
 // ---- forward / backward-data ------------------------------------------------------------------------------------
 // MIRROR = false: forward convolution; MIRROR = true: backward-data (separate instantiations so that profiles list the
@@ -306,7 +632,16 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_fwd_kerne
     auto k_loop = [&](auto tn_c) {
         constexpr int TN = decltype(tn_c)::value;
         int stage = 0;
+#ifdef SSDK_CONV_TRACE
+        const bool trace_on = pi == 0 && (blockIdx.x % 31) == 0 && blockIdx.x / 31 < 32;
+        const int trace_blk = blockIdx.x / 31;
+        if (trace_on && (tid & 63) == 0)   // slot 3 of slice 0: where the wave runs (HW_ID, XCC_ID) and what it computes
+            g_trace[((trace_blk * 4 + wave) * 64) * 8 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg((15 << 11) | 4) |
+                                                             ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) |
+                                                             ((unsigned long long)TN << 40) | ((unsigned long long)m_tile << 44);
+#endif
         for (int slice = slice_begin; slice < n_slices; ++slice) {
+            TRACE(0)
             const float* a_cur = a_rd + stage * (kBM * kLdsStride);
             const float* b_cur = b_rd + stage * (kMaxTN * 32 * kLdsStride);
 #pragma unroll
@@ -323,14 +658,21 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_fwd_kerne
                 // unconditional (straight-line code the scheduler can spread between the MFMAs): past the last slice the
                 // loads degenerate to element 0 of the operands (c >= Cc) and the stage written is never read
                 if (gk == 0) store_slice(stage ^ 1);
+#ifdef SSDK_CONV_TRACE
+                if (gk == 0) { TRACE(1) }
+                if (gk == 2) { TRACE(3) }
+                if (gk == 3) { TRACE(4) }
+#endif
                 if (gk == 1) {
                     load_slice();
                     // keep the prefetch HERE: left alone the scheduler sinks the loads to the end of the slice (it reuses the
                     // staging registers for fragment reads), which exposes their latency at the top of the next slice
                     __builtin_amdgcn_sched_barrier(0);
+                    TRACE(2)
                 }
             }
             __syncthreads();
+            TRACE(5)
             stage ^= 1;
         }
     };
@@ -341,57 +683,7 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_fwd_kerne
         default: k_loop(std::integral_constant<int, 1>{}); break;
     }
 
-    // epilogue: C/D map of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
-    if (SCATTER) {
-        // row = a pixel with a non-zero output gradient; column n = tap * Cin + c: add the product into the input-gradient
-        // pixel that tap connects it to (yo - pad + ky, xo - pad + kx).  32 consecutive lanes = 32 consecutive c of one tap.
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int m = m_tile * kBM + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (m >= M) continue;
-            const int pid = g.row_list ? g.row_list[m] : m;
-            const int b = pid / hw, r = pid % hw;
-            const int yo = (r / g.Wout) * g.stride, xo = (r % g.Wout) * g.stride;
-#pragma unroll
-            for (int j = 0; j < kMaxTN; ++j) {
-                if (j >= tn) continue;
-                const int n = n_begin + j * 32 + r32;
-                if (n >= N) continue;
-                const int tap = n / g.sc_cin, c = n % g.sc_cin;
-                const int ty = yo - g.pad + tap / g.ksize, tx = xo - g.pad + tap % g.ksize;
-                if (ty >= 0 && ty < g.Hin && tx >= 0 && tx < g.Win)
-                    atomicAdd(g.o0 + (long long)b * g.ob0 + ((long long)ty * g.Win + tx) * g.os0 + c, acc[j][e]);
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int m = m_tile * kBM + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (m >= M) continue;
-        const int b = m / hw, pix = m % hw;
-#pragma unroll
-        for (int j = 0; j < kMaxTN; ++j) {
-            if (j >= tn) continue;
-            const int n = n_begin + j * 32 + r32;
-            if (n >= N) continue;
-            float v = acc[j][e];
-            if (n < g.n0) {
-                if (g.bias0 && ksp == 0) v += g.bias0[n];
-                float* dst = g.o0 + (long long)b * g.ob0 + (long long)pix * g.os0 + n;
-                if (g.k_splits > 1) { atomicAdd(dst, v); continue; }
-                if (g.relu) v = fmaxf(v, 0.0f);
-                *dst = v;
-            } else {
-                const int n1 = n - g.n0;
-                if (g.bias1 && ksp == 0) v += g.bias1[n1];
-                float* dst = g.o1 + (long long)b * g.ob1 + (long long)pix * g.os1 + n1;
-                if (g.k_splits > 1) { atomicAdd(dst, v); continue; }
-                if (g.relu) v = fmaxf(v, 0.0f);
-                *dst = v;
-            }
-        }
-    }
+    conv_epilogue<SCATTER>(g, acc, m_tile * kBM, wave, r32, h, tn, n_begin, M, N, hw, ksp);
 }
 
 // ---- backward-weights ------------------------------------------------------------------------------------------
@@ -732,13 +1024,14 @@ struct ZeroList {
 };
 
 static void finish_problem(ConvProblem& g) {
+    g.n0_pad = g.n0;
     const int N = g.n0 + g.n1;
     g.tiles_n = cdiv(N, 32);
     g.n_blocks = cdiv(g.tiles_n, kMaxTN);
     g.m_tiles = cdiv(g.B * g.Hout * g.Wout, kBM);
+    g.m_tiles256 = cdiv(g.B * g.Hout * g.Wout, 256);
     g.k_splits = 1;
 }
-static int problem_blocks(const ConvProblem& g) { return cdiv(g.m_tiles, 8) * 8 * g.n_blocks * g.k_splits; }
 static long long problem_block_work(const ConvProblem& g) {
     const int chunks = cdiv(g.Cc, kBK);
     return (long long)g.ksize * g.ksize * chunks * cdiv(g.tiles_n, g.n_blocks) / g.k_splits;
@@ -756,8 +1049,39 @@ static bool maybe_split_k(ConvProblem& g) {
     return true;
 }
 
-// orders the problems by decreasing work per workgroup (longest first), assigns block ranges, launches
+// decides the kernel (LDS-DMA or register staged; 128- or 256-pixel tiles), orders the problems by decreasing work per
+// workgroup (longest first), assigns block ranges, launches
 static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t s, bool generic = false, bool scatter = false) {
+    bool vec4 = true, strided = false;
+    for (int i = 0; i < count; ++i) {
+        const ConvProblem& g = probs[i];
+        if (g.Cc % 4 || g.a_pstride % 4 || g.a_bstride % 4 || ((uintptr_t)g.a & 15) || ((uintptr_t)g.w0 & 15) || (g.w1 && ((uintptr_t)g.w1 & 15))) vec4 = false;
+        strided = strided || g.stride != 1;
+    }
+    // LDS-DMA kernel: 16-byte rows, whole 32-channel chunks, stride-1 taps when mirrored, all byte offsets below 2^31
+    bool dma = vec4 && !(mirror && strided) && !getenv("SSDK_CONV_NO_DMA");
+    for (int i = 0; i < count && dma; ++i) {
+        ConvProblem& g = probs[i];
+        const long long span_a = ((long long)g.B * g.a_bstride + (long long)(g.ksize + g.pad) * ((long long)g.Win + 1) * g.a_pstride) * 4;
+        const long long w0_bytes = (long long)g.n0 * (scatter ? 1 : g.ksize * g.ksize) * g.Cc * 4, w1_bytes = (long long)g.n1 * g.ksize * g.ksize * g.Cc * 4;
+        if (g.Cc % kBK || span_a >= (1LL << 31) - 4096 || w0_bytes >= (1LL << 31) - 4096 || w1_bytes >= (1LL << 31) - 4096) { dma = false; break; }
+        g.w0_bytes = (unsigned)w0_bytes;
+        g.w1_bytes = (unsigned)w1_bytes;
+    }
+    for (int i = 0; i < count; ++i) {   // column space of the chosen kernel (see ConvProblem::n0_pad)
+        ConvProblem& g = probs[i];
+        g.n0_pad = (dma && g.n1 > 0) ? cdiv(g.n0, 8) * 8 : g.n0;
+        g.tiles_n = cdiv(g.n0_pad + g.n1, 32);
+        g.n_blocks = cdiv(g.tiles_n, kMaxTN);
+    }
+    // 8-wave / 256-pixel tiling: measured 3 % (B=128) to 14 % (B=32) MORE cycles than two 4-wave workgroups per CU on the
+    // SSD-300 heads (one barrier stalls all eight waves of the CU at once) -- kept as an opt-in experiment only
+    bool w8 = false;
+    if (dma && !scatter && getenv("SSDK_CONV_W8")) {
+        long long blocks256 = 0;
+        for (int i = 0; i < count; ++i) blocks256 += (long long)probs[i].m_tiles256 * probs[i].n_blocks * probs[i].k_splits;
+        w8 = blocks256 >= 384;
+    }
     ConvGroup grp;
     int order[kMaxProblems];
     for (int i = 0; i < count; ++i) order[i] = i;
@@ -765,19 +1089,24 @@ static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t 
         for (int j = i + 1; j < count; ++j)
             if (problem_block_work(probs[order[j]]) > problem_block_work(probs[order[i]])) { int t = order[i]; order[i] = order[j]; order[j] = t; }
     int begin = 0;
-    bool vec4 = true;
     for (int i = 0; i < count; ++i) {
         ConvProblem& g = probs[order[i]];
         g.block_begin = begin;
-        begin += problem_blocks(g);
-        if (g.Cc % 4 || g.a_pstride % 4 || g.a_bstride % 4 || ((uintptr_t)g.a & 15) || ((uintptr_t)g.w0 & 15) || (g.w1 && ((uintptr_t)g.w1 & 15))) vec4 = false;
+        begin += cdiv(w8 ? g.m_tiles256 : g.m_tiles, 8) * 8 * g.n_blocks * g.k_splits;
         grp.p[i] = g;
     }
     grp.count = count;
     grp.total_blocks = begin;
-    bool strided = false;
-    for (int i = 0; i < count; ++i) strided = strided || probs[i].stride != 1;
-    if (scatter) {
+    if (dma && w8) {
+        if (mirror) hipLaunchKernelGGL((igemm_dma_kernel<true, false, false, 8>), dim3(begin), dim3(512), 0, s, grp);
+        else if (generic) hipLaunchKernelGGL((igemm_dma_kernel<false, true, false, 8>), dim3(begin), dim3(512), 0, s, grp);
+        else hipLaunchKernelGGL((igemm_dma_kernel<false, false, false, 8>), dim3(begin), dim3(512), 0, s, grp);
+    } else if (dma) {
+        if (scatter) hipLaunchKernelGGL((igemm_dma_kernel<false, false, true, 4>), dim3(begin), dim3(kConvThreads), 0, s, grp);
+        else if (mirror) hipLaunchKernelGGL((igemm_dma_kernel<true, false, false, 4>), dim3(begin), dim3(kConvThreads), 0, s, grp);
+        else if (generic) hipLaunchKernelGGL((igemm_dma_kernel<false, true, false, 4>), dim3(begin), dim3(kConvThreads), 0, s, grp);
+        else hipLaunchKernelGGL((igemm_dma_kernel<false, false, false, 4>), dim3(begin), dim3(kConvThreads), 0, s, grp);
+    } else if (scatter) {
         SSDK_REQUIRE(vec4, SSDK_E_UNSUPPORTED, "scatter dgrad needs 16-byte aligned rows");
         hipLaunchKernelGGL((igemm_fwd_kernel<4, false, false, false, true>), dim3(begin), dim3(kConvThreads), 0, s, grp);
     } else if (mirror && strided) {

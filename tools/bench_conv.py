@@ -18,6 +18,7 @@ def main():
     ap.add_argument('--config', default='ssd_300_vgg16_voc')
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--reps', type=int, default=10)
+    ap.add_argument('--fwd-only', action='store_true')
     ap.add_argument('--sparse', type=float, default=0.0, help='fraction of zero dY rows (per anchor) in the backward input')
     args = ap.parse_args()
     cfg = syn.CONFIGS[args.config]
@@ -40,6 +41,9 @@ def main():
         return e0.elapsed_time(e1) / reps
 
     t_fwd = timed(lambda: multi_level_heads(xs, xs, heads), args.reps)
+    if args.fwd_only:
+        print(f'{args.config} B={B}: fwd {t_fwd:.3f} ms = {flops / t_fwd / 1e9:.1f} TFLOP/s')
+        return
     scores, locs = multi_level_heads(xs, xs, heads)
     gs = torch.randn_like(scores)
     gl = torch.randn_like(locs)
