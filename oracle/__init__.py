@@ -265,3 +265,16 @@ def anchors(cfg_anchor, size, levels, use_fma=True):
     else:
         raise ValueError(p['type'])
     return np.concatenate(outs, axis=0)
+
+
+def mean_average_precision(pred, gt_list, num_classes, iou_threshold=0.5, voc=False):
+    """detection/metrics/mean_average_precision.py:10-116 -> (mAP, ap[num_classes] with NaN for classes without ground truth)"""
+    pred = _f32(np.asarray(pred, np.float32).reshape(-1, 7))
+    stride = int(gt_list[0].shape[1]) if len(gt_list) else 6
+    rows, offs = pack_gt(gt_list, stride)
+    ap = np.empty(num_classes, np.float32)
+    fn = lib().orc_mean_average_precision
+    fn.restype = C.c_double
+    m = fn(_p(pred), C.c_int64(pred.shape[0]), _p(rows), C.c_int(stride), _p(offs), C.c_int(len(gt_list)), C.c_int(num_classes),
+           C.c_float(iou_threshold), C.c_int(int(voc)), _p(ap))
+    return float(m), ap

@@ -847,3 +847,111 @@ void orc_multibox_loss_ex(const float* scores, const float* locs, const float* a
         }
     }
 }
+
+/*
+ * detection/metrics/mean_average_precision.py:10-116  mean_average_precision
+ *   pred [N,7]: image id, corner box, class id, score.  gt rows [sum G, gstride] (corner box, class at 4, difficult at 6 when
+ *   gstride > 6 -- :22), gt_off[num_images + 1].  Class ids are integers in [0, num_classes).
+ *   ap_out[num_classes]: AP of every class that has at least one counted (non-difficult) ground truth (:33-34), NaN elsewhere;
+ *   returns the mean over those classes (:111).  Score ties (the reference's argsort is unstable, :40): lower row first.
+ *   All arithmetic that the reference does in fp32 tensors (cumulative counts, precision, recall, running max, dot /
+ *   11-point mean) is done in fp32 in the same order; torch.max propagates NaN (:95-96).
+ */
+double orc_mean_average_precision(const float* pred, int64_t n, const float* gt, int gstride, const int32_t* gt_off, int num_images,
+                                 int num_classes, float iou_threshold, int voc, float* ap_out) {
+    const int ignore_difficult = gstride > 6;                                    /* :22 */
+    const int64_t total_gt = gt_off[num_images];
+    int64_t* total_positive = (int64_t*)calloc((size_t)num_classes, sizeof(int64_t));
+    for (int64_t g = 0; g < total_gt; ++g) {                                     /* :27-35 */
+        const int c = (int)gt[g * gstride + 4];
+        if (c < 0 || c >= num_classes) continue;
+        if (!ignore_difficult || gt[g * gstride + 6] == 0.0f) total_positive[c] += 1;
+    }
+    orc_kv* order = (orc_kv*)malloc(sizeof(orc_kv) * (size_t)(n > 0 ? n : 1));  /* :40-41 */
+    for (int64_t i = 0; i < n; ++i) { order[i].v = pred[i * 7 + 6]; order[i].i = (int32_t)i; }
+    qsort(order, (size_t)n, sizeof(orc_kv), cmp_desc_stable);
+    uint8_t* matched = (uint8_t*)calloc((size_t)(total_gt > 0 ? total_gt : 1), 1);
+    /* per class: the running (tp, fp) lists of :51-52 in prediction order */
+    int64_t* cnt = (int64_t*)calloc((size_t)num_classes, sizeof(int64_t));
+    for (int64_t i = 0; i < n; ++i) { const int c = (int)pred[i * 7 + 5]; if (c >= 0 && c < num_classes) cnt[c] += 1; }
+    int64_t* start = (int64_t*)malloc(sizeof(int64_t) * (size_t)(num_classes + 1));
+    start[0] = 0;
+    for (int c = 0; c < num_classes; ++c) start[c + 1] = start[c] + cnt[c];
+    float* tp = (float*)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+    float* fp = (float*)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+    int64_t* fill = (int64_t*)calloc((size_t)num_classes, sizeof(int64_t));
+    for (int64_t k = 0; k < n; ++k) {                                            /* :47-70 */
+        const float* p = pred + (int64_t)order[k].i * 7;
+        const int id = (int)p[0], c = (int)p[5];
+        if (c < 0 || c >= num_classes) continue;
+        const int64_t pos = start[c] + fill[c];
+        float t = fill[c] ? tp[pos - 1] : 0.0f, f = fill[c] ? fp[pos - 1] : 0.0f;
+        fill[c] += 1;
+        /* IoU against the ground truths of this class in this image, in row order; first maximum; NaN propagates */
+        int have = 0;
+        int64_t best_g = -1;
+        float best = 0.0f;
+        const float parea = area4(p[1], p[2], p[3], p[4]);
+        if (id >= 0 && id < num_images)
+            for (int64_t g = gt_off[id]; g < gt_off[id + 1]; ++g) {
+                const float* q = gt + g * gstride;
+                if ((int)q[4] != c) continue;
+                const float v = iou_pair(p + 1, parea, q, area4(q[0], q[1], q[2], q[3]));
+                if (!have || (v > best && best == best) || (v != v && best == best)) { best = v; best_g = g; }
+                have = 1;
+            }
+        if (!have) f += 1.0f;                                                    /* :54-56 */
+        else if (best > iou_threshold) {                                         /* :60 */
+            if (!ignore_difficult || gt[best_g * gstride + 6] == 0.0f) {         /* :61 */
+                if (!matched[best_g]) { t += 1.0f; matched[best_g] = 1; }       /* :62-64 */
+                else f += 1.0f;                                                  /* :66 */
+            }
+        } else f += 1.0f;                                                        /* :68 */
+        tp[pos] = t;
+        fp[pos] = f;
+    }
+    double map_sum = 0.0;
+    int map_n = 0;
+    for (int c = 0; c < num_classes; ++c) {
+        ap_out[c] = NAN;
+        if (!total_positive[c]) continue;                                        /* :74-75, :80 */
+        int64_t m = cnt[c];
+        const float* tpc = tp + start[c];
+        const float* fpc = fp + start[c];
+        float one_tp = 0.0f, one_fp = 1.0f;
+        if (m == 0) { m = 1; tpc = &one_tp; fpc = &one_fp; }                     /* :81-89 */
+        float* prec = (float*)malloc(sizeof(float) * (size_t)(m + 1));
+        float* rec = (float*)malloc(sizeof(float) * (size_t)(m + 2));
+        for (int64_t i = 0; i < m; ++i) prec[i] = tpc[i] / (tpc[i] + fpc[i]);    /* :91 */
+        prec[m] = 0.0f;                                                          /* :92 */
+        for (int64_t i = m; i >= 1; --i) prec[i - 1] = tmaxf(prec[i - 1], prec[i]);   /* :94-95 */
+        const float tot = (float)total_positive[c];
+        float ap;
+        if (voc) {                                                               /* :99-103 */
+            for (int64_t i = 0; i < m; ++i) rec[i] = tpc[i] / tot;
+            rec[m] = 1.0f;
+            float acc = 0.0f;
+            for (int k = 0; k <= 10; ++k) {
+                const float thr = (float)(0.0 + k * 0.1);                        /* torch.arange(0, 1.1, .1): double arithmetic, fp32 result */
+                int64_t idx = 0;
+                for (int64_t i = 0; i <= m; ++i) idx += thr > rec[i];
+                acc += prec[idx];
+            }
+            ap = acc / 11.0f;
+        } else {                                                                 /* :104-106 */
+            rec[0] = 0.0f;
+            for (int64_t i = 0; i < m; ++i) rec[i + 1] = tpc[i] / tot;
+            rec[m + 1] = 1.0f;
+            float acc = 0.0f;
+            for (int64_t i = 0; i <= m; ++i) acc += (rec[i + 1] - rec[i]) * prec[i];
+            ap = acc;
+        }
+        ap_out[c] = ap;
+        map_sum += (double)ap;                                                   /* :108, :111: python floats */
+        map_n += 1;
+        free(prec);
+        free(rec);
+    }
+    free(total_positive); free(order); free(matched); free(cnt); free(start); free(tp); free(fp); free(fill);
+    return map_n ? map_sum / map_n : (double)NAN;
+}

@@ -87,3 +87,56 @@ def make_feature_maps(batch, levels, seed=23):
     """list[L] of NCHW fp32 N(0,1) source maps at the §8 shapes (head-only microbench input)."""
     rng = np.random.default_rng(seed)
     return [rng.standard_normal((batch, cin, h, h), dtype=np.float32) for cin, h, _ in levels]
+
+
+def make_map_case(seed, num_images=12, num_classes=6, with_difficult=True, max_gt=6, size=300.0, dup=0.3, noise_fp=2, empty_images=True,
+                  unique_scores=True, difficult_p=0.2):
+    """Seeded input of detection/metrics/mean_average_precision.py: (predictions [N,7], gts list of [G_i, 6 or 7]).
+
+    Ground truths: random corner boxes, classes 1..num_classes-1, optional difficult column (20 %).  Predictions: a jittered copy of
+    ~75 % of the ground truths, duplicates of some of them (a second hit on a matched box is a false positive), and random boxes
+    with random classes (incl. classes the image does not contain).  Scores are distinct unless ``unique_scores`` is False."""
+    rng = np.random.default_rng(seed)
+    gts, preds = [], []
+    for i in range(num_images):
+        g = int(rng.integers(0 if empty_images else 1, max_gt + 1))
+        xy = rng.uniform(0, 0.7 * size, (g, 2))
+        wh = rng.uniform(0.05, 0.4, (g, 2)) * size
+        box = np.concatenate([xy, np.minimum(xy + wh, size - 1)], 1)
+        cls = rng.integers(1, num_classes, (g, 1)).astype(np.float64)
+        cols = [box, cls, np.ones((g, 1))]
+        if with_difficult:
+            cols.append((rng.random((g, 1)) < difficult_p).astype(np.float64))
+        gts.append(np.concatenate(cols, 1).astype(np.float32).reshape(g, 7 if with_difficult else 6))
+        rows = []
+        for k in range(g):
+            if rng.random() < 0.75:
+                for _ in range(1 + int(rng.random() < dup)):
+                    jit = rng.normal(0, 0.06, 4) * np.tile(wh[k], 2)
+                    rows.append(np.concatenate([[i], box[k] + jit, cls[k], [rng.uniform(0.2, 1.0)]]))
+        for _ in range(int(rng.integers(0, noise_fp + 1))):
+            xy2 = rng.uniform(0, 0.7 * size, 2)
+            rows.append(np.concatenate([[i], xy2, xy2 + rng.uniform(0.05, 0.4, 2) * size, [rng.integers(1, num_classes)], [rng.uniform(0.01, 0.6)]]))
+        if rows:
+            preds.append(np.stack(rows))
+    pred = np.concatenate(preds, 0).astype(np.float32) if preds else np.zeros((0, 7), np.float32)
+    if unique_scores and pred.shape[0]:
+        s = pred[:, 6]
+        while np.unique(s).size != s.size:
+            s += rng.uniform(0, 1e-4, s.size).astype(np.float32)
+    elif pred.shape[0]:
+        pred[:, 6] = np.round(pred[:, 6] * 20) / 20          # many exact ties
+    pred = pred[rng.permutation(pred.shape[0])]
+    return np.ascontiguousarray(pred, dtype=np.float32), gts
+
+
+# golden cases of tests/golden/map.npz: name -> make_map_case kwargs; each is run with voc = False and True
+MAP_CASES = {
+    'small_diff': dict(seed=11, num_images=12, num_classes=6, with_difficult=True),
+    'small_nodiff': dict(seed=12, num_images=12, num_classes=6, with_difficult=False),
+    'many_classes': dict(seed=13, num_images=40, num_classes=21, with_difficult=True, max_gt=8, noise_fp=4),
+    'dense_dups': dict(seed=14, num_images=6, num_classes=3, with_difficult=True, max_gt=10, dup=0.9, noise_fp=6),
+    'no_empty': dict(seed=15, num_images=25, num_classes=81, with_difficult=False, max_gt=5, empty_images=False),
+    'few_difficult': dict(seed=20, num_images=30, num_classes=8, with_difficult=True, max_gt=7, difficult_p=0.08),
+    'few_difficult2': dict(seed=30, num_images=30, num_classes=8, with_difficult=True, max_gt=7, difficult_p=0.08),
+}

@@ -244,3 +244,20 @@ def test_extra_losses_match_reference(tag):
     np.testing.assert_allclose(ds, dense_from_rows(g[tag + '_dscores_rows'], g[tag + '_dscores_vals'], (B, A, nc)), rtol=2e-4, atol=2e-7)
     np.testing.assert_allclose(dl, dense_from_rows(g[tag + '_dlocs_rows'], g[tag + '_dlocs_vals'], (B, A, 4)), rtol=2e-4, atol=2e-7)
     assert bool(g[tag + '_target_mutated']) == (not np.array_equal(target, g['target']))
+
+
+# ---- mean average precision: oracle vs the reference's own outputs ---------------------------------------
+@pytest.mark.parametrize('voc', [False, True])
+@pytest.mark.parametrize('name', sorted(syn.MAP_CASES))
+def test_mean_average_precision_vs_reference(name, voc):
+    """detection/metrics/mean_average_precision.py:10-116: mAP and the per-class APs the reference logs, incl. its NaN for a
+    class whose best-scored prediction hits a difficult box (0/0 precision, :91)."""
+    g = load_golden('map')
+    kw = syn.MAP_CASES[name]
+    pred, gts = syn.make_map_case(**kw)
+    assert pred.shape[0] == int(g[name + '_n'])
+    tag = f'{name}_{"voc" if voc else "area"}'
+    m, ap = oracle.mean_average_precision(pred, gts, kw['num_classes'], 0.5, voc)
+    ref = float(g[tag + '_map'])
+    assert (np.isnan(m) and np.isnan(ref)) or abs(m - ref) <= 1e-6
+    np.testing.assert_allclose(ap, g[tag + '_ap_logged'], atol=1.5e-6, equal_nan=True)

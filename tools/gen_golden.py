@@ -409,6 +409,47 @@ def gen_losses_extra(out_dir):
     print(f'losses_extra -> {path} ({os.path.getsize(path) / 1e3:.1f} KB)')
 
 
+def gen_map(out_dir):
+    """detection/metrics/mean_average_precision.py on seeded cases (synthetic.make_map_case): mAP and the per-class APs
+    (the reference only returns the mean; the per-class values are read from its verbose log lines)."""
+    import logging
+    from detection.metrics.mean_average_precision import mean_average_precision
+    from single_shot_detection_amd import synthetic as syn
+
+    class _Grab(logging.Handler):
+        def __init__(self):
+            super().__init__()
+            self.lines = []
+
+        def emit(self, record):
+            self.lines.append(record.getMessage())
+
+    res = {}
+    for name, kw in syn.MAP_CASES.items():
+        pred, gts = syn.make_map_case(**kw)
+        assert np.unique(pred[:, 6]).size == pred.shape[0]
+        labels = {c: f'c{c}' for c in range(kw['num_classes'])}
+        for voc in (False, True):
+            grab = _Grab()
+            logging.getLogger().addHandler(grab)
+            logging.getLogger().setLevel(logging.INFO)
+            m = mean_average_precision(torch.from_numpy(pred.copy()), [torch.from_numpy(g.copy()) for g in gts], labels, 0.5, voc=voc, verbose=True)
+            logging.getLogger().removeHandler(grab)
+            ap = np.full(kw['num_classes'], np.nan, np.float64)
+            for line in grab.lines:
+                if line.startswith('c') and ': ' in line:
+                    c, v = line.split(': ')
+                    ap[int(c[1:])] = float(v)
+            tag = f'{name}_{"voc" if voc else "area"}'
+            res[tag + '_map'] = np.float64(m)
+            res[tag + '_ap_logged'] = ap          # 6 decimals (the reference's log format)
+        res[name + '_pred_sha'] = sha(pred)
+        res[name + '_n'] = np.int64(pred.shape[0])
+    path = os.path.join(out_dir, 'map.npz')
+    np.savez_compressed(path, **res)
+    print(f'map -> {path} ({os.path.getsize(path) / 1e3:.1f} KB)')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(REPO, 'tests', 'golden'))
@@ -423,6 +464,8 @@ def main():
         gen_heads(args.out)
     if args.only in (None, 'losses_extra'):
         gen_losses_extra(args.out)
+    if args.only in (None, 'map'):
+        gen_map(args.out)
     for name, b in batches.items():
         if args.only in (None, name):
             gen_config(name, args.out, b)
