@@ -301,6 +301,21 @@ int ssdk_sigmoid_gate_fwd(const float* x, const float* z, int batch, int hw, int
 int ssdk_sigmoid_gate_bwd(const float* x, const float* z, const float* dout, int batch, int hw, int channels, float* dx,
                           float* dz, void* stream);
 
+/* ---- evaluation metric -----------------------------------------------------------------------------
+ * detection/metrics/mean_average_precision.py:10-116  mean_average_precision(predictions, gts, class_labels, iou_threshold, voc)
+ *   predictions [n_pred, 7] device: image id, corner box, class id, score (the rows bf/eval.py:58-66 builds from the
+ *   postprocessor's output).  Ground truth as for ssdk_encode_ground_truth: rows [total_gt, gt_stride] + offsets
+ *   int32[num_images + 1]; class at column 4; difficult flag at column 6 when gt_stride > 6 (reference :22).
+ *   Class ids are integers in [0, num_classes).  ap_out[num_classes]: AP of every class with at least one counted ground
+ *   truth, NaN for the others; map_out[1] (double): their mean (:111).  voc != 0: 11-point interpolation (:99-103).
+ *   Score ties (the reference's argsort is unstable): lower prediction row first.  The reference's 0/0 -> NaN precision
+ *   for a class whose best prediction hits a difficult box is reproduced. */
+size_t ssdk_mean_average_precision_workspace_bytes(long long n_pred, long long total_gt, int num_classes);
+int ssdk_mean_average_precision(const float* predictions, long long n_pred, const float* gt_rows, int gt_stride,
+                                const int* gt_offsets, int num_images, long long total_gt, int num_classes,
+                                float iou_threshold, int voc, float* ap_out, double* map_out, void* workspace,
+                                size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,314 @@
+// metrics.hip -- mean average precision on the device.
+//
+// Reference: detection/metrics/mean_average_precision.py:10-116 -- a Python loop over every prediction in descending score
+// order (one box_utils.iou call, several .item() syncs and dict updates per prediction), then per class a Python loop for the
+// running maximum of the precision.  bf/eval.py:63-69 moves all predictions to the host first.
+//
+// Here: two stable radix sorts (rocPRIM through hipCUB) give the predictions in (class, score desc) order -- the order of the
+// per-class cumulative counts -- and in (image, class, score desc) order, in which the greedy matching of :47-70 is
+// independent between (image, class) groups: one thread walks one group, against the <= G_i ground truths of that image.
+// A workgroup per class then does the cumulative sums, precision / recall, the reverse NaN-propagating running maximum and
+// the area / 11-point integration with block scans, in fp32 like the reference's tensors.
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+
+namespace ssdk {
+
+constexpr int kMapThreads = 256;
+
+struct MapWs {
+    unsigned long long* key_a;   // [n]
+    unsigned long long* key_b;   // [n]  sorted (class, score) keys -- read by map_ap_kernel
+    unsigned long long* key_c;   // [n]  sorted image keys (scratch)
+    unsigned* val_a;             // [n]
+    unsigned* val_b;             // [n]
+    unsigned* perm_b;            // [n]  prediction row at position j of the (class, score desc) order
+    unsigned char* flag;         // [n]  by prediction row: 0 = neither, 1 = true positive, 2 = false positive
+    unsigned char* matched;      // [total_gt]
+    float* prec;                 // [n]  by (class, score) position
+    float* rec;                  // [n]
+    int* total_positive;         // [num_classes]
+    void* cub_temp;
+    size_t cub_bytes;
+    size_t total;
+};
+
+static size_t cub_temp_bound(long long n) { return (size_t)n * 32 + (16u << 20); }
+
+static MapWs carve_map(void* base, long long n, long long total_gt, int num_classes) {
+    Carver c(base);
+    MapWs w;
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    w.key_a = c.take<unsigned long long>(nn);
+    w.key_b = c.take<unsigned long long>(nn);
+    w.key_c = c.take<unsigned long long>(nn);
+    w.val_a = c.take<unsigned>(nn);
+    w.val_b = c.take<unsigned>(nn);
+    w.perm_b = c.take<unsigned>(nn);
+    w.flag = c.take<unsigned char>(nn);
+    w.matched = c.take<unsigned char>((size_t)(total_gt > 0 ? total_gt : 1));
+    w.prec = c.take<float>(nn);
+    w.rec = c.take<float>(nn);
+    w.total_positive = c.take<int>((size_t)num_classes);
+    w.cub_bytes = cub_temp_bound(n);
+    w.cub_temp = c.take<unsigned char>(w.cub_bytes);
+    w.total = c.off;
+    return w;
+}
+
+// order-preserving map of a float onto unsigned, inverted: ascending key = descending score
+__device__ __forceinline__ unsigned desc_key(float s) {
+    const unsigned u = __float_as_uint(s);
+    return ~((u & 0x80000000u) ? ~u : (u | 0x80000000u));
+}
+
+// keys of the (class, score desc) order; counted ground truths per class (:27-35)
+__global__ void map_prepare_kernel(const float* __restrict__ pred, long long n, const float* __restrict__ gt, int gstride, long long total_gt,
+                                   int num_classes, unsigned long long* key, unsigned* val, int* total_positive) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int c = (int)pred[i * 7 + 5];
+        const bool ok = c >= 0 && c < num_classes;
+        key[i] = ok ? ((unsigned long long)(unsigned)c << 32) | desc_key(pred[i * 7 + 6]) : ~0ull;   // foreign classes sort last
+        val[i] = (unsigned)i;
+    }
+    if (i < total_gt) {
+        const int c = (int)gt[i * gstride + 4];
+        if (c >= 0 && c < num_classes && (gstride <= 6 || gt[i * gstride + 6] == 0.0f)) atomicAdd(&total_positive[c], 1);
+    }
+}
+
+// second sort key: the image of the prediction at position j of the (class, score) order
+__global__ void map_image_key_kernel(const float* __restrict__ pred, long long n, const unsigned* __restrict__ perm_b, unsigned long long* key,
+                                     unsigned* val) {
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const unsigned r = perm_b[j];
+    key[j] = (unsigned long long)(unsigned)(int)pred[(long long)r * 7];
+    val[j] = r;
+}
+
+// greedy matching (:47-70): the thread at the head of an (image, class) group walks the group in score order
+__global__ void map_match_kernel(const float* __restrict__ pred, long long n, const unsigned* __restrict__ perm_a, const float* __restrict__ gt,
+                                 int gstride, const int* __restrict__ gt_off, int num_images, int num_classes, float thr,
+                                 unsigned char* matched, unsigned char* flag) {
+    const long long j0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j0 >= n) return;
+    const float* p0 = pred + (long long)perm_a[j0] * 7;
+    const int id = (int)p0[0], c = (int)p0[5];
+    if (c < 0 || c >= num_classes) { flag[perm_a[j0]] = 0; return; }
+    if (j0 > 0) {
+        const float* q = pred + (long long)perm_a[j0 - 1] * 7;
+        if ((int)q[0] == id && (int)q[5] == c) return;   // not the head of its group
+    }
+    const bool ignore_difficult = gstride > 6;
+    const int g_begin = (id >= 0 && id < num_images) ? gt_off[id] : 0, g_end = (id >= 0 && id < num_images) ? gt_off[id + 1] : 0;
+    for (long long j = j0; j < n; ++j) {
+        const unsigned row = perm_a[j];
+        const float* p = pred + (long long)row * 7;
+        if ((int)p[0] != id || (int)p[5] != c) break;
+        const float4 pb = make_float4(p[1], p[2], p[3], p[4]);
+        const float parea = area4(pb.x, pb.y, pb.z, pb.w);
+        bool have = false;
+        int best_g = -1;
+        float best = 0.0f;
+        for (int g = g_begin; g < g_end; ++g) {
+            const float* q = gt + (long long)g * gstride;
+            if ((int)q[4] != c) continue;
+            const float4 qb = make_float4(q[0], q[1], q[2], q[3]);
+            const float v = iou_corner(pb, parea, qb, area4(qb.x, qb.y, qb.z, qb.w));
+            if (!have || (v > best && best == best) || (v != v && best == best)) { best = v; best_g = g; }   // first max, NaN propagates
+            have = true;
+        }
+        unsigned char f = 2;                                                        // :54-56, :68: false positive
+        if (have && best > thr) {                                                   // :60
+            if (!ignore_difficult || gt[(long long)best_g * gstride + 6] == 0.0f) { // :61
+                if (!matched[best_g]) { matched[best_g] = 1; f = 1; }              // :62-64
+            } else {
+                f = 0;                                                              // difficult hit: neither counter moves
+            }
+        }
+        flag[row] = f;
+    }
+}
+
+struct OpTmax { __device__ __forceinline__ float operator()(float a, float b) const { return tmaxf(a, b); } };
+
+// one workgroup per class: cumulative counts -> precision / recall -> reverse running max -> AP (:77-108)
+__global__ void __launch_bounds__(kMapThreads) map_ap_kernel(const unsigned long long* __restrict__ key_b, const unsigned* __restrict__ perm_b, long long n,
+                                                             const unsigned char* __restrict__ flag, const int* __restrict__ total_positive, int voc,
+                                                             float* prec, float* rec, float* ap_out) {
+    typedef hipcub::BlockScan<int2, kMapThreads> ScanI2;
+    typedef hipcub::BlockScan<float, kMapThreads> ScanF;
+    typedef hipcub::BlockReduce<float, kMapThreads> ReduceF;
+    __shared__ union {
+        typename ScanI2::TempStorage si;
+        typename ScanF::TempStorage sf;
+        typename ReduceF::TempStorage rf;
+    } tmp;
+    __shared__ long long s_range[2];
+    __shared__ int s_cnt[11];
+    __shared__ float s_vocp[11];
+    __shared__ float s_carry_f;
+
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const int tot_i = total_positive[c];
+    if (tot_i == 0) {   // class without counted ground truth: not part of the mean (:74-75, :80)
+        if (tid == 0) ap_out[c] = __uint_as_float(0x7FC00000u);
+        return;
+    }
+    if (tid < 2) {      // segment of this class in the (class, score) order: lower bounds of c << 32 and (c + 1) << 32
+        const unsigned long long want = (unsigned long long)(unsigned)(c + tid) << 32;
+        long long lo = 0, hi = n;
+        while (lo < hi) {
+            const long long mid = (lo + hi) >> 1;
+            if (key_b[mid] < want) lo = mid + 1; else hi = mid;
+        }
+        s_range[tid] = lo;
+    }
+    if (tid < 11) { s_cnt[tid] = 0; s_vocp[tid] = 0.0f; }
+    __syncthreads();
+    const long long begin = s_range[0], m = s_range[1] - s_range[0];
+    const float tot = (float)tot_i;
+    if (m == 0) {       // no prediction of this class: tp = [0], fp = [1] (:81-89) -> AP = 0 either way
+        if (tid == 0) ap_out[c] = 0.0f;
+        return;
+    }
+    float thr[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) thr[k] = (float)(0.0 + k * 0.1);   // torch.arange(0, 1.1, .1)
+    int my_cnt[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) my_cnt[k] = 0;
+
+    // pass 1, forward: cumulative (tp, fp) -> precision, recall
+    int2 carry = make_int2(0, 0);
+    struct AddI2 { __device__ __forceinline__ int2 operator()(const int2& a, const int2& b) const { return make_int2(a.x + b.x, a.y + b.y); } };
+    for (long long base = 0; base < m; base += kMapThreads) {
+        const long long i = base + tid;
+        int2 v = make_int2(0, 0);
+        if (i < m) {
+            const unsigned char f = flag[perm_b[begin + i]];
+            v = make_int2(f == 1, f == 2);
+        }
+        int2 incl, agg;
+        ScanI2(tmp.si).InclusiveScan(v, incl, AddI2(), agg);
+        __syncthreads();
+        if (i < m) {
+            const float tp = (float)(carry.x + incl.x), fp = (float)(carry.y + incl.y);
+            const float p = tp / (tp + fp), r = tp / tot;      // :91, :97
+            prec[begin + i] = p;
+            rec[begin + i] = r;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) my_cnt[k] += thr[k] > r;
+        }
+        carry = make_int2(carry.x + agg.x, carry.y + agg.y);
+    }
+    if (voc) {
+#pragma unroll
+        for (int k = 0; k < 11; ++k)
+            if (my_cnt[k]) atomicAdd(&s_cnt[k], my_cnt[k]);
+    }
+    if (tid == 0) s_carry_f = 0.0f;   // precision[m] = 0 (:92)
+    __syncthreads();
+
+    // pass 2, backward: running maximum (:94-95), then the integral
+    float acc = 0.0f;
+    const long long chunks = (m + kMapThreads - 1) / kMapThreads;
+    for (long long ch = chunks - 1; ch >= 0; --ch) {
+        // thread t handles position i = ch * T + (T - 1 - t): scanning t upwards walks i downwards
+        const long long i = ch * kMapThreads + (kMapThreads - 1 - tid);
+        const float neg_inf = __uint_as_float(0xFF800000u);
+        float v = i < m ? prec[begin + i] : neg_inf;
+        float incl;
+        ScanF(tmp.sf).InclusiveScan(v, incl, OpTmax());
+        const float carry_f = s_carry_f;
+        __syncthreads();
+        const float pm = tmaxf(incl, carry_f);
+        if (i < m) {
+            if (voc) {
+#pragma unroll
+                for (int k = 0; k < 11; ++k)
+                    if ((long long)s_cnt[k] == i) s_vocp[k] = pm;
+            } else {
+                const float r = rec[begin + i], r_prev = i > 0 ? rec[begin + i - 1] : 0.0f;
+                acc += (r - r_prev) * pm;                         // (recall[1:] - recall[:-1]) . precision (:105-106)
+            }
+        }
+        if (tid == kMapThreads - 1) s_carry_f = pm;               // lowest position of the chunk
+        __syncthreads();
+    }
+    if (voc) {
+        if (tid == 0) {
+            float s = 0.0f;
+            for (int k = 0; k < 11; ++k) s += s_vocp[k];          // indexes == m select precision[m] = 0 (s_vocp stays 0)
+            ap_out[c] = s / 11.0f;
+        }
+    } else {
+        // the last term (1 - recall[m-1]) * precision[m] is (finite) * 0
+        const float sum = ReduceF(tmp.rf).Sum(acc);
+        if (tid == 0) ap_out[c] = sum;
+    }
+}
+
+__global__ void map_mean_kernel(const float* __restrict__ ap, const int* __restrict__ total_positive, int num_classes, double* map_out) {
+    if (threadIdx.x || blockIdx.x) return;
+    double s = 0.0;
+    int cnt = 0;
+    for (int c = 0; c < num_classes; ++c)
+        if (total_positive[c]) { s += (double)ap[c]; ++cnt; }   // :111 (python floats)
+    *map_out = cnt ? s / cnt : (double)__uint_as_float(0x7FC00000u);
+}
+
+}  // namespace ssdk
+
+using namespace ssdk;
+
+extern "C" size_t ssdk_mean_average_precision_workspace_bytes(long long n_pred, long long total_gt, int num_classes) {
+    if (n_pred < 0 || total_gt < 0 || num_classes <= 0) return 0;
+    return carve_map(nullptr, n_pred, total_gt, num_classes).total;
+}
+
+extern "C" int ssdk_mean_average_precision(const float* predictions, long long n_pred, const float* gt_rows, int gt_stride,
+                                           const int* gt_offsets, int num_images, long long total_gt, int num_classes,
+                                           float iou_threshold, int voc, float* ap_out, double* map_out, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+    SSDK_REQUIRE(n_pred >= 0 && n_pred < (1LL << 31) && total_gt >= 0 && total_gt < (1LL << 31) && num_images >= 0 && num_classes > 0 && num_classes < (1 << 20),
+                 SSDK_E_INVALID, "ssdk_mean_average_precision: n_pred=%lld total_gt=%lld num_images=%d num_classes=%d", n_pred, total_gt, num_images, num_classes);
+    SSDK_REQUIRE(gt_stride >= 5 && gt_offsets && ap_out && map_out && (n_pred == 0 || predictions) && (total_gt == 0 || gt_rows), SSDK_E_INVALID,
+                 "ssdk_mean_average_precision: null pointer or gt_stride=%d < 5", gt_stride);
+    MapWs w = carve_map(workspace, n_pred, total_gt, num_classes);
+    SSDK_REQUIRE(workspace && workspace_bytes >= w.total, SSDK_E_WORKSPACE, "ssdk_mean_average_precision: workspace %zu < %zu bytes", workspace_bytes, w.total);
+    hipStream_t s = (hipStream_t)stream;
+    SSDK_CHECK_HIP(hipMemsetAsync(w.total_positive, 0, sizeof(int) * (size_t)num_classes, s));
+    SSDK_CHECK_HIP(hipMemsetAsync(w.matched, 0, (size_t)(total_gt > 0 ? total_gt : 1), s));
+    const long long work = n_pred > total_gt ? n_pred : total_gt;
+    if (work > 0) {
+        hipLaunchKernelGGL(map_prepare_kernel, dim3((unsigned)cdiv((int)work, 256)), dim3(256), 0, s, predictions, n_pred, gt_rows, gt_stride, total_gt, num_classes,
+                           w.key_a, w.val_a, w.total_positive);
+        SSDK_CHECK_LAUNCH("map_prepare_kernel");
+    }
+    if (n_pred > 0) {
+        const int n = (int)n_pred;
+        size_t need = 0;
+        SSDK_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, need, w.key_a, w.key_b, w.val_a, w.perm_b, n, 0, 64, s));
+        SSDK_REQUIRE(need <= w.cub_bytes, SSDK_E_WORKSPACE, "ssdk_mean_average_precision: sort scratch %zu > %zu bytes", need, w.cub_bytes);
+        // (class, score desc): stable, so equal scores keep the lower row first.  All 64 bits: foreign classes carry ~0.
+        size_t bytes = w.cub_bytes;
+        SSDK_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(w.cub_temp, bytes, w.key_a, w.key_b, w.val_a, w.perm_b, n, 0, 64, s));
+        hipLaunchKernelGGL(map_image_key_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, predictions, n_pred, w.perm_b, w.key_a, w.val_a);
+        SSDK_CHECK_LAUNCH("map_image_key_kernel");
+        // stable sort by image on top: (image, class, score desc); val_b = prediction rows in that order
+        bytes = w.cub_bytes;
+        SSDK_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(w.cub_temp, bytes, w.key_a, w.key_c, w.val_a, w.val_b, n, 0, 32, s));
+        hipLaunchKernelGGL(map_match_kernel, dim3((unsigned)cdiv(n, 128)), dim3(128), 0, s, predictions, n_pred, w.val_b, gt_rows, gt_stride, gt_offsets, num_images,
+                           num_classes, iou_threshold, w.matched, w.flag);
+        SSDK_CHECK_LAUNCH("map_match_kernel");
+    }
+    hipLaunchKernelGGL(map_ap_kernel, dim3((unsigned)num_classes), dim3(kMapThreads), 0, s, w.key_b, w.perm_b, n_pred, w.flag, w.total_positive, voc, w.prec, w.rec, ap_out);
+    SSDK_CHECK_LAUNCH("map_ap_kernel");
+    hipLaunchKernelGGL(map_mean_kernel, dim3(1), dim3(64), 0, s, ap_out, w.total_positive, num_classes, map_out);
+    SSDK_CHECK_LAUNCH("map_mean_kernel");
+    return SSDK_OK;
+}
