@@ -301,6 +301,19 @@ int ssdk_sigmoid_gate_fwd(const float* x, const float* z, int batch, int hw, int
 int ssdk_sigmoid_gate_bwd(const float* x, const float* z, const float* dout, int batch, int hw, int channels, float* dx,
                           float* dz, void* stream);
 
+/* ---- device-resident input side ---------------------------------------------------------------------
+ * bf/core/batch_container.py:25-45  BatchContainer.mixup_ with the random draws (lam ~ Beta(alpha, alpha), index = randperm(B),
+ * roll = rand(B) < p) made by the caller exactly as the reference makes them on the host.
+ *   images: out[i] = roll[i] ? lam * in[i] + (1 - lam) * in[index[i]] : in[i]   (out-of-place; fp32, two roundings like the
+ *   reference's separate multiply and add; lam and 1 - lam are rounded to fp32 first, as torch does for a python scalar).
+ *   ground truth (packed rows [total, gt_stride] + int32 offsets [B + 1], as for ssdk_encode_ground_truth): image i keeps its
+ *   rows with score (column 5) * lam followed by the rows of image index[i] with score * (1 - lam) when roll[i], unchanged
+ *   otherwise (:33-43).  rows_out must hold 2 * total rows; offsets_out [B + 1] is written on the device. */
+int ssdk_mixup_images(const float* in, float* out, int batch, long long per_image, const int* index, const unsigned char* roll,
+                      double lam, void* stream);
+int ssdk_mixup_ground_truth(const float* rows_in, int gt_stride, const int* offsets_in, int batch, const int* index,
+                            const unsigned char* roll, double lam, float* rows_out, int* offsets_out, void* stream);
+
 /* ---- evaluation metric -----------------------------------------------------------------------------
  * detection/metrics/mean_average_precision.py:10-116  mean_average_precision(predictions, gts, class_labels, iou_threshold, voc)
  *   predictions [n_pred, 7] device: image id, corner box, class id, score (the rows bf/eval.py:58-66 builds from the

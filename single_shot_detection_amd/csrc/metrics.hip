@@ -312,3 +312,92 @@ extern "C" int ssdk_mean_average_precision(const float* predictions, long long n
     SSDK_CHECK_LAUNCH("map_mean_kernel");
     return SSDK_OK;
 }
+
+// ---- device-resident input side: mixup (bf/core/batch_container.py:25-45) ----------------------------------------------
+namespace ssdk {
+
+// HBM-bound: 2 reads + 1 write of 16 B per lane for mixed images, a plain copy for the others
+__global__ void mixup_images_kernel(const float4* __restrict__ in, float4* __restrict__ out, long long per_image4, const int* __restrict__ index,
+                                    const unsigned char* __restrict__ roll, float lam, float oml) {
+    const int b = blockIdx.y;
+    const bool mix = roll[b] != 0;
+    const float4* a = in + (long long)b * per_image4;
+    const float4* o = in + (long long)index[b] * per_image4;
+    float4* d = out + (long long)b * per_image4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per_image4; i += (long long)gridDim.x * blockDim.x) {
+        float4 v = a[i];
+        if (mix) {
+            const float4 w = o[i];   // (this TU is built -ffp-contract=off: multiply and add round separately, like the two torch ops)
+            v = make_float4(lam * v.x + oml * w.x, lam * v.y + oml * w.y, lam * v.z + oml * w.z, lam * v.w + oml * w.w);
+        }
+        d[i] = v;
+    }
+}
+__global__ void mixup_images_tail_kernel(const float* __restrict__ in, float* __restrict__ out, long long per_image, long long done, const int* __restrict__ index,
+                                         const unsigned char* __restrict__ roll, float lam, float oml) {
+    const int b = blockIdx.y;
+    const long long i = done + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per_image) return;
+    const float v = in[(long long)b * per_image + i];
+    out[(long long)b * per_image + i] = roll[b] ? lam * v + oml * in[(long long)index[b] * per_image + i] : v;
+}
+
+// one workgroup: offsets by a serial scan over the (small) batch, then the row copies
+__global__ void mixup_gt_kernel(const float* __restrict__ rows_in, int stride, const int* __restrict__ off_in, int batch, const int* __restrict__ index,
+                                const unsigned char* __restrict__ roll, float lam, float oml, float* __restrict__ rows_out, int* __restrict__ off_out) {
+    extern __shared__ int s_off[];
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int b = 0; b < batch; ++b) {
+            s_off[b] = acc;
+            acc += (off_in[b + 1] - off_in[b]) + (roll[b] ? off_in[index[b] + 1] - off_in[index[b]] : 0);
+        }
+        s_off[batch] = acc;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b <= batch; b += blockDim.x) off_out[b] = s_off[b];
+    for (int b = 0; b < batch; ++b) {
+        const int own = off_in[b + 1] - off_in[b];
+        const int other = roll[b] ? off_in[index[b] + 1] - off_in[index[b]] : 0;
+        const int total = (own + other) * stride;
+        for (int e = threadIdx.x; e < total; e += blockDim.x) {
+            const int r = e / stride, c = e % stride;
+            const bool second = r >= own;
+            float v = second ? rows_in[(long long)(off_in[index[b]] + r - own) * stride + c] : rows_in[(long long)(off_in[b] + r) * stride + c];
+            if (c == 5 && roll[b]) v *= second ? oml : lam;   // :38, :40 (SCORE_INDEX)
+            rows_out[(long long)(s_off[b] + r) * stride + c] = v;
+        }
+    }
+}
+
+}  // namespace ssdk
+
+extern "C" int ssdk_mixup_images(const float* in, float* out, int batch, long long per_image, const int* index, const unsigned char* roll,
+                                 double lam, void* stream) {
+    SSDK_REQUIRE(in && out && index && roll && batch > 0 && batch <= 65535 && per_image > 0 && in != out, SSDK_E_INVALID,
+                 "ssdk_mixup_images: batch=%d per_image=%lld (out-of-place only)", batch, per_image);
+    hipStream_t s = (hipStream_t)stream;
+    const float lam_f = (float)lam, oml_f = (float)(1.0 - lam);
+    const bool vec = (per_image % 4 == 0) && (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+    if (vec) {
+        const long long n4 = per_image / 4;
+        const unsigned gx = (unsigned)(n4 / 256 / 4 > 0 ? (n4 / 256 / 4 < 1024 ? n4 / 256 / 4 : 1024) : 1);
+        hipLaunchKernelGGL(mixup_images_kernel, dim3(gx, (unsigned)batch), dim3(256), 0, s, reinterpret_cast<const float4*>(in), reinterpret_cast<float4*>(out), n4, index,
+                           roll, lam_f, oml_f);
+    } else {
+        hipLaunchKernelGGL(mixup_images_tail_kernel, dim3((unsigned)((per_image + 255) / 256), (unsigned)batch), dim3(256), 0, s, in, out, per_image, 0LL, index, roll,
+                           lam_f, oml_f);
+    }
+    SSDK_CHECK_LAUNCH("mixup_images_kernel");
+    return SSDK_OK;
+}
+
+extern "C" int ssdk_mixup_ground_truth(const float* rows_in, int gt_stride, const int* offsets_in, int batch, const int* index,
+                                       const unsigned char* roll, double lam, float* rows_out, int* offsets_out, void* stream) {
+    SSDK_REQUIRE(offsets_in && index && roll && rows_out && offsets_out && batch > 0 && batch <= 8192 && gt_stride >= 6, SSDK_E_INVALID,
+                 "ssdk_mixup_ground_truth: batch=%d gt_stride=%d", batch, gt_stride);
+    hipLaunchKernelGGL(mixup_gt_kernel, dim3(1), dim3(256), sizeof(int) * (size_t)(batch + 1), (hipStream_t)stream, rows_in, gt_stride, offsets_in, batch, index, roll,
+                       (float)lam, (float)(1.0 - lam), rows_out, offsets_out);
+    SSDK_CHECK_LAUNCH("mixup_gt_kernel");
+    return SSDK_OK;
+}

@@ -58,3 +58,35 @@ def test_map_mirror_api_and_edge_cases():
     m1, _ = _run(np.concatenate([pred, extra]), gts, kw['num_classes'], False)
     m2, _ = oracle.mean_average_precision(np.concatenate([pred, extra]), gts, kw['num_classes'], 0.5, False)
     assert abs(m1 - m2) <= 2e-6
+
+
+# ---- device-resident mixup -------------------------------------------------------------------------------
+@pytest.mark.parametrize('case', ['a', 'b', 'c'])
+def test_mixup_vs_reference_golden(case):
+    """BatchContainer.mixup_ (bf/core/batch_container.py:25-45): same seeds -> same draws -> bit-identical images and targets."""
+    from single_shot_detection_amd.bf.core.batch_container import BatchContainer
+    from single_shot_detection_amd.bf.core.target_types import TargetTypes
+    g = load_golden('mixup')
+    B, alpha, p, seed = g[case + '_args']
+    B, seed = int(B), int(seed)
+    shape = tuple(int(v) for v in g[case + '_shape'])
+    imgs = np.random.default_rng(seed).standard_normal((B,) + shape).astype(np.float32)
+    gts = syn.make_ground_truth(B, 64, 9, seed=seed)
+    batch = BatchContainer([(torch.from_numpy(imgs[i].copy()), torch.from_numpy(gts[i].copy())) for i in range(B)], TargetTypes.Boxes)
+    batch.to_(torch.device('cuda:0'))
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    batch.mixup_(float(alpha), float(p))
+    out_imgs, out_t = batch.get()
+    assert out_imgs.is_cuda and all(t.is_cuda for t in out_t)
+    assert np.array_equal(out_imgs.cpu().numpy().view(np.uint32), g[case + '_imgs_out'].view(np.uint32))
+    offs = g[case + '_offs_out']
+    assert [t.size(0) for t in out_t] == list(np.diff(offs))
+    rows = torch.cat(list(out_t), 0).cpu().numpy() if offs[-1] else np.zeros((0, 6), np.float32)
+    assert np.array_equal(rows.view(np.uint32), g[case + '_rows_out'].view(np.uint32))
+    # the mixed targets feed the soft-target path of the assigner unchanged
+    from single_shot_detection_amd.detection.target_assigner import TargetAssigner
+    anchors = torch.from_numpy(oracle.anchors(syn.CONFIGS['ssd_mb2_voc']['anchor'], 300, syn.CONFIGS['ssd_mb2_voc']['levels'])).cuda()
+    target = TargetAssigner(0.5, 0.5).encode_ground_truth(list(out_t), anchors)
+    ref = oracle.encode_ground_truth([t.cpu().numpy() for t in out_t], anchors.cpu().numpy(), 0.5, 0.5)
+    assert np.array_equal(target.cpu().numpy().view(np.uint32), ref.view(np.uint32))

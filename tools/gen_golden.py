@@ -450,6 +450,39 @@ def gen_map(out_dir):
     print(f'map -> {path} ({os.path.getsize(path) / 1e3:.1f} KB)')
 
 
+def gen_mixup(out_dir):
+    """bf/core/batch_container.py:25-45 BatchContainer.mixup_ on a seeded batch; the draws are re-made in the same order to record them."""
+    from bf.core.batch_container import BatchContainer
+    from bf.core.target_types import TargetTypes
+    from single_shot_detection_amd import synthetic as syn
+    res = {}
+    for case, (B, shape, alpha, p, seed) in {'a': (6, (3, 8, 12), 1.5, 0.5, 3), 'b': (5, (3, 7, 9), 0.4, 0.9, 4), 'c': (4, (1, 5, 5), 2.0, 0.0, 5)}.items():
+        rng = np.random.default_rng(seed)
+        imgs = rng.standard_normal((B,) + shape).astype(np.float32)
+        gts = syn.make_ground_truth(B, 64, 9, seed=seed)
+        batch = BatchContainer([(torch.from_numpy(imgs[i].copy()), torch.from_numpy(gts[i].copy())) for i in range(B)], TargetTypes.Boxes)
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        lam = np.random.beta(alpha, alpha)
+        index = torch.randperm(B)
+        roll = torch.rand(B) < p
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        batch.mixup_(alpha, p)
+        out_imgs, out_t = batch.get()
+        res[case + '_args'] = np.array([B, alpha, p, seed], np.float64)
+        res[case + '_shape'] = np.array(shape, np.int64)
+        res[case + '_lam'] = np.float64(lam)
+        res[case + '_index'] = index.numpy().astype(np.int32)
+        res[case + '_roll'] = roll.numpy().astype(np.uint8)
+        res[case + '_imgs_out'] = out_imgs.numpy()
+        res[case + '_rows_out'] = np.concatenate([t.numpy().reshape(-1, 6) for t in out_t], 0).astype(np.float32)
+        res[case + '_offs_out'] = np.concatenate([[0], np.cumsum([t.size(0) for t in out_t])]).astype(np.int32)
+    path = os.path.join(out_dir, 'mixup.npz')
+    np.savez_compressed(path, **res)
+    print(f'mixup -> {path} ({os.path.getsize(path) / 1e3:.1f} KB)')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(REPO, 'tests', 'golden'))
@@ -466,6 +499,8 @@ def main():
         gen_losses_extra(args.out)
     if args.only in (None, 'map'):
         gen_map(args.out)
+    if args.only in (None, 'mixup'):
+        gen_mixup(args.out)
     for name, b in batches.items():
         if args.only in (None, name):
             gen_config(name, args.out, b)
