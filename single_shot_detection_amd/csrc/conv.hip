@@ -79,6 +79,11 @@ struct ConvProblem {
     const int* row_list;
     const int* row_count;
     int sc_cin;  // scatter: output channels per tap (n = tap * sc_cin + c)
+    // SCATTER, segmented rows (anchor-granular sparse backward): the row space is `segs` segments of seg_cap rows, of which the
+    // first seg_count[s] exist; segment s multiplies with the weight block w0 + s * w_seg_stride
+    const int* seg_count;
+    int seg_cap, segs;
+    long long w_seg_stride;
     // column index space: [0, n0) = rows of w0, [n0, n0_pad) unused, [n0_pad, n0_pad + n1) = rows of w1.  n0_pad = n0 except for
     // the LDS-DMA kernel, which rounds it up to 8 so that every 8-row DMA piece reads ONE weight tensor (one descriptor)
     int n0_pad;
@@ -260,8 +265,19 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? SSDK_CONV_WAVES : 1) 
     const int K = taps * Cc;
     const int N = g.n0_pad + g.n1;
     const int hw = g.Hout * g.Wout;
-    const int M = (SCATTER && g.row_list) ? *g.row_count : g.B * hw;
-    if (SCATTER && m_tile * BM >= M) return;
+    int M = (SCATTER && g.row_list && !g.seg_count) ? *g.row_count : g.B * hw;   // one past the last existing row
+    int m_base = m_tile * BM;                                                     // first row of this workgroup
+    const float* w0p = g.w0;
+    if (SCATTER && g.seg_count) {
+        const int tiles_per_seg = (g.seg_cap + BM - 1) / BM;
+        const int seg = m_tile / tiles_per_seg, local = m_tile % tiles_per_seg;
+        const int cnt = g.seg_count[seg];
+        if (local * BM >= cnt) return;
+        m_base = seg * g.seg_cap + local * BM;
+        M = seg * g.seg_cap + cnt;
+        w0p += (long long)seg * g.w_seg_stride;
+    }
+    if (SCATTER && m_base >= M) return;
 
     const int base_t = g.tiles_n / g.n_blocks, rem_t = g.tiles_n % g.n_blocks;
     const int tn = base_t + (n_block < rem_t ? 1 : 0);
@@ -283,12 +299,13 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? SSDK_CONV_WAVES : 1) 
     for (int i = 0; i < 4; ++i) {
         const int row = 8 * i + (lane >> 3);                       // row inside the wave's 32
         const int src_chunk = (lane & 7) ^ ((row >> 1) & 7);       // swizzle (row + 32*wave has the same bits 1..3)
-        const int m = m_tile * BM + wave * 32 + row;
+        const int m = m_base + wave * 32 + row;
         a_vo[i] = kOobBit;
         a_nmask[i] = 0;
         if (m < M) {
             if (SCATTER) {
-                a_vo[i] = (unsigned)((g.row_list ? g.row_list[m] : m) * a_ps + src_chunk * 4) * 4u;
+                // (pixel-sparse rows index the dense packed dY through row_list; segmented rows are stored compacted)
+                a_vo[i] = (unsigned)((g.seg_count ? m : (g.row_list ? g.row_list[m] : m)) * a_ps + src_chunk * 4) * 4u;
             } else {
                 const int b = m / hw, r = m % hw;
                 const int y = r / g.Wout, x = r % g.Wout;
@@ -329,10 +346,10 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? SSDK_CONV_WAVES : 1) 
     }
 
     // buffer descriptors (wave-uniform): A window starts `shift` elements before the tensor, W window spans both segments
-    const long long a_records = ((long long)g.B * g.a_bstride - shift) * 4;
+    const long long a_records = (SCATTER && g.seg_count) ? (long long)g.segs * g.seg_cap * a_ps * 4 : ((long long)g.B * g.a_bstride - shift) * 4;
     const __amdgpu_buffer_rsrc_t rsrc_a =
         __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(g.a + shift), 0, (int)(a_records > 0x7FFFFFFFLL ? 0x7FFFFFFFLL : a_records), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_w0 = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(g.w0), 0, (int)g.w0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w0 = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(w0p), 0, (int)g.w0_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_w1 = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(g.w1 ? g.w1 : g.w0), 0, (int)(g.w1 ? g.w1_bytes : 0), 0x00020000);
 
     // position of the next slice to stage: channel chunk outer, tap inner (the taps of a chunk re-read rows still in L1/L2)
@@ -438,7 +455,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? SSDK_CONV_WAVES : 1) 
         case 2: k_loop(std::integral_constant<int, 2>{}); break;
         default: k_loop(std::integral_constant<int, 1>{}); break;
     }
-    conv_epilogue<SCATTER>(g, acc, m_tile * BM, wave, r32, h, tn, n_begin, M, N, hw, ksp);
+    conv_epilogue<SCATTER>(g, acc, m_base, wave, r32, h, tn, n_begin, M, N, hw, ksp);
 }
 
 // ---- forward / backward-data ------------------------------------------------------------------------------------
@@ -701,6 +718,11 @@ struct WgradProblem {
     int want_mode;
     const int* row_list;   // sparse: contract only over these pixel ids (*row_count of them)
     const int* row_count;
+    // segmented (anchor-granular sparse backward): `segs` independent problems that share x: segment s has seg_count[s] rows of dy at
+    // dy + s * seg_cap * Npad, their pixel ids at row_list + s * seg_cap, and adds into dw0 + s * dw0_seg / dw1 + s * dw1_seg
+    const int* seg_count;
+    int segs, seg_cap;
+    long long dw0_seg, dw1_seg;
 };
 struct WgradGroup {
     int count;
@@ -727,8 +749,19 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_wgrad_ker
     const int ksp = id % g.k_splits; id /= g.k_splits;
     const int cb = id % g.c_blocks; id /= g.c_blocks;
     const int nt = id % g.n_tiles; id /= g.n_tiles;
-    const int tap = id;
+    const int tap = id % taps;
+    const int seg = id / taps;
     const int ky = tap / g.ksize, kx = tap % g.ksize;
+    const float* dy_p = g.dy;
+    const int* rows_p = g.row_list;
+    float* dw0_p = g.dw0;
+    float* dw1_p = g.dw1;
+    if (g.seg_count) {
+        dy_p += (long long)seg * g.seg_cap * g.Npad;
+        rows_p += (long long)seg * g.seg_cap;
+        dw0_p += (long long)seg * g.dw0_seg;
+        if (dw1_p) dw1_p += (long long)seg * g.dw1_seg;
+    }
 
     const int base_t = g.c_tiles32 / g.c_blocks, rem_t = g.c_tiles32 % g.c_blocks;
     const int tn = base_t + (cb < rem_t ? 1 : 0);
@@ -736,7 +769,7 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_wgrad_ker
     const int n_begin = nt * 128;
 
     const int hw = g.Hout * g.Wout;
-    const int M = g.row_list ? *g.row_count : g.B * hw;   // rows of the contraction (compacted when sparse)
+    const int M = g.seg_count ? g.seg_count[seg] : (g.row_list ? *g.row_count : g.B * hw);   // rows of the contraction (compacted when sparse)
     const int slices_total = (M + 31) / 32;
     const int per = (slices_total + g.k_splits - 1) / g.k_splits;
     const int s_begin = ksp * per, s_end = min(slices_total, s_begin + per);
@@ -760,8 +793,9 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_wgrad_ker
             const int mi = s * 32 + srow + p * 8;
             float4 vd = make_float4(0.f, 0.f, 0.f, 0.f), vx = vd;
             if (mi < M) {
-                const int m = g.row_list ? g.row_list[mi] : mi;
-                if (n_begin + scol < g.Npad) vd = *reinterpret_cast<const float4*>(g.dy + (long long)m * g.Npad + n_begin + scol);
+                const int m = rows_p ? rows_p[mi] : mi;   // pixel id of row mi
+                // (segmented: the dy rows are stored compacted, row mi of the segment; otherwise dy is indexed by pixel)
+                if (n_begin + scol < g.Npad) vd = *reinterpret_cast<const float4*>(dy_p + (long long)(g.seg_count ? mi : m) * g.Npad + n_begin + scol);
                 const int c = c_begin + scol;
                 if (scol < tn * 32 && c < Cc) {
                     const int b = m / hw, pix = m % hw;
@@ -817,7 +851,7 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_wgrad_ker
     for (int e = 0; e < 16; ++e) {
         const int n = n_begin + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (n >= N) continue;
-        float* row = n < g.n0 ? g.dw0 + (long long)n * K : g.dw1 + (long long)(n - g.n0) * K;
+        float* row = n < g.n0 ? dw0_p + (long long)n * K : dw1_p + (long long)(n - g.n0) * K;
 #pragma unroll
         for (int j = 0; j < kMaxTN; ++j) {
             if (j >= tn) continue;
@@ -839,6 +873,10 @@ struct PackLevel {
     float* out; float* db0; float* db1;
     int* row_list; int* row_count;
     int block_begin;
+    // anchor-granular rows (ga == NULL: not produced): anchor type k of a pixel owns C score columns [k*C, (k+1)*C) and 4 loc
+    // columns; every anchor with a non-zero gradient becomes one row [Jpad] of segment k: C scores, 4 locs, zero padding
+    int nb, C, Jpad, cap;
+    float* ga; int* apix; int* acount;
 };
 struct PackGroup {
     int count, B;
@@ -876,6 +914,13 @@ __global__ void __launch_bounds__(256) pack_dy_kernel(PackGroup grp) {
 #pragma unroll
     for (int k = 0; k < kPackColIters; ++k) acc[k] = 0.0f;
     unsigned mine = 0u;
+    // anchor type of each of this lane's columns (bit mask positions): fixed for the block
+    unsigned char col_anchor[kPackColIters];
+#pragma unroll
+    for (int k = 0; k < kPackColIters; ++k) {
+        const int n = k * 64 + lane;
+        col_anchor[k] = (L.ga && n < N) ? (unsigned char)(n < n0 ? n / L.C : (n - n0) / 4) : (unsigned char)31;
+    }
     for (int r = wave; r < kPackRows; r += 4) {
         const int m = m0 + r;
         if (m >= M) break;
@@ -884,6 +929,7 @@ __global__ void __launch_bounds__(256) pack_dy_kernel(PackGroup grp) {
         const float* lrow = dl ? dl + (long long)b * lb + (long long)p * n1 : nullptr;
         float* orow = out + (long long)m * Npad;
         bool nz = false;
+        unsigned amask = 0u;   // anchor types of this row that carry a gradient (as seen by this lane)
 #pragma unroll
         for (int k = 0; k < kPackColIters; ++k) {
             if (k >= iters) break;
@@ -893,9 +939,22 @@ __global__ void __launch_bounds__(256) pack_dy_kernel(PackGroup grp) {
                 orow[n] = v;
                 acc[k] += v;
                 nz = nz || v != 0.0f;
+                if (v != 0.0f) amask |= 1u << (col_anchor[k] & 31);
             }
         }
         if (__ballot(nz)) mine |= 1u << r;
+        if (L.ga) {
+            for (int a = 0; a < L.nb; ++a) {
+                if (!__ballot((amask >> a) & 1u)) continue;   // (uniform)
+                int idx = 0;
+                if (lane == 0) idx = atomicAdd(L.acount + a, 1);
+                idx = __shfl(idx, 0, kWave);
+                float* grow = L.ga + ((long long)a * L.cap + idx) * L.Jpad;
+                for (int j = lane; j < L.Jpad; j += kWave)
+                    grow[j] = j < L.C ? srow[a * L.C + j] : (j < L.C + 4 ? lrow[a * 4 + j - L.C] : 0.0f);
+                if (lane == 0) L.apix[(long long)a * L.cap + idx] = m;
+            }
+        }
     }
 #pragma unroll
     for (int k = 0; k < kPackColIters; ++k)
@@ -919,10 +978,23 @@ __global__ void __launch_bounds__(256) pack_dy_kernel(PackGroup grp) {
 // mode[i] = 1 (sparse backward) when fewer than 70 % of the level's pixel rows carry a gradient, else 0 (dense).
 // The sparse forms never do more multiplies than the dense ones; what they add is the scatter's atomic traffic
 // (rows * 9 * Cin * 4 bytes), which costs about a third of the dense GEMM time at full density.
-struct LevelTotals { int v[kMaxProblems]; };
-__global__ void decide_sparse_kernel(const int* __restrict__ counts, LevelTotals totals, int n, int* __restrict__ mode) {
+// Mode 2 (anchor-granular rows): a row is one ANCHOR with a non-zero gradient -- C + 4 columns instead of the nb * (C + 4) of
+// its pixel -- multiplied with the weight rows of its anchor type only.  With hard-negative mining a pixel rarely has more than
+// one sampled anchor, so this does 1/nb of the multiplies of mode 1.  Chosen when rows * Jpad < 0.8 * pixel_rows * Npad.
+constexpr int kMaxAnchorTypes = 16;
+struct LevelTotals { int v[kMaxProblems]; int nb[kMaxProblems]; int jpad[kMaxProblems]; int npad[kMaxProblems]; int force; };
+__global__ void decide_sparse_kernel(const int* __restrict__ counts, const int* __restrict__ acounts, LevelTotals totals, int n, int* __restrict__ mode) {
     const int i = threadIdx.x;
-    if (i < n) mode[i] = ((long long)counts[i] * 10 < (long long)totals.v[i] * 7) ? 1 : 0;
+    if (i >= n) return;
+    int m = ((long long)counts[i] * 10 < (long long)totals.v[i] * 7) ? 1 : 0;
+    if (totals.nb[i] > 0) {
+        long long rows = 0;
+        for (int k = 0; k < totals.nb[i]; ++k) rows += acounts[i * kMaxAnchorTypes + k];
+        if (m == 1 && rows * totals.jpad[i] * 10 < (long long)counts[i] * totals.npad[i] * 8) m = 2;
+        if (totals.force == 2) m = 2;
+    }
+    if (totals.force == 0 || totals.force == 1) m = totals.force;
+    mode[i] = m;
 }
 
 // db[n] += sum over rows of dy[row][n]   (dense [M][N] rows)
@@ -975,6 +1047,60 @@ __global__ void __launch_bounds__(256) transpose_tapmajor_kernel(const float* __
     for (int r = ty; r < 32; r += 8) {
         const int c = cb + r, n = nb + tx;
         if (n < Npad && c < Cc) wt[((long long)tap * Cc + c) * Npad + n] = tile[tx][r];
+    }
+}
+
+// All weight re-layouts of one heads backward in ONE launch (18 launches of ~5 us each before): a job table, 32x32 tiles.
+//   kind 0: out[c][tap][n]  (n < Npad)  = W[n][tap][c]   (dense dgrad)          kind 1: out[tap][c][n] = W[n][tap][c]  (scatter dgrad)
+//   kind 2: out[k][tap*Cc + c][j] (j < Jpad) = anchor type k's C score rows + 4 loc rows (anchor-granular scatter dgrad)
+struct TransposeJob {
+    const float* w0; const float* w1; float* out;
+    int kind, n0, n1, Npad, taps, Cc, C, Jpad;
+    int tiles_x, tiles_y, block_begin;   // tiles_x * tiles_y * depth blocks, depth = taps (kinds 0, 1) or anchor types (kind 2)
+};
+constexpr int kMaxTransposeJobs = 3 * kMaxProblems;
+struct TransposeGroup { int count; TransposeJob j[kMaxTransposeJobs]; };
+__global__ void __launch_bounds__(256) transpose_group_kernel(TransposeGroup grp) {
+    __shared__ float tile[32][33];
+    int ji = 0;
+#pragma unroll 1
+    for (int i = 1; i < grp.count; ++i)
+        if ((int)blockIdx.x >= grp.j[i].block_begin) ji = i;
+    const TransposeJob& J = grp.j[ji];
+    int id = blockIdx.x - J.block_begin;
+    const int bx = id % J.tiles_x; id /= J.tiles_x;
+    const int by = id % J.tiles_y; id /= J.tiles_y;
+    const int bz = id;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    if (J.kind == 2) {
+        const int K = J.taps * J.Cc, k = bz, jb = bx * 32, nb_ = by * 32;
+        for (int r = ty; r < 32; r += 8) {
+            const int j = jb + r, n = nb_ + tx;
+            float v = 0.0f;
+            if (n < K) {
+                if (j < J.C) v = J.w0[((long long)k * J.C + j) * K + n];
+                else if (j < J.C + 4) v = J.w1[((long long)k * 4 + (j - J.C)) * K + n];
+            }
+            tile[r][tx] = v;
+        }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {
+            const int n = nb_ + r, j = jb + tx;
+            if (n < K && j < J.Jpad) J.out[((long long)k * K + n) * J.Jpad + j] = tile[tx][r];
+        }
+        return;
+    }
+    const int N = J.n0 + J.n1, tap = bz, nb = bx * 32, cb = by * 32, taps = J.taps, Cc = J.Cc;
+    for (int r = ty; r < 32; r += 8) {
+        const int n = nb + r, c = cb + tx;
+        float v = 0.0f;
+        if (n < N && c < Cc) v = n < J.n0 ? J.w0[((long long)n * taps + tap) * Cc + c] : J.w1[((long long)(n - J.n0) * taps + tap) * Cc + c];
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = cb + r, n = nb + tx;
+        if (n < J.Npad && c < Cc) J.out[(J.kind == 0 ? ((long long)c * taps + tap) : ((long long)tap * Cc + c)) * J.Npad + n] = tile[tx][r];
     }
 }
 
@@ -1097,6 +1223,8 @@ static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t 
     }
     grp.count = count;
     grp.total_blocks = begin;
+    for (int i = 0; i < count; ++i)
+        SSDK_REQUIRE(dma || !grp.p[i].seg_count, SSDK_E_UNSUPPORTED, "segmented scatter rows need the LDS-DMA kernel");
     if (dma && w8) {
         if (mirror) hipLaunchKernelGGL((igemm_dma_kernel<true, false, false, 8>), dim3(begin), dim3(512), 0, s, grp);
         else if (generic) hipLaunchKernelGGL((igemm_dma_kernel<false, true, false, 8>), dim3(begin), dim3(512), 0, s, grp);
@@ -1135,6 +1263,13 @@ static int check_level(const char* fn, int batch, const ssdk_head_level& lv) {
 }
 
 static inline int npad_of(const ssdk_head_level& lv) { return cdiv(lv.n_score + lv.n_loc, 32) * 32; }
+// anchor types per pixel (0: unknown -- no loc head, or a layout the anchor-granular backward does not cover)
+static inline int anchor_types_of(const ssdk_head_level& lv) {
+    if (lv.n_loc <= 0 || lv.n_loc % 4) return 0;
+    const int nb = lv.n_loc / 4;
+    return (nb <= kMaxAnchorTypes && lv.n_score % nb == 0 && lv.cin % kBK == 0) ? nb : 0;
+}
+static inline int jpad_of(const ssdk_head_level& lv) { return cdiv(lv.n_score / (lv.n_loc / 4) + 4, 32) * 32; }
 
 extern "C" int ssdk_heads_fwd(const ssdk_head_level* levels, int n_levels, int batch, float* scores,
                               long long scores_batch_stride, float* locs, long long locs_batch_stride, void* stream) {
@@ -1164,6 +1299,10 @@ struct HeadsBwdWs {
     float* wd[kMaxProblems];
     float* wt[kMaxProblems];
     int* row_list[kMaxProblems];
+    float* ga[kMaxProblems];    // anchor-granular gradient rows [nb][B*HW][Jpad] (NULL: level has no loc head -> no anchor mode)
+    int* apix[kMaxProblems];    // their pixel ids [nb][B*HW]
+    float* wa[kMaxProblems];    // per-anchor-type transposed weights [nb][9*Cin][Jpad]
+    int* acounts;               // [kMaxProblems][kMaxAnchorTypes]
     int* counts;  // [kMaxProblems] non-zero gradient rows per level
     int* totals;  // [kMaxProblems] pixel rows per level
     int* mode;    // [kMaxProblems] 1 = sparse backward, 0 = dense
@@ -1173,11 +1312,19 @@ static HeadsBwdWs carve_heads_bwd(void* ws, const ssdk_head_level* levels, int n
     Carver c(ws);
     HeadsBwdWs w{};
     w.counts = c.take<int>(kMaxProblems);
+    w.acounts = c.take<int>(kMaxProblems * kMaxAnchorTypes);
     w.totals = c.take<int>(kMaxProblems);
     w.mode = c.take<int>(kMaxProblems);
     for (int i = 0; i < n_levels; ++i) {
         const ssdk_head_level& lv = levels[i];
         const size_t npad = (size_t)npad_of(lv), M = (size_t)batch * lv.h * lv.w;
+        const int nb = anchor_types_of(lv);
+        if (nb) {
+            const size_t jpad = (size_t)jpad_of(lv);
+            w.ga[i] = c.take<float>((size_t)nb * M * jpad);
+            w.apix[i] = c.take<int>((size_t)nb * M);
+            w.wa[i] = c.take<float>((size_t)nb * 9 * lv.cin * jpad);
+        }
         w.dyp[i] = c.take<float>(M * npad);
         w.wd[i] = c.take<float>((size_t)lv.cin * 9 * npad);
         w.wt[i] = c.take<float>((size_t)lv.cin * 9 * npad);
@@ -1201,7 +1348,7 @@ static void size_wgrad_splits(WgradGroup& wg, int n, int density_div) {
     for (int i = 0; i < n; ++i) {
         WgradProblem& g = wg.p[i];
         const int slices = cdiv(cdiv(g.B * g.Hout * g.Wout, density_div), 32);
-        const int tiles = g.ksize * g.ksize * g.n_tiles * g.c_blocks;
+        const int tiles = g.ksize * g.ksize * g.n_tiles * g.c_blocks * (g.seg_count ? g.segs : 1);
         int ks = cdiv(512, tiles);
         if (cdiv(slices, 64) > ks) ks = cdiv(slices, 64);
         if (ks > slices / 2) ks = slices / 2;
@@ -1232,8 +1379,18 @@ extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int b
         SSDK_REQUIRE(npad_of(levels[i]) <= kPackColIters * 64, SSDK_E_UNSUPPORTED, "ssdk_heads_bwd: n_score + n_loc = %d exceeds %d",
                      levels[i].n_score + levels[i].n_loc, kPackColIters * 64);
         h_totals.v[i] = batch * levels[i].h * levels[i].w;
+        h_totals.nb[i] = anchor_types_of(levels[i]);
+        // (the anchor-granular form exists on the LDS-DMA kernel only: operands below 2 GiB)
+        if (getenv("SSDK_CONV_NO_DMA") || (long long)h_totals.nb[i] * h_totals.v[i] * (h_totals.nb[i] ? jpad_of(levels[i]) : 0) * 4 >= (1LL << 31) - 65536) h_totals.nb[i] = 0;
+        h_totals.jpad[i] = h_totals.nb[i] ? jpad_of(levels[i]) : 0;
+        h_totals.npad[i] = npad_of(levels[i]);
+    }
+    {   // test / experiment hook: SSDK_HEADS_BWD_MODE = 0 dense, 1 pixel-sparse, 2 anchor-granular (where available), unset: by density
+        const char* f = getenv("SSDK_HEADS_BWD_MODE");
+        h_totals.force = f ? atoi(f) : -1;
     }
     SSDK_CHECK_HIP(hipMemsetAsync(w.counts, 0, sizeof(int) * kMaxProblems, s));
+    SSDK_CHECK_HIP(hipMemsetAsync(w.acounts, 0, sizeof(int) * kMaxProblems * kMaxAnchorTypes, s));
 
     // 0. zero everything the atomics of this call add into, in one launch (two when > 32 buffers)
     {
@@ -1262,29 +1419,36 @@ extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int b
             L.ds = dscores + lv.scores_offset; L.dl = lv.n_loc ? dlocs + lv.locs_offset : nullptr;
             L.n0 = lv.n_score; L.n1 = lv.n_loc; L.Npad = npad_of(lv); L.HW = lv.h * lv.w;
             L.out = w.dyp[i]; L.db0 = lv.db_score; L.db1 = lv.db_loc; L.row_list = w.row_list[i]; L.row_count = w.counts + i;
+            if (h_totals.nb[i]) {
+                L.nb = h_totals.nb[i]; L.C = lv.n_score / L.nb; L.Jpad = h_totals.jpad[i]; L.cap = batch * L.HW;
+                L.ga = w.ga[i]; L.apix = w.apix[i]; L.acount = w.acounts + i * kMaxAnchorTypes;
+            }
             L.block_begin = begin;
             begin += cdiv(batch * L.HW, kPackRows);
         }
         hipLaunchKernelGGL(pack_dy_kernel, dim3(begin), dim3(256), 0, s, pg);
         SSDK_CHECK_LAUNCH("pack_dy_kernel");
     }
-    hipLaunchKernelGGL(decide_sparse_kernel, dim3(1), dim3(64), 0, s, w.counts, h_totals, n_levels, w.mode);
+    hipLaunchKernelGGL(decide_sparse_kernel, dim3(1), dim3(64), 0, s, w.counts, w.acounts, h_totals, n_levels, w.mode);
     SSDK_CHECK_LAUNCH("decide_sparse_kernel");
 
     // 2. backward-data.  dense: dX[m][c] = sum_(tap,n) dY[m + pad - tap][n] * W[n][tap][c] (output stationary);
     //    sparse: T[row][tap*Cin + c] = dY[row][:] . W[:, tap, c] for the non-zero rows only, scatter-added into dX.
-    ConvProblem dense[kMaxProblems], sparse[kMaxProblems];
-    int n_dgrad = 0;
+    ConvProblem dense[kMaxProblems], sparse[kMaxProblems], anchor[kMaxProblems];
+    int n_dgrad = 0, n_anchor = 0;
+    TransposeGroup tg{};
+    int t_blocks = 0;
     for (int i = 0; i < n_levels; ++i) {
         const ssdk_head_level& lv = levels[i];
         if (!lv.dx) continue;
         const int npad = npad_of(lv), hw = lv.h * lv.w;
-        hipLaunchKernelGGL(transpose_taps_kernel, dim3(cdiv(npad, 32), cdiv(lv.cin, 32), 9), dim3(256), 0, s, lv.w_score, lv.w_loc,
-                           lv.n_score, lv.n_loc, npad, 9, lv.cin, w.wd[i]);
-        SSDK_CHECK_LAUNCH("transpose_taps_kernel");
-        hipLaunchKernelGGL(transpose_tapmajor_kernel, dim3(cdiv(npad, 32), cdiv(lv.cin, 32), 9), dim3(256), 0, s, lv.w_score, lv.w_loc,
-                           lv.n_score, lv.n_loc, npad, 9, lv.cin, w.wt[i]);
-        SSDK_CHECK_LAUNCH("transpose_tapmajor_kernel");
+        for (int kind = 0; kind < 2; ++kind) {
+            TransposeJob& J = tg.j[tg.count++];
+            J.w0 = lv.w_score; J.w1 = lv.w_loc; J.out = kind == 0 ? w.wd[i] : w.wt[i];
+            J.kind = kind; J.n0 = lv.n_score; J.n1 = lv.n_loc; J.Npad = npad; J.taps = 9; J.Cc = lv.cin;
+            J.tiles_x = cdiv(npad, 32); J.tiles_y = cdiv(lv.cin, 32); J.block_begin = t_blocks;
+            t_blocks += J.tiles_x * J.tiles_y * 9;
+        }
         ConvProblem g{};
         g.a = w.dyp[i]; g.a_bstride = (long long)hw * npad; g.a_pstride = npad; g.Cc = npad;
         g.B = batch; g.Hout = lv.h; g.Wout = lv.w; g.Hin = lv.h; g.Win = lv.w; g.ksize = 3; g.stride = 1; g.pad = 1;
@@ -1299,6 +1463,27 @@ extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int b
         finish_problem(q);  // m_tiles for the worst case; workgroups past the real row count exit at once
         sparse[n_dgrad] = q;
         ++n_dgrad;
+        if (h_totals.nb[i]) {   // anchor-granular rows: segment k = anchor type k, weights Wa[k]
+            const int nb = h_totals.nb[i], jpad = h_totals.jpad[i], C = lv.n_score / nb;
+            TransposeJob& J = tg.j[tg.count++];
+            J.w0 = lv.w_score; J.w1 = lv.w_loc; J.out = w.wa[i];
+            J.kind = 2; J.taps = 9; J.Cc = lv.cin; J.C = C; J.Jpad = jpad;
+            J.tiles_x = cdiv(jpad, 32); J.tiles_y = cdiv(9 * lv.cin, 32); J.block_begin = t_blocks;
+            t_blocks += J.tiles_x * J.tiles_y * nb;
+            ConvProblem r = q;
+            r.a = w.ga[i]; r.a_pstride = jpad; r.Cc = jpad; r.a_bstride = (long long)hw * jpad * nb;
+            r.w0 = w.wa[i]; r.row_list = w.apix[i]; r.row_count = nullptr;
+            r.seg_count = w.acounts + i * kMaxAnchorTypes; r.seg_cap = batch * hw; r.segs = nb; r.w_seg_stride = (long long)9 * lv.cin * jpad;
+            r.want_mode = 2;
+            finish_problem(r);
+            r.m_tiles = nb * cdiv(batch * hw, kBM);
+            r.m_tiles256 = nb * cdiv(batch * hw, 256);
+            anchor[n_anchor++] = r;
+        }
+    }
+    if (tg.count) {
+        hipLaunchKernelGGL(transpose_group_kernel, dim3(t_blocks), dim3(256), 0, s, tg);
+        SSDK_CHECK_LAUNCH("transpose_group_kernel");
     }
     if (n_dgrad) {
         int rc = launch_group(dense, n_dgrad, true, s);
@@ -1306,10 +1491,14 @@ extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int b
         rc = launch_group(sparse, n_dgrad, false, s, false, true);
         if (rc) return rc;
     }
+    if (n_anchor) {
+        int rc = launch_group(anchor, n_anchor, false, s, false, true);
+        if (rc) return rc;
+    }
 
     // 3. backward-weights, dense (all pixels) or sparse (only the listed rows)
-    WgradGroup wd_{}, ws_{};
-    int n_wgrad = 0;
+    WgradGroup wd_{}, ws_{}, wa_{};
+    int n_wgrad = 0, n_wanchor = 0;
     for (int i = 0; i < n_levels; ++i) {
         const ssdk_head_level& lv = levels[i];
         if (!lv.dw_score) continue;
@@ -1326,6 +1515,15 @@ extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int b
         g.want_mode = 1; g.row_list = w.row_list[i]; g.row_count = w.counts + i;
         ws_.p[n_wgrad] = g;
         ++n_wgrad;
+        if (h_totals.nb[i]) {
+            const int nb = h_totals.nb[i], C = lv.n_score / nb;
+            WgradProblem a = g;
+            a.dy = w.ga[i]; a.Npad = h_totals.jpad[i]; a.n0 = C; a.n1 = 4; a.n_tiles = 1;
+            a.row_list = w.apix[i]; a.row_count = nullptr; a.want_mode = 2;
+            a.seg_count = w.acounts + i * kMaxAnchorTypes; a.segs = nb; a.seg_cap = batch * lv.h * lv.w;
+            a.dw0_seg = (long long)C * 9 * lv.cin; a.dw1_seg = (long long)4 * 9 * lv.cin;
+            wa_.p[n_wanchor++] = a;
+        }
     }
     if (n_wgrad) {
         size_wgrad_splits(wd_, n_wgrad, 1);
@@ -1333,6 +1531,11 @@ extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int b
         SSDK_CHECK_LAUNCH("igemm_wgrad_kernel");
         size_wgrad_splits(ws_, n_wgrad, 4);  // sparse mode means < 1/4 of the rows
         hipLaunchKernelGGL(igemm_wgrad_kernel, dim3(ws_.total_blocks), dim3(kConvThreads), 0, s, ws_);
+        SSDK_CHECK_LAUNCH("igemm_wgrad_kernel");
+    }
+    if (n_wanchor) {
+        size_wgrad_splits(wa_, n_wanchor, 16);   // anchor mode: a few % of the anchors of one type
+        hipLaunchKernelGGL(igemm_wgrad_kernel, dim3(wa_.total_blocks), dim3(kConvThreads), 0, s, wa_);
         SSDK_CHECK_LAUNCH("igemm_wgrad_kernel");
     }
     return SSDK_OK;

@@ -62,10 +62,15 @@ def test_heads_layout_vs_reference_golden():
     ([(24, 7, 3), (40, 5, 5)], 7, 3),                                                            # Cin % 32 != 0, odd N
     ([(256, 8, 9)], 80, 1),                                                                      # retina level (nb=9, C=80)
 ])
-@pytest.mark.parametrize('pixel_density', [1.0, 0.05])
-def test_heads_vs_torch_cpu_conv(levels, C, B, pixel_density):
-    """pixel_density 1.0 exercises the dense backward kernels, 0.05 the sparse ones (compacted wgrad, scatter dgrad):
-    the device picks the path from the fraction of pixel rows that carry a gradient."""
+@pytest.mark.parametrize('pixel_density,mode', [(1.0, None), (0.05, None), (0.05, '1'), (0.05, '2'), (0.4, '0'), (0.4, '1'), (0.4, '2')])
+def test_heads_vs_torch_cpu_conv(levels, C, B, pixel_density, mode, monkeypatch):
+    """pixel_density 1.0 exercises the dense backward kernels, < 1 the sparse ones: the device picks the path (0 dense, 1 rows =
+    pixels with a gradient: compacted wgrad + scatter dgrad, 2 rows = single anchors with a gradient) from the densities;
+    SSDK_HEADS_BWD_MODE forces one so that every form is checked on the same gradients."""
+    if mode is None:
+        monkeypatch.delenv('SSDK_HEADS_BWD_MODE', raising=False)
+    else:
+        monkeypatch.setenv('SSDK_HEADS_BWD_MODE', mode)
     rng = np.random.default_rng(17)
     weights, xs_np = {}, []
     for i, (cin, h, nb) in enumerate(levels):
@@ -91,9 +96,11 @@ def test_heads_vs_torch_cpu_conv(levels, C, B, pixel_density):
         for cin, h, nb in levels:
             keep = torch.from_numpy((rng.random((B, h * h, 1)) < pixel_density).astype(np.float32))
             keep[:, 0] = 1.0  # at least one row per image so that the list is never empty
+            # ... and inside a kept pixel only some anchors (like hard-negative mining: rarely more than one per pixel)
+            akeep = torch.from_numpy((rng.random((B, h * h, nb, 1)) < 0.4).astype(np.float32)) * keep.view(B, h * h, 1, 1)
             ns, nl = h * h * nb * C, h * h * nb * 4
-            gs[:, s_off:s_off + ns] = (gs[:, s_off:s_off + ns].view(B, h * h, nb * C) * keep).view(B, -1)
-            gl[:, l_off:l_off + nl] = (gl[:, l_off:l_off + nl].view(B, h * h, nb * 4) * keep).view(B, -1)
+            gs[:, s_off:s_off + ns] = (gs[:, s_off:s_off + ns].view(B, h * h, nb, C) * akeep).view(B, -1)
+            gl[:, l_off:l_off + nl] = (gl[:, l_off:l_off + nl].view(B, h * h, nb, 4) * akeep).view(B, -1)
             s_off += ns
             l_off += nl
     ((scores_ref * gs).sum() + (locs_ref * gl).sum()).backward()
