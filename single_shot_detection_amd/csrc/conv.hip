@@ -93,6 +93,7 @@ struct ConvProblem {
 struct ConvGroup {
     int count;
     int total_blocks;
+    const int* vtab;   // compact tile list of a sparse launch (see igemm_dma_kernel), NULL otherwise
     ConvProblem p[kMaxProblems];
 };
 
@@ -134,8 +135,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvProblem& g, const f32x16
                                               int n_begin, int M, int N, int hw, int ksp) {
     // epilogue: C/D map of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
     if (SCATTER) {
-        // row = a pixel with a non-zero output gradient; column n = tap * Cin + c: add the product into the input-gradient
-        // pixel that tap connects it to (yo - pad + ky, xo - pad + kx).  32 consecutive lanes = 32 consecutive c of one tap.
+        // row = a pixel (or one anchor of a pixel) with a non-zero output gradient; column n = tap * Cin + c: add the product into
+        // the input-gradient pixel that tap connects it to (yo - pad + ky, xo - pad + kx).  32 consecutive lanes = 32 consecutive c
+        // of one tap.  When Cin % 32 == 0 a 32-column tile lies inside one tap: tap and first channel are per-tile scalars (the
+        // four integer divisions per ELEMENT of the general form were most of the time of a sparse backward workgroup).
+        const bool tile_uniform = (g.sc_cin & 31) == 0;
+        int dyj[kMaxTN], dxj[kMaxTN], cbj[kMaxTN];
+#pragma unroll
+        for (int j = 0; j < kMaxTN; ++j) {
+            const int n0j = n_begin + j * 32;
+            const int tap = n0j / g.sc_cin;
+            dyj[j] = tap / g.ksize - g.pad;
+            dxj[j] = tap % g.ksize - g.pad;
+            cbj[j] = n0j % g.sc_cin;
+        }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int m = m_base + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -143,15 +156,21 @@ __device__ __forceinline__ void conv_epilogue(const ConvProblem& g, const f32x16
             const int pid = g.row_list ? g.row_list[m] : m;
             const int b = pid / hw, r = pid % hw;
             const int yo = (r / g.Wout) * g.stride, xo = (r % g.Wout) * g.stride;
+            float* const img = g.o0 + (long long)b * g.ob0;
 #pragma unroll
             for (int j = 0; j < kMaxTN; ++j) {
                 if (j >= tn) continue;
                 const int n = n_begin + j * 32 + r32;
                 if (n >= N) continue;
-                const int tap = n / g.sc_cin, c = n % g.sc_cin;
-                const int ty = yo - g.pad + tap / g.ksize, tx = xo - g.pad + tap % g.ksize;
-                if (ty >= 0 && ty < g.Hin && tx >= 0 && tx < g.Win)
-                    atomicAdd(g.o0 + (long long)b * g.ob0 + ((long long)ty * g.Win + tx) * g.os0 + c, acc[j][e]);
+                int ty, tx, c;
+                if (tile_uniform) {
+                    ty = yo + dyj[j]; tx = xo + dxj[j]; c = cbj[j] + r32;
+                } else {
+                    const int tap = n / g.sc_cin;
+                    c = n % g.sc_cin;
+                    ty = yo - g.pad + tap / g.ksize; tx = xo - g.pad + tap % g.ksize;
+                }
+                if (ty >= 0 && ty < g.Hin && tx >= 0 && tx < g.Win) atomicAdd(img + ((long long)ty * g.Win + tx) * g.os0 + c, acc[j][e]);
             }
         }
         return;
@@ -226,7 +245,7 @@ constexpr unsigned kOobBit = 0x80000000u;
 // does between two independent workgroups (cycle stamps: 12.0k vs 8.7k cycles per slice), and the W slice is staged once
 // for 256 pixels.  The host picks WAVES = 8 when the 256-pixel tiling still fills the chip.
 template <bool MIRROR, bool GENERIC, bool SCATTER, int WAVES>
-__global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? SSDK_CONV_WAVES : 1) igemm_dma_kernel(ConvGroup grp) {
+__device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_tile, int n_block, int ksp) {
     constexpr int BM = 32 * WAVES;              // output pixels per workgroup
     constexpr int kWPieces = 16 / WAVES;        // W pieces (8 rows) each wave stages per slice
     // FOUR separate LDS objects (two stages x two operands), not one array: the compiler orders a ds_read behind an
@@ -236,22 +255,6 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? SSDK_CONV_WAVES : 1) 
     __shared__ __attribute__((aligned(1024))) float s_a1[BM * kBK];
     __shared__ __attribute__((aligned(1024))) float s_b0[kMaxTN * 32 * kBK];
     __shared__ __attribute__((aligned(1024))) float s_b1[kMaxTN * 32 * kBK];
-
-    int pi = 0;
-#pragma unroll 1
-    for (int i = 1; i < grp.count; ++i)
-        if ((int)blockIdx.x >= grp.p[i].block_begin) pi = i;
-    const ConvProblem& g = grp.p[pi];
-
-    if (g.mode && *g.mode != g.want_mode) return;
-    const int id_all = blockIdx.x - g.block_begin;
-    const int ksp = id_all % g.k_splits;
-    const int id = id_all / g.k_splits;
-    const int per_chunk = 8 * g.n_blocks;   // (both tilings pad the M tiles to a multiple of 8)
-    const int chunk = id / per_chunk, within = id % per_chunk;
-    const int m_tile = chunk * 8 + (within & 7);
-    const int n_block = within >> 3;
-    if (m_tile >= (WAVES == 4 ? g.m_tiles : g.m_tiles256)) return;
 
     const int Cc = g.Cc;
     const int ks = g.ksize;
@@ -456,6 +459,57 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? SSDK_CONV_WAVES : 1) 
         default: k_loop(std::integral_constant<int, 1>{}); break;
     }
     conv_epilogue<SCATTER>(g, acc, m_base, wave, r32, h, tn, n_begin, M, N, hw, ksp);
+}
+
+
+// vtab (sparse backward only): a compact list of the row tiles that exist, built on the device after the rows were counted --
+//   [0] number of virtual workgroups, [1 + p] first virtual workgroup of problem p (p = 0 .. count), then per problem
+//   kMaxAnchorTypes + 1 tile prefixes over its segments.  Without it the grid must cover the worst case (every anchor sampled):
+//   72 000 workgroups for the SSD-300 heads, of which ~4 000 have rows, and a workgroup that only finds out that it has
+//   nothing to do still occupies one of the two 64 KB LDS slots of a CU for ~2 us (measured: 350 of the 480 us of the launch).
+constexpr int kVtabSegs = 16 + 1;
+constexpr int kVtabInts = 1 + (kMaxProblems + 1) + kMaxProblems * kVtabSegs;
+
+template <bool MIRROR, bool GENERIC, bool SCATTER, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? SSDK_CONV_WAVES : 1) igemm_dma_kernel(ConvGroup grp) {
+    if (SCATTER && grp.vtab) {
+        const int* vt = grp.vtab;
+        const int total = vt[0];
+        for (int vb = blockIdx.x; vb < total; vb += gridDim.x) {
+            int pi = 0;
+#pragma unroll 1
+            for (int i = 1; i < grp.count; ++i)
+                if (vb >= vt[1 + i]) pi = i;
+            const ConvProblem& g = grp.p[pi];
+            const int local = vb - vt[1 + pi];
+            const int n_block = local % g.n_blocks, t = local / g.n_blocks;
+            const int* tp = vt + 1 + (kMaxProblems + 1) + pi * kVtabSegs;
+            int seg = 0;
+#pragma unroll 1
+            for (int q = 1; q < (g.seg_count ? g.segs : 1); ++q)
+                if (t >= tp[q]) seg = q;
+            const int tiles_per_seg = ((g.seg_count ? g.seg_cap : g.B * g.Hout * g.Wout) + 32 * WAVES - 1) / (32 * WAVES);
+            dma_tile<MIRROR, GENERIC, SCATTER, WAVES>(g, pi, seg * tiles_per_seg + (t - tp[seg]), n_block, 0);
+            __syncthreads();   // the next tile's first DMA overwrites LDS stage 0
+        }
+        return;
+    }
+    int pi = 0;
+#pragma unroll 1
+    for (int i = 1; i < grp.count; ++i)
+        if ((int)blockIdx.x >= grp.p[i].block_begin) pi = i;
+    const ConvProblem& g = grp.p[pi];
+
+    if (g.mode && *g.mode != g.want_mode) return;
+    const int id_all = blockIdx.x - g.block_begin;
+    const int ksp = id_all % g.k_splits;
+    const int id = id_all / g.k_splits;
+    const int per_chunk = 8 * g.n_blocks;   // (both tilings pad the M tiles to a multiple of 8)
+    const int chunk = id / per_chunk, within = id % per_chunk;
+    const int m_tile = chunk * 8 + (within & 7);
+    const int n_block = within >> 3;
+    if (m_tile >= (WAVES == 4 ? g.m_tiles : g.m_tiles256)) return;
+    dma_tile<MIRROR, GENERIC, SCATTER, WAVES>(g, pi, m_tile, n_block, ksp);
 }
 
 // ---- forward / backward-data ------------------------------------------------------------------------------------
@@ -982,6 +1036,7 @@ __global__ void __launch_bounds__(256) pack_dy_kernel(PackGroup grp) {
 // its pixel -- multiplied with the weight rows of its anchor type only.  With hard-negative mining a pixel rarely has more than
 // one sampled anchor, so this does 1/nb of the multiplies of mode 1.  Chosen when rows * Jpad < 0.8 * pixel_rows * Npad.
 constexpr int kMaxAnchorTypes = 16;
+static_assert(kVtabSegs == kMaxAnchorTypes + 1, "vtab layout");
 struct LevelTotals { int v[kMaxProblems]; int nb[kMaxProblems]; int jpad[kMaxProblems]; int npad[kMaxProblems]; int force; };
 __global__ void decide_sparse_kernel(const int* __restrict__ counts, const int* __restrict__ acounts, LevelTotals totals, int n, int* __restrict__ mode) {
     const int i = threadIdx.x;
@@ -995,6 +1050,32 @@ __global__ void decide_sparse_kernel(const int* __restrict__ counts, const int* 
     }
     if (totals.force == 0 || totals.force == 1) m = totals.force;
     mode[i] = m;
+}
+
+// builds the compact tile list of a sparse scatter launch (igemm_dma_kernel, vtab): one thread, <= 8 problems x 16 segments
+struct VtabArgs {
+    int count;
+    struct { const int* counts; int segs; const int* mode; int want; int n_blocks; } p[kMaxProblems];
+    int* vtab;
+};
+__global__ void build_vtab_kernel(VtabArgs a) {
+    if (threadIdx.x || blockIdx.x) return;
+    int* vt = a.vtab;
+    int v = 0;
+    for (int i = 0; i < a.count; ++i) {
+        vt[1 + i] = v;
+        int* tp = vt + 1 + (kMaxProblems + 1) + i * kVtabSegs;
+        int t = 0;
+        const bool on = !a.p[i].mode || *a.p[i].mode == a.p[i].want;
+        for (int k = 0; k < a.p[i].segs; ++k) {
+            tp[k] = t;
+            if (on) t += (a.p[i].counts[k] + kBM - 1) / kBM;
+        }
+        tp[a.p[i].segs] = t;
+        v += t * a.p[i].n_blocks;
+    }
+    vt[1 + a.count] = v;
+    vt[0] = v;
 }
 
 // db[n] += sum over rows of dy[row][n]   (dense [M][N] rows)
@@ -1056,6 +1137,7 @@ __global__ void __launch_bounds__(256) transpose_tapmajor_kernel(const float* __
 struct TransposeJob {
     const float* w0; const float* w1; float* out;
     int kind, n0, n1, Npad, taps, Cc, C, Jpad;
+    const int* mode;   // the layout is produced only when *mode == kind (backward mode of the level: 0 dense, 1 pixel rows, 2 anchor rows)
     int tiles_x, tiles_y, block_begin;   // tiles_x * tiles_y * depth blocks, depth = taps (kinds 0, 1) or anchor types (kind 2)
 };
 constexpr int kMaxTransposeJobs = 3 * kMaxProblems;
@@ -1067,6 +1149,7 @@ __global__ void __launch_bounds__(256) transpose_group_kernel(TransposeGroup grp
     for (int i = 1; i < grp.count; ++i)
         if ((int)blockIdx.x >= grp.j[i].block_begin) ji = i;
     const TransposeJob& J = grp.j[ji];
+    if (J.mode && *J.mode != J.kind) return;
     int id = blockIdx.x - J.block_begin;
     const int bx = id % J.tiles_x; id /= J.tiles_x;
     const int by = id % J.tiles_y; id /= J.tiles_y;
@@ -1177,7 +1260,7 @@ static bool maybe_split_k(ConvProblem& g) {
 
 // decides the kernel (LDS-DMA or register staged; 128- or 256-pixel tiles), orders the problems by decreasing work per
 // workgroup (longest first), assigns block ranges, launches
-static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t s, bool generic = false, bool scatter = false) {
+static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t s, bool generic = false, bool scatter = false, int* vtab = nullptr) {
     bool vec4 = true, strided = false;
     for (int i = 0; i < count; ++i) {
         const ConvProblem& g = probs[i];
@@ -1223,12 +1306,29 @@ static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t 
     }
     grp.count = count;
     grp.total_blocks = begin;
+    grp.vtab = nullptr;
     for (int i = 0; i < count; ++i)
         SSDK_REQUIRE(dma || !grp.p[i].seg_count, SSDK_E_UNSUPPORTED, "segmented scatter rows need the LDS-DMA kernel");
     if (dma && w8) {
         if (mirror) hipLaunchKernelGGL((igemm_dma_kernel<true, false, false, 8>), dim3(begin), dim3(512), 0, s, grp);
         else if (generic) hipLaunchKernelGGL((igemm_dma_kernel<false, true, false, 8>), dim3(begin), dim3(512), 0, s, grp);
         else hipLaunchKernelGGL((igemm_dma_kernel<false, false, false, 8>), dim3(begin), dim3(512), 0, s, grp);
+    } else if (dma && scatter && vtab) {
+        // sparse backward: only the row tiles that exist (listed on the device), walked by a fixed grid of 8 workgroups per CU
+        VtabArgs va{};
+        va.count = count;
+        va.vtab = vtab;
+        for (int i = 0; i < count; ++i) {
+            const ConvProblem& g = grp.p[i];
+            va.p[i].counts = g.seg_count ? g.seg_count : g.row_count;
+            va.p[i].segs = g.seg_count ? g.segs : 1;
+            va.p[i].mode = g.mode; va.p[i].want = g.want_mode; va.p[i].n_blocks = g.n_blocks;
+            SSDK_REQUIRE(va.p[i].counts && g.k_splits == 1, SSDK_E_INVALID, "launch_group: a tile list needs device-side row counts and no split-K");
+        }
+        hipLaunchKernelGGL(build_vtab_kernel, dim3(1), dim3(64), 0, s, va);
+        SSDK_CHECK_LAUNCH("build_vtab_kernel");
+        grp.vtab = vtab;
+        hipLaunchKernelGGL((igemm_dma_kernel<false, false, true, 4>), dim3(2048), dim3(kConvThreads), 0, s, grp);
     } else if (dma) {
         if (scatter) hipLaunchKernelGGL((igemm_dma_kernel<false, false, true, 4>), dim3(begin), dim3(kConvThreads), 0, s, grp);
         else if (mirror) hipLaunchKernelGGL((igemm_dma_kernel<true, false, false, 4>), dim3(begin), dim3(kConvThreads), 0, s, grp);
@@ -1303,6 +1403,7 @@ struct HeadsBwdWs {
     int* apix[kMaxProblems];    // their pixel ids [nb][B*HW]
     float* wa[kMaxProblems];    // per-anchor-type transposed weights [nb][9*Cin][Jpad]
     int* acounts;               // [kMaxProblems][kMaxAnchorTypes]
+    int* vtab[2];               // compact tile lists of the two sparse scatter launches
     int* counts;  // [kMaxProblems] non-zero gradient rows per level
     int* totals;  // [kMaxProblems] pixel rows per level
     int* mode;    // [kMaxProblems] 1 = sparse backward, 0 = dense
@@ -1313,6 +1414,8 @@ static HeadsBwdWs carve_heads_bwd(void* ws, const ssdk_head_level* levels, int n
     HeadsBwdWs w{};
     w.counts = c.take<int>(kMaxProblems);
     w.acounts = c.take<int>(kMaxProblems * kMaxAnchorTypes);
+    w.vtab[0] = c.take<int>(kVtabInts);
+    w.vtab[1] = c.take<int>(kVtabInts);
     w.totals = c.take<int>(kMaxProblems);
     w.mode = c.take<int>(kMaxProblems);
     for (int i = 0; i < n_levels; ++i) {
@@ -1445,7 +1548,7 @@ extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int b
         for (int kind = 0; kind < 2; ++kind) {
             TransposeJob& J = tg.j[tg.count++];
             J.w0 = lv.w_score; J.w1 = lv.w_loc; J.out = kind == 0 ? w.wd[i] : w.wt[i];
-            J.kind = kind; J.n0 = lv.n_score; J.n1 = lv.n_loc; J.Npad = npad; J.taps = 9; J.Cc = lv.cin;
+            J.kind = kind; J.n0 = lv.n_score; J.n1 = lv.n_loc; J.Npad = npad; J.taps = 9; J.Cc = lv.cin; J.mode = w.mode + i;
             J.tiles_x = cdiv(npad, 32); J.tiles_y = cdiv(lv.cin, 32); J.block_begin = t_blocks;
             t_blocks += J.tiles_x * J.tiles_y * 9;
         }
@@ -1467,7 +1570,7 @@ extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int b
             const int nb = h_totals.nb[i], jpad = h_totals.jpad[i], C = lv.n_score / nb;
             TransposeJob& J = tg.j[tg.count++];
             J.w0 = lv.w_score; J.w1 = lv.w_loc; J.out = w.wa[i];
-            J.kind = 2; J.taps = 9; J.Cc = lv.cin; J.C = C; J.Jpad = jpad;
+            J.kind = 2; J.taps = 9; J.Cc = lv.cin; J.C = C; J.Jpad = jpad; J.mode = w.mode + i;
             J.tiles_x = cdiv(jpad, 32); J.tiles_y = cdiv(9 * lv.cin, 32); J.block_begin = t_blocks;
             t_blocks += J.tiles_x * J.tiles_y * nb;
             ConvProblem r = q;
@@ -1488,11 +1591,11 @@ extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int b
     if (n_dgrad) {
         int rc = launch_group(dense, n_dgrad, true, s);
         if (rc) return rc;
-        rc = launch_group(sparse, n_dgrad, false, s, false, true);
+        rc = launch_group(sparse, n_dgrad, false, s, false, true, w.vtab[0]);
         if (rc) return rc;
     }
     if (n_anchor) {
-        int rc = launch_group(anchor, n_anchor, false, s, false, true);
+        int rc = launch_group(anchor, n_anchor, false, s, false, true, w.vtab[1]);
         if (rc) return rc;
     }
 
