@@ -777,6 +777,7 @@ struct WgradProblem {
     const int* seg_count;
     int segs, seg_cap;
     long long dw0_seg, dw1_seg;
+    unsigned dy_bytes, x_bytes;   // LDS-DMA kernel: buffer descriptor sizes (dy: one segment when segmented)
 };
 struct WgradGroup {
     int count;
@@ -911,6 +912,173 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_wgrad_ker
             if (j >= tn) continue;
             const int c = c_begin + j * 32 + r32;
             if (c < Cc) atomicAdd(row + (long long)tap * Cc + c, acc[j][e]);
+        }
+    }
+}
+
+// ---- backward-weights, LDS-DMA staging ----------------------------------------------------------------------------------
+// dW[n][tap][c] += sum over pixels m of dY[m][n] * X[m shifted by tap][c].  Workgroup = one tap, 128 n, up to 128 c, a range
+// of 32-pixel slices (split-K, fp32 atomics at the end).  Both operands are staged as they lie in memory, [pixel][channel]:
+// a DMA piece (64 lanes x 16 B) is 2 pixels x 512 B, 32 pieces per slice, no swizzle needed because the fragment reads walk
+// along a pixel row.  MFMA A operand = dY^T, B operand = X:
+//   * lane (r, h) reads dY[pixel 2s + h][4r .. 4r + 3] with ONE ds_read_b128 and uses the four values as the A operands of four
+//     MFMAs -- MFMA q then produces the output rows n = 4 i + q (a permutation undone in the epilogue) -- and X[pixel][32 w + r]
+//     with one ds_read_b32: 2 LDS instructions per 4 MFMAs (the first wgrad kernel issued 5 ds_read_b32 per 4 MFMAs);
+//   * wave w owns output columns c = 32 w .. 32 w + 31 of the workgroup's c block and all 128 n (64 accumulator registers);
+//   * the per-pixel source offsets (row gather for the sparse forms, image / y / x decomposition, border test for this tap) are
+//     computed by lanes 0..7 of each wave -- one pixel each, two slices ahead -- and handed to the piece lanes with ds_bpermute.
+__device__ __forceinline__ void fast_divmod(int m, int d, float rcp, int& q, int& r) {   // exact for 0 <= m < 2^24
+    q = (int)((float)m * rcp);
+    r = m - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) { ++q; r -= d; }
+}
+
+__global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_wgrad_dma_kernel(WgradGroup grp) {
+    __shared__ __attribute__((aligned(1024))) float s_dy0[32 * 128];
+    __shared__ __attribute__((aligned(1024))) float s_dy1[32 * 128];
+    __shared__ __attribute__((aligned(1024))) float s_x0[32 * 128];
+    __shared__ __attribute__((aligned(1024))) float s_x1[32 * 128];
+
+    int pi = 0;
+#pragma unroll 1
+    for (int i = 1; i < grp.count; ++i)
+        if ((int)blockIdx.x >= grp.p[i].block_begin) pi = i;
+    const WgradProblem& g = grp.p[pi];
+    if (g.mode && *g.mode != g.want_mode) return;
+    const int Cc = g.Cc;
+    const int N = g.n0 + g.n1;
+    const int taps = g.ksize * g.ksize;
+    int id = blockIdx.x - g.block_begin;
+    const int ksp = id % g.k_splits; id /= g.k_splits;
+    const int cb = id % g.c_blocks; id /= g.c_blocks;
+    const int nt = id % g.n_tiles; id /= g.n_tiles;
+    const int tap = id % taps;
+    const int seg = id / taps;
+    const int ky = tap / g.ksize, kx = tap % g.ksize;
+    const float* dy_p = g.dy;
+    const int* rows_p = g.row_list;
+    float* dw0_p = g.dw0;
+    float* dw1_p = g.dw1;
+    if (g.seg_count) {
+        dy_p += (long long)seg * g.seg_cap * g.Npad;
+        rows_p += (long long)seg * g.seg_cap;
+        dw0_p += (long long)seg * g.dw0_seg;
+        if (dw1_p) dw1_p += (long long)seg * g.dw1_seg;
+    }
+    const int base_t = g.c_tiles32 / g.c_blocks, rem_t = g.c_tiles32 % g.c_blocks;
+    const int tn = base_t + (cb < rem_t ? 1 : 0);
+    const int c_begin = (cb * base_t + min(cb, rem_t)) * 32;
+    const int n_begin = nt * 128;
+    const int hw = g.Hout * g.Wout;
+    const int M = g.seg_count ? g.seg_count[seg] : (g.row_list ? *g.row_count : g.B * hw);
+    const int slices_total = (M + 31) / 32;
+    const int per = (slices_total + g.k_splits - 1) / g.k_splits;
+    const int s_begin = ksp * per, s_end = min(slices_total, s_begin + per);
+    if (s_begin >= s_end) return;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32 = lane & 31, h = lane >> 5;
+    const bool wave_live = wave < tn;
+
+    const __amdgpu_buffer_rsrc_t rsrc_dy = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(dy_p), 0, (int)g.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(g.x), 0, (int)g.x_bytes, 0x00020000);
+    // column part of this lane's 16 bytes inside the 512-byte row window of a piece (bit 31 = outside the operand: zeros)
+    const int col4 = (lane & 31) * 4;
+    const unsigned dy_col = (n_begin + col4 < g.Npad) ? (unsigned)(n_begin + col4) * 4u : kOobBit;
+    const unsigned x_col = (col4 < tn * 32 && c_begin + col4 < Cc) ? (unsigned)(c_begin + col4) * 4u : kOobBit;
+    const float rcp_hw = 1.0f / (float)hw, rcp_w = 1.0f / (float)g.Wout;
+    const int dy_row_bytes = g.Npad * 4, x_pix_bytes = Cc * 4;
+
+    // pixel lanes: lane l < 8 of wave w owns pixel 8 w + l of a slice
+    auto load_id = [&](int sl) -> int {      // pixel id of my pixel in slice sl (only meaningful on the pixel lanes)
+        const int mi = sl * 32 + wave * 8 + (lane & 7);
+        return (rows_p && sl < s_end && mi < M) ? rows_p[mi] : mi;
+    };
+    auto pixel_offsets = [&](int sl, int m, unsigned& dyo, unsigned& xo) {
+        const int mi = sl * 32 + wave * 8 + (lane & 7);
+        dyo = kOobBit;
+        xo = kOobBit;
+        if (sl < s_end && mi < M) {
+            dyo = (unsigned)(g.seg_count ? mi : m) * (unsigned)dy_row_bytes;
+            int b, pix, y, x;
+            fast_divmod(m, hw, rcp_hw, b, pix);
+            fast_divmod(pix, g.Wout, rcp_w, y, x);
+            const int iy = y * g.stride - g.pad + ky, ix = x * g.stride - g.pad + kx;
+            if (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) xo = (unsigned)((b * g.Hin + iy) * g.Win + ix) * (unsigned)x_pix_bytes;
+        }
+    };
+    auto issue = [&](int stage, unsigned dyo, unsigned xo) {   // the wave's 4 dY pieces and 4 X pieces of one slice
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int src = 2 * i + (lane >> 5);
+            const unsigned d = (unsigned)__shfl((int)dyo, src, kWave), x = (unsigned)__shfl((int)xo, src, kWave);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_dy, (lds_ptr_t)((stage ? s_dy1 : s_dy0) + (wave * 8 + 2 * i) * 128), 16, (dy_col & kOobBit) ? kOobBit : d + dy_col, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)((stage ? s_x1 : s_x0) + (wave * 8 + 2 * i) * 128), 16, (x_col & kOobBit) ? kOobBit : x + x_col, 0, 0, 0);
+        }
+    };
+    // (row offsets below 2^31 -- checked on the host -- plus a column part < 2^20: an invalid pixel keeps bit 31 set after the add)
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[q][e] = 0.0f;
+
+    unsigned dyo1, xo1, dyo2, xo2;
+    {
+        unsigned dyo0, xo0;
+        pixel_offsets(s_begin, load_id(s_begin), dyo0, xo0);
+        issue(0, dyo0, xo0);
+        pixel_offsets(s_begin + 1, load_id(s_begin + 1), dyo1, xo1);
+    }
+    int id2 = load_id(s_begin + 2);
+    __syncthreads();
+
+    auto body = [&](auto st_c, int sl) {
+        constexpr int ST = decltype(st_c)::value;
+        issue(ST ^ 1, dyo1, xo1);                                  // slice sl + 1 lands while slice sl is multiplied
+        pixel_offsets(sl + 2, id2, dyo2, xo2);
+        id2 = load_id(sl + 3);
+        if (wave_live) {
+            const float* ady = (ST ? s_dy1 : s_dy0) + h * 128 + 4 * r32;
+            const float* bx = (ST ? s_x1 : s_x0) + h * 128 + wave * 32 + r32;
+            f32x4 av[2];
+            float bv[2];
+            av[0] = *reinterpret_cast<const f32x4*>(ady);
+            bv[0] = bx[0];
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) {
+                if (k2 + 1 < 16) {
+                    av[(k2 + 1) & 1] = *reinterpret_cast<const f32x4*>(ady + (k2 + 1) * 256);
+                    bv[(k2 + 1) & 1] = bx[(k2 + 1) * 256];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k2 & 1][q], bv[k2 & 1], acc[q], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        dyo1 = dyo2;
+        xo1 = xo2;
+    };
+    for (int sl = s_begin; sl < s_end; sl += 2) {
+        body(std::integral_constant<int, 0>{}, sl);
+        if (sl + 1 < s_end) body(std::integral_constant<int, 1>{}, sl + 1);
+    }
+    if (!wave_live) return;
+    const long long K = (long long)taps * Cc;
+    const int c = c_begin + wave * 32 + r32;
+    if (c >= Cc) return;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int i = (e & 3) + 8 * (e >> 2) + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = n_begin + 4 * i + q;   // MFMA q, row i
+            if (n >= N) continue;
+            float* row = n < g.n0 ? dw0_p + (long long)n * K : dw1_p + (long long)(n - g.n0) * K;
+            atomicAdd(row + (long long)tap * Cc + c, acc[q][e]);
         }
     }
 }
@@ -1446,6 +1614,24 @@ extern "C" size_t ssdk_heads_bwd_workspace_bytes(const ssdk_head_level* levels, 
 // K (= pixel rows) is split so that every problem contributes >= ~512 workgroups (tiny maps are latency bound at one
 // wave per SIMD: more, shorter workgroups) and no workgroup walks more than 64 slices; each split costs one 64 KB
 // atomic tile, so never fewer than 2 slices per split.
+// picks the LDS-DMA kernel when every problem of the group qualifies (16-byte rows, operands below 2 GiB, pixel count below 2^24)
+static int launch_wgrad(WgradGroup& wg, hipStream_t s) {
+    bool dma = !getenv("SSDK_CONV_NO_DMA");
+    for (int i = 0; i < wg.count && dma; ++i) {
+        WgradProblem& g = wg.p[i];
+        const long long rows = g.seg_count ? g.seg_cap : (long long)g.B * g.Hout * g.Wout;
+        const long long dy_bytes = rows * g.Npad * 4, x_bytes = (long long)g.B * g.Hin * g.Win * g.Cc * 4;
+        if (g.Npad % 4 || g.Cc % 4 || ((uintptr_t)g.dy & 15) || ((uintptr_t)g.x & 15) || dy_bytes >= (1LL << 31) - 65536 || x_bytes >= (1LL << 31) - 65536 ||
+            (long long)g.B * g.Hout * g.Wout >= (1 << 24)) { dma = false; break; }
+        g.dy_bytes = (unsigned)dy_bytes;
+        g.x_bytes = (unsigned)x_bytes;
+    }
+    if (dma) hipLaunchKernelGGL(igemm_wgrad_dma_kernel, dim3(wg.total_blocks), dim3(kConvThreads), 0, s, wg);
+    else hipLaunchKernelGGL(igemm_wgrad_kernel, dim3(wg.total_blocks), dim3(kConvThreads), 0, s, wg);
+    SSDK_CHECK_LAUNCH("igemm_wgrad_kernel");
+    return SSDK_OK;
+}
+
 static void size_wgrad_splits(WgradGroup& wg, int n, int density_div) {
     int begin = 0;
     for (int i = 0; i < n; ++i) {
@@ -1630,16 +1816,13 @@ extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int b
     }
     if (n_wgrad) {
         size_wgrad_splits(wd_, n_wgrad, 1);
-        hipLaunchKernelGGL(igemm_wgrad_kernel, dim3(wd_.total_blocks), dim3(kConvThreads), 0, s, wd_);
-        SSDK_CHECK_LAUNCH("igemm_wgrad_kernel");
+        { int rc = launch_wgrad(wd_, s); if (rc) return rc; }
         size_wgrad_splits(ws_, n_wgrad, 4);  // sparse mode means < 1/4 of the rows
-        hipLaunchKernelGGL(igemm_wgrad_kernel, dim3(ws_.total_blocks), dim3(kConvThreads), 0, s, ws_);
-        SSDK_CHECK_LAUNCH("igemm_wgrad_kernel");
+        { int rc = launch_wgrad(ws_, s); if (rc) return rc; }
     }
     if (n_wanchor) {
         size_wgrad_splits(wa_, n_wanchor, 16);   // anchor mode: a few % of the anchors of one type
-        hipLaunchKernelGGL(igemm_wgrad_kernel, dim3(wa_.total_blocks), dim3(kConvThreads), 0, s, wa_);
-        SSDK_CHECK_LAUNCH("igemm_wgrad_kernel");
+        { int rc = launch_wgrad(wa_, s); if (rc) return rc; }
     }
     return SSDK_OK;
 }
@@ -1781,8 +1964,7 @@ extern "C" int ssdk_conv2d_bwd(const ssdk_conv_desc* descs, int n, int batch, in
     }
     if (n_wgrad) {
         size_wgrad_splits(wg, n_wgrad, 1);
-        hipLaunchKernelGGL(igemm_wgrad_kernel, dim3(wg.total_blocks), dim3(kConvThreads), 0, s, wg);
-        SSDK_CHECK_LAUNCH("igemm_wgrad_kernel");
+        { int rc2 = launch_wgrad(wg, s); if (rc2) return rc2; }
     }
     return SSDK_OK;
 }
