@@ -1088,6 +1088,7 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_wgrad_dma
 // Also appends the ids of the rows that are not entirely zero to row_list (order inside a block preserved, blocks in
 // completion order) and counts them: the loss gradient is non-zero only on sampled anchors, i.e. on a few % of the pixels.
 constexpr int kPackRows = 32;
+constexpr int kMaxAnchorTypes_ = 16;   // (= kMaxAnchorTypes; the last counter of a level doubles as its "not sparse" flag, so nb <= 15)
 constexpr int kPackColIters = 12;  // Npad <= 768 (RetinaNet: 9 * (80 + 4) = 756)
 struct PackLevel {
     const float* ds; const float* dl;
@@ -1126,12 +1127,17 @@ __global__ void __launch_bounds__(256) pack_dy_kernel(PackGroup grp) {
     __shared__ unsigned s_flag;
     __shared__ int s_base;
     __shared__ float s_sum[4][kPackColIters * 64];
+    __shared__ unsigned s_amask[kPackRows];       // anchor types with a gradient, per row of the block
+    __shared__ unsigned s_acol[kMaxAnchorTypes_]; // per anchor type: which rows of the block have it
+    __shared__ int s_abase[kMaxAnchorTypes_];     // per anchor type: first row index reserved in its segment (-1: not stored)
     const int M = B * HW;
     const int m0 = block * kPackRows;
     const int N = n0 + n1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int iters = (Npad + 63) >> 6;
     if (threadIdx.x == 0) s_flag = 0u;
+    if (threadIdx.x < kPackRows) s_amask[threadIdx.x] = 0u;
+    __syncthreads();
     float acc[kPackColIters];
 #pragma unroll
     for (int k = 0; k < kPackColIters; ++k) acc[k] = 0.0f;
@@ -1165,17 +1171,11 @@ __global__ void __launch_bounds__(256) pack_dy_kernel(PackGroup grp) {
             }
         }
         if (__ballot(nz)) mine |= 1u << r;
-        if (L.ga) {
-            for (int a = 0; a < L.nb; ++a) {
-                if (!__ballot((amask >> a) & 1u)) continue;   // (uniform)
-                int idx = 0;
-                if (lane == 0) idx = atomicAdd(L.acount + a, 1);
-                idx = __shfl(idx, 0, kWave);
-                float* grow = L.ga + ((long long)a * L.cap + idx) * L.Jpad;
-                for (int j = lane; j < L.Jpad; j += kWave)
-                    grow[j] = j < L.C ? srow[a * L.C + j] : (j < L.C + 4 ? lrow[a * 4 + j - L.C] : 0.0f);
-                if (lane == 0) L.apix[(long long)a * L.cap + idx] = m;
-            }
+        if (L.ga) {   // which anchor types of this row carry a gradient (wave-wide OR of the lanes' masks)
+            unsigned row_mask = 0u;
+            for (int a = 0; a < L.nb; ++a)
+                if (__ballot((amask >> a) & 1u)) row_mask |= 1u << a;
+            if (lane == 0) s_amask[r] = row_mask;
         }
     }
 #pragma unroll
@@ -1195,6 +1195,44 @@ __global__ void __launch_bounds__(256) pack_dy_kernel(PackGroup grp) {
     __syncthreads();
     if (threadIdx.x < kPackRows && ((flags >> threadIdx.x) & 1u))
         row_list[s_base + __popc(flags & ((1u << threadIdx.x) - 1u))] = m0 + (int)threadIdx.x;
+    if (!L.ga) return;
+    // anchor-granular rows: ONE atomic per (block, anchor type) reserves the block's rows in segment k (an atomic per anchor
+    // serialises on 4..9 counters: 2 ms at full density), then the waves copy the C + 4 values of every listed anchor.
+    // A block in which more than half of the anchors carry a gradient is not "sparse": it stores nothing and marks the level
+    // (acount[kMaxAnchorTypes - 1] != 0 -> decide_sparse_kernel never picks the anchor form for it).
+    if (threadIdx.x < L.nb) {
+        unsigned col = 0u;
+        for (int r = 0; r < kPackRows; ++r) col |= ((s_amask[r] >> threadIdx.x) & 1u) << r;
+        s_acol[threadIdx.x] = col;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+        for (int a = 0; a < L.nb; ++a) total += __popc(s_acol[a]);
+        const bool dense = 2 * total > kPackRows * L.nb;
+        if (dense) atomicOr(L.acount + (kMaxAnchorTypes_ - 1), 1);
+        for (int a = 0; a < L.nb; ++a) {
+            const int c = __popc(s_acol[a]);
+            s_abase[a] = (!dense && c) ? atomicAdd(L.acount + a, c) : -1;
+        }
+    }
+    __syncthreads();
+    for (int r = wave; r < kPackRows; r += 4) {
+        const unsigned row_mask = s_amask[r];
+        if (!row_mask) continue;
+        const int m = m0 + r;
+        const int b = m / HW, p = m % HW;
+        const float* srow = ds + (long long)b * sb + (long long)p * n0;
+        const float* lrow = dl + (long long)b * lb + (long long)p * n1;
+        for (int a = 0; a < L.nb; ++a) {
+            if (!((row_mask >> a) & 1u) || s_abase[a] < 0) continue;
+            const int idx = s_abase[a] + __popc(s_acol[a] & ((1u << r) - 1u));
+            float* grow = L.ga + ((long long)a * L.cap + idx) * L.Jpad;
+            for (int j = lane; j < L.Jpad; j += kWave)
+                grow[j] = j < L.C ? srow[a * L.C + j] : (j < L.C + 4 ? lrow[a * 4 + j - L.C] : 0.0f);
+            if (lane == 0) L.apix[(long long)a * L.cap + idx] = m;
+        }
+    }
 }
 
 // mode[i] = 1 (sparse backward) when fewer than 70 % of the level's pixel rows carry a gradient, else 0 (dense).
@@ -1204,7 +1242,7 @@ __global__ void __launch_bounds__(256) pack_dy_kernel(PackGroup grp) {
 // its pixel -- multiplied with the weight rows of its anchor type only.  With hard-negative mining a pixel rarely has more than
 // one sampled anchor, so this does 1/nb of the multiplies of mode 1.  Chosen when rows * Jpad < 0.8 * pixel_rows * Npad.
 constexpr int kMaxAnchorTypes = 16;
-static_assert(kVtabSegs == kMaxAnchorTypes + 1, "vtab layout");
+static_assert(kVtabSegs == kMaxAnchorTypes + 1 && kMaxAnchorTypes_ == kMaxAnchorTypes, "vtab layout");
 struct LevelTotals { int v[kMaxProblems]; int nb[kMaxProblems]; int jpad[kMaxProblems]; int npad[kMaxProblems]; int force; };
 __global__ void decide_sparse_kernel(const int* __restrict__ counts, const int* __restrict__ acounts, LevelTotals totals, int n, int* __restrict__ mode) {
     const int i = threadIdx.x;
@@ -1213,8 +1251,9 @@ __global__ void decide_sparse_kernel(const int* __restrict__ counts, const int* 
     if (totals.nb[i] > 0) {
         long long rows = 0;
         for (int k = 0; k < totals.nb[i]; ++k) rows += acounts[i * kMaxAnchorTypes + k];
-        if (m == 1 && rows * totals.jpad[i] * 10 < (long long)counts[i] * totals.npad[i] * 8) m = 2;
-        if (totals.force == 2) m = 2;
+        const bool complete = acounts[i * kMaxAnchorTypes + kMaxAnchorTypes - 1] == 0;   // no block gave up storing its anchors
+        if (complete && m == 1 && rows * totals.jpad[i] * 10 < (long long)counts[i] * totals.npad[i] * 8) m = 2;
+        if (complete && totals.force == 2) m = 2;
     }
     if (totals.force == 0 || totals.force == 1) m = totals.force;
     mode[i] = m;
@@ -1535,7 +1574,7 @@ static inline int npad_of(const ssdk_head_level& lv) { return cdiv(lv.n_score + 
 static inline int anchor_types_of(const ssdk_head_level& lv) {
     if (lv.n_loc <= 0 || lv.n_loc % 4) return 0;
     const int nb = lv.n_loc / 4;
-    return (nb <= kMaxAnchorTypes && lv.n_score % nb == 0 && lv.cin % kBK == 0) ? nb : 0;
+    return (nb < kMaxAnchorTypes && lv.n_score % nb == 0 && lv.cin % kBK == 0) ? nb : 0;
 }
 static inline int jpad_of(const ssdk_head_level& lv) { return cdiv(lv.n_score / (lv.n_loc / 4) + 4, 32) * 32; }
 
