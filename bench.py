@@ -108,7 +108,12 @@ class HotPath(object):
         self.params = [p for p in self.heads.parameters()] + ([p for p in self.extras.parameters()] if self.extras is not None else []) + \
                       ([p for p in self.tower.parameters()] if self.tower is not None else [])
         self.opt = torch.optim.SGD(self.params, lr=1e-3, momentum=0.9, weight_decay=5e-4)
-        self.bucket = GradBucket(self.params)
+        # exchange step (N > 1): the head gradients are complete as soon as the heads' backward has run, so their ring starts
+        # there and overlaps with the backward of the extras / tower; a second, small bucket carries the rest
+        self.head_params = [p for p in self.heads.parameters()]
+        self.rest_params = [p for p in self.params if all(p is not q for q in self.head_params)]
+        self.bucket_heads = GradBucket(self.head_params)
+        self.bucket_rest = GradBucket(self.rest_params) if self.rest_params else None
         self.fwd_events = []
 
     def pyramid(self):
@@ -130,6 +135,15 @@ class HotPath(object):
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
+        if getattr(self, 'two_phase', False):
+            # N > 1: cut the graph in front of the heads, so that the first autograd pass stops at the heads' inputs
+            # (a pyramid level also feeds the next extras layer; its gradient through that path belongs to the second pass)
+            same = loc_sources is score_sources
+            self.head_sources = list(score_sources) + ([] if same else list(loc_sources))
+            cut = [t.detach().requires_grad_(t.requires_grad) for t in self.head_sources]
+            score_sources = cut[:len(score_sources)]
+            loc_sources = score_sources if same else cut[len(score_sources):]
+            self.head_inputs = cut
         out = multi_level_heads(score_sources, loc_sources, self.heads)
         if timed:
             e1.record()
@@ -137,15 +151,41 @@ class HotPath(object):
         return out
 
     def train_step(self, world=1, timed=False):
+        self.two_phase = world > 1 or getattr(self, 'force_two_phase', False)
         self.opt.zero_grad(set_to_none=True)
         for s in self.inputs:
             s.grad = None
         scores, locs = self.forward_heads(timed)
         target = self.assigner.encode_ground_truth(self.gt, self.anchors)
         loss, class_loss, loc_loss = self.criterion((scores, locs), self.anchors, target)
-        loss.backward()
-        if world > 1:
-            self.bucket.allreduce_()    # one flat fp32 bucket over RCCL/xGMI
+        if self.two_phase:
+            # same kernels as loss.backward(), in two autograd passes so that the ring over the head gradients (one flat fp32
+            # bucket, RCCL over xGMI) runs while the extras / tower are still being differentiated
+            need = [t for t in self.head_inputs if t.requires_grad]
+            grads = torch.autograd.grad(loss, self.head_params + need)
+            for p, g in zip(self.head_params, grads):
+                p.grad = g
+            self.bucket_heads.start_()
+            src, src_g = [], []
+            gi = iter(grads[len(self.head_params):])
+            for cut, orig in zip(self.head_inputs, self.head_sources):
+                if not cut.requires_grad:
+                    continue
+                g = next(gi)
+                if orig.is_leaf:
+                    orig.grad = g if orig.grad is None else orig.grad + g
+                else:
+                    src.append(orig)
+                    src_g.append(g)
+            if src:
+                torch.autograd.backward(src, grad_tensors=src_g)
+            if self.bucket_rest is not None:
+                self.bucket_rest.start_()
+            self.bucket_heads.finish_()
+            if self.bucket_rest is not None:
+                self.bucket_rest.finish_()
+        else:
+            loss.backward()
         self.opt.step()
         return loss
 
@@ -212,11 +252,17 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})')
+    if os.environ.get('SSDK_BENCH_ONE_GPU'):   # rehearsal of the N > 1 code path on a one-GPU box (with SSDK_BENCH_BACKEND=gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=device)   # nccl == RCCL on ROCm
+        backend = os.environ.get('SSDK_BENCH_BACKEND', 'nccl')   # nccl == RCCL on ROCm
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if world > 1:

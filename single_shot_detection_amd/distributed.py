@@ -16,11 +16,19 @@ class GradBucket(object):
 
     def allreduce_(self, group=None, average=True):
         """In-place all-reduce of ``p.grad`` for every parameter of the bucket."""
+        self.start_(group)
+        self.finish_(group, average)
+
+    def start_(self, group=None):
+        """Packs the gradients into the flat bucket and STARTS the all-reduce (async): whatever the caller launches next
+        -- the backward of the layers in front of these parameters -- overlaps with the ring.  ``finish_`` waits and
+        writes the averaged gradients back."""
+        self._work, self._grads, self._views = None, None, None
         if not dist.is_initialized() or dist.get_world_size(group) == 1:
             return
         grads = [p.grad for p in self.params]
         if any(g is None for g in grads):
-            raise RuntimeError('GradBucket.allreduce_: a parameter has no gradient')
+            raise RuntimeError('GradBucket: a parameter has no gradient')
         dev = grads[0].device
         if self.flat is None or self.flat.device != dev:
             self.flat = torch.empty((self.numel,), dtype=torch.float32, device=dev)
@@ -29,10 +37,17 @@ class GradBucket(object):
             views.append(self.flat[off:off + g.numel()].view(g.shape))
             off += g.numel()
         torch._foreach_copy_(views, grads)   # strided (channels_last) grads are laid into the bucket logically
-        dist.all_reduce(self.flat, group=group)
+        self._work = dist.all_reduce(self.flat, group=group, async_op=True)
+        self._grads, self._views = grads, views
+
+    def finish_(self, group=None, average=True):
+        if getattr(self, '_work', None) is None:
+            return
+        self._work.wait()
         if average:
             self.flat.div_(dist.get_world_size(group))
-        torch._foreach_copy_(grads, views)
+        torch._foreach_copy_(self._grads, self._views)
+        self._work, self._grads, self._views = None, None, None
 
 
 def shard_batch(items, rank, world):

@@ -209,3 +209,24 @@ def test_m2det512_step_fn_train():
     with torch.no_grad():
         _, dets, _ = step_fn(1, 'eval', (imgs, gt), state)
     assert len(dets) == B and all(d.shape[1] == 6 for d in dets)
+
+
+def test_bench_two_phase_backward_matches_single_backward():
+    """bench.py's N > 1 step differentiates in two autograd passes (heads first, so that their gradient ring can start early):
+    the gradients must be those of a single loss.backward()."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(os.path.dirname(__file__), '..', 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for cfg in ('ssd_mb2_voc', 'ssd_300_vgg16_voc', 'retina_rn50_500_coco'):
+        hp = bench.HotPath(cfg, 2, torch.device('cuda:0'))
+        hp.opt = torch.optim.SGD(hp.params, lr=0.0)            # keep the weights fixed between the two runs
+        hp.train_step()
+        ref = [p.grad.clone() for p in hp.params]
+        ref_in = [t.grad.clone() for t in hp.inputs]
+        hp.force_two_phase = True
+        hp.train_step()
+        for p, r in zip(list(hp.params) + list(hp.inputs), ref + ref_in):
+            scale = float(r.abs().max()) + 1e-12
+            assert float((p.grad - r).abs().max()) <= 2e-5 * scale + 1e-7
