@@ -64,14 +64,17 @@ __device__ __forceinline__ float quad_sum(float v) {
 __global__ void __launch_bounds__(kPostThreads) post_select_kernel(const float* __restrict__ scores, int A, int C, int softmax,
                                                                    float score_thr, int tiles_per_image,
                                                                    u64* __restrict__ cand, int* __restrict__ cand_count) {
+    // LDS = the 64 x C tile only (20 KB at C = 81 -> 7 workgroups per CU): the probabilities overwrite the logits in place, then
+    // one wave per class reads its column (stride C: conflict-free for odd C, 2-way for C = 80), ballots p > threshold, reserves
+    // the hits with one global atomic and stores them in row order.  (The first version kept per-class candidate lists of
+    // worst-case size in LDS -- 41 KB more, 2 workgroups per CU -- and ran at 0.9 TB/s on the logits.)
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const int ncls = softmax ? C - 1 : C;
     float* s_tile = reinterpret_cast<float*>(s_raw);
-    u64* s_list = reinterpret_cast<u64*>(s_raw + align_up((size_t)kPostTileRows * C * 4, 16));
-    int* s_cnt = reinterpret_cast<int*>(s_list + (size_t)ncls * kPostTileRows);
-    int* s_base = s_cnt + ncls;
+    int* s_cnt = reinterpret_cast<int*>(s_raw + align_up((size_t)kPostTileRows * C * 4, 16));
 
     const int i = blockIdx.y;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
     for (int tile = blockIdx.x; tile < tiles_per_image; tile += gridDim.x) {
         const int a0 = tile * kPostTileRows;
         const int rows = min(kPostTileRows, A - a0);
@@ -85,49 +88,47 @@ __global__ void __launch_bounds__(kPostThreads) post_select_kernel(const float* 
         } else {
             for (int t = threadIdx.x; t < nfloat; t += kPostThreads) s_tile[t] = src[t];
         }
-        for (int c = threadIdx.x; c < ncls; c += kPostThreads) s_cnt[c] = 0;
         __syncthreads();
         const int row = threadIdx.x >> 2, q = threadIdx.x & 3;
-        const float* x = s_tile + row * C;
+        float* x = s_tile + row * C;
         const bool live = row < rows;
-        const unsigned akey = 0xFFFFFFFFu - (unsigned)(a0 + row);
         if (softmax) {  // postprocessor.py:43 F.softmax(dim=-1), :46-48 drop column 0
             float m = -INFINITY;
             if (live)
                 for (int c = q; c < C; c += 4) m = fmaxf(m, x[c]);
             m = quad_max(m);
-            float s = 0.0f;
+            float sum = 0.0f;
             if (live)
-                for (int c = q; c < C; c += 4) s += expf(x[c] - m);
-            s = quad_sum(s);
+                for (int c = q; c < C; c += 4) sum += expf(x[c] - m);
+            sum = quad_sum(sum);
             if (live)
-                for (int c = q; c < C; c += 4) {
-                    if (c == 0) continue;
-                    const float p = expf(x[c] - m) / s;
-                    if (p > score_thr) {  // :63
-                        const int slot = atomicAdd(&s_cnt[c - 1], 1);
-                        s_list[(c - 1) * kPostTileRows + slot] = ((u64)__float_as_uint(p) << 32) | akey;
-                    }
-                }
+                for (int c = q; c < C; c += 4) x[c] = expf(x[c] - m) / sum;
         } else if (live) {
-            for (int c = q; c < C; c += 4) {
-                const float p = 1.0f / (1.0f + expf(-x[c]));
-                if (p > score_thr) {
-                    const int slot = atomicAdd(&s_cnt[c], 1);
-                    s_list[c * kPostTileRows + slot] = ((u64)__float_as_uint(p) << 32) | akey;
-                }
-            }
+            for (int c = q; c < C; c += 4) x[c] = 1.0f / (1.0f + expf(-x[c]));
+        }
+        __syncthreads();
+        const unsigned akey = 0xFFFFFFFFu - (unsigned)(a0 + lane);
+        const int c_off = softmax ? 1 : 0;
+        // hits per class (one wave per class), then ALL the reservations of the tile in flight at once (a wave that reserves
+        // class after class waits for one returning atomic per class: 20 dependent round trips), then the stores
+        for (int c = wave; c < ncls; c += kPostThreads / kWave) {
+            const float p = lane < rows ? s_tile[lane * C + c + c_off] : 0.0f;
+            const unsigned long long mask = __ballot(lane < rows && p > score_thr);   // :63
+            if (lane == 0) s_cnt[c] = __popcll(mask);
         }
         __syncthreads();
         for (int c = threadIdx.x; c < ncls; c += kPostThreads) {
             const int n = s_cnt[c];
-            s_base[c] = n ? atomicAdd(&cand_count[i * ncls + c], n) : 0;
+            s_cnt[c] = n ? atomicAdd(&cand_count[i * ncls + c], n) : -1;
         }
         __syncthreads();
-        const int lane = lane_id();
-        for (int c = threadIdx.x >> 6; c < ncls; c += kPostThreads / kWave) {
-            const int n = s_cnt[c];
-            if (lane < n) cand[((size_t)i * ncls + c) * A + s_base[c] + lane] = s_list[c * kPostTileRows + lane];
+        for (int c = wave; c < ncls; c += kPostThreads / kWave) {
+            const int base = s_cnt[c];
+            if (base < 0) continue;   // (uniform)
+            const float p = lane < rows ? s_tile[lane * C + c + c_off] : 0.0f;
+            const bool hit = lane < rows && p > score_thr;
+            const unsigned long long mask = __ballot(hit);
+            if (hit) cand[((size_t)i * ncls + c) * A + base + __popcll(mask & ((1ull << lane) - 1ull))] = ((u64)__float_as_uint(p) << 32) | akey;
         }
     }
 }
@@ -487,7 +488,7 @@ extern "C" int ssdk_postprocess(const float* scores, const float* locs, const fl
     if (nms_candidates) SSDK_CHECK_HIP(hipMemsetAsync(nms_candidates, 0, sizeof(int64_t) * (size_t)batch, s));
 
     const int tiles = cdiv(num_anchors, kPostTileRows);
-    const size_t lds = align_up((size_t)kPostTileRows * num_classes * 4, 16) + (size_t)ncls * kPostTileRows * 8 + (size_t)ncls * 8;
+    const size_t lds = align_up((size_t)kPostTileRows * num_classes * 4, 16) + (size_t)ncls * 4;
     SSDK_REQUIRE(lds <= 160 * 1024 - 1024, SSDK_E_UNSUPPORTED, "ssdk_postprocess: num_classes=%d needs %zu bytes of LDS", num_classes, lds);
     SSDK_CHECK_HIP(hipFuncSetAttribute((const void*)post_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int gx = tiles < 1024 ? tiles : 1024;
