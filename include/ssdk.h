@@ -301,6 +301,16 @@ int ssdk_sigmoid_gate_fwd(const float* x, const float* z, int batch, int hw, int
 int ssdk_sigmoid_gate_bwd(const float* x, const float* z, const float* dout, int batch, int hw, int channels, float* dx,
                           float* dz, void* stream);
 
+/* ---- depthwise convolution (bf/modules/conv.py:39-85 DepthwiseConv2dBn: depthwise k x k, groups = channels, then a 1x1 pointwise
+ * convolution; `use_depthwise` configs such as samples/ssd_mb2_voc.py).  NHWC activations, weights [channels][k*k] (= the memory of
+ * torch's [C,1,k,k] parameter), optional bias.  HBM-bound stencil; the pointwise half is ssdk_conv2d_*.
+ *   fwd: y[b,yo,xo,c] = bias[c] + sum_tap w[c][tap] * x[b, yo*stride - pad + ky, xo*stride - pad + kx, c]
+ *   bwd: dx (may be NULL), dw [channels][k*k] and db (may be NULL) are OVERWRITTEN (accumulate == 0) or added to. */
+int ssdk_depthwise_conv2d_fwd(const float* x, const float* w, const float* bias, int batch, int hin, int win, int channels, int ksize,
+                              int stride, int pad, float* y, void* stream);
+int ssdk_depthwise_conv2d_bwd(const float* x, const float* w, const float* dy, int batch, int hin, int win, int channels, int ksize,
+                              int stride, int pad, float* dx, float* dw, float* db, int accumulate, void* stream);
+
 /* ---- device-resident input side ---------------------------------------------------------------------
  * bf/core/batch_container.py:25-45  BatchContainer.mixup_ with the random draws (lam ~ Beta(alpha, alpha), index = randperm(B),
  * roll = rand(B) < p) made by the caller exactly as the reference makes them on the host.

@@ -54,12 +54,32 @@ class DepthwiseConv2dBn(nn.Module):
         if activation_params is not None:
             self.depthwise_activation = getattr(nn, activation_params['name'])(**activation_params['args'])
         self.pointwise_conv = nn.Conv2d(in_channels, out_channels, kernel_size=1, bias=bias)
+        self.pointwise_conv.weight.data = self.pointwise_conv.weight.data.contiguous(memory_format=torch.channels_last)
         if use_bn:
             self.pointwise_bn = nn.BatchNorm2d(out_channels, **batch_norm_params)
         if activation_params is not None:
             self.pointwise_activation = getattr(nn, activation_params['name'])(**activation_params['args'])
 
-    def forward(self, x):  # conv.py:72-85
+    def _hip_ok(self):
+        d, pw = self.depthwise_conv, self.pointwise_conv
+        acts = [self._modules.get('depthwise_activation'), self._modules.get('pointwise_activation')]
+        return (d.kernel_size[0] == d.kernel_size[1] and d.kernel_size[0] <= 5 and d.stride[0] == d.stride[1]
+                and d.padding[0] == d.padding[1] and d.dilation == (1, 1) and d.padding_mode == 'zeros' and d.in_channels % 4 == 0
+                and pw.out_channels % 4 == 0 and all(a is None or isinstance(a, nn.ReLU) for a in acts))
+
+    def forward(self, x):  # conv.py:72-85: depthwise conv -> BN -> act -> pointwise conv -> BN -> act
+        if self._hip_ok():   # libssdk: depthwise stencil (csrc/norm.hip) + 1x1 implicit GEMM (csrc/conv.hip) + BatchNorm/ReLU kernels
+            has_bn = 'depthwise_bn' in self._modules
+            d, pw = self.depthwise_conv, self.pointwise_conv
+            x = ops.depthwise_conv2d(x, d.weight, d.bias, stride=d.stride[0], padding=d.padding[0])
+            if has_bn:
+                x = ops.batch_norm(x, self.depthwise_bn, relu='depthwise_activation' in self._modules)
+            elif 'depthwise_activation' in self._modules:
+                x = torch.relu(x)
+            x = ops.conv2d(x, pw.weight, pw.bias, relu='pointwise_activation' in self._modules and not has_bn)
+            if has_bn:
+                x = ops.batch_norm(x, self.pointwise_bn, relu='pointwise_activation' in self._modules)
+            return x
         for name in ('depthwise_conv', 'depthwise_bn', 'depthwise_activation', 'pointwise_conv', 'pointwise_bn',
                      'pointwise_activation'):
             if name in self._modules:

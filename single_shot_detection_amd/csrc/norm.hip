@@ -426,3 +426,184 @@ extern "C" int ssdk_sigmoid_gate_bwd(const float* x, const float* z, const float
     SSDK_CHECK_LAUNCH("gate_bwd_kernel");
     return SSDK_OK;
 }
+
+// ---- depthwise convolution (bf/modules/conv.py:39-85) ----------------------------------------------------------------------
+// HBM-bound stencils on NHWC maps: a thread owns 4 consecutive channels of one output pixel (16-byte loads / stores, the k*k
+// weights of its channels in registers).  Backward-weights: every thread accumulates its pixels' products for its 4 channels,
+// a workgroup reduces over its pixels through LDS and adds one partial per (channel, tap) with an atomic.
+namespace ssdk {
+
+constexpr int kDwMaxTaps = 25;   // up to 5 x 5
+
+__global__ void __launch_bounds__(256) dw_fwd_kernel(const float4* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, int B, int Hin,
+                                                     int Win, int C4, int ks, int stride, int pad, int Hout, int Wout, float4* __restrict__ y) {
+    const long long total = (long long)B * Hout * Wout * C4;
+    const int taps = ks * ks;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long long p = i / C4;
+        const int xo = (int)(p % Wout); p /= Wout;
+        const int yo = (int)(p % Hout);
+        const int b = (int)(p / Hout);
+        float4 acc = bias ? *reinterpret_cast<const float4*>(bias + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* wc = w + (long long)c4 * 4 * taps;
+        for (int ky = 0; ky < ks; ++ky) {
+            const int iy = yo * stride - pad + ky;
+            if (iy < 0 || iy >= Hin) continue;
+            for (int kx = 0; kx < ks; ++kx) {
+                const int ix = xo * stride - pad + kx;
+                if (ix < 0 || ix >= Win) continue;
+                const float4 v = x[((long long)(b * Hin + iy) * Win + ix) * C4 + c4];
+                const int t = ky * ks + kx;
+                acc.x = fmaf(wc[t], v.x, acc.x);
+                acc.y = fmaf(wc[taps + t], v.y, acc.y);
+                acc.z = fmaf(wc[2 * taps + t], v.z, acc.z);
+                acc.w = fmaf(wc[3 * taps + t], v.w, acc.w);
+            }
+        }
+        y[i] = acc;
+    }
+}
+
+// dx[b,iy,ix,c] = sum over taps with (iy + pad - ky) % stride == 0 ... of w[c][tap] * dy[b,(iy+pad-ky)/stride,(ix+pad-kx)/stride,c]
+__global__ void __launch_bounds__(256) dw_dgrad_kernel(const float4* __restrict__ dy, const float* __restrict__ w, int B, int Hin, int Win, int C4, int ks,
+                                                       int stride, int pad, int Hout, int Wout, float4* __restrict__ dx, int accumulate) {
+    const long long total = (long long)B * Hin * Win * C4;
+    const int taps = ks * ks;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long long p = i / C4;
+        const int ix = (int)(p % Win); p /= Win;
+        const int iy = (int)(p % Hin);
+        const int b = (int)(p / Hin);
+        float4 acc = accumulate ? dx[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* wc = w + (long long)c4 * 4 * taps;
+        for (int ky = 0; ky < ks; ++ky) {
+            const int ty = iy + pad - ky;
+            if (ty < 0 || ty % stride || ty / stride >= Hout) continue;
+            for (int kx = 0; kx < ks; ++kx) {
+                const int tx = ix + pad - kx;
+                if (tx < 0 || tx % stride || tx / stride >= Wout) continue;
+                const float4 v = dy[((long long)(b * Hout + ty / stride) * Wout + tx / stride) * C4 + c4];
+                const int t = ky * ks + kx;
+                acc.x = fmaf(wc[t], v.x, acc.x);
+                acc.y = fmaf(wc[taps + t], v.y, acc.y);
+                acc.z = fmaf(wc[2 * taps + t], v.z, acc.z);
+                acc.w = fmaf(wc[3 * taps + t], v.w, acc.w);
+            }
+        }
+        dx[i] = acc;
+    }
+}
+
+// grid (C4 blocks of 64 channel-quads, pixel chunks): thread (cq, ps) = channel quad cq of the block, pixel phase ps of 4
+__global__ void __launch_bounds__(256) dw_wgrad_kernel(const float4* __restrict__ x, const float4* __restrict__ dy, int B, int Hin, int Win, int C4, int ks,
+                                                       int stride, int pad, int Hout, int Wout, int pixels_per_block, float* __restrict__ dw,
+                                                       float* __restrict__ db) {
+    __shared__ float s_red[4][64][4];
+    const int taps = ks * ks;
+    const int cq = threadIdx.x & 63, ps = threadIdx.x >> 6;
+    const int c4 = blockIdx.x * 64 + cq;
+    const long long M = (long long)B * Hout * Wout;
+    const long long p0 = (long long)blockIdx.y * pixels_per_block, p1 = p0 + pixels_per_block < M ? p0 + pixels_per_block : M;
+    float4 acc[kDwMaxTaps];
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < kDwMaxTaps; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < C4) {
+        for (long long p = p0 + ps; p < p1; p += 4) {
+            const int xo = (int)(p % Wout);
+            const int yo = (int)((p / Wout) % Hout);
+            const int b = (int)(p / ((long long)Wout * Hout));
+            const float4 g = dy[p * C4 + c4];
+            bsum.x += g.x; bsum.y += g.y; bsum.z += g.z; bsum.w += g.w;
+#pragma unroll
+            for (int t = 0; t < kDwMaxTaps; ++t) {
+                if (t >= taps) break;
+                const int iy = yo * stride - pad + t / ks, ix = xo * stride - pad + t % ks;
+                if (iy < 0 || iy >= Hin || ix < 0 || ix >= Win) continue;
+                const float4 v = x[((long long)(b * Hin + iy) * Win + ix) * C4 + c4];
+                acc[t].x = fmaf(g.x, v.x, acc[t].x);
+                acc[t].y = fmaf(g.y, v.y, acc[t].y);
+                acc[t].z = fmaf(g.z, v.z, acc[t].z);
+                acc[t].w = fmaf(g.w, v.w, acc[t].w);
+            }
+        }
+    }
+    // reduce the 4 pixel phases through LDS, one tap at a time; phase 0 adds the block's partial
+    for (int t = -1; t < taps; ++t) {
+        const float4 v = t < 0 ? bsum : acc[t < 0 ? 0 : t];
+        __syncthreads();
+        s_red[ps][cq][0] = v.x; s_red[ps][cq][1] = v.y; s_red[ps][cq][2] = v.z; s_red[ps][cq][3] = v.w;
+        __syncthreads();
+        if (ps == 0 && c4 < C4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float sum = s_red[0][cq][e] + s_red[1][cq][e] + s_red[2][cq][e] + s_red[3][cq][e];
+                if (t < 0) { if (db) atomicAdd(db + c4 * 4 + e, sum); }
+                else atomicAdd(dw + (long long)(c4 * 4 + e) * taps + t, sum);
+            }
+        }
+    }
+}
+
+__global__ void zero_small_kernel(float* a, long long na, float* b, long long nb) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += (long long)gridDim.x * blockDim.x) {
+        if (i < na) a[i] = 0.0f;
+        else b[i - na] = 0.0f;
+    }
+}
+
+}  // namespace ssdk
+
+static int dw_check(const char* fn, int batch, int hin, int win, int channels, int ksize, int stride, int pad) {
+    SSDK_REQUIRE(batch > 0 && hin > 0 && win > 0 && channels > 0 && channels % 4 == 0 && ksize >= 1 && ksize * ksize <= ssdk::kDwMaxTaps && stride >= 1 && pad >= 0 &&
+                     hin + 2 * pad >= ksize && win + 2 * pad >= ksize,
+                 SSDK_E_INVALID, "%s: batch=%d H=%d W=%d C=%d (%%4) k=%d stride=%d pad=%d", fn, batch, hin, win, channels, ksize, stride, pad);
+    return SSDK_OK;
+}
+
+extern "C" int ssdk_depthwise_conv2d_fwd(const float* x, const float* w, const float* bias, int batch, int hin, int win, int channels, int ksize,
+                                         int stride, int pad, float* y, void* stream) {
+    int rc = dw_check("ssdk_depthwise_conv2d_fwd", batch, hin, win, channels, ksize, stride, pad);
+    if (rc) return rc;
+    SSDK_REQUIRE(x && w && y && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)bias) & 15) == 0, SSDK_E_INVALID, "ssdk_depthwise_conv2d_fwd: null or unaligned pointer");
+    const int ho = (hin + 2 * pad - ksize) / stride + 1, wo = (win + 2 * pad - ksize) / stride + 1;
+    const long long total = (long long)batch * ho * wo * (channels / 4);
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
+    hipLaunchKernelGGL(ssdk::dw_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(x), w, bias, batch, hin, win,
+                       channels / 4, ksize, stride, pad, ho, wo, reinterpret_cast<float4*>(y));
+    SSDK_CHECK_LAUNCH("dw_fwd_kernel");
+    return SSDK_OK;
+}
+
+extern "C" int ssdk_depthwise_conv2d_bwd(const float* x, const float* w, const float* dy, int batch, int hin, int win, int channels, int ksize,
+                                         int stride, int pad, float* dx, float* dw, float* db, int accumulate, void* stream) {
+    int rc = dw_check("ssdk_depthwise_conv2d_bwd", batch, hin, win, channels, ksize, stride, pad);
+    if (rc) return rc;
+    SSDK_REQUIRE(x && w && dy && (dx || dw) && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0, SSDK_E_INVALID,
+                 "ssdk_depthwise_conv2d_bwd: null or unaligned pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int ho = (hin + 2 * pad - ksize) / stride + 1, wo = (win + 2 * pad - ksize) / stride + 1, c4 = channels / 4;
+    if (dx) {
+        const long long total = (long long)batch * hin * win * c4;
+        const unsigned blocks = (unsigned)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
+        hipLaunchKernelGGL(ssdk::dw_dgrad_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(dy), w, batch, hin, win, c4, ksize, stride, pad, ho,
+                           wo, reinterpret_cast<float4*>(dx), accumulate);
+        SSDK_CHECK_LAUNCH("dw_dgrad_kernel");
+    }
+    if (dw) {
+        if (!accumulate) {
+            hipLaunchKernelGGL(ssdk::zero_small_kernel, dim3(8), dim3(256), 0, s, dw, (long long)channels * ksize * ksize, db, db ? (long long)channels : 0LL);
+            SSDK_CHECK_LAUNCH("zero_small_kernel");
+        }
+        const long long M = (long long)batch * ho * wo;
+        int chunks = (int)((M + 255) / 256);   // >= 256 pixels per block ...
+        if (chunks > 512) chunks = 512;         // ... and at most 512 partials per (channel, tap)
+        const int ppb = (int)((M + chunks - 1) / chunks);
+        hipLaunchKernelGGL(ssdk::dw_wgrad_kernel, dim3((unsigned)((c4 + 63) / 64), (unsigned)chunks), dim3(256), 0, s, reinterpret_cast<const float4*>(x),
+                           reinterpret_cast<const float4*>(dy), batch, hin, win, c4, ksize, stride, pad, ho, wo, ppb, dw, db);
+        SSDK_CHECK_LAUNCH("dw_wgrad_kernel");
+    }
+    return SSDK_OK;
+}

@@ -253,3 +253,43 @@ class _GateFn(torch.autograd.Function):
 
 def sigmoid_gate(x, z):
     return _GateFn.apply(x, z)
+
+
+class _DepthwiseFn(torch.autograd.Function):
+    """Depthwise k x k convolution (groups = channels) on libssdk; weight is torch's [C, 1, k, k] parameter."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad):
+        lib = _lib.lib()
+        _lib.require_cuda(x, weight)
+        x = _nhwc(x)
+        B, C, H, W = x.shape
+        k = weight.shape[-1]
+        w = weight.float().contiguous()
+        b = None if bias is None else bias.float().contiguous()
+        ho, wo = _out_dim(H, k, stride, pad), _out_dim(W, k, stride, pad)
+        y = torch.empty((B, C, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        _lib.check(lib.ssdk_depthwise_conv2d_fwd(_dp(x), _dp(w), _dp(b), B, H, W, C, k, stride, pad, _dp(y), _lib.current_stream()),
+                   'ssdk_depthwise_conv2d_fwd')
+        ctx.save_for_backward(x, w)
+        ctx.meta = (stride, pad, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.lib()
+        x, w = ctx.saved_tensors
+        stride, pad, has_bias = ctx.meta
+        B, C, H, W = x.shape
+        k = w.shape[-1]
+        dy = _nhwc(dy)
+        dx = torch.empty_like(x, memory_format=torch.channels_last) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w)
+        db = torch.empty((C,), dtype=torch.float32, device=x.device) if has_bias else None
+        _lib.check(lib.ssdk_depthwise_conv2d_bwd(_dp(x), _dp(w), _dp(dy), B, H, W, C, k, stride, pad, _dp(dx), _dp(dw), _dp(db), 0,
+                                                 _lib.current_stream()), 'ssdk_depthwise_conv2d_bwd')
+        return dx, dw, db, None, None
+
+
+def depthwise_conv2d(x, weight, bias=None, stride=1, padding=0):
+    return _DepthwiseFn.apply(x, weight, bias, int(stride), int(padding))

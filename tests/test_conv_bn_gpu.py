@@ -53,6 +53,23 @@ def _compare_module(gpu_m, ref_m, x_np, train, rtol=2e-4, atol=2e-4):
         np.testing.assert_allclose(b1.cpu().numpy(), b2.numpy(), rtol=1e-4, atol=1e-5, err_msg=n1)
 
 
+class _RefDepthwise(nn.Module):
+    """bf/modules/conv.py:39-85 with stock torch ops (CPU reference)."""
+    def __init__(self, m):
+        super().__init__()
+        self.mods = nn.ModuleDict({k: copy.deepcopy(v) for k, v in m._modules.items()})
+
+    def forward(self, x):
+        for name in ('depthwise_conv', 'depthwise_bn', 'depthwise_activation', 'pointwise_conv', 'pointwise_bn', 'pointwise_activation'):
+            if name in self.mods:
+                x = self.mods[name](x)
+        return x
+
+
+def _ref_of(m):
+    return _RefDepthwise(m) if isinstance(m, conv.DepthwiseConv2dBn) else _RefConv2dBn(m)
+
+
 @pytest.mark.parametrize('train', [True, False])
 @pytest.mark.parametrize('cin,cout,k,stride,pad,hw', [(512, 256, 1, 1, 0, 18), (256, 512, 3, 2, 1, 18), (128, 256, 3, 2, 1, 5),
                                                       (128, 256, 3, 1, 0, 3), (64, 32, 3, 2, 1, 2)])
@@ -234,3 +251,59 @@ def test_m2det_neck_vs_torch():
         scale = float(p2.grad.abs().max()) + 1e-6
         # biases feeding a BatchNorm have an analytically zero gradient: what is left is rounding noise, hence the absolute floor
         np.testing.assert_allclose(p1.grad.cpu().numpy(), p2.grad.numpy(), rtol=5e-3, atol=5e-3 * scale + 2e-4, err_msg=n1)
+
+
+def test_ssd_mb2_depthwise_extras_chain_vs_torch():
+    """samples/ssd_mb2_voc.py: use_depthwise extras 1280@10 -> 512@5 -> 256@3 -> 256@2 -> 128@1, every block on libssdk."""
+    from single_shot_detection_amd.bf.modules.conv import DepthwiseConv2dBn
+    rng = np.random.default_rng(13)
+    extras = detector_builder.get_extras([1280], use_depthwise=True, layers=(('s', 512), ('s', 256), ('s', 256), ('s', 128)))
+    _randomize(extras, rng)
+    ref = nn.ModuleList([nn.Sequential(*[_ref_of(b) for b in blk]) for blk in extras])
+    extras = extras.cuda()
+    assert any(isinstance(m, DepthwiseConv2dBn) for m in extras.modules())
+    x_np = rng.standard_normal((4, 1280, 10, 10), dtype=np.float32)
+    xr = torch.from_numpy(x_np).requires_grad_(True)
+    xg = torch.from_numpy(x_np).cuda().requires_grad_(True)
+    outs_r, outs_g, cr, cg = [], [], xr, xg
+    for blk_g, blk_r, want in zip(extras, ref, (5, 3, 2, 1)):
+        cr, cg = blk_r(cr), blk_g(cg)
+        assert cg.shape[2] == want
+        outs_r.append(cr); outs_g.append(cg)
+        np.testing.assert_allclose(cg.detach().cpu().numpy(), cr.detach().numpy(), rtol=3e-3, atol=3e-3)
+    # 1x1 maps in train-mode BatchNorm over 4 samples are ill-conditioned: differentiate a weighted sum of the first three levels
+    gws = [torch.from_numpy(rng.standard_normal(tuple(o.shape), dtype=np.float32)) for o in outs_r[:3]]
+    sum((o * g).sum() for o, g in zip(outs_r[:3], gws)).backward()
+    sum((o * g.cuda()).sum() for o, g in zip(outs_g[:3], gws)).backward()
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-2, atol=1e-2 * (1 + float(xr.grad.abs().max())))
+
+
+@pytest.mark.parametrize('cin,cout,h,k,stride,pad', [(32, 64, 10, 3, 2, 1), (64, 32, 7, 3, 1, 1), (16, 24, 9, 5, 2, 2), (1280, 512, 10, 3, 2, 1)])
+def test_depthwise_conv2d_bn_vs_torch(cin, cout, h, k, stride, pad):
+    """DepthwiseConv2dBn (bf/modules/conv.py:39-85, the `use_depthwise` extras of samples/ssd_mb2_voc.py) on libssdk vs stock torch CPU."""
+    from single_shot_detection_amd.bf.modules.conv import DepthwiseConv2dBn
+    rng = np.random.default_rng(31)
+    torch.manual_seed(0)
+    blk = DepthwiseConv2dBn(cin, cout, kernel_size=k, stride=stride, padding=pad)
+    _randomize(blk, rng)
+    ref = _RefDepthwise(blk)
+    blk = blk.cuda()
+    assert blk._hip_ok()
+    x_np = rng.standard_normal((4, cin, h, h), dtype=np.float32)
+    xr = torch.from_numpy(x_np).requires_grad_(True)
+    xg = torch.from_numpy(x_np).cuda().requires_grad_(True)
+    yr, yg = ref(xr), blk(xg)
+    assert yg.shape == yr.shape
+    np.testing.assert_allclose(yg.detach().cpu().numpy(), yr.detach().numpy(), rtol=2e-3, atol=2e-3)
+    gw = torch.from_numpy(rng.standard_normal(tuple(yr.shape), dtype=np.float32))
+    (yr * gw).sum().backward()
+    (yg * gw.cuda()).sum().backward()
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=5e-3, atol=5e-3 * (1 + float(xr.grad.abs().max())))
+    for (n1, p1), (n2, p2) in zip(sorted(blk.named_parameters()), sorted(ref.mods.named_parameters())):
+        assert n1 == n2
+        scale = float(p2.grad.abs().max()) + 1e-6
+        np.testing.assert_allclose(p1.grad.cpu().numpy(), p2.grad.numpy(), rtol=5e-3, atol=5e-3 * scale + 2e-4, err_msg=n1)
+    # eval mode (running statistics)
+    blk.eval(); ref.eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(blk(xg).cpu().numpy(), ref(xr).numpy(), rtol=2e-3, atol=2e-3)
