@@ -8,8 +8,15 @@ views of one packed buffer."""
 import numpy as np
 import torch
 
+import enum
+
 from ... import _lib
-from .target_types import TargetTypes
+
+
+class TargetTypes(enum.Enum):
+    """What a batch carries besides the images (the reference keeps this enum in bf/core/target_types.py)."""
+    Boxes = 'boxes'
+    NoTarget = 'no_target'
 
 SCORE_INDEX = 5   # bf/datasets/detection_dataset.py:14
 GT_ROW = 6

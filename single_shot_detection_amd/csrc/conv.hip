@@ -244,10 +244,16 @@ constexpr unsigned kOobBit = 0x80000000u;
 // w + 4 share a SIMD: the barrier keeps the two in step, so the slot-1 wave cannot fall behind its partner the way it
 // does between two independent workgroups (cycle stamps: 12.0k vs 8.7k cycles per slice), and the W slice is staged once
 // for 256 pixels.  The host picks WAVES = 8 when the 256-pixel tiling still fills the chip.
-template <bool MIRROR, bool GENERIC, bool SCATTER, int WAVES>
+template <bool MIRROR, bool GENERIC, bool SCATTER, int WAVES, int BK>
 __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_tile, int n_block, int ksp) {
-    constexpr int BM = 32 * WAVES;              // output pixels per workgroup
-    constexpr int kWPieces = 16 / WAVES;        // W pieces (8 rows) each wave stages per slice
+    // BK = K slice: 32 floats (128-byte rows, 8 rows per DMA piece, 64 KB of LDS: 2 workgroups per CU) or 16 floats (64-byte rows,
+    // 16 rows per piece, 32 KB: 3 workgroups per CU at <= 170 VGPRs, a barrier every 32 MFMAs instead of 64)
+    constexpr int BM = 32 * WAVES;                         // output pixels per workgroup
+    constexpr int kRowsPerPiece = 1024 / (BK * 4);         // rows of one 1 KB DMA piece
+    constexpr int kChunks = BK / 4;                        // 16-byte chunks per row
+    constexpr int kAPieces = 32 / kRowsPerPiece;           // A pieces each wave stages per slice (its own 32 rows)
+    constexpr int kWPieces = (128 / kRowsPerPiece) / WAVES;   // W pieces each wave stages per slice
+    constexpr int kBK = BK;                                // (shadows the file-level constant inside this function)
     // FOUR separate LDS objects (two stages x two operands), not one array: the compiler orders a ds_read behind an
     // in-flight LDS-DMA (s_waitcnt vmcnt(0) in front of the read) unless alias scopes prove they touch different objects,
     // and only distinct __shared__ variables get such scopes.
@@ -296,12 +302,14 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
     //   mirror:   pixel part (y + pad, x + pad) >= 0;  tap part -(ky*Win + kx) >= -((ks-1)*(Win+1))
     const int a_ps = g.a_pstride, win_ps = g.Win * a_ps;
     const int shift = SCATTER ? 0 : (MIRROR ? -(ks - 1) * (win_ps + a_ps) : -g.pad * (win_ps + a_ps));   // elements, <= 0
-    unsigned a_vo[4], a_nmask[4], w_vo[4];   // (w_vo: 16 / WAVES entries used)
+    unsigned a_vo[4], a_nmask[4], w_vo[4];   // (kAPieces / kWPieces entries used)
     bool w_seg1[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = 8 * i + (lane >> 3);                       // row inside the wave's 32
-        const int src_chunk = (lane & 7) ^ ((row >> 1) & 7);       // swizzle (row + 32*wave has the same bits 1..3)
+    for (int i = 0; i < kAPieces; ++i) {
+        const int row = kRowsPerPiece * i + lane / kChunks;        // row inside the wave's 32
+        // swizzle: chunk position q of row r holds source chunk q ^ f(r); f = (r >> 1) & 7 for 128-byte rows, (r >> 2) & 3 for
+        // 64-byte rows (conflict-free ds_read_b128 over the 16-lane groups of the instruction; row + 32 * wave has the same f)
+        const int src_chunk = (lane % kChunks) ^ (BK == 32 ? (row >> 1) & 7 : (row >> 2) & 3);
         const int m = m_base + wave * 32 + row;
         a_vo[i] = kOobBit;
         a_nmask[i] = 0;
@@ -338,14 +346,14 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
     }
 #pragma unroll
     for (int i = 0; i < kWPieces; ++i) {
-        const int wrow = (wave * kWPieces + i) * 8 + (lane >> 3);   // row of the 128-row W slice
-        const int src_chunk = (lane & 7) ^ ((wrow >> 1) & 7);
+        const int wrow = (wave * kWPieces + i) * kRowsPerPiece + lane / kChunks;   // row of the 128-row W slice
+        const int src_chunk = (lane % kChunks) ^ (BK == 32 ? (wrow >> 1) & 7 : (wrow >> 2) & 3);
         const int n = n_begin + wrow;
-        // (n0_pad is a multiple of 8 and pieces start at multiples of 8: a piece never mixes the two weight tensors)
+        // (n0_pad is a multiple of the rows of a piece: a piece never mixes the two weight tensors)
         w_vo[i] = (wrow < tn * 32 && n < N && !(n >= g.n0 && n < g.n0_pad))
                       ? (unsigned)((n < g.n0 ? n : n - g.n0_pad) * K) * 4u + (unsigned)src_chunk * 16u
                       : kOobBit;
-        w_seg1[i] = n_begin + (wave * kWPieces + i) * 8 >= g.n0_pad;   // uniform: which tensor this piece reads
+        w_seg1[i] = n_begin + (wave * kWPieces + i) * kRowsPerPiece >= g.n0_pad;   // uniform: which tensor this piece reads
     }
 
     // buffer descriptors (wave-uniform): A window starts `shift` elements before the tensor, W window spans both segments
@@ -378,11 +386,11 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
         ld_chunk += wrap_t ? 1 : 0;
     };
     auto stage_piece = [&](int DST, int i) {   // DST is a literal at every call site (folds after inlining)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)((DST ? s_a1 : s_a0) + (wave * 32 + 8 * i) * kBK), 16,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)((DST ? s_a1 : s_a0) + (wave * 32 + kRowsPerPiece * i) * kBK), 16,
                                                  a_vo[i] | ((a_nmask[i] >> tap_bit) << 31), so_a, 0, 0);
     };
     auto stage_w_piece = [&](int DST, int i) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_seg1[i] ? rsrc_w1 : rsrc_w0, (lds_ptr_t)((DST ? s_b1 : s_b0) + ((wave * (16 / WAVES) + i) * 8) * kBK), 16, w_vo[i],
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_seg1[i] ? rsrc_w1 : rsrc_w0, (lds_ptr_t)((DST ? s_b1 : s_b0) + ((wave * ((128 / (1024 / (BK * 4))) / WAVES) + i) * (1024 / (BK * 4))) * kBK), 16, w_vo[i],
                                                  so_w, 0, 0);
     };
 
@@ -393,12 +401,12 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
 
     // fragment reads: lane (r, h) reads source chunk 2*gk + h of its row, stored at position (2*gk + h) ^ ((r >> 1) & 7)
-    const int pos0 = h ^ ((r32 >> 1) & 7);
+    const int pos0 = h ^ (BK == 32 ? (r32 >> 1) & 7 : (r32 >> 2) & 3);
     const int a_row = (wave * 32 + r32) * kBK, b_row = r32 * kBK;
 
     slice_offsets(true);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) stage_piece(0, i);
+    for (int i = 0; i < kAPieces; ++i) stage_piece(0, i);
 #pragma unroll
     for (int i = 0; i < kWPieces; ++i) stage_w_piece(0, i);
     __syncthreads();   // (waits for the DMA: it is a pending LDS write of this wave)
@@ -430,7 +438,7 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
 #pragma unroll
             for (int gk = 0; gk < kBK / 8; ++gk) {
                 if (gk + 1 < kBK / 8) read_frags((gk + 1) & 1, gk + 1);
-                stage_piece(ST ^ 1, gk);
+                if (gk < kAPieces) stage_piece(ST ^ 1, gk);
                 if (gk < kWPieces) stage_w_piece(ST ^ 1, gk);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -470,8 +478,8 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
 constexpr int kVtabSegs = 16 + 1;
 constexpr int kVtabInts = 1 + (kMaxProblems + 1) + kMaxProblems * kVtabSegs;
 
-template <bool MIRROR, bool GENERIC, bool SCATTER, int WAVES>
-__global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? SSDK_CONV_WAVES : 1) igemm_dma_kernel(ConvGroup grp) {
+template <bool MIRROR, bool GENERIC, bool SCATTER, int WAVES, int BK = 32>
+__global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? (BK == 16 ? 3 : SSDK_CONV_WAVES) : 1) igemm_dma_kernel(ConvGroup grp) {
     if (SCATTER && grp.vtab) {
         const int* vt = grp.vtab;
         const int total = vt[0];
@@ -489,7 +497,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? SSDK_CONV_WAVES : 1) 
             for (int q = 1; q < (g.seg_count ? g.segs : 1); ++q)
                 if (t >= tp[q]) seg = q;
             const int tiles_per_seg = ((g.seg_count ? g.seg_cap : g.B * g.Hout * g.Wout) + 32 * WAVES - 1) / (32 * WAVES);
-            dma_tile<MIRROR, GENERIC, SCATTER, WAVES>(g, pi, seg * tiles_per_seg + (t - tp[seg]), n_block, 0);
+            dma_tile<MIRROR, GENERIC, SCATTER, WAVES, BK>(g, pi, seg * tiles_per_seg + (t - tp[seg]), n_block, 0);
             __syncthreads();   // the next tile's first DMA overwrites LDS stage 0
         }
         return;
@@ -509,7 +517,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? SSDK_CONV_WAVES : 1) 
     const int m_tile = chunk * 8 + (within & 7);
     const int n_block = within >> 3;
     if (m_tile >= (WAVES == 4 ? g.m_tiles : g.m_tiles256)) return;
-    dma_tile<MIRROR, GENERIC, SCATTER, WAVES>(g, pi, m_tile, n_block, ksp);
+    dma_tile<MIRROR, GENERIC, SCATTER, WAVES, BK>(g, pi, m_tile, n_block, ksp);
 }
 
 // ---- forward / backward-data ------------------------------------------------------------------------------------
@@ -1484,9 +1492,11 @@ static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t 
         g.w0_bytes = (unsigned)w0_bytes;
         g.w1_bytes = (unsigned)w1_bytes;
     }
+    // 16-float K slices (3 workgroups per CU): opt-in experiment for the plain forward launch
+    const bool bk16 = dma && !mirror && !generic && !scatter && getenv("SSDK_CONV_BK16");
     for (int i = 0; i < count; ++i) {   // column space of the chosen kernel (see ConvProblem::n0_pad)
         ConvProblem& g = probs[i];
-        g.n0_pad = (dma && g.n1 > 0) ? cdiv(g.n0, 8) * 8 : g.n0;
+        g.n0_pad = (dma && g.n1 > 0) ? cdiv(g.n0, bk16 ? 16 : 8) * (bk16 ? 16 : 8) : g.n0;
         g.tiles_n = cdiv(g.n0_pad + g.n1, 32);
         g.n_blocks = cdiv(g.tiles_n, kMaxTN);
     }
@@ -1540,6 +1550,7 @@ static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t 
         if (scatter) hipLaunchKernelGGL((igemm_dma_kernel<false, false, true, 4>), dim3(begin), dim3(kConvThreads), 0, s, grp);
         else if (mirror) hipLaunchKernelGGL((igemm_dma_kernel<true, false, false, 4>), dim3(begin), dim3(kConvThreads), 0, s, grp);
         else if (generic) hipLaunchKernelGGL((igemm_dma_kernel<false, true, false, 4>), dim3(begin), dim3(kConvThreads), 0, s, grp);
+        else if (bk16) hipLaunchKernelGGL((igemm_dma_kernel<false, false, false, 4, 16>), dim3(begin), dim3(kConvThreads), 0, s, grp);
         else hipLaunchKernelGGL((igemm_dma_kernel<false, false, false, 4>), dim3(begin), dim3(kConvThreads), 0, s, grp);
     } else if (scatter) {
         SSDK_REQUIRE(vec4, SSDK_E_UNSUPPORTED, "scatter dgrad needs 16-byte aligned rows");
