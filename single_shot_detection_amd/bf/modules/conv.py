@@ -6,6 +6,16 @@ import torch.nn as nn
 from ... import ops
 
 
+def _norm_act(x, bn, act):
+    """BatchNorm (+ ReLU) on libssdk for a plain nn.BatchNorm2d.  Anything else -- in particular the SyncBatchNorm that
+    detection.init(distributed=True) converts to (reference: apex convert_syncbn_model, detection/init.py:85), whose batch statistics
+    are all-reduced over the ranks -- keeps its own torch kernels, so that the distributed semantics are the reference's."""
+    if type(bn) is nn.BatchNorm2d:
+        return ops.batch_norm(x, bn, relu=act is not None)
+    x = bn(x)
+    return act(x) if act is not None else x
+
+
 class Conv2dBn(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, groups=1, bias=False, use_bn=True,
                  activation_params={'name': 'ReLU', 'args': {'inplace': True}}, batch_norm_params={}):
@@ -32,7 +42,7 @@ class Conv2dBn(nn.Module):
             c = self.conv
             x = ops.conv2d(x, c.weight, c.bias, stride=c.stride[0], padding=c.padding[0], relu=has_act and not has_bn)
             if has_bn:
-                x = ops.batch_norm(x, self.bn, relu=has_act)
+                x = _norm_act(x, self.bn, self._modules.get('activation'))
             return x
         # grouped / depthwise / exotic variants (neck-side, out of the hot-path scope): stock PyTorch-ROCm modules
         x = self.conv(x)
@@ -73,12 +83,12 @@ class DepthwiseConv2dBn(nn.Module):
             d, pw = self.depthwise_conv, self.pointwise_conv
             x = ops.depthwise_conv2d(x, d.weight, d.bias, stride=d.stride[0], padding=d.padding[0])
             if has_bn:
-                x = ops.batch_norm(x, self.depthwise_bn, relu='depthwise_activation' in self._modules)
+                x = _norm_act(x, self.depthwise_bn, self._modules.get('depthwise_activation'))
             elif 'depthwise_activation' in self._modules:
                 x = torch.relu(x)
             x = ops.conv2d(x, pw.weight, pw.bias, relu='pointwise_activation' in self._modules and not has_bn)
             if has_bn:
-                x = ops.batch_norm(x, self.pointwise_bn, relu='pointwise_activation' in self._modules)
+                x = _norm_act(x, self.pointwise_bn, self._modules.get('pointwise_activation'))
             return x
         for name in ('depthwise_conv', 'depthwise_bn', 'depthwise_activation', 'pointwise_conv', 'pointwise_bn',
                      'pointwise_activation'):

@@ -45,7 +45,8 @@ class SharedConvPredictor(nn.Module):
         if isinstance(block, conv.Conv2dBn) and isinstance(self.activation, nn.ReLU) and block._hip_ok():
             c = block.conv
             ys = ops.conv2d(list(xs), c.weight, c.bias, stride=c.stride[0], padding=c.padding[0], relu=True)
-            return [ops.batch_norm(y, norm) for norm, y in zip(norms, ys)]
+            # (a SyncBatchNorm -- detection.init(distributed=True) -- keeps torch's kernels: its statistics are all-reduced over the ranks)
+            return [ops.batch_norm(y, norm) if type(norm) is nn.BatchNorm2d else norm(y) for norm, y in zip(norms, ys)]
         return [norm(self.activation(block(x))) for norm, x in zip(norms, xs)]   # depthwise towers: stock ops
 
     def forward(self, sources):  # predictors.py:60-76: conv -> activation -> per-level norm

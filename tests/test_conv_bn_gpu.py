@@ -307,3 +307,19 @@ def test_depthwise_conv2d_bn_vs_torch(cin, cout, h, k, stride, pad):
     blk.eval(); ref.eval()
     with torch.no_grad():
         np.testing.assert_allclose(blk(xg).cpu().numpy(), ref(xr).numpy(), rtol=2e-3, atol=2e-3)
+
+
+def test_conv2dbn_with_syncbatchnorm_keeps_torch_norm():
+    """detection.init(distributed=True) converts BatchNorm2d to SyncBatchNorm: the conv stays on libssdk, the norm on torch's kernels."""
+    rng = np.random.default_rng(3)
+    m = conv.Conv2dBn(32, 64, kernel_size=3, stride=2, padding=1, bias=False)
+    _randomize(m, rng)
+    ref = _RefConv2dBn(m)
+    gpu = nn.SyncBatchNorm.convert_sync_batchnorm(m).cuda()
+    assert isinstance(gpu.bn, nn.SyncBatchNorm)
+    x = rng.standard_normal((4, 32, 9, 9), dtype=np.float32)
+    for train in (True, False):
+        gpu.train(train); ref.train(train)
+        yg = gpu(torch.from_numpy(x).cuda())
+        yr = ref(torch.from_numpy(x))
+        np.testing.assert_allclose(yg.detach().cpu().numpy(), yr.detach().numpy(), rtol=1e-3, atol=1e-3)
