@@ -327,23 +327,30 @@ __global__ void __launch_bounds__(kPostThreads) post_nms_kernel(const float4* __
         }
         return;
     }
-    for (int t = tid; t < m * W; t += kPostThreads) {
-        const int k = t / W, w = t % W;
-        const float4 bk = s_box[k];
-        const float ak = s_area[k];
-        u64 bits = 0;
-        const int j0 = w * 64;
-        for (int jj = 0; jj < 64; ++jj) {
-            const int j = j0 + jj;
-            if (j > k && j < m) {
-                const float4 bj = s_box[j];
-                const float iw = clamp0(tminf(bk.z, bj.z) - tmaxf(bk.x, bj.x));
-                const float ih = clamp0(tminf(bk.w, bj.w) - tmaxf(bk.y, bj.y));
-                const float inter = iw * ih;
-                if (inter / (ak + s_area[j] - inter) > nms_thr) bits |= 1ull << jj;
+    // IoU bit matrix, strict upper triangle only (j > k).  A work item is a 16-column quarter of one 64-bit word of one row, so the
+    // longest dependent chain of a thread is 16 IoUs (LDS read + division each) and the triangle spreads over the 256 threads;
+    // the four 16-bit parts of a word are stored side by side (little endian: part q = bits 16q .. 16q+15 of s_mask[k][w]).
+    {
+        unsigned short* m16 = reinterpret_cast<unsigned short*>(&s_mask[0][0]);
+        for (int t = tid; t < m * W * 4; t += kPostThreads) {
+            const int k = t / (W * 4), r = t % (W * 4), w = r >> 2, q = r & 3;
+            const int j0 = w * 64 + q * 16;
+            const int jj_begin = k + 1 > j0 ? k + 1 - j0 : 0, jj_end = m - j0 < 16 ? m - j0 : 16;
+            unsigned bits = 0;
+            if (jj_begin < jj_end) {
+                const float4 bk = s_box[k];
+                const float ak = s_area[k];
+                for (int jj = jj_begin; jj < jj_end; ++jj) {
+                    const int j = j0 + jj;
+                    const float4 bj = s_box[j];
+                    const float iw = clamp0(tminf(bk.z, bj.z) - tmaxf(bk.x, bj.x));
+                    const float ih = clamp0(tminf(bk.w, bj.w) - tmaxf(bk.y, bj.y));
+                    const float inter = iw * ih;
+                    if (inter / (ak + s_area[j] - inter) > nms_thr) bits |= 1u << jj;
+                }
             }
+            m16[(k * (kMaxPerClass / 64) + w) * 4 + q] = (unsigned short)bits;
         }
-        s_mask[k][w] = bits;
     }
     __syncthreads();
     if (tid < kWave) {  // greedy sweep on one wave; lane l owns rows l, l+64, l+128, l+192
@@ -355,12 +362,14 @@ __global__ void __launch_bounds__(kPostThreads) post_nms_kernel(const float4* __
         u64 removed[4] = {0, 0, 0, 0}, keep[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int kend = min(64, m - s * 64);
+            const int kend = min(64, m - s * 64);   // (<= 0 for the segments past m: no iterations)
             for (int l = 0; l < kend; ++l) {
                 if (!((removed[s] >> l) & 1ull)) {
                     keep[s] |= 1ull << l;
+                    // row k only has bits at j > k: words below the diagonal segment are empty, words past W do not exist
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) removed[w] |= readlane_u64(row[s][w], l);
+                    for (int w = 0; w < 4; ++w)
+                        if (w >= s && w < W) removed[w] |= readlane_u64(row[s][w], l);
                 }
             }
         }
