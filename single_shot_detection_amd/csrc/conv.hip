@@ -130,8 +130,8 @@ struct GVecT<1> { typedef const float __attribute__((address_space(1))) * type; 
 
 
 // Epilogue shared by the GEMM kernels: bias, optional ReLU, store (or atomic add for split-K / scatter).
-template <bool SCATTER>
-__device__ __forceinline__ void conv_epilogue(const ConvProblem& g, const f32x16 (&acc)[kMaxTN], int m_base, int wave, int r32, int h, int tn,
+template <bool SCATTER, int NT>
+__device__ __forceinline__ void conv_epilogue(const ConvProblem& g, const f32x16 (&acc)[NT], int m_base, int wave, int r32, int h, int tn,
                                               int n_begin, int M, int N, int hw, int ksp) {
     // epilogue: C/D map of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
     if (SCATTER) {
@@ -140,9 +140,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvProblem& g, const f32x16
         // of one tap.  When Cin % 32 == 0 a 32-column tile lies inside one tap: tap and first channel are per-tile scalars (the
         // four integer divisions per ELEMENT of the general form were most of the time of a sparse backward workgroup).
         const bool tile_uniform = (g.sc_cin & 31) == 0;
-        int dyj[kMaxTN], dxj[kMaxTN], cbj[kMaxTN];
+        int dyj[NT], dxj[NT], cbj[NT];
 #pragma unroll
-        for (int j = 0; j < kMaxTN; ++j) {
+        for (int j = 0; j < NT; ++j) {
             const int n0j = n_begin + j * 32;
             const int tap = n0j / g.sc_cin;
             dyj[j] = tap / g.ksize - g.pad;
@@ -158,7 +158,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvProblem& g, const f32x16
             const int yo = (r / g.Wout) * g.stride, xo = (r % g.Wout) * g.stride;
             float* const img = g.o0 + (long long)b * g.ob0;
 #pragma unroll
-            for (int j = 0; j < kMaxTN; ++j) {
+            for (int j = 0; j < NT; ++j) {
                 if (j >= tn) continue;
                 const int n = n_begin + j * 32 + r32;
                 if (n >= N) continue;
@@ -181,7 +181,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvProblem& g, const f32x16
         if (m >= M) continue;
         const int b = m / hw, pix = m % hw;
 #pragma unroll
-        for (int j = 0; j < kMaxTN; ++j) {
+        for (int j = 0; j < NT; ++j) {
             if (j >= tn) continue;
             const int n = n_begin + j * 32 + r32;
             if (n >= N) continue;
@@ -244,7 +244,7 @@ constexpr unsigned kOobBit = 0x80000000u;
 // w + 4 share a SIMD: the barrier keeps the two in step, so the slot-1 wave cannot fall behind its partner the way it
 // does between two independent workgroups (cycle stamps: 12.0k vs 8.7k cycles per slice), and the W slice is staged once
 // for 256 pixels.  The host picks WAVES = 8 when the 256-pixel tiling still fills the chip.
-template <bool MIRROR, bool GENERIC, bool SCATTER, int WAVES, int BK>
+template <bool MIRROR, bool GENERIC, bool SCATTER, int WAVES, int BK, int MAXTN>
 __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_tile, int n_block, int ksp) {
     // BK = K slice: 32 floats (128-byte rows, 8 rows per DMA piece, 64 KB of LDS: 2 workgroups per CU) or 16 floats (64-byte rows,
     // 16 rows per piece, 32 KB: 3 workgroups per CU at <= 170 VGPRs, a barrier every 32 MFMAs instead of 64)
@@ -252,15 +252,16 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
     constexpr int kRowsPerPiece = 1024 / (BK * 4);         // rows of one 1 KB DMA piece
     constexpr int kChunks = BK / 4;                        // 16-byte chunks per row
     constexpr int kAPieces = 32 / kRowsPerPiece;           // A pieces each wave stages per slice (its own 32 rows)
-    constexpr int kWPieces = (128 / kRowsPerPiece) / WAVES;   // W pieces each wave stages per slice
+    // MAXTN = 32-column tiles per workgroup: 4 (128 columns, 64 KB of LDS) or 6 (192 columns, 80 KB: two workgroups fill the CU's 160 KB)
+    constexpr int kWPieces = (MAXTN * 32 / kRowsPerPiece) / WAVES;   // W pieces each wave stages per slice
     constexpr int kBK = BK;                                // (shadows the file-level constant inside this function)
     // FOUR separate LDS objects (two stages x two operands), not one array: the compiler orders a ds_read behind an
     // in-flight LDS-DMA (s_waitcnt vmcnt(0) in front of the read) unless alias scopes prove they touch different objects,
     // and only distinct __shared__ variables get such scopes.
     __shared__ __attribute__((aligned(1024))) float s_a0[BM * kBK];
     __shared__ __attribute__((aligned(1024))) float s_a1[BM * kBK];
-    __shared__ __attribute__((aligned(1024))) float s_b0[kMaxTN * 32 * kBK];
-    __shared__ __attribute__((aligned(1024))) float s_b1[kMaxTN * 32 * kBK];
+    __shared__ __attribute__((aligned(1024))) float s_b0[MAXTN * 32 * kBK];
+    __shared__ __attribute__((aligned(1024))) float s_b1[MAXTN * 32 * kBK];
 
     const int Cc = g.Cc;
     const int ks = g.ksize;
@@ -302,8 +303,8 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
     //   mirror:   pixel part (y + pad, x + pad) >= 0;  tap part -(ky*Win + kx) >= -((ks-1)*(Win+1))
     const int a_ps = g.a_pstride, win_ps = g.Win * a_ps;
     const int shift = SCATTER ? 0 : (MIRROR ? -(ks - 1) * (win_ps + a_ps) : -g.pad * (win_ps + a_ps));   // elements, <= 0
-    unsigned a_vo[4], a_nmask[4], w_vo[4];   // (kAPieces / kWPieces entries used)
-    bool w_seg1[4];
+    unsigned a_vo[4], a_nmask[4], w_vo[6];   // (kAPieces / kWPieces entries used)
+    bool w_seg1[6];
 #pragma unroll
     for (int i = 0; i < kAPieces; ++i) {
         const int row = kRowsPerPiece * i + lane / kChunks;        // row inside the wave's 32
@@ -390,13 +391,13 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
                                                  a_vo[i] | ((a_nmask[i] >> tap_bit) << 31), so_a, 0, 0);
     };
     auto stage_w_piece = [&](int DST, int i) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_seg1[i] ? rsrc_w1 : rsrc_w0, (lds_ptr_t)((DST ? s_b1 : s_b0) + ((wave * ((128 / (1024 / (BK * 4))) / WAVES) + i) * (1024 / (BK * 4))) * kBK), 16, w_vo[i],
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_seg1[i] ? rsrc_w1 : rsrc_w0, (lds_ptr_t)((DST ? s_b1 : s_b0) + ((wave * ((MAXTN * 32 / (1024 / (BK * 4))) / WAVES) + i) * (1024 / (BK * 4))) * kBK), 16, w_vo[i],
                                                  so_w, 0, 0);
     };
 
-    f32x16 acc[kMaxTN];
+    f32x16 acc[MAXTN];
 #pragma unroll
-    for (int j = 0; j < kMaxTN; ++j)
+    for (int j = 0; j < MAXTN; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
 
@@ -440,6 +441,7 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
                 if (gk + 1 < kBK / 8) read_frags((gk + 1) & 1, gk + 1);
                 if (gk < kAPieces) stage_piece(ST ^ 1, gk);
                 if (gk < kWPieces) stage_w_piece(ST ^ 1, gk);
+                if (gk + kBK / 8 < kWPieces) stage_w_piece(ST ^ 1, gk + kBK / 8);   // (192-column workgroups: 6 W pieces per wave)
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk)
@@ -461,6 +463,8 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
         }
     };
     switch (tn) {
+        case 6: if constexpr (MAXTN >= 6) { k_loop(std::integral_constant<int, 6>{}); } break;
+        case 5: if constexpr (MAXTN >= 6) { k_loop(std::integral_constant<int, 5>{}); } break;
         case 4: k_loop(std::integral_constant<int, 4>{}); break;
         case 3: k_loop(std::integral_constant<int, 3>{}); break;
         case 2: k_loop(std::integral_constant<int, 2>{}); break;
@@ -478,7 +482,7 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
 constexpr int kVtabSegs = 16 + 1;
 constexpr int kVtabInts = 1 + (kMaxProblems + 1) + kMaxProblems * kVtabSegs;
 
-template <bool MIRROR, bool GENERIC, bool SCATTER, int WAVES, int BK = 32>
+template <bool MIRROR, bool GENERIC, bool SCATTER, int WAVES, int BK = 32, int MAXTN = kMaxTN>
 __global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? (BK == 16 ? 3 : SSDK_CONV_WAVES) : 1) igemm_dma_kernel(ConvGroup grp) {
     if (SCATTER && grp.vtab) {
         const int* vt = grp.vtab;
@@ -497,7 +501,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? (BK == 16 ? 3 : SSDK_
             for (int q = 1; q < (g.seg_count ? g.segs : 1); ++q)
                 if (t >= tp[q]) seg = q;
             const int tiles_per_seg = ((g.seg_count ? g.seg_cap : g.B * g.Hout * g.Wout) + 32 * WAVES - 1) / (32 * WAVES);
-            dma_tile<MIRROR, GENERIC, SCATTER, WAVES, BK>(g, pi, seg * tiles_per_seg + (t - tp[seg]), n_block, 0);
+            dma_tile<MIRROR, GENERIC, SCATTER, WAVES, BK, MAXTN>(g, pi, seg * tiles_per_seg + (t - tp[seg]), n_block, 0);
             __syncthreads();   // the next tile's first DMA overwrites LDS stage 0
         }
         return;
@@ -517,7 +521,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? (BK == 16 ? 3 : SSDK_
     const int m_tile = chunk * 8 + (within & 7);
     const int n_block = within >> 3;
     if (m_tile >= (WAVES == 4 ? g.m_tiles : g.m_tiles256)) return;
-    dma_tile<MIRROR, GENERIC, SCATTER, WAVES, BK>(g, pi, m_tile, n_block, ksp);
+    dma_tile<MIRROR, GENERIC, SCATTER, WAVES, BK, MAXTN>(g, pi, m_tile, n_block, ksp);
 }
 
 // ---- forward / backward-data ------------------------------------------------------------------------------------
@@ -1494,11 +1498,13 @@ static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t 
     }
     // 16-float K slices (3 workgroups per CU): opt-in experiment for the plain forward launch
     const bool bk16 = dma && !mirror && !generic && !scatter && getenv("SSDK_CONV_BK16");
+    // 192-column workgroups (6 column tiles) for the plain forward launch: opt-in experiment
+    const bool tn6 = dma && !mirror && !generic && !scatter && !bk16 && getenv("SSDK_CONV_TN6");
     for (int i = 0; i < count; ++i) {   // column space of the chosen kernel (see ConvProblem::n0_pad)
         ConvProblem& g = probs[i];
         g.n0_pad = (dma && g.n1 > 0) ? cdiv(g.n0, bk16 ? 16 : 8) * (bk16 ? 16 : 8) : g.n0;
         g.tiles_n = cdiv(g.n0_pad + g.n1, 32);
-        g.n_blocks = cdiv(g.tiles_n, kMaxTN);
+        g.n_blocks = cdiv(g.tiles_n, tn6 ? 6 : kMaxTN);
     }
     // 8-wave / 256-pixel tiling: measured 3 % (B=128) to 14 % (B=32) MORE cycles than two 4-wave workgroups per CU on the
     // SSD-300 heads (one barrier stalls all eight waves of the CU at once) -- kept as an opt-in experiment only
@@ -1551,6 +1557,7 @@ static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t 
         else if (mirror) hipLaunchKernelGGL((igemm_dma_kernel<true, false, false, 4>), dim3(begin), dim3(kConvThreads), 0, s, grp);
         else if (generic) hipLaunchKernelGGL((igemm_dma_kernel<false, true, false, 4>), dim3(begin), dim3(kConvThreads), 0, s, grp);
         else if (bk16) hipLaunchKernelGGL((igemm_dma_kernel<false, false, false, 4, 16>), dim3(begin), dim3(kConvThreads), 0, s, grp);
+        else if (tn6) hipLaunchKernelGGL((igemm_dma_kernel<false, false, false, 4, 32, 6>), dim3(begin), dim3(kConvThreads), 0, s, grp);
         else hipLaunchKernelGGL((igemm_dma_kernel<false, false, false, 4>), dim3(begin), dim3(kConvThreads), 0, s, grp);
     } else if (scatter) {
         SSDK_REQUIRE(vec4, SSDK_E_UNSUPPORTED, "scatter dgrad needs 16-byte aligned rows");

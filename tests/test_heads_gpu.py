@@ -122,21 +122,22 @@ def test_heads_vs_torch_cpu_conv(levels, C, B, pixel_density, mode, monkeypatch)
             np.testing.assert_allclose(heads[i][k].bias.grad.cpu().numpy(), bref.grad.numpy(), rtol=1e-4, atol=1e-4)
 
 
-def test_heads_forward_bk16_variant(monkeypatch):
-    """The 16-float K-slice instantiation of the LDS-DMA kernel (opt-in: 3 workgroups per CU; measured 5 % more cycles at batch 32
-    because n_score is padded to 16) must give the same forward as the default."""
+@pytest.mark.parametrize('flag', ['SSDK_CONV_BK16', 'SSDK_CONV_TN6'])
+def test_heads_forward_experimental_variants(monkeypatch, flag):
+    """Opt-in instantiations of the LDS-DMA kernel that were measured and not adopted -- 16-float K slices (3 workgroups per CU: +5 %
+    cycles at batch 32, n_score is padded to 16) and 192-column workgroups (+6 % cycles) -- must give the same forward as the default."""
     rng = np.random.default_rng(5)
-    levels, C, B = [(64, 9, 4), (128, 5, 6)], 21, 3
+    levels, C, B = [(64, 9, 4), (128, 5, 6), (96, 12, 9)], 21, 3
     weights = {}
     for i, (cin, h, nb) in enumerate(levels):
         for k, nout in (('score', nb * C), ('loc', nb * 4)):
             weights[(k, i)] = (rng.standard_normal((nout, cin, 3, 3), dtype=np.float32) * np.float32(0.05), rng.standard_normal((nout,), dtype=np.float32))
     heads = build_heads(levels, C, weights)
     xs = [torch.from_numpy(rng.standard_normal((B, cin, h, h), dtype=np.float32)).cuda() for cin, h, _ in levels]
-    monkeypatch.delenv('SSDK_CONV_BK16', raising=False)
+    monkeypatch.delenv(flag, raising=False)
     with torch.no_grad():
         s0, l0 = multi_level_heads(xs, xs, heads)
-        monkeypatch.setenv('SSDK_CONV_BK16', '1')
+        monkeypatch.setenv(flag, '1')
         s1, l1 = multi_level_heads(xs, xs, heads)
     np.testing.assert_allclose(s1.cpu().numpy(), s0.cpu().numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(l1.cpu().numpy(), l0.cpu().numpy(), rtol=1e-5, atol=1e-5)
