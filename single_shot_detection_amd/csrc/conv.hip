@@ -1435,14 +1435,17 @@ using namespace ssdk;
 
 struct ZeroList {
     ZeroArgs a;
-    ZeroList() { a.count = 0; }
+    bool overflow;   // more than kMaxZero buffers between two launches: a caller bug, reported by launch() (never dropped silently)
+    ZeroList() : overflow(false) { a.count = 0; }
     void add(float* p, size_t n) {
-        if (!p || !n || a.count >= kMaxZero) return;
+        if (!p || !n) return;
+        if (a.count >= kMaxZero) { overflow = true; return; }
         a.ptr[a.count] = p;
         a.n[a.count] = n;
         ++a.count;
     }
     int launch(hipStream_t s) {
+        SSDK_REQUIRE(!overflow, SSDK_E_INVALID, "ZeroList: more than %d buffers queued for one zeroing launch", kMaxZero);
         if (!a.count) return SSDK_OK;
         hipLaunchKernelGGL(zero_many_kernel, dim3(256, a.count), dim3(256), 0, s, a);
         SSDK_CHECK_LAUNCH("zero_many_kernel");
