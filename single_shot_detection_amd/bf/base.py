@@ -1,7 +1,7 @@
 """Plain-torch backbone stand-ins with torchvision's module indexing (torchvision is not installed in this image and
 pretrained weights cannot be fetched).  Out of the hot path (north_star: "backbone stays PyTorch-ROCm"); they exist
 so that ``detection.init`` can be driven end to end.  Architectures are the published ones (VGG-16-BN config D;
-ResNet-50 bottlenecks); weights are randomly initialised."""
+ResNet-50 bottlenecks; MobileNetV2 inverted residuals); weights are randomly initialised."""
 import torch.nn as nn
 
 
@@ -52,7 +52,38 @@ class _ResNet50(nn.Module):
                                       stage(512, 256, 6, 2), stage(1024, 512, 3, 2))
 
 
-_ZOO = {'torchvision_vgg16_bn': _Vgg16Bn, 'torchvision_resnet50': _ResNet50}
+def _conv_bn_relu6(cin, cout, k, stride, groups=1):
+    return nn.Sequential(nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, groups=groups, bias=False), nn.BatchNorm2d(cout), nn.ReLU6(inplace=True))
+
+
+class _InvertedResidual(nn.Module):
+    def __init__(self, cin, cout, stride, expand):
+        super().__init__()
+        hidden = cin * expand
+        layers = [] if expand == 1 else [_conv_bn_relu6(cin, hidden, 1, 1)]
+        layers += [_conv_bn_relu6(hidden, hidden, 3, stride, groups=hidden), nn.Conv2d(hidden, cout, 1, bias=False), nn.BatchNorm2d(cout)]
+        self.conv = nn.Sequential(*layers)
+        self.residual = stride == 1 and cin == cout
+
+    def forward(self, x):
+        return x + self.conv(x) if self.residual else self.conv(x)
+
+
+class _MobileNetV2(nn.Module):
+    SETTING = [(1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 3, 1), (6, 160, 3, 2), (6, 320, 1, 1)]   # t, c, n, s
+
+    def __init__(self, pretrained=False, **kwargs):
+        super().__init__()
+        layers, c = [_conv_bn_relu6(3, 32, 3, 2)], 32
+        for t, cout, n, s in self.SETTING:
+            for i in range(n):
+                layers.append(_InvertedResidual(c, cout, s if i == 0 else 1, t))
+                c = cout
+        layers.append(_conv_bn_relu6(c, 1280, 1, 1))
+        self.features = nn.Sequential(*layers)   # 19 modules; samples/ssd_mb2_voc.py taps 13 (96 ch, stride 16) and 18 (1280 ch, stride 32)
+
+
+_ZOO = {'torchvision_vgg16_bn': _Vgg16Bn, 'torchvision_resnet50': _ResNet50, 'torchvision_mobilenet_v2': _MobileNetV2}
 
 
 def create_base(name, weight=None, **model_args):

@@ -230,3 +230,50 @@ def test_bench_two_phase_backward_matches_single_backward():
         for p, r in zip(list(hp.params) + list(hp.inputs), ref + ref_in):
             scale = float(r.abs().max()) + 1e-12
             assert float((p.grad - r).abs().max()) <= 2e-5 * scale + 1e-7
+
+
+MB2 = {
+    'base': {'name': 'torchvision_mobilenet_v2', 'pretrained': False},
+    'detector': {'num_classes': 21, 'use_depthwise': True, 'features': {'name': 'Features', 'out_layers': (13, 18)},
+                 'extras': {'layers': (('s', 512), ('s', 256), ('s', 256), ('s', 128))}},
+    'anchor_generator': {'type': 'ssd', 'num_scales': 6, 'min_scale': 0.1, 'max_scale': 1.05,
+                         'aspect_ratios': [[1.0, 2.0]] + [[1.0, 2.0, 3.0]] * 3 + [[1.0, 2.0]] * 2},
+}
+
+
+def test_ssd_mb2_step_fn_train_and_eval():
+    """samples/ssd_mb2_voc.py (BASELINE config 0) through detection.init: depthwise extras on libssdk, A = 2 268."""
+    torch.manual_seed(9)
+    dev = torch.device('cuda:0')
+    wrapper, init_state, step_fn = det_init.init(
+        dev, MB2, {'xy_scale': 10.0, 'wh_scale': 5.0},
+        {'score_threshold': .01, 'max_total': 200, 'nms': {'max_per_class': 100, 'overlap_threshold': .45}, 'score_converter': 'SOFTMAX'},
+        {'classification_loss': {'name': 'CrossEntropyLoss'}, 'localization_loss': {'name': 'SmoothL1Loss'},
+         'classification_weight': 1.0, 'localization_weight': 1.0},
+        {'name': 'hard_negative_mining', 'negative_per_positive_ratio': 3, 'min_negative_per_image': 5},
+        {'matched_threshold': 0.5, 'unmatched_threshold': 0.5})
+    detector = wrapper.model
+    detector.train()
+    B = 2
+    imgs = torch.from_numpy(np.random.default_rng(31).standard_normal((B, 3, 300, 300), dtype=np.float32))
+    gt_np = syn.make_ground_truth(B, 300, 21, seed=4)
+    gt = [torch.from_numpy(g) for g in gt_np]
+    loss, (scores, locs), state = step_fn(0, 'train', (imgs, gt), init_state())
+    assert scores.shape == (B, 2268 * 21) and locs.shape == (B, 2268 * 4)
+    cfg = syn.CONFIGS['ssd_mb2_voc']
+    anchors = oracle.anchors(cfg['anchor'], 300, cfg['levels'])
+    target = oracle.encode_ground_truth(gt_np, anchors, 0.5, 0.5)
+    s_np, l_np = scores.detach().cpu().numpy(), locs.detach().cpu().numpy()
+    mask = oracle.hard_negative_mining(s_np, target, 3, 5)
+    vals, _, _ = oracle.multibox_loss(s_np, l_np, anchors, target, mask, kind='ce', grads=False)
+    assert abs(loss.item() - vals[0]) <= 1e-4 + 1e-5 * abs(vals[0]), (loss.item(), vals)
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in detector.parameters() if p.requires_grad)
+    detector.eval()
+    with torch.no_grad():
+        _, dets, _ = step_fn(1, 'eval', (imgs, gt), state)
+        s_e, l_e, pri = detector(imgs.to(dev))
+    assert np.array_equal(pri.cpu().numpy().view(np.uint32), anchors.view(np.uint32))
+    ref = oracle.postprocess(s_e.cpu().numpy(), l_e.cpu().numpy(), anchors, softmax=True, nms_thr=0.45)
+    for d, r in zip(dets, ref):
+        assert d.shape[1] == 6 and abs(d.shape[0] - r.shape[0]) <= 1
