@@ -277,3 +277,43 @@ def test_ssd_mb2_step_fn_train_and_eval():
     ref = oracle.postprocess(s_e.cpu().numpy(), l_e.cpu().numpy(), anchors, softmax=True, nms_thr=0.45)
     for d, r in zip(dets, ref):
         assert d.shape[1] == 6 and abs(d.shape[0] - r.shape[0]) <= 1
+
+
+SSD512 = {
+    'base': {'name': 'torchvision_vgg16_bn', 'pretrained': False},
+    'detector': {'num_classes': 81, 'use_depthwise': False,
+                 'features': {'name': 'Features', 'out_layers': (32, 42), 'last_feature_layer': 42},
+                 'extras': {'layers': (('s', 512), ('s', 256), ('s', 256), ('s', 256), ('s', 256))}},
+    'anchor_generator': {'type': 'ssd', 'num_scales': 7, 'min_scale': 0.1, 'max_scale': 1.05,
+                         'aspect_ratios': [[1.0, 2.0]] + [[1.0, 2.0, 3.0]] * 4 + [[1.0, 2.0]] * 2},
+}
+
+
+def test_ssd512_step_fn_train():
+    """samples/ssd_512_vgg16_coco.py through detection.init: seven levels, A = 24 564."""
+    torch.manual_seed(13)
+    dev = torch.device('cuda:0')
+    wrapper, init_state, step_fn = det_init.init(
+        dev, SSD512, {'xy_scale': 10.0, 'wh_scale': 5.0},
+        {'score_threshold': .01, 'max_total': 200, 'nms': {'max_per_class': 100, 'overlap_threshold': .45}, 'score_converter': 'SOFTMAX'},
+        {'classification_loss': {'name': 'CrossEntropyLoss'}, 'localization_loss': {'name': 'SmoothL1Loss'},
+         'classification_weight': 1.0, 'localization_weight': 1.0},
+        {'name': 'hard_negative_mining', 'negative_per_positive_ratio': 3, 'min_negative_per_image': 5},
+        {'matched_threshold': 0.5, 'unmatched_threshold': 0.5})
+    detector = wrapper.model
+    detector.train()
+    B = 2
+    imgs = torch.from_numpy(np.random.default_rng(37).standard_normal((B, 3, 512, 512), dtype=np.float32))
+    gt_np = syn.make_ground_truth(B, 512, 81, seed=6)
+    gt = [torch.from_numpy(g) for g in gt_np]
+    loss, (scores, locs), state = step_fn(0, 'train', (imgs, gt), init_state())
+    assert scores.shape == (B, 24564 * 81) and locs.shape == (B, 24564 * 4)
+    cfg = syn.CONFIGS['ssd_512_vgg16_coco']
+    anchors = oracle.anchors(cfg['anchor'], 512, cfg['levels'])
+    target = oracle.encode_ground_truth(gt_np, anchors, 0.5, 0.5)
+    s_np, l_np = scores.detach().cpu().numpy(), locs.detach().cpu().numpy()
+    mask = oracle.hard_negative_mining(s_np, target, 3, 5)
+    vals, _, _ = oracle.multibox_loss(s_np, l_np, anchors, target, mask, kind='ce', grads=False)
+    assert abs(loss.item() - vals[0]) <= 1e-4 + 1e-5 * abs(vals[0]), (loss.item(), vals)
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in detector.parameters() if p.requires_grad)
