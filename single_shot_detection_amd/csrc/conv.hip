@@ -15,18 +15,25 @@
 // contiguous 128-byte line; weights are [n][tap][cin] (= torch channels_last memory of the OIHW parameter).
 //
 // Tiling (wave = 64 lanes): workgroup = 4 waves = 128 output pixels x (32*tn) channels, tn <= 4 balanced per level
-// (N = 340 -> 4+4+3 tiles, N = 510 -> 4+4+4+4); wave w owns pixel rows 32w..32w+31 and all tn column tiles (tn
-// accumulators of 16 registers), ~150 VGPRs and 37 KB of LDS per workgroup -> 3 workgroups per CU, so a SIMD always
-// has another wave's MFMAs to issue while one wave waits on a barrier or an LDS read.  K is walked in slices of 32;
-// the next slice is prefetched global -> registers while the current one is multiplied out of LDS (rows padded to 36
-// floats: conflict-free ds_read_b128, one b128 read feeds four MFMAs of a tile).
+// (N = 344 -> 4+4+3 tiles, N = 512 -> 4+4+4+4); wave w owns pixel rows 32w..32w+31 and all tn column tiles (tn
+// accumulators of 16 registers).  K is walked in slices of 32, channel chunk outer, tap inner.
+//
+// Two implementations of the same GEMM:
+//   * igemm_dma_kernel (the hot one): the slices travel global -> LDS by LDS-DMA (buffer_load ... lds), two LDS stages, one
+//     barrier per slice, XOR-swizzled unpadded rows, zero fill by out-of-range buffer offsets -- see the comment in front of
+//     dma_tile().  Forward, dense stride-1 dgrad (mirrored taps), scatter-form dgrad; 146 VGPRs, 64 KB LDS, 2 workgroups per CU.
+//   * igemm_fwd_kernel: the same pipeline with the next slice staged through registers (global_load -> ds_write_b128, LDS rows
+//     padded to 36 floats).  Fallback for channel counts that are not multiples of 32, operands of 2 GiB and more, and the
+//     dense dgrad of strided convolutions; ~11 % more cycles than the DMA form.
 //
 // Backward: pack_dy_kernel gathers each level's slice of dscores|dlocs into 16-byte aligned, zero padded rows
-// [pixel][Npad] (the [B, A*C] rows are only 4/8-byte aligned when nb*C is odd) and sums the bias gradients on the way.
-// Backward-data is the SAME kernel with mirrored taps, A = packed dY, W = per-tap transposed weights.
-// Backward-weights (igemm_wgrad_kernel) contracts over pixels: both operands are read in their natural
-// [pixel][channel] form, K = pixels is split across workgroups and partial tiles are accumulated with fp32 atomics
-// shaped as two 128-byte segments per wave instruction.
+// [pixel][Npad] (the [B, A*C] rows are only 4/8-byte aligned when nb*C is odd), sums the bias gradients on the way and lists
+// the pixel rows / the single anchors that carry a gradient.  Backward-data is the forward kernel with mirrored taps (dense)
+// or its scatter form over the listed rows (sparse, and every strided convolution).  Backward-weights contracts over pixels
+// (igemm_wgrad_dma_kernel; igemm_wgrad_kernel is its register-staged fallback): both operands are read in their natural
+// [pixel][channel] form, K = pixels is split across workgroups and partial tiles are accumulated with fp32 atomics.
+// Which of the three backward forms (dense / pixel rows / anchor rows) a level takes is decided on the device from the row
+// counts (decide_sparse_kernel); see DESIGN.md 4.
 #include <stdlib.h>
 
 #include <type_traits>
