@@ -108,6 +108,7 @@ class HotPath(object):
         self.params = [p for p in self.heads.parameters()] + ([p for p in self.extras.parameters()] if self.extras is not None else []) + \
                       ([p for p in self.tower.parameters()] if self.tower is not None else [])
         self.opt = torch.optim.SGD(self.params, lr=1e-3, momentum=0.9, weight_decay=5e-4)
+        self.opt_split = None   # N > 1: one optimizer per gradient bucket (built on first use), so the head update overlaps the second ring
         # exchange step (N > 1): the head gradients are complete as soon as the heads' backward has run, so their ring starts
         # there and overlaps with the backward of the extras / tower; a second, small bucket carries the rest
         self.head_params = [p for p in self.heads.parameters()]
@@ -152,7 +153,7 @@ class HotPath(object):
 
     def train_step(self, world=1, timed=False):
         self.two_phase = world > 1 or getattr(self, 'force_two_phase', False)
-        self.opt.zero_grad(set_to_none=True)
+        self.opt.zero_grad(set_to_none=True)   # (shared parameters: also clears the gradients the split optimizers see)
         for s in self.inputs:
             s.grad = None
         scores, locs = self.forward_heads(timed)
@@ -182,10 +183,17 @@ class HotPath(object):
             if self.bucket_rest is not None:
                 self.bucket_rest.start_()
             self.bucket_heads.finish_()
-            if self.bucket_rest is not None:
-                self.bucket_rest.finish_()
-        else:
-            loss.backward()
+            if self.bucket_rest is None:
+                self.opt.step()
+                return loss
+            if self.opt_split is None:   # same hyper-parameters, disjoint parameter sets: the update is the one self.opt would make
+                kw = dict(lr=1e-3, momentum=0.9, weight_decay=5e-4)
+                self.opt_split = (torch.optim.SGD(self.head_params, **kw), torch.optim.SGD(self.rest_params, **kw))
+            self.opt_split[0].step()        # head parameters: their averaged gradients are complete; the second ring is still running
+            self.bucket_rest.finish_()
+            self.opt_split[1].step()
+            return loss
+        loss.backward()
         self.opt.step()
         return loss
 
