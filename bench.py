@@ -35,6 +35,7 @@ from single_shot_detection_amd.distributed import GradBucket  # noqa: E402
 # extras of the SSD sample files (samples/ssd_300_vgg16_voc.py:16-18, ssd_512_vgg16_coco.py)
 TOWER = {'retina_rn50_500_coco': dict(num_layers=4, num_channels=256, kernel_size=3)}
 EXTRAS = {'ssd_300_vgg16_voc': (('s', 512), ('s', 256), ('s', 256), ('s', 256)),
+          'ssd_300_vgg16_voc_c21': (('s', 512), ('s', 256), ('s', 256), ('s', 256)),
           'ssd_512_vgg16_coco': (('s', 512), ('s', 256), ('s', 256), ('s', 256), ('s', 256))}
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense

@@ -44,6 +44,11 @@ CONFIGS = {
 }
 
 
+# BASELINE.json calls the SSD-300 workload "VOC-20-class" while the sample file hard-codes num_classes = 81: the
+# 21-column variant of the same geometry, for bench.py --config ssd_300_vgg16_voc_c21 (not a golden config)
+CONFIGS['ssd_300_vgg16_voc_c21'] = dict(CONFIGS['ssd_300_vgg16_voc'], num_classes=21)
+
+
 def num_anchors(cfg):
     return sum(h * h * nb for _, h, nb in cfg['levels'])
 
