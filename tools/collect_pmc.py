@@ -8,8 +8,8 @@ kernel (the first launch of each kernel, which includes cold caches, is dropped 
 import collections, csv, glob, json, sys
 
 KEYS = {   # json key suffix -> substring of the kernel name
-    'igemm_fwd_heads': 'igemm_dma_kernel<false, false, false, 4>',
-    'igemm_scatter_dgrad': 'igemm_dma_kernel<false, false, true, 4>',
+    'igemm_fwd_heads': 'igemm_dma_kernel<false, false, false, 4',
+    'igemm_scatter_dgrad': 'igemm_dma_kernel<false, false, true, 4',
     'igemm_wgrad': 'igemm_wgrad_dma_kernel',
     'loss_bwd': 'loss_bwd_kernel', 'loss_fwd': 'loss_fwd_kernel', 'hnm_rows': 'hnm_rows_kernel', 'hnm_select': 'hnm_select_kernel',
     'pack_dy': 'pack_dy_kernel', 'assign': 'assign_kernel', 'gt_argmax': 'gt_argmax_kernel',
