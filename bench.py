@@ -34,6 +34,8 @@ from single_shot_detection_amd.distributed import GradBucket  # noqa: E402
 
 # extras of the SSD sample files (samples/ssd_300_vgg16_voc.py:16-18, ssd_512_vgg16_coco.py)
 TOWER = {'retina_rn50_500_coco': dict(num_layers=4, num_channels=256, kernel_size=3)}
+# M2Det: the MLFPN neck (8 TUMs x 6 scales + SFAM, samples/m2det_512_vgg16_coco.py:10-17) sits between the two VGG taps and the heads
+NECK = {'m2det_512_vgg16_coco': dict(taps=[(512, 64), (1024, 32)], num_scales=6, num_tums=8, base_reduced_channels=[512, 256])}
 EXTRAS = {'ssd_300_vgg16_voc': (('s', 512), ('s', 256), ('s', 256), ('s', 256)),
           'ssd_300_vgg16_voc_c21': (('s', 512), ('s', 256), ('s', 256), ('s', 256)),
           'ssd_512_vgg16_coco': (('s', 512), ('s', 256), ('s', 256), ('s', 256), ('s', 256))}
@@ -84,7 +86,20 @@ class HotPath(object):
         if cfg_name in TOWER:
             from single_shot_detection_amd.detection.modules.predictors import SharedConvPredictor
             self.tower = SharedConvPredictor([l[0] for l in self.levels], [l[2] for l in self.levels], self.C, False, **TOWER[cfg_name]).to(device)
-        fm = syn.make_feature_maps(batch, self.levels[:n_in], seed=seed)
+        self.neck = None
+        in_levels = self.levels[:n_in]
+        if cfg_name in NECK and not os.environ.get('SSDK_BENCH_NO_NECK'):
+            from single_shot_detection_amd.bf.modules.features import MultilevelFeaturePyramid
+            nk = dict(NECK[cfg_name])
+            taps = nk.pop('taps')
+
+            class _Taps(torch.nn.Module):   # only the channel counts of the two taps are needed to size the reducers
+                def __init__(self):
+                    super().__init__()
+                    self.features = torch.nn.Sequential(torch.nn.Conv2d(3, taps[0][0], 1), torch.nn.Conv2d(taps[0][0], taps[1][0], 1))
+            self.neck = MultilevelFeaturePyramid(_Taps(), out_layers=(0, 1), **nk).to(device)
+            in_levels = [(c, h, 0) for c, h in taps]
+        fm = syn.make_feature_maps(batch, in_levels, seed=seed)
         self.inputs = [torch.from_numpy(x).to(device).contiguous(memory_format=torch.channels_last).requires_grad_(True) for x in fm]
         p = dict(cfg['anchor'])
         gens = getattr(anchor_generators, p.pop('type')).build_anchor_generators(**p)
@@ -107,7 +122,8 @@ class HotPath(object):
         self.post = Postprocessor(box_coder, score_threshold=0.01, nms={'max_per_class': 100, 'overlap_threshold': cfg['nms_thr']},
                                   score_converter=cfg['score_converter'], max_total=200)
         self.params = [p for p in self.heads.parameters()] + ([p for p in self.extras.parameters()] if self.extras is not None else []) + \
-                      ([p for p in self.tower.parameters()] if self.tower is not None else [])
+                      ([p for p in self.tower.parameters()] if self.tower is not None else []) + \
+                      ([p for n, p in self.neck.named_parameters() if not n.startswith('base.')] if self.neck is not None else [])
         self.opt = torch.optim.SGD(self.params, lr=1e-3, momentum=0.9, weight_decay=5e-4)
         self.opt_split = None   # N > 1: one optimizer per gradient bucket (built on first use), so the head update overlaps the second ring
         # exchange step (N > 1): the head gradients are complete as soon as the heads' backward has run, so their ring starts
@@ -120,6 +136,8 @@ class HotPath(object):
 
     def pyramid(self):
         sources = list(self.inputs)
+        if self.neck is not None:
+            sources, _ = self.neck.neck(sources)
         if self.extras is not None:
             x = sources[-1]
             for layer in self.extras:   # detector.py:39-43
@@ -342,8 +360,10 @@ def main():
             'value': value, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'{args.config}: extras conv-BN-ReLU + heads fwd+bwd (fp32 MFMA) + IoU-match + HNM/multibox loss fwd+bwd + SGD on '
-                                   f'head/extras params; backbone taps N(0,1) NHWC at the probed shapes, C={hp.C}, A={A}, G~U{{1..8}}',
+            'config': {'workload': f'{args.config}: ' + ('MLFPN neck (8 TUMs + SFAM) + ' if hp.neck is not None else '') +
+                                   ('extras conv-BN-ReLU + ' if hp.extras is not None else '') + ('shared-conv tower + ' if hp.tower is not None else '') +
+                                   f'heads fwd+bwd (fp32 MFMA) + IoU-match + ' + ('HNM' if hp.cfg['loss'] == 'ce_hnm' else 'naive sampler') +
+                                   f'/multibox loss fwd+bwd + SGD on the head-side params; backbone taps N(0,1) NHWC at the probed shapes, C={hp.C}, A={A}, G~U{{1..8}}',
                        'global_batch': world * args.batch, 'per_gpu_batch': args.batch, 'parallelism': f'dp{world}'},
             'nms_boxes_per_sec': world * cand / dtp, 'postprocess_images_per_sec': world * args.batch / dtp,
             'eval_images_per_sec': world * args.batch / dte, 'nms_candidates_per_image': cand / args.batch,

@@ -212,6 +212,11 @@ class MultilevelFeaturePyramid(Features):
 
     def forward(self, x):
         sources, _ = super(MultilevelFeaturePyramid, self).forward(x)
+        return self.neck(sources)
+
+    def neck(self, sources):
+        """Everything behind the backbone taps (features.py:363-393); separate so that a caller that already holds the taps
+        (bench.py) can drive the libssdk part alone."""
         base_reduced = [reducer(source) for reducer, source in zip(self.base_reducers, sources)]
         size = base_reduced[0].shape[2:]
         upscaled = [base_reduced[0]] + [ops.upsample_nearest(f, size) for f in base_reduced[1:]]   # features.py:369-371
