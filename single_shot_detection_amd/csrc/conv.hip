@@ -36,6 +36,8 @@
 // counts (decide_sparse_kernel); see DESIGN.md 4.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include <type_traits>
 
 #include "common.h"
@@ -1106,7 +1108,7 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_wgrad_dma
 // out[m][n] (n < Npad) = n < n0 ? ds[b*sb + p*n0 + n] : (n < n0+n1 ? dl[b*lb + p*n1 + n-n0] : 0);  db += column sums
 // Also appends the ids of the rows that are not entirely zero to row_list (order inside a block preserved, blocks in
 // completion order) and counts them: the loss gradient is non-zero only on sampled anchors, i.e. on a few % of the pixels.
-constexpr int kPackRows = 32;
+constexpr int kPackRows = 32;   // rows per workgroup (<= 64: row masks are 64-bit; 64 rows take the same time)
 constexpr int kMaxAnchorTypes_ = 16;   // (= kMaxAnchorTypes; the last counter of a level doubles as its "not sparse" flag, so nb <= 15)
 constexpr int kPackColIters = 12;  // Npad <= 768 (RetinaNet: 9 * (80 + 4) = 756)
 struct PackLevel {
@@ -1125,6 +1127,76 @@ struct PackGroup {
     long long sb, lb;
     PackLevel lv[kMaxProblems];
 };
+// Main pass of pack_dy_kernel for one wave: rows wave, wave + 4, ... of the kPackRows-row block, ITERS 64-column trips per row.
+// Per lane and trip the column's source (score / loc / padding), its offset inside the source row and the bit of its anchor
+// type are fixed for the block, so a row costs one select + one add per load and no branches; two rows are in flight.
+// (The first version re-derived source and bounds per element behind divergent branches: ~25 instructions per load, 2 TB/s.)
+// Returns the mask of this wave's rows that are not entirely zero; leaves the wave's column sums in `sum`.
+template <int ITERS>
+__device__ __forceinline__ unsigned long long pack_rows(const PackLevel& L, const float* __restrict__ ds, const float* __restrict__ dl, long long sb,
+                                              long long lb, int B, int m0, int M, float* __restrict__ sum, unsigned* __restrict__ s_amask) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: row bases stay in SGPRs)
+    const int n0 = L.n0, n1 = L.n1, N = n0 + n1, Npad = L.Npad, HW = L.HW;
+    // per lane and trip: 4 bits of anchor type (kept packed: registers are what bounds the rows in flight)
+    unsigned long long anchor_of = 0ull;
+    float acc[ITERS];
+    const float inv_c = 1.0f / (float)(L.C > 0 ? L.C : 1);
+#pragma unroll
+    for (int k = 0; k < ITERS; ++k) {
+        const int n = k * 64 + lane;
+        const int a = n < n0 ? (int)(((float)n + 0.5f) * inv_c) : (n - n0) >> 2;   // n / C, exact for n < 2^20
+        anchor_of |= (unsigned long long)((L.ga && n < N) ? a : 15) << (4 * k);    // (type 15 does not exist: nb <= 15)
+        acc[k] = 0.0f;
+    }
+    unsigned long long mine = 0ull;
+    constexpr int U = ITERS <= 8 ? 2 : 1;   // rows of the wave in flight
+    for (int r0 = wave; r0 < kPackRows; r0 += 4 * U) {
+        if (m0 + r0 >= M) break;
+        float v[U][ITERS];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int m = min(m0 + r0 + 4 * u, M - 1);   // (a row past the end re-reads the last one; it is not consumed)
+            const int b = m / HW, p = m - b * HW;
+            const float* srow = ds + (long long)b * sb + (long long)p * n0;
+            const float* lrow = dl ? dl + (long long)b * lb + (long long)p * n1 : srow;
+#pragma unroll
+            for (int k = 0; k < ITERS; ++k) {
+                // branch-free: one load per trip from a selected base (a load behind a branch makes the compiler wait for
+                // every earlier load at the join); padding columns re-read element 0 and are zeroed
+                const int n = k * 64 + lane;
+                const float* base = n >= n0 ? lrow : srow;
+                const float x = base[n < n0 ? n : (n < N ? n - n0 : 0)];
+                v[u][k] = n < N ? x : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + 4 * u, m = m0 + r;
+            if (m >= M) continue;
+            float* orow = L.out + (long long)m * Npad;
+            unsigned amask = 0u;   // anchor types of this row that carry a gradient (as seen by this lane)
+#pragma unroll
+            for (int k = 0; k < ITERS; ++k) {
+                const float x = v[u][k];
+                if (k * 64 + lane < Npad) orow[k * 64 + lane] = x;
+                acc[k] += x;
+                amask |= x != 0.0f ? ((1u << ((unsigned)(anchor_of >> (4 * k)) & 15u)) | 0x80000000u) : 0u;
+            }
+            if (__ballot(amask != 0u)) mine |= 1ull << r;
+            if (L.ga) {   // which anchor types of this row carry a gradient (wave-wide OR of the lanes' masks)
+                unsigned row_mask = 0u;
+                for (int a = 0; a < L.nb; ++a)
+                    if (__ballot((amask >> a) & 1u)) row_mask |= 1u << a;
+                if (lane == 0) s_amask[r] = row_mask;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < ITERS; ++k) sum[k * 64 + lane] = acc[k];
+    return mine;
+}
+
+template <int ITERS>
 __global__ void __launch_bounds__(256) pack_dy_kernel(PackGroup grp) {
     int pi = 0;
 #pragma unroll 1
@@ -1134,72 +1206,29 @@ __global__ void __launch_bounds__(256) pack_dy_kernel(PackGroup grp) {
     const float* __restrict__ ds = L.ds;
     const float* __restrict__ dl = L.dl;
     const long long sb = grp.sb, lb = grp.lb;
-    const int n0 = L.n0, n1 = L.n1, Npad = L.Npad, B = grp.B, HW = L.HW;
-    float* __restrict__ out = L.out;
+    const int n0 = L.n0, n1 = L.n1, B = grp.B, HW = L.HW;
     float* __restrict__ db0 = L.db0;
     float* __restrict__ db1 = L.db1;
     int* __restrict__ row_list = L.row_list;
     int* __restrict__ row_count = L.row_count;
     const int block = blockIdx.x - L.block_begin;
-    // wave w packs rows w, w+4, ... of the 32-row block; lane l owns columns l, l+64, ... : every load and store of a
+    // wave w packs rows w, w+4, ... of the kPackRows-row block; lane l owns columns l, l+64, ... : every load and store of a
     // wave instruction is 256 contiguous bytes
-    __shared__ unsigned s_flag;
+    __shared__ unsigned long long s_flag;
     __shared__ int s_base;
     __shared__ float s_sum[4][kPackColIters * 64];
     __shared__ unsigned s_amask[kPackRows];       // anchor types with a gradient, per row of the block
-    __shared__ unsigned s_acol[kMaxAnchorTypes_]; // per anchor type: which rows of the block have it
+    __shared__ unsigned long long s_acol[kMaxAnchorTypes_]; // per anchor type: which rows of the block have it
     __shared__ int s_abase[kMaxAnchorTypes_];     // per anchor type: first row index reserved in its segment (-1: not stored)
     const int M = B * HW;
     const int m0 = block * kPackRows;
     const int N = n0 + n1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int iters = (Npad + 63) >> 6;
-    if (threadIdx.x == 0) s_flag = 0u;
+    if (threadIdx.x == 0) s_flag = 0ull;
     if (threadIdx.x < kPackRows) s_amask[threadIdx.x] = 0u;
     __syncthreads();
-    float acc[kPackColIters];
-#pragma unroll
-    for (int k = 0; k < kPackColIters; ++k) acc[k] = 0.0f;
-    unsigned mine = 0u;
-    // anchor type of each of this lane's columns (bit mask positions): fixed for the block
-    unsigned char col_anchor[kPackColIters];
-#pragma unroll
-    for (int k = 0; k < kPackColIters; ++k) {
-        const int n = k * 64 + lane;
-        col_anchor[k] = (L.ga && n < N) ? (unsigned char)(n < n0 ? n / L.C : (n - n0) / 4) : (unsigned char)31;
-    }
-    for (int r = wave; r < kPackRows; r += 4) {
-        const int m = m0 + r;
-        if (m >= M) break;
-        const int b = m / HW, p = m % HW;
-        const float* srow = ds + (long long)b * sb + (long long)p * n0;
-        const float* lrow = dl ? dl + (long long)b * lb + (long long)p * n1 : nullptr;
-        float* orow = out + (long long)m * Npad;
-        bool nz = false;
-        unsigned amask = 0u;   // anchor types of this row that carry a gradient (as seen by this lane)
-#pragma unroll
-        for (int k = 0; k < kPackColIters; ++k) {
-            if (k >= iters) break;
-            const int n = k * 64 + lane;
-            if (n < Npad) {
-                const float v = n < n0 ? srow[n] : (n < N ? lrow[n - n0] : 0.0f);
-                orow[n] = v;
-                acc[k] += v;
-                nz = nz || v != 0.0f;
-                if (v != 0.0f) amask |= 1u << (col_anchor[k] & 31);
-            }
-        }
-        if (__ballot(nz)) mine |= 1u << r;
-        if (L.ga) {   // which anchor types of this row carry a gradient (wave-wide OR of the lanes' masks)
-            unsigned row_mask = 0u;
-            for (int a = 0; a < L.nb; ++a)
-                if (__ballot((amask >> a) & 1u)) row_mask |= 1u << a;
-            if (lane == 0) s_amask[r] = row_mask;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < kPackColIters; ++k)
-        if (k < iters) s_sum[wave][k * 64 + lane] = acc[k];
+    unsigned long long mine = 0ull;
+    mine = pack_rows<ITERS>(L, ds, dl, sb, lb, B, m0, M, s_sum[wave], s_amask);
     if (lane == 0 && mine) atomicOr(&s_flag, mine);
     __syncthreads();
     for (int n = threadIdx.x; n < N; n += 256) {
@@ -1209,30 +1238,27 @@ __global__ void __launch_bounds__(256) pack_dy_kernel(PackGroup grp) {
             else if (db1) atomicAdd(db1 + (n - n0), t);
         }
     }
-    const unsigned flags = s_flag;
-    if (threadIdx.x == 0) s_base = flags ? atomicAdd(row_count, __popc(flags)) : 0;
+    const unsigned long long flags = s_flag;
+    if (threadIdx.x == 0) s_base = flags ? atomicAdd(row_count, __popcll(flags)) : 0;
     __syncthreads();
-    if (threadIdx.x < kPackRows && ((flags >> threadIdx.x) & 1u))
-        row_list[s_base + __popc(flags & ((1u << threadIdx.x) - 1u))] = m0 + (int)threadIdx.x;
+    if (threadIdx.x < kPackRows && ((flags >> threadIdx.x) & 1ull))
+        row_list[s_base + __popcll(flags & ((1ull << threadIdx.x) - 1ull))] = m0 + (int)threadIdx.x;
     if (!L.ga) return;
     // anchor-granular rows: ONE atomic per (block, anchor type) reserves the block's rows in segment k (an atomic per anchor
     // serialises on 4..9 counters: 2 ms at full density), then the waves copy the C + 4 values of every listed anchor.
     // A block in which more than half of the anchors carry a gradient is not "sparse": it stores nothing and marks the level
     // (acount[kMaxAnchorTypes - 1] != 0 -> decide_sparse_kernel never picks the anchor form for it).
-    if (threadIdx.x < L.nb) {
-        unsigned col = 0u;
-        for (int r = 0; r < kPackRows; ++r) col |= ((s_amask[r] >> threadIdx.x) & 1u) << r;
-        s_acol[threadIdx.x] = col;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int total = 0;
-        for (int a = 0; a < L.nb; ++a) total += __popc(s_acol[a]);
+    if (wave == 0) {   // lane a = anchor type a: its rows of the block, its reservation (the nb atomics travel together)
+        unsigned long long col = 0ull;
+        if (lane < L.nb)
+            for (int r = 0; r < kPackRows; ++r) col |= (unsigned long long)((s_amask[r] >> lane) & 1u) << r;
+        const int c = __popcll(col);
+        const int total = wave_allreduce(c, OpAddI());
         const bool dense = 2 * total > kPackRows * L.nb;
-        if (dense) atomicOr(L.acount + (kMaxAnchorTypes_ - 1), 1);
-        for (int a = 0; a < L.nb; ++a) {
-            const int c = __popc(s_acol[a]);
-            s_abase[a] = (!dense && c) ? atomicAdd(L.acount + a, c) : -1;
+        if (lane == 0 && dense) atomicOr(L.acount + (kMaxAnchorTypes_ - 1), 1);
+        if (lane < L.nb) {
+            s_acol[lane] = col;
+            s_abase[lane] = (!dense && c) ? atomicAdd(L.acount + lane, c) : -1;
         }
     }
     __syncthreads();
@@ -1245,7 +1271,7 @@ __global__ void __launch_bounds__(256) pack_dy_kernel(PackGroup grp) {
         const float* lrow = dl + (long long)b * lb + (long long)p * n1;
         for (int a = 0; a < L.nb; ++a) {
             if (!((row_mask >> a) & 1u) || s_abase[a] < 0) continue;
-            const int idx = s_abase[a] + __popc(s_acol[a] & ((1u << r) - 1u));
+            const int idx = s_abase[a] + __popcll(s_acol[a] & ((1ull << r) - 1ull));
             float* grow = L.ga + ((long long)a * L.cap + idx) * L.Jpad;
             for (int j = lane; j < L.Jpad; j += kWave)
                 grow[j] = j < L.C ? srow[a * L.C + j] : (j < L.C + 4 ? lrow[a * 4 + j - L.C] : 0.0f);
@@ -1782,7 +1808,12 @@ extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int b
             L.block_begin = begin;
             begin += cdiv(batch * L.HW, kPackRows);
         }
-        hipLaunchKernelGGL(pack_dy_kernel, dim3(begin), dim3(256), 0, s, pg);
+        // one instantiation per launch: column trips of the widest level (6 / 8 / 12: Npad <= 384 / 512 / 768)
+        int max_npad = 0;
+        for (int i = 0; i < n_levels; ++i) max_npad = std::max(max_npad, pg.lv[i].Npad);
+        if (max_npad <= 384) hipLaunchKernelGGL(pack_dy_kernel<6>, dim3(begin), dim3(256), 0, s, pg);
+        else if (max_npad <= 512) hipLaunchKernelGGL(pack_dy_kernel<8>, dim3(begin), dim3(256), 0, s, pg);
+        else hipLaunchKernelGGL(pack_dy_kernel<12>, dim3(begin), dim3(256), 0, s, pg);
         SSDK_CHECK_LAUNCH("pack_dy_kernel");
     }
     hipLaunchKernelGGL(decide_sparse_kernel, dim3(1), dim3(64), 0, s, w.counts, w.acounts, h_totals, n_levels, w.mode);
