@@ -1390,12 +1390,15 @@ struct TransposeJob {
     const float* w0; const float* w1; float* out;
     int kind, n0, n1, Npad, taps, Cc, C, Jpad;
     const int* mode;   // the layout is produced only when *mode == kind (backward mode of the level: 0 dense, 1 pixel rows, 2 anchor rows)
-    int tiles_x, tiles_y, block_begin;   // tiles_x * tiles_y * depth blocks, depth = taps (kinds 0, 1) or anchor types (kind 2)
+    int tiles_x, tiles_y, block_begin;   // tiles_x * tiles_y * depth blocks, depth = kTrDepth (kinds 0, 1) or anchor types (kind 2)
 };
 constexpr int kMaxTransposeJobs = 3 * kMaxProblems;
+constexpr int kTrDepth = 3;   // kinds 0, 1: workgroups per (n, c) tile, each walks taps / kTrDepth taps
+constexpr int kTrJ = 96;   // rows (C + 4 columns of one anchor type, padded) a kind-2 workgroup moves at once
 struct TransposeGroup { int count; TransposeJob j[kMaxTransposeJobs]; };
 __global__ void __launch_bounds__(256) transpose_group_kernel(TransposeGroup grp) {
-    __shared__ float tile[32][33];
+    __shared__ float tile2[kTrJ][65];               // kind 2
+    float (*tile)[33] = reinterpret_cast<float (*)[33]>(&tile2[0][0]);   // kinds 0, 1: 32 x 33
     int ji = 0;
 #pragma unroll 1
     for (int i = 1; i < grp.count; ++i)
@@ -1408,34 +1411,47 @@ __global__ void __launch_bounds__(256) transpose_group_kernel(TransposeGroup grp
     const int bz = id;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     if (J.kind == 2) {
-        const int K = J.taps * J.Cc, k = bz, jb = bx * 32, nb_ = by * 32;
+        // one workgroup = kTrJ rows j (all of them when Jpad <= kTrJ) x 64 columns n of anchor type k: wave-wide 256-byte row
+        // segments in (branch-free, several in flight), ONE contiguous 64 x Jpad block out
+        const int K = J.taps * J.Cc, k = bz, jb = bx * kTrJ, nb_ = by * 64, C = J.C;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int n = nb_ + lane;
+#pragma unroll 8
+        for (int i = 0; i < kTrJ / 4; ++i) {
+            const int jl = wave + 4 * i, j = jb + jl;
+            const bool real = j < C + 4 && n < K;
+            const float* row = j < C ? J.w0 + ((long long)k * C + (real ? j : 0)) * K : J.w1 + ((long long)k * 4 + (real ? j - C : 0)) * K;
+            const float v = row[real ? n : 0];
+            tile2[jl][lane] = real ? v : 0.0f;
+        }
+        __syncthreads();
+        const int jw = min(kTrJ, J.Jpad - jb);
+        const float inv_jw = 1.0f / (float)jw;
+        float* out = J.out + ((long long)k * K + nb_) * J.Jpad + jb;
+        for (int e = threadIdx.x; e < 64 * jw; e += 256) {
+            const int nl = (int)(((float)e + 0.5f) * inv_jw), jl = e - nl * jw;   // e / jw, exact for e < 2^20
+            if (nb_ + nl < K) out[(long long)nl * J.Jpad + jl] = tile2[jl][nl];
+        }
+        return;
+    }
+    // kinds 0, 1: a workgroup walks a third of the taps of its 32 x 32 (n, c) tile.  (A workgroup per tap: 9x the workgroups, which
+    // in the usual sparse step are launched only to find their layout is not wanted; one workgroup for all taps: 18 dependent
+    // memory round trips, the long pole of the launch whenever a small level does want the layout.)
+    const int N = J.n0 + J.n1, nb = bx * 32, cb = by * 32, taps = J.taps, Cc = J.Cc;
+    const int per = (taps + kTrDepth - 1) / kTrDepth;
+    for (int tap = bz * per; tap < min(taps, (bz + 1) * per); ++tap) {
         for (int r = ty; r < 32; r += 8) {
-            const int j = jb + r, n = nb_ + tx;
+            const int n = nb + r, c = cb + tx;
             float v = 0.0f;
-            if (n < K) {
-                if (j < J.C) v = J.w0[((long long)k * J.C + j) * K + n];
-                else if (j < J.C + 4) v = J.w1[((long long)k * 4 + (j - J.C)) * K + n];
-            }
+            if (n < N && c < Cc) v = n < J.n0 ? J.w0[((long long)n * taps + tap) * Cc + c] : J.w1[((long long)(n - J.n0) * taps + tap) * Cc + c];
             tile[r][tx] = v;
         }
         __syncthreads();
         for (int r = ty; r < 32; r += 8) {
-            const int n = nb_ + r, j = jb + tx;
-            if (n < K && j < J.Jpad) J.out[((long long)k * K + n) * J.Jpad + j] = tile[tx][r];
+            const int c = cb + r, n = nb + tx;
+            if (n < J.Npad && c < Cc) J.out[(J.kind == 0 ? ((long long)c * taps + tap) : ((long long)tap * Cc + c)) * J.Npad + n] = tile[tx][r];
         }
-        return;
-    }
-    const int N = J.n0 + J.n1, tap = bz, nb = bx * 32, cb = by * 32, taps = J.taps, Cc = J.Cc;
-    for (int r = ty; r < 32; r += 8) {
-        const int n = nb + r, c = cb + tx;
-        float v = 0.0f;
-        if (n < N && c < Cc) v = n < J.n0 ? J.w0[((long long)n * taps + tap) * Cc + c] : J.w1[((long long)(n - J.n0) * taps + tap) * Cc + c];
-        tile[r][tx] = v;
-    }
-    __syncthreads();
-    for (int r = ty; r < 32; r += 8) {
-        const int c = cb + r, n = nb + tx;
-        if (n < J.Npad && c < Cc) J.out[(J.kind == 0 ? ((long long)c * taps + tap) : ((long long)tap * Cc + c)) * J.Npad + n] = tile[tx][r];
+        __syncthreads();
     }
 }
 
@@ -1825,17 +1841,23 @@ extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int b
     int n_dgrad = 0, n_anchor = 0;
     TransposeGroup tg{};
     int t_blocks = 0;
+    // (the tap-walking jobs first: where one of them is wanted its workgroups are the long ones and must not start last)
     for (int i = 0; i < n_levels; ++i) {
         const ssdk_head_level& lv = levels[i];
         if (!lv.dx) continue;
-        const int npad = npad_of(lv), hw = lv.h * lv.w;
+        const int npad = npad_of(lv);
         for (int kind = 0; kind < 2; ++kind) {
             TransposeJob& J = tg.j[tg.count++];
             J.w0 = lv.w_score; J.w1 = lv.w_loc; J.out = kind == 0 ? w.wd[i] : w.wt[i];
             J.kind = kind; J.n0 = lv.n_score; J.n1 = lv.n_loc; J.Npad = npad; J.taps = 9; J.Cc = lv.cin; J.mode = w.mode + i;
             J.tiles_x = cdiv(npad, 32); J.tiles_y = cdiv(lv.cin, 32); J.block_begin = t_blocks;
-            t_blocks += J.tiles_x * J.tiles_y * 9;
+            t_blocks += J.tiles_x * J.tiles_y * kTrDepth;
         }
+    }
+    for (int i = 0; i < n_levels; ++i) {
+        const ssdk_head_level& lv = levels[i];
+        if (!lv.dx) continue;
+        const int npad = npad_of(lv), hw = lv.h * lv.w;
         ConvProblem g{};
         g.a = w.dyp[i]; g.a_bstride = (long long)hw * npad; g.a_pstride = npad; g.Cc = npad;
         g.B = batch; g.Hout = lv.h; g.Wout = lv.w; g.Hin = lv.h; g.Win = lv.w; g.ksize = 3; g.stride = 1; g.pad = 1;
@@ -1855,7 +1877,7 @@ extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int b
             TransposeJob& J = tg.j[tg.count++];
             J.w0 = lv.w_score; J.w1 = lv.w_loc; J.out = w.wa[i];
             J.kind = 2; J.taps = 9; J.Cc = lv.cin; J.C = C; J.Jpad = jpad; J.mode = w.mode + i;
-            J.tiles_x = cdiv(jpad, 32); J.tiles_y = cdiv(9 * lv.cin, 32); J.block_begin = t_blocks;
+            J.tiles_x = cdiv(jpad, kTrJ); J.tiles_y = cdiv(9 * lv.cin, 64); J.block_begin = t_blocks;
             t_blocks += J.tiles_x * J.tiles_y * nb;
             ConvProblem r = q;
             r.a = w.ga[i]; r.a_pstride = jpad; r.Cc = jpad; r.a_bstride = (long long)hw * jpad * nb;
