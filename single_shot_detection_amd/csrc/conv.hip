@@ -158,6 +158,48 @@ __device__ __forceinline__ void conv_epilogue(const ConvProblem& g, const f32x16
             dxj[j] = tap % g.ksize - g.pad;
             cbj[j] = n0j % g.sc_cin;
         }
+        if (tile_uniform) {
+            // Lane l works out row (l & 31) of the wave ONCE: the element offset of its pixel in dX and which of the taps land inside
+            // the map; every accumulator element then fetches its row's pair with two cross-lane reads and costs a bit test, an
+            // add and the atomic.  (Deriving pixel, tap and bounds per element was ~2,600 instructions per lane and tile -- more
+            // than the tile's MFMAs take.)
+            long long roff = 0;
+            unsigned rmask = 0u;
+            {
+                const int m = m_base + wave * 32 + r32;
+                if (m < M) {
+                    const int pid = g.row_list ? g.row_list[m] : m;
+                    const int b = pid / hw, r = pid - b * hw;
+                    const int yq = r / g.Wout, yo = yq * g.stride, xo = (r - yq * g.Wout) * g.stride;
+                    roff = (long long)b * g.ob0 + ((long long)yo * g.Win + xo) * g.os0;
+                    for (int ky = 0; ky < g.ksize; ++ky)
+                        for (int kx = 0; kx < g.ksize; ++kx) {
+                            const int ty = yo - g.pad + ky, tx = xo - g.pad + kx;
+                            if (ty >= 0 && ty < g.Hin && tx >= 0 && tx < g.Win) rmask |= 1u << (ky * g.ksize + kx);
+                        }
+                }
+            }
+            long long dj[NT];
+            unsigned bitj[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                dj[j] = ((long long)dyj[j] * g.Win + dxj[j]) * g.os0 + cbj[j] + r32;
+                bitj[j] = (j < tn && n_begin + j * 32 + r32 < N) ? 1u << ((dyj[j] + g.pad) * g.ksize + dxj[j] + g.pad) : 0u;
+            }
+            const unsigned lo = (unsigned)(unsigned long long)roff, hi = (unsigned)((unsigned long long)roff >> 32);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int src = (e & 3) + 8 * (e >> 2) + 4 * h;
+                const unsigned mask_e = (unsigned)__shfl((int)rmask, src, kWave);
+                const unsigned long long off_e = (unsigned long long)(unsigned)__shfl((int)lo, src, kWave) |
+                                                 ((unsigned long long)(unsigned)__shfl((int)hi, src, kWave) << 32);
+                float* const row = g.o0 + (long long)off_e;
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    if (mask_e & bitj[j]) atomicAdd(row + dj[j], acc[j][e]);
+            }
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int m = m_base + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
