@@ -14,15 +14,16 @@
 namespace ssdk {
 
 constexpr int kBnRows = 64;
+// (rows per bn_reduce workgroup; 16-row workgroups on the small maps were slower: 4x the same-address fp64 atomics per channel)
 
 // MODE 0: s0 = sum x, s1 = sum x^2.   MODE 1 (backward): s0 = sum dy', s1 = sum dy' * xhat, dy' = relu ? dy * (y > 0) : dy
 // Workgroup = 64 rows; wave w takes rows w, w+4, ...; lane l owns float4 columns l, l+64, ... (whole 1 KB lines per wave).
 template <int MODE>
 __global__ void __launch_bounds__(256) bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
-                                                        long long rows, int C, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                        int relu, double* __restrict__ sums) {
+                                                        long long rows, int rows_per_block, int C, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, int relu, double* __restrict__ sums) {
     __shared__ float4 s_part[2][4][64];
-    const long long r0 = (long long)blockIdx.x * kBnRows, r1 = min(rows, r0 + kBnRows);
+    const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C4 = C >> 2;
     for (int cbase = 0; cbase < C4; cbase += 64) {
@@ -31,23 +32,41 @@ __global__ void __launch_bounds__(256) bn_reduce_kernel(const float* __restrict_
         if (c4 < C4) {
             float4 m4 = a0, rs4 = a0;
             if (MODE == 1) { m4 = reinterpret_cast<const float4*>(mean)[c4]; rs4 = reinterpret_cast<const float4*>(rstd)[c4]; }
-            for (long long r = r0 + wave; r < r1; r += 4) {
-                const float4 xv = reinterpret_cast<const float4*>(x + r * C)[c4];
-                if (MODE == 0) {
-                    a0.x += xv.x; a0.y += xv.y; a0.z += xv.z; a0.w += xv.w;
-                    a1.x += xv.x * xv.x; a1.y += xv.y * xv.y; a1.z += xv.z * xv.z; a1.w += xv.w * xv.w;
-                } else {
-                    float4 g = reinterpret_cast<const float4*>(dy + r * C)[c4];
-                    if (relu) {
-                        const float4 yv = reinterpret_cast<const float4*>(y + r * C)[c4];
-                        if (!(yv.x > 0.f)) g.x = 0.f;
-                        if (!(yv.y > 0.f)) g.y = 0.f;
-                        if (!(yv.z > 0.f)) g.z = 0.f;
-                        if (!(yv.w > 0.f)) g.w = 0.f;
+            // four rows per trip, all their loads issued before the first is consumed (a row per trip made every wave wait one
+            // memory round trip per row: 10-24 us on the small pyramid maps); rows past the end re-read the last row, weight 0
+            for (long long r = r0 + wave; r < r1; r += 16) {
+                float4 xv[4], gv[4], yv[4];
+                float wgt[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long long ru = r + 4 * u;
+                    wgt[u] = ru < r1 ? 1.0f : 0.0f;
+                    const long long rr = ru < r1 ? ru : r1 - 1;
+                    xv[u] = reinterpret_cast<const float4*>(x + rr * C)[c4];
+                    if (MODE == 1) {
+                        gv[u] = reinterpret_cast<const float4*>(dy + rr * C)[c4];
+                        if (relu) yv[u] = reinterpret_cast<const float4*>(y + rr * C)[c4];
                     }
-                    a0.x += g.x; a0.y += g.y; a0.z += g.z; a0.w += g.w;
-                    a1.x += g.x * ((xv.x - m4.x) * rs4.x); a1.y += g.y * ((xv.y - m4.y) * rs4.y);
-                    a1.z += g.z * ((xv.z - m4.z) * rs4.z); a1.w += g.w * ((xv.w - m4.w) * rs4.w);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (wgt[u] == 0.0f) continue;
+                    const float4 xu = xv[u];
+                    if (MODE == 0) {
+                        a0.x += xu.x; a0.y += xu.y; a0.z += xu.z; a0.w += xu.w;
+                        a1.x += xu.x * xu.x; a1.y += xu.y * xu.y; a1.z += xu.z * xu.z; a1.w += xu.w * xu.w;
+                    } else {
+                        float4 g = gv[u];
+                        if (relu) {
+                            if (!(yv[u].x > 0.f)) g.x = 0.f;
+                            if (!(yv[u].y > 0.f)) g.y = 0.f;
+                            if (!(yv[u].z > 0.f)) g.z = 0.f;
+                            if (!(yv[u].w > 0.f)) g.w = 0.f;
+                        }
+                        a0.x += g.x; a0.y += g.y; a0.z += g.z; a0.w += g.w;
+                        a1.x += g.x * ((xu.x - m4.x) * rs4.x); a1.y += g.y * ((xu.y - m4.y) * rs4.y);
+                        a1.z += g.z * ((xu.z - m4.z) * rs4.z); a1.w += g.w * ((xu.w - m4.w) * rs4.w);
+                    }
                 }
             }
         }
@@ -186,8 +205,9 @@ extern "C" int ssdk_batchnorm_fwd(const float* x, long long rows, int channels, 
         SSDK_REQUIRE(workspace && workspace_bytes >= ssdk_batchnorm_workspace_bytes(channels), SSDK_E_WORKSPACE, "ssdk_batchnorm_fwd: workspace too small");
         double* sums = (double*)workspace;
         SSDK_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)channels, s));
-        hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3((unsigned)((rows + kBnRows - 1) / kBnRows)), dim3(256), 0, s, x, (const float*)nullptr,
-                           (const float*)nullptr, rows, channels, (const float*)nullptr, (const float*)nullptr, 0, sums);
+        const int rpb = kBnRows;
+        hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, s, x, (const float*)nullptr,
+                           (const float*)nullptr, rows, rpb, channels, (const float*)nullptr, (const float*)nullptr, 0, sums);
         SSDK_CHECK_LAUNCH("bn_reduce_kernel");
     } else {
         hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(channels, 256)), dim3(256), 0, s, running_mean, running_var, channels, eps, save_mean, save_rstd);
@@ -210,7 +230,8 @@ extern "C" int ssdk_batchnorm_bwd(const float* x, const float* y, const float* d
     hipStream_t s = (hipStream_t)stream;
     double* sums = (double*)workspace;
     SSDK_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)channels, s));
-    hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3((unsigned)((rows + kBnRows - 1) / kBnRows)), dim3(256), 0, s, x, y, dy, rows, channels, save_mean,
+    const int rpb = kBnRows;
+    hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, s, x, y, dy, rows, rpb, channels, save_mean,
                        save_rstd, relu, sums);
     SSDK_CHECK_LAUNCH("bn_reduce_kernel");
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_blocks(rows * channels, 256)), dim3(256), 0, s, x, y, dy, rows, channels, save_mean,
