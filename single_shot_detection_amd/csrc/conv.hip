@@ -226,32 +226,56 @@ __device__ __forceinline__ void conv_epilogue(const ConvProblem& g, const f32x16
         }
         return;
     }
+    // Everything that is fixed per column (which output, column inside it, bias) or per row (element offset of the pixel in both
+    // outputs) is worked out once -- the row part by lane (row & 31), fetched with cross-lane reads -- so an element costs a
+    // select, an add and its store.  (Phase stamps: re-deriving them per element from the problem record made the epilogue of a
+    // 128 x 128 tile 16 us, twice its K loop on the pyramid tail's 1x1 convolutions.)
+    const int n0 = g.n0, n0_pad = g.n0_pad;
+    const bool split = g.k_splits > 1, relu = g.relu != 0;
+    float* const o0 = g.o0;
+    float* const o1 = g.o1;
+    long long off0 = 0, off1 = 0;   // lane l: row (l & 31) of this wave
+    {
+        const int m = m_base + wave * 32 + r32;
+        if (m < M) {
+            const int b = m / hw, pix = m - b * hw;
+            off0 = (long long)b * g.ob0 + (long long)pix * g.os0;
+            off1 = o1 ? (long long)b * g.ob1 + (long long)pix * g.os1 : 0;
+        } else {
+            off0 = -1;   // (no element offset is negative)
+        }
+    }
+    int colj[NT];
+    float biasj[NT];
+    unsigned is1 = 0u, valid = 0u;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n_begin + j * 32 + r32;
+        const bool second = n >= n0;
+        const bool ok = j < tn && n < N && !(second && n < n0_pad);   // (n0 .. n0_pad: padding columns between the two heads)
+        colj[j] = second ? n - n0_pad : n;
+        const float* bias = second ? g.bias1 : g.bias0;
+        biasj[j] = (ok && bias && ksp == 0) ? bias[colj[j]] : 0.0f;
+        if (second) is1 |= 1u << j;
+        if (ok) valid |= 1u << j;
+    }
+    const unsigned lo0 = (unsigned)(unsigned long long)off0, hi0 = (unsigned)((unsigned long long)off0 >> 32);
+    const unsigned lo1 = (unsigned)(unsigned long long)off1, hi1 = (unsigned)((unsigned long long)off1 >> 32);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-        const int m = m_base + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (m >= M) continue;
-        const int b = m / hw, pix = m % hw;
+        const int src = (e & 3) + 8 * (e >> 2) + 4 * h;
+        const long long r0 = (long long)((unsigned long long)(unsigned)__shfl((int)lo0, src, kWave) | ((unsigned long long)(unsigned)__shfl((int)hi0, src, kWave) << 32));
+        if (r0 < 0) continue;
+        float* const p0 = o0 + r0;
+        float* p1 = p0;
+        if (o1) p1 = o1 + (long long)((unsigned long long)(unsigned)__shfl((int)lo1, src, kWave) | ((unsigned long long)(unsigned)__shfl((int)hi1, src, kWave) << 32));
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            if (j >= tn) continue;
-            const int n = n_begin + j * 32 + r32;
-            if (n >= N) continue;
-            float v = acc[j][e];
-            if (n < g.n0) {
-                if (g.bias0 && ksp == 0) v += g.bias0[n];
-                float* dst = g.o0 + (long long)b * g.ob0 + (long long)pix * g.os0 + n;
-                if (g.k_splits > 1) { atomicAdd(dst, v); continue; }
-                if (g.relu) v = fmaxf(v, 0.0f);
-                *dst = v;
-            } else {
-                if (n < g.n0_pad) continue;   // padding columns between the two heads
-                const int n1 = n - g.n0_pad;
-                if (g.bias1 && ksp == 0) v += g.bias1[n1];
-                float* dst = g.o1 + (long long)b * g.ob1 + (long long)pix * g.os1 + n1;
-                if (g.k_splits > 1) { atomicAdd(dst, v); continue; }
-                if (g.relu) v = fmaxf(v, 0.0f);
-                *dst = v;
-            }
+            if (!((valid >> j) & 1u)) continue;
+            float* const dst = (((is1 >> j) & 1u) ? p1 : p0) + colj[j];
+            const float v = acc[j][e] + biasj[j];
+            if (split) atomicAdd(dst, v);
+            else *dst = relu ? fmaxf(v, 0.0f) : v;
         }
     }
 }
@@ -295,8 +319,18 @@ constexpr unsigned kOobBit = 0x80000000u;
 // w + 4 share a SIMD: the barrier keeps the two in step, so the slot-1 wave cannot fall behind its partner the way it
 // does between two independent workgroups (cycle stamps: 12.0k vs 8.7k cycles per slice), and the W slice is staged once
 // for 256 pixels.  The host picks WAVES = 8 when the 256-pixel tiling still fills the chip.
+#ifdef SSDK_CONV_PHASE
+// experiment only (never built into the shipped library; tools/phase_conv.py): 100 MHz wall-clock stamps of the first 64
+// workgroups at tile start / K loop start / epilogue start / end
+__device__ unsigned long long g_phase[64 * 4];
+extern "C" int ssdk_debug_read_phase(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 64 * 4); }
+#define PHASE(i) if (threadIdx.x == 0 && blockIdx.x < 64) g_phase[blockIdx.x * 4 + (i)] = wall_clock64();
+#else
+#define PHASE(i)
+#endif
 template <bool MIRROR, bool GENERIC, bool SCATTER, int WAVES, int BK, int MAXTN>
 __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_tile, int n_block, int ksp) {
+    PHASE(0)
     // BK = K slice: 32 floats (128-byte rows, 8 rows per DMA piece, 64 KB of LDS: 2 workgroups per CU) or 16 floats (64-byte rows,
     // 16 rows per piece, 32 KB: 3 workgroups per CU at <= 170 VGPRs, a barrier every 32 MFMAs instead of 64)
     constexpr int BM = 32 * WAVES;                         // output pixels per workgroup
@@ -513,6 +547,7 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
             if (slice + 1 < n_slices) body(std::integral_constant<int, 1>{}, slice + 1);
         }
     };
+    PHASE(1)
     switch (tn) {
         case 6: if constexpr (MAXTN >= 6) { k_loop(std::integral_constant<int, 6>{}); } break;
         case 5: if constexpr (MAXTN >= 6) { k_loop(std::integral_constant<int, 5>{}); } break;
@@ -521,7 +556,9 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
         case 2: k_loop(std::integral_constant<int, 2>{}); break;
         default: k_loop(std::integral_constant<int, 1>{}); break;
     }
+    PHASE(2)
     conv_epilogue<SCATTER>(g, acc, m_base, wave, r32, h, tn, n_begin, M, N, hw, ksp);
+    PHASE(3)
 }
 
 
@@ -1570,6 +1607,13 @@ static bool maybe_split_k(ConvProblem& g) {
     g.k_splits = ks;
     return true;
 }
+// Atomic epilogues (split K, scatter) leave a CU at about one 256-byte wave instruction per 50 ns (MI355X_MICROARCH.md, Global
+// float atomics): the 256 of a 128-column tile take 13 us -- phase stamps of the pyramid tail's convolutions showed 3 us of
+// prologue, 8 us of K loop and 13 us of epilogue.  While the launch is smaller than the chip, halve the columns per workgroup
+// instead: twice the workgroups, each with half the atomics, on CUs that were idle.
+static void narrow_for_atomics(ConvProblem& g) {
+    while (g.n_blocks < g.tiles_n && (long long)g.m_tiles * g.n_blocks * g.k_splits <= 256) g.n_blocks = std::min(g.tiles_n, g.n_blocks * 2);
+}
 
 // decides the kernel (LDS-DMA or register staged; 128- or 256-pixel tiles), orders the problems by decreasing work per
 // workgroup (longest first), assigns block ranges, launches
@@ -1599,6 +1643,7 @@ static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t 
         g.n0_pad = (dma && g.n1 > 0) ? cdiv(g.n0, bk16 ? 16 : 8) * (bk16 ? 16 : 8) : g.n0;
         g.tiles_n = cdiv(g.n0_pad + g.n1, 32);
         g.n_blocks = cdiv(g.tiles_n, tn6 ? 6 : kMaxTN);
+        if (!vtab && (scatter || g.k_splits > 1)) narrow_for_atomics(g);
     }
     // 8-wave / 256-pixel tiling: measured 3 % (B=128) to 14 % (B=32) MORE cycles than two 4-wave workgroups per CU on the
     // SSD-300 heads (one barrier stalls all eight waves of the CU at once) -- kept as an opt-in experiment only
@@ -1788,6 +1833,9 @@ static void size_wgrad_splits(WgradGroup& wg, int n, int density_div) {
     for (int i = 0; i < n; ++i) {
         WgradProblem& g = wg.p[i];
         const int slices = cdiv(cdiv(g.B * g.Hout * g.Wout, density_div), 32);
+        // (small problems -- tiles x row slices <= 1024 --: 32-channel instead of 128-channel workgroups first -- a quarter of the atomics each, see narrow_for_atomics --
+        // and only then split K)
+        while (g.c_blocks < g.c_tiles32 && (long long)g.ksize * g.ksize * g.n_tiles * g.c_blocks * (g.seg_count ? g.segs : 1) * slices <= 1024) g.c_blocks = std::min(g.c_tiles32, g.c_blocks * 2);
         const int tiles = g.ksize * g.ksize * g.n_tiles * g.c_blocks * (g.seg_count ? g.segs : 1);
         int ks = cdiv(512, tiles);
         if (cdiv(slices, 64) > ks) ks = cdiv(slices, 64);
@@ -2069,6 +2117,7 @@ extern "C" int ssdk_conv2d_bwd(const ssdk_conv_desc* descs, int n, int batch, in
             g.w0 = wd; g.n0 = d.cin; g.n1 = 0;
             g.o0 = d.dx; g.ob0 = (long long)d.hin * d.win * d.cin; g.os0 = d.cin;
             finish_problem(g);
+            if (maybe_split_k(g)) zl.add(d.dx, (size_t)batch * d.hin * d.win * d.cin);   // (small maps: K = taps * cout is one long chain per tile)
             dgrad[n_dgrad++] = g;
         } else if (d.dx) {
             // strided: input stationary.  T[out pixel][tap*cin + c] = dy[out pixel][:] . W[:, tap, c], scatter-added into
