@@ -1170,15 +1170,20 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_wgrad_dma
     const long long K = (long long)taps * Cc;
     const int c = c_begin + wave * 32 + r32;
     if (c >= Cc) return;
+    // (everything but n * K hoisted out of the 64 elements: the two row bases already carry tap, channel and the -n0 shift)
+    const int n0 = g.n0;
+    float* const base0 = dw0_p + (long long)tap * Cc + c;
+    float* const base1 = dw1_p ? dw1_p + (long long)tap * Cc + c - (long long)n0 * K : base0;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int i = (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int nq = n_begin + 4 * i;
+        const long long nK = (long long)nq * K;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int n = n_begin + 4 * i + q;   // MFMA q, row i
+            const int n = nq + q;   // MFMA q, row i
             if (n >= N) continue;
-            float* row = n < g.n0 ? dw0_p + (long long)n * K : dw1_p + (long long)(n - g.n0) * K;
-            atomicAdd(row + (long long)tap * Cc + c, acc[q][e]);
+            atomicAdd((n < n0 ? base0 : base1) + nK + q * K, acc[q][e]);
         }
     }
 }
