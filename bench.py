@@ -36,6 +36,15 @@ from single_shot_detection_amd.distributed import GradBucket  # noqa: E402
 TOWER = {'retina_rn50_500_coco': dict(num_layers=4, num_channels=256, kernel_size=3)}
 # M2Det: the MLFPN neck (8 TUMs x 6 scales + SFAM, samples/m2det_512_vgg16_coco.py:10-17) sits between the two VGG taps and the heads
 NECK = {'m2det_512_vgg16_coco': dict(taps=[(512, 64), (1024, 32)], num_scales=6, num_tums=8, base_reduced_channels=[512, 256])}
+def _sgd(params, **kw):
+    """torch.optim.SGD, single-pass (fused) implementation where this torch build has it (the default foreach form is four
+    passes over parameters, gradients and momentum buffers)."""
+    try:
+        return torch.optim.SGD(params, fused=True, **kw)
+    except (TypeError, RuntimeError, ValueError):
+        return torch.optim.SGD(params, **kw)
+
+
 EXTRAS = {'ssd_300_vgg16_voc': (('s', 512), ('s', 256), ('s', 256), ('s', 256)),
           'ssd_300_vgg16_voc_c21': (('s', 512), ('s', 256), ('s', 256), ('s', 256)),
           'ssd_512_vgg16_coco': (('s', 512), ('s', 256), ('s', 256), ('s', 256), ('s', 256))}
@@ -124,7 +133,7 @@ class HotPath(object):
         self.params = [p for p in self.heads.parameters()] + ([p for p in self.extras.parameters()] if self.extras is not None else []) + \
                       ([p for p in self.tower.parameters()] if self.tower is not None else []) + \
                       ([p for n, p in self.neck.named_parameters() if not n.startswith('base.')] if self.neck is not None else [])
-        self.opt = torch.optim.SGD(self.params, lr=1e-3, momentum=0.9, weight_decay=5e-4)
+        self.opt = _sgd(self.params, lr=1e-3, momentum=0.9, weight_decay=5e-4)
         self.opt_split = None   # N > 1: one optimizer per gradient bucket (built on first use), so the head update overlaps the second ring
         # exchange step (N > 1): the head gradients are complete as soon as the heads' backward has run, so their ring starts
         # there and overlaps with the backward of the extras / tower; a second, small bucket carries the rest
@@ -207,7 +216,7 @@ class HotPath(object):
                 return loss
             if self.opt_split is None:   # same hyper-parameters, disjoint parameter sets: the update is the one self.opt would make
                 kw = dict(lr=1e-3, momentum=0.9, weight_decay=5e-4)
-                self.opt_split = (torch.optim.SGD(self.head_params, **kw), torch.optim.SGD(self.rest_params, **kw))
+                self.opt_split = (_sgd(self.head_params, **kw), _sgd(self.rest_params, **kw))
             self.opt_split[0].step()        # head parameters: their averaged gradients are complete; the second ring is still running
             self.bucket_rest.finish_()
             self.opt_split[1].step()

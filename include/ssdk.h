@@ -271,11 +271,13 @@ size_t ssdk_batchnorm_workspace_bytes(int channels);
  * torch.nn.BatchNorm2d forward on [rows = batch*H*W][channels] (NHWC), optional fused ReLU after it (conv.py:33-35).
  * training != 0: batch statistics (biased variance), running_mean / running_var updated with `momentum` (unbiased
  * variance) when non-NULL; else running statistics.  save_mean / save_rstd [channels] are kept for the backward.
+ * num_batches_tracked DEV int64 [1] or NULL: the module's counter, incremented by one in training mode
+ * (torch.nn.modules.batchnorm._BatchNorm.forward does `self.num_batches_tracked.add_(1)` -- a launch of its own per layer).
  */
 int ssdk_batchnorm_fwd(const float* x, long long rows, int channels, const float* gamma, const float* beta,
-                       float* running_mean, float* running_var, float momentum, float eps, int training, int relu,
-                       float* y, float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
-                       void* stream);
+                       float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
+                       int training, int relu, float* y, float* save_mean, float* save_rstd, void* workspace,
+                       size_t workspace_bytes, void* stream);
 /* y is the forward output (needed only when relu != 0, for the mask). */
 int ssdk_batchnorm_bwd(const float* x, const float* y, const float* dy, long long rows, int channels, const float* gamma,
                        const float* save_mean, const float* save_rstd, int relu, int training, float* dx, float* dgamma,

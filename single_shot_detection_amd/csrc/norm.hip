@@ -124,8 +124,10 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float4* __restrict_
                                                        const float4* __restrict__ beta, int relu, float4* __restrict__ y,
                                                        const double* __restrict__ sums, long long rows, float eps, float momentum,
                                                        float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                       float* __restrict__ save_mean, float* __restrict__ save_rstd) {
+                                                       float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                                                       long long* __restrict__ num_batches_tracked) {
     const int C = C4 * 4;
+    if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
     if (sums && blockIdx.x == 0) {
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
             float m, rs, uv;
@@ -194,8 +196,9 @@ using namespace ssdk;
 extern "C" size_t ssdk_batchnorm_workspace_bytes(int channels) { return align_up((size_t)2 * channels * sizeof(double), 256); }
 
 extern "C" int ssdk_batchnorm_fwd(const float* x, long long rows, int channels, const float* gamma, const float* beta,
-                                  float* running_mean, float* running_var, float momentum, float eps, int training, int relu, float* y,
-                                  float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes, void* stream) {
+                                  float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
+                                  int training, int relu, float* y, float* save_mean, float* save_rstd, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
     SSDK_REQUIRE(x && y && save_mean && save_rstd && rows > 0 && channels > 0, SSDK_E_INVALID, "ssdk_batchnorm_fwd: bad arguments");
     SSDK_REQUIRE(channels % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, SSDK_E_UNSUPPORTED,
                  "ssdk_batchnorm_fwd: channels %% 4 != 0 or buffers not 16-byte aligned");
@@ -217,7 +220,7 @@ extern "C" int ssdk_batchnorm_fwd(const float* x, long long rows, int channels, 
     hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_blocks(n4, 256)), dim3(256), 0, s, (const float4*)x, n4, channels / 4, (const float4*)save_mean,
                        (const float4*)save_rstd, (const float4*)gamma, (const float4*)beta, relu, (float4*)y,
                        training ? (const double*)workspace : (const double*)nullptr, rows, eps, momentum, running_mean, running_var, save_mean,
-                       save_rstd);
+                       save_rstd, training ? (long long*)num_batches_tracked : (long long*)nullptr);
     SSDK_CHECK_LAUNCH("bn_apply_kernel");
     return SSDK_OK;
 }

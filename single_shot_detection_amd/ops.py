@@ -93,7 +93,7 @@ def conv2d(xs, weight, bias=None, stride=1, padding=0, relu=False):
 
 class _BatchNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training, relu):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, training, relu):
         lib = _lib.lib()
         _lib.require_cuda(x)
         x = _nhwc(x)
@@ -105,8 +105,8 @@ class _BatchNormFn(torch.autograd.Function):
         ws = torch.empty((lib.ssdk_batchnorm_workspace_bytes(C),), dtype=torch.uint8, device=x.device)
         g = None if gamma is None else gamma.float().contiguous()
         b = None if beta is None else beta.float().contiguous()
-        _lib.check(lib.ssdk_batchnorm_fwd(_dp(x), rows, C, _dp(g), _dp(b), _dp(running_mean), _dp(running_var), float(momentum),
-                                          float(eps), int(training), int(relu), _dp(y), _dp(mean), _dp(rstd), _dp(ws), ws.numel(),
+        _lib.check(lib.ssdk_batchnorm_fwd(_dp(x), rows, C, _dp(g), _dp(b), _dp(running_mean), _dp(running_var),
+                                          _dp(num_batches_tracked) if training else None, float(momentum), float(eps), int(training), int(relu), _dp(y), _dp(mean), _dp(rstd), _dp(ws), ws.numel(),
                                           _lib.current_stream()), 'ssdk_batchnorm_fwd')
         ctx.save_for_backward(x, y if relu else x.new_empty(0), g if g is not None else x.new_empty(0), mean, rstd)
         ctx.meta = (bool(relu), bool(training), gamma is not None, beta is not None)
@@ -127,7 +127,7 @@ class _BatchNormFn(torch.autograd.Function):
         _lib.check(lib.ssdk_batchnorm_bwd(_dp(x), _dp(y) if relu else None, _dp(dy), B * H * W, C, _dp(g) if has_g else None, _dp(mean),
                                           _dp(rstd), int(relu), int(training), _dp(dx), _dp(dgamma), _dp(dbeta), _dp(ws), ws.numel(),
                                           _lib.current_stream()), 'ssdk_batchnorm_bwd')
-        return dx, dgamma if has_g else None, dbeta if has_b else None, None, None, None, None, None, None
+        return dx, dgamma if has_g else None, dbeta if has_b else None, None, None, None, None, None, None, None
 
 
 def batch_norm(x, bn, relu=False):
@@ -135,9 +135,10 @@ def batch_norm(x, bn, relu=False):
     if bn.momentum is None or not bn.track_running_stats:
         raise NotImplementedError('BatchNorm2d with momentum=None / track_running_stats=False is not on the GPU path')
     training = bn.training
-    if training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-    return _BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, training, relu)
+    nbt = bn.num_batches_tracked   # incremented inside the library's launch (torch: a launch of its own per layer)
+    if nbt is not None:
+        assert nbt.dtype == torch.int64 and nbt.is_cuda
+    return _BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, nbt, bn.momentum, bn.eps, training, relu)
 
 
 class _UpsampleAddFn(torch.autograd.Function):
