@@ -109,6 +109,20 @@ __device__ __forceinline__ T block_sum(T v, T* red) {
     return s;
 }
 
+// Global -> LDS copy of n4 float4 (both 16-byte aligned) by a 256-thread workgroup with 8 loads per thread in flight.
+// Loads AND stores are branch-free: indices past the end are clamped to the last element, which is then written several
+// times with the same value.  (A `for (t < n4) lds[t] = src[t]` loop compiles to load / s_waitcnt vmcnt(0) / ds_write per
+// trip -- one memory round trip per 4 KB -- and a predicated store makes the optimiser sink each load into its branch again.)
+__device__ __forceinline__ void stage_tile_f4(float4* __restrict__ lds, const float4* __restrict__ src, int n4) {
+    for (int base = 0; base < n4; base += 8 * 256) {
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = src[min(base + (int)threadIdx.x + k * 256, n4 - 1)];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) lds[min(base + (int)threadIdx.x + k * 256, n4 - 1)] = v[k];
+    }
+}
+
 #endif  // __HIPCC__
 
 }  // namespace ssdk

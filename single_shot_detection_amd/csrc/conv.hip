@@ -1812,7 +1812,7 @@ extern "C" size_t ssdk_heads_bwd_workspace_bytes(const ssdk_head_level* levels, 
     return total;
 }
 
-// K (= pixel rows) is split so that every problem contributes >= ~512 workgroups (tiny maps are latency bound at one
+// K (= pixel rows) is split so that every problem contributes >= ~256 workgroups (tiny maps are latency bound at one
 // wave per SIMD: more, shorter workgroups) and no workgroup walks more than 64 slices; each split costs one 64 KB
 // atomic tile, so never fewer than 2 slices per split.
 // picks the LDS-DMA kernel when every problem of the group qualifies (16-byte rows, operands below 2 GiB, pixel count below 2^24)
@@ -1842,7 +1842,7 @@ static void size_wgrad_splits(WgradGroup& wg, int n, int density_div) {
         // and only then split K)
         while (g.c_blocks < g.c_tiles32 && (long long)g.ksize * g.ksize * g.n_tiles * g.c_blocks * (g.seg_count ? g.segs : 1) * slices <= 1024) g.c_blocks = std::min(g.c_tiles32, g.c_blocks * 2);
         const int tiles = g.ksize * g.ksize * g.n_tiles * g.c_blocks * (g.seg_count ? g.segs : 1);
-        int ks = cdiv(512, tiles);
+        int ks = cdiv(256, tiles);   // (512 measured 6 % slower over the step's weight-gradient launches, 128 10 % slower)
         if (cdiv(slices, 64) > ks) ks = cdiv(slices, 64);
         if (ks > slices / 2) ks = slices / 2;
         if (ks < 1) ks = 1;

@@ -89,8 +89,7 @@ __global__ void __launch_bounds__(kLossThreads) hnm_rows_kernel(const float* __r
         const int nfloat = rows * C;
         const float* src = scores + r0 * C;  // 16-byte aligned: r0*C*4 = tile*256*C
         __syncthreads();
-        for (int t = threadIdx.x; t < (nfloat >> 2); t += kLossThreads)
-            reinterpret_cast<float4*>(s_tile)[t] = reinterpret_cast<const float4*>(src)[t];
+        if (nfloat >> 2) stage_tile_f4(reinterpret_cast<float4*>(s_tile), reinterpret_cast<const float4*>(src), nfloat >> 2);
         for (int t = (nfloat & ~3) + threadIdx.x; t < nfloat; t += kLossThreads) s_tile[t] = src[t];
         __syncthreads();
         const int row = threadIdx.x >> 2, q = threadIdx.x & 3;

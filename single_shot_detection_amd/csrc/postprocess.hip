@@ -82,8 +82,7 @@ __global__ void __launch_bounds__(kPostThreads) post_select_kernel(const float* 
         const float* src = scores + ((size_t)i * A + a0) * C;
         __syncthreads();
         if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
-            for (int t = threadIdx.x; t < (nfloat >> 2); t += kPostThreads)
-                reinterpret_cast<float4*>(s_tile)[t] = reinterpret_cast<const float4*>(src)[t];
+            if (nfloat >> 2) stage_tile_f4(reinterpret_cast<float4*>(s_tile), reinterpret_cast<const float4*>(src), nfloat >> 2);
             for (int t = (nfloat & ~3) + threadIdx.x; t < nfloat; t += kPostThreads) s_tile[t] = src[t];
         } else {
             for (int t = threadIdx.x; t < nfloat; t += kPostThreads) s_tile[t] = src[t];
