@@ -28,6 +28,7 @@ constexpr int kTileRows = 64;
 constexpr int kLossThreads = 256;
 constexpr float kMarkPositive = -INFINITY;  // bgloss marker: positive anchor (sampler.py:22 sets -inf for non-negatives)
 constexpr float kMarkIgnore = -1.0f;        // bgloss marker: ignored anchor (class -1)
+constexpr int kSelMaxChunks = 128;          // hnm_select_kernel's tie table: anchors / 1024 (beyond it: the sequential tie pass)
 constexpr int kSelCache = 8;                // values per thread that hnm_select_kernel keeps in registers (8 * 1024 anchors)
 
 struct LossState {  // lives in the workspace, written by finalize_kernel, read by the backward
@@ -119,6 +120,7 @@ __global__ void __launch_bounds__(1024) hnm_select_kernel(const float* __restric
     __shared__ unsigned s_hist[256];
     __shared__ int s_cnt[2];
     __shared__ unsigned s_prefix, s_need, s_wave_cnt[16], s_run;
+    __shared__ unsigned s_eq[kSelMaxChunks * 16];   // tie pass: keys equal to the threshold per (chunk of 1024 anchors, wave)
     const int i = blockIdx.x, tid = threadIdx.x;
     const float* v = bgloss + (size_t)i * A;
     uint8_t* out = sampled + (size_t)i * A;
@@ -185,22 +187,105 @@ __global__ void __launch_bounds__(1024) hnm_select_kernel(const float* __restric
             }
         }
         __syncthreads();
-        if (tid == 0) {
-            unsigned acc = 0;
-            int b = 255;
-            for (; b > 0; --b) {
-                if (acc + s_hist[b] >= need) break;
-                acc += s_hist[b];
+        if (tid < kWave) {
+            // wave 0 finds the digit: lane l owns bins 4l .. 4l+3; `above` = keys in the bins above its group (suffix sum over the
+            // lanes).  The bin is the largest b with (keys in bins > b) + hist[b] >= need.  (One thread walking the 256 bins was
+            // 255 dependent LDS reads per pass: ~8 us of the kernel's 58, four times.)
+            const int l = tid;
+            const unsigned h0 = s_hist[4 * l], h1 = s_hist[4 * l + 1], h2 = s_hist[4 * l + 2], h3 = s_hist[4 * l + 3];
+            const unsigned mine = h0 + h1 + h2 + h3;
+            unsigned incl = mine;   // inclusive suffix sum: lanes >= l
+#pragma unroll
+            for (int d = 1; d < kWave; d <<= 1) {
+                const unsigned t = __shfl_down(incl, d, kWave);
+                if (l + d < kWave) incl += t;
             }
-            s_prefix = prefix | ((unsigned)b << shift);
-            s_need = need - acc;
+            unsigned acc = incl - mine;
+            int found = -1;
+            unsigned rest = 0;
+            const unsigned hq[4] = {h0, h1, h2, h3};
+#pragma unroll
+            for (int q = 3; q >= 0; --q) {
+                if (found < 0) {
+                    if (acc + hq[q] >= need) { found = 4 * l + q; rest = need - acc; }
+                    else acc += hq[q];
+                }
+            }
+            // the lane whose group holds the crossing reports it (highest such lane = highest bin); none (need > keys: cannot
+            // happen for n <= #negatives) falls back to bin 0 like the sequential walk did
+            const unsigned long long hit = __ballot(found >= 0);
+            if (hit) {
+                const int src = 63 - __clzll((long long)hit);
+                if (l == src) { s_prefix = prefix | ((unsigned)found << shift); s_need = rest; }
+            } else if (l == 0) {
+                s_prefix = prefix;
+                s_need = need - (incl - h0);
+            }
         }
         __syncthreads();
         prefix = s_prefix; need = s_need;
         __syncthreads();
     }
-    // prefix = key of the n-th largest; `need` of the anchors whose key == prefix are taken, lowest index first
+    // prefix = key of the n-th largest; `need` of the anchors whose key == prefix are taken, lowest index first.
+    // Chunk k = anchors k*1024 .. k*1024+1023 (the register cache's mapping).  Pass 1: per (chunk, wave) the number of keys equal
+    // to the threshold; wave 0 turns the table into exclusive prefixes; pass 2: every anchor knows its rank among the ties.
+    // (Three barriers in all; a barrier-separated running count per chunk cost 27.)
     const unsigned thr = prefix;
+    const int chunks = (A + 1023) / 1024;
+    const int w = tid >> 6, lane = lane_id();
+    if (chunks <= kSelMaxChunks) {
+        unsigned long long bal[kSelCache];
+#pragma unroll
+        for (int k = 0; k < kSelCache; ++k) {
+            const float x = cache[k];
+            bal[k] = __ballot(x >= 0.0f && neg_key(x) == thr);
+            if (lane == 0 && k < chunks) s_eq[k * 16 + w] = (unsigned)__popcll(bal[k]);
+        }
+        for (int k = kSelCache; k < chunks; ++k) {
+            const int a = k * 1024 + tid;
+            const float x = a < A ? v[a] : kMarkIgnore;
+            const unsigned long long bk = __ballot(x >= 0.0f && neg_key(x) == thr);
+            if (lane == 0) s_eq[k * 16 + w] = (unsigned)__popcll(bk);
+        }
+        __syncthreads();
+        if (tid < kWave) {   // exclusive prefix over the chunks * 16 entries: each lane a contiguous run, wave scan of the run totals
+            const int entries = chunks * 16, per = (entries + kWave - 1) / kWave;
+            const int e0 = min(tid * per, entries), e1 = min(e0 + per, entries);
+            unsigned run = 0;
+            for (int e = e0; e < e1; ++e) run += s_eq[e];
+            unsigned incl = run;
+#pragma unroll
+            for (int d = 1; d < kWave; d <<= 1) {
+                const unsigned t = __shfl_up(incl, d, kWave);
+                if (tid >= d) incl += t;
+            }
+            unsigned acc = incl - run;
+            for (int e = e0; e < e1; ++e) { const unsigned c = s_eq[e]; s_eq[e] = acc; acc += c; }
+        }
+        __syncthreads();
+        const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int k = 0; k < kSelCache; ++k) {
+            const int a = k * 1024 + tid;
+            if (a < A) {
+                const float x = cache[k];
+                const bool neg = x >= 0.0f;
+                const unsigned key = neg ? neg_key(x) : 0u;
+                const unsigned before = s_eq[k * 16 + w] + (unsigned)__popcll(bal[k] & below);
+                out[a] = (x == kMarkPositive) || (neg && key > thr) || (neg && key == thr && before < need);
+            }
+        }
+        for (int k = kSelCache; k < chunks; ++k) {
+            const int a = k * 1024 + tid;
+            const float x = a < A ? v[a] : kMarkIgnore;
+            const bool neg = x >= 0.0f;
+            const unsigned key = neg ? neg_key(x) : 0u;
+            const unsigned long long bk = __ballot(neg && key == thr);
+            if (a < A) out[a] = (x == kMarkPositive) || (neg && key > thr) || (neg && key == thr && s_eq[k * 16 + w] + (unsigned)__popcll(bk & below) < need);
+        }
+        return;
+    }
+    // (more chunks than the table holds -- A > 131 072: a barrier-separated running count per chunk)
     if (tid == 0) s_run = 0;
     __syncthreads();
     for (int base = 0; base < A; base += blockDim.x) {
@@ -211,12 +296,11 @@ __global__ void __launch_bounds__(1024) hnm_select_kernel(const float* __restric
         const unsigned key = neg ? neg_key(x) : 0u;
         const bool eq = neg && key == thr;
         const unsigned long long bal = __ballot(eq);
-        const int w = tid >> 6;
-        if (lane_id() == 0) s_wave_cnt[w] = (unsigned)__popcll(bal);
+        if (lane == 0) s_wave_cnt[w] = (unsigned)__popcll(bal);
         __syncthreads();
         unsigned before = s_run;
         for (int k = 0; k < w; ++k) before += s_wave_cnt[k];
-        before += (unsigned)__popcll(bal & ((1ull << lane_id()) - 1ull));
+        before += (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
         if (a < A) out[a] = (x == kMarkPositive) || (neg && key > thr) || (eq && before < need);
         __syncthreads();
         if (tid == 0) {
