@@ -168,6 +168,29 @@ def test_hnm_edge_cases():
         # images 0,1: distinct floats -> exact; 2,3: exact as well because both break ties by lower index
         assert np.array_equal(got, ref), (ratio, min_neg, (got != ref).sum(axis=1))
 
+@pytest.mark.parametrize('A', [8732, 20000, 140000])
+def test_hnm_ties_across_chunks(A):
+    """Heavy ties at anchor counts that span several 1024-anchor chunks of hnm_select_kernel's tie table (9, 20) and one past the
+    table (137 chunks: the sequential tie pass): the index-ordered tie break must hold across chunk and wave boundaries."""
+    rng = np.random.default_rng(17)
+    B, C = 2, 5
+    # 24 prototype rows with well separated background losses, dealt at random: equal rows give bit-equal losses in both
+    # implementations, different prototypes differ by far more than the rounding of either log-sum-exp
+    proto = rng.standard_normal((24, C), dtype=np.float32)
+    proto[:, 0] = np.linspace(-3.0, 3.0, 24, dtype=np.float32)
+    logits = proto[rng.integers(0, 24, (B, A))]
+    logits[1] = 0.5                                                               # every loss identical
+    cls = np.zeros((B, A), np.float32)
+    cls[0, ::97] = 2
+    cls[0, 5::211] = -1
+    cls[1, 3::1000] = 1
+    target = np.zeros((B, A, 6), np.float32)
+    target[..., 4] = cls
+    for ratio, min_neg in ((3, 5), (7.5, 0)):
+        ref = oracle.hard_negative_mining(logits, target, ratio, min_neg)
+        got = sampler.hard_negative_mining(torch.from_numpy(logits).cuda(), torch.from_numpy(cls).cuda().long(), ratio, min_neg).cpu().numpy()
+        assert np.array_equal(got, ref), (A, ratio, min_neg, (got != ref).sum(axis=1))
+
 
 def test_custom_sampler_callable_and_ignore_rows():
     """A user sampler (reference signature) that also samples ignored anchors: CE must skip class -1 rows."""
