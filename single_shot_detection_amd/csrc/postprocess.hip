@@ -165,21 +165,53 @@ __device__ int block_topk_sorted(const u64* __restrict__ keys, int n, int K, u64
         for (int shift = 56; shift >= 0; shift -= 8) {
             for (int b = tid; b < 256; b += nthr) s_hist[b] = 0;
             __syncthreads();
-            for (int k = tid; k < n; k += nthr) {
-                const u64 key = keys[k];
-                if (shift == 56 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&s_hist[(unsigned)(key >> shift) & 255u], 1u);
+            for (int k0 = tid; k0 < n; k0 += 4 * nthr) {   // four keys per trip, loads first (branch-free: clamped index)
+                u64 key[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) key[u] = keys[min(k0 + u * nthr, n - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (k0 + u * nthr < n && (shift == 56 || (key[u] >> (shift + 8)) == (prefix >> (shift + 8))))
+                        atomicAdd(&s_hist[(unsigned)(key[u] >> shift) & 255u], 1u);
             }
             __syncthreads();
-            if (tid == 0) {
-                unsigned cum = above;
-                int b = 255;
-                for (; b > 0; --b) {
-                    if (cum + s_hist[b] >= (unsigned)K) break;
-                    cum += s_hist[b];
+            if (tid < kWave) {
+                // wave 0 finds the digit (lane l owns bins 4l .. 4l+3, suffix sums over the lanes): the largest b with
+                // above + (keys in bins > b) + hist[b] >= K.  One thread walking the bins was 255 dependent LDS reads per pass.
+                const int l = tid;
+                const unsigned h0 = s_hist[4 * l], h1 = s_hist[4 * l + 1], h2 = s_hist[4 * l + 2], h3 = s_hist[4 * l + 3];
+                const unsigned mine = h0 + h1 + h2 + h3;
+                unsigned incl = mine;
+#pragma unroll
+                for (int d = 1; d < kWave; d <<= 1) {
+                    const unsigned t = __shfl_down(incl, d, kWave);
+                    if (l + d < kWave) incl += t;
                 }
-                s_misc[0] = prefix | ((u64)b << shift);
-                s_misc[1] = cum;                // new `above`
-                s_misc[2] = cum + s_hist[b];    // keys >= new prefix
+                unsigned cum = above + (incl - mine);
+                int found = -1;
+                unsigned cum_at = 0, h_at = 0;
+                const unsigned hq[4] = {h0, h1, h2, h3};
+#pragma unroll
+                for (int q = 3; q >= 0; --q) {
+                    if (found < 0) {
+                        if (cum + hq[q] >= (unsigned)K) { found = 4 * l + q; cum_at = cum; h_at = hq[q]; }
+                        else cum += hq[q];
+                    }
+                }
+                const unsigned long long hit = __ballot(found >= 0);
+                if (hit) {
+                    const int src = 63 - __clzll((long long)hit);
+                    if (l == src) {
+                        s_misc[0] = prefix | ((u64)found << shift);
+                        s_misc[1] = cum_at;             // new `above`
+                        s_misc[2] = cum_at + h_at;      // keys >= new prefix
+                    }
+                } else if (l == 0) {   // fewer than K keys in range: bin 0, like the sequential walk
+                    const unsigned c0 = above + (incl - h0);
+                    s_misc[0] = prefix;
+                    s_misc[1] = c0;
+                    s_misc[2] = c0 + h0;
+                }
             }
             __syncthreads();
             prefix = s_misc[0];
@@ -194,12 +226,16 @@ __device__ int block_topk_sorted(const u64* __restrict__ keys, int n, int K, u64
     int* s_n = reinterpret_cast<int*>(&s_misc[3]);
     if (tid == 0) *s_n = 0;
     __syncthreads();
-    for (int k = tid; k < n; k += nthr) {
-        const u64 key = keys[k];
-        if (key >= lower) {
-            const int slot = atomicAdd(s_n, 1);
-            if (slot < kSortCap) s_keys[slot] = key;
-        }
+    for (int k0 = tid; k0 < n; k0 += 4 * nthr) {   // (four loads in flight per thread; the sort below makes slot order irrelevant)
+        u64 key[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) key[u] = keys[min(k0 + u * nthr, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k0 + u * nthr < n && key[u] >= lower) {
+                const int slot = atomicAdd(s_n, 1);
+                if (slot < kSortCap) s_keys[slot] = key[u];
+            }
     }
     __syncthreads();
     const int m = min(*s_n, kSortCap);
