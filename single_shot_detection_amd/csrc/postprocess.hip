@@ -98,10 +98,15 @@ __global__ void __launch_bounds__(kPostThreads) post_select_kernel(const float* 
             m = quad_max(m);
             float sum = 0.0f;
             if (live)
-                for (int c = q; c < C; c += 4) sum += expf(x[c] - m);
+                for (int c = q; c < C; c += 4) {   // exp(x - max) is computed ONCE and kept in the tile (the kernel is bound by
+                    const float e = expf(x[c] - m);   // its exp / divide arithmetic, not by the 20 KB of logits per tile)
+                    x[c] = e;
+                    sum += e;
+                }
             sum = quad_sum(sum);
             if (live)
-                for (int c = q; c < C; c += 4) x[c] = expf(x[c] - m) / sum;
+                for (int c = q; c < C; c += 4) x[c] = x[c] / sum;   // (dividing only the entries near the threshold, in the per-class
+                                                                    //  pass, measured slower: 83 -> 93 us)
         } else if (live) {
             for (int c = q; c < C; c += 4) x[c] = 1.0f / (1.0f + expf(-x[c]));
         }
