@@ -449,10 +449,20 @@ __global__ void __launch_bounds__(kPostThreads) post_merge_kernel(int ncls, int 
     extern __shared__ int s_prefix[];  // [ncls + 1]
     const int i = blockIdx.x, tid = threadIdx.x;
     const int* cnt = pc_count + (size_t)i * ncls;
-    if (tid == 0) {
-        int acc = 0;
-        for (int c = 0; c < ncls; ++c) { s_prefix[c] = acc; acc += cnt[c]; }
-        s_prefix[ncls] = acc;
+    if (tid < kWave) {   // exclusive prefix of the per-class counts: each lane a contiguous run of classes, wave scan of the run totals
+        const int per = (ncls + kWave - 1) / kWave;   // (one thread adding up ncls dependent global loads was ~10 us of this kernel)
+        const int c0 = min(tid * per, ncls), c1 = min(c0 + per, ncls);
+        int run = 0;
+        for (int c = c0; c < c1; ++c) run += cnt[c];
+        int incl = run;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const int t = __shfl_up(incl, d, kWave);
+            if (tid >= d) incl += t;
+        }
+        int acc = incl - run;
+        for (int c = c0; c < c1; ++c) { s_prefix[c] = acc; acc += cnt[c]; }
+        if (tid == kWave - 1) s_prefix[ncls] = incl;
     }
     __syncthreads();
     const int T = s_prefix[ncls];
