@@ -1882,12 +1882,11 @@ extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int b
         const char* f = getenv("SSDK_HEADS_BWD_MODE");
         h_totals.force = f ? atoi(f) : -1;
     }
-    SSDK_CHECK_HIP(hipMemsetAsync(w.counts, 0, sizeof(int) * kMaxProblems, s));
-    SSDK_CHECK_HIP(hipMemsetAsync(w.acounts, 0, sizeof(int) * kMaxProblems * kMaxAnchorTypes, s));
-
-    // 0. zero everything the atomics of this call add into, in one launch (two when > 32 buffers)
+    // 0. zero everything the atomics of this call add into, in one launch (two when > 32 buffers); the row / anchor counters ride along
     {
         ZeroList zl;
+        zl.add(reinterpret_cast<float*>(w.counts), kMaxProblems);
+        zl.add(reinterpret_cast<float*>(w.acounts), (size_t)kMaxProblems * kMaxAnchorTypes);
         for (int i = 0; i < n_levels; ++i) {
             const ssdk_head_level& lv = levels[i];
             const size_t hw = (size_t)lv.h * lv.w;
