@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the detection hot path on MI355X (driver contract: see the task statement).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched under torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+        N > 1: one rank per GPU over RCCL.  Started by torch.distributed.run (RANK / WORLD_SIZE in the environment) the process is
+        one of the ranks; started plainly it first becomes the parent of N fresh rank processes (single_shot_detection_amd/launch.py,
+        the role of bf/training/helpers.py:129-142) and relays rank 0's JSON line -- the parent itself never touches a GPU.
 
 A "step" is one pass of the hot path over one batch of synthetic input, inputs resident in HBM:
     pyramid tail: conv-BN-ReLU extras on the last backbone tap (SSD configs)        H2
@@ -29,6 +32,7 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
+from single_shot_detection_amd import launch as _launch  # noqa: E402
 from single_shot_detection_amd import synthetic as syn  # noqa: E402
 from single_shot_detection_amd.distributed import GradBucket  # noqa: E402
 
@@ -139,8 +143,9 @@ class HotPath(object):
         # there and overlaps with the backward of the extras / tower; a second, small bucket carries the rest
         self.head_params = [p for p in self.heads.parameters()]
         self.rest_params = [p for p in self.params if all(p is not q for q in self.head_params)]
-        self.bucket_heads = GradBucket(self.head_params)
-        self.bucket_rest = GradBucket(self.rest_params) if self.rest_params else None
+        # flat fp32 buckets; attach_() makes the weight-gradient kernels write straight into them (no pack / unpack pass per step)
+        self.bucket_heads = GradBucket(self.head_params).attach_(device)
+        self.bucket_rest = GradBucket(self.rest_params).attach_(device) if self.rest_params else None
         self.fwd_events = []
 
     def pyramid(self):
@@ -272,6 +277,113 @@ def cpu_baseline(hp, sample_images=4):
                       f'({t_conv * 1e3:.1f} ms/img), {threads} threads'}
 
 
+def gpu_time_us(fn, inner=10, reps=5):
+    """Median device time of one ``fn()`` in microseconds: ``inner`` back-to-back calls between two events on the launch stream, behind
+    ~1 ms of queued spin so that the host is ahead of the GPU when the first one starts (a 20 us call is otherwise timed as the
+    host's enqueue rate)."""
+    fn()
+    torch.cuda.synchronize()
+    out = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(2_000_000)
+        e0.record()
+        for _ in range(inner):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        out.append(e0.elapsed_time(e1) * 1e3 / inner)
+    return float(np.median(out))
+
+
+def hbm_legs(device, cfg_name='ssd_300_vgg16_voc', batch=64):
+    """north_star's batch-64 HBM check: the streaming calls of the path on device-resident synthetic inputs, each
+    event-timed on its own; achieved = algorithmic bytes / time, against the 8 TB/s HBM3E figure."""
+    import ctypes
+    from single_shot_detection_amd import _lib
+    hp = HotPath(cfg_name, batch, device)
+    A, C, B = hp.anchors.shape[0], hp.C, batch
+    legs = {}
+
+    def leg(name, us, nbytes, note):
+        gbs = nbytes / (us * 1e-6) / 1e9
+        legs[name] = {'us': us, 'algorithmic_bytes': nbytes, 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS,
+                      'what': note}
+
+    # T1-T3: IoU match + target encode, 41*A bytes per image (anchors 16*A read once per image + 24*A target + mask); ground truth packed once
+    # (the packing is host work that runs ahead of the stream), the library call itself is what is timed
+    from single_shot_detection_amd.detection.target_assigner import pack_ground_truth
+    lib = _lib.lib()
+    rows, offs, total = pack_ground_truth(hp.gt, device)
+    tgt = torch.empty((B, A, 6), dtype=torch.float32, device=device)
+    ews = torch.empty((max(lib.ssdk_encode_ground_truth_workspace_bytes(B, total), 4096),), dtype=torch.uint8, device=device)
+    leg('encode_ground_truth', gpu_time_us(lambda: _lib.check(lib.ssdk_encode_ground_truth(
+        _lib.ptr(rows), 6, _lib.ptr(offs), B, total, _lib.ptr(hp.anchors), A, 0.5, 0.5, _lib.ptr(tgt), None, _lib.ptr(ews), ews.numel(),
+        _lib.current_stream()), 'encode')), 41.0 * A * B, 'ssdk_encode_ground_truth (IoU + matcher + target rows)')
+    logits = torch.from_numpy(syn.make_logits(B, A, C, seed=2)).to(device)
+    locs = torch.from_numpy(syn.make_locs(B, A, seed=3, scale=0.5)).to(device)
+    trained = logits.clone().view(B, A, C)
+    trained[..., 0] += 6.0
+    trained = trained.view(B, -1)
+    for tag, sc in (('worst_case', logits), ('trained_like', trained)):
+        us = gpu_time_us(lambda: hp.post.postprocess_padded((sc, locs), hp.anchors), inner=5)
+        leg(f'postprocess_{tag}', us, 4.0 * A * (C + 4) * B, 'ssdk_postprocess: score convert + threshold + per-class top-100 + decode + NMS + top-200')
+        legs[f'postprocess_{tag}']['nms_candidates_per_image'] = float(hp.post.last_nms_candidates.sum().item()) / B
+    # S1 + L1: sampler (reads the logits once), loss forward, loss backward (writes dscores + dlocs)
+    target = hp.assigner.encode_ground_truth(hp.gt, hp.anchors)
+    from single_shot_detection_amd.detection import sampler as smp
+    ws = smp.loss_workspace(B, A, C, device)
+    mask = torch.empty((B, A), dtype=torch.uint8, device=device)
+    cls_col = target[..., 4]
+    leg('hard_negative_mining', gpu_time_us(lambda: _lib.check(lib.ssdk_hard_negative_mining(
+        _lib.ptr(logits), cls_col.data_ptr(), 6, B, A, C, 3.0, 5, _lib.ptr(mask), _lib.ptr(ws), ws.numel(), _lib.current_stream()), 'hnm')),
+        4.0 * A * C * B, 'ssdk_hard_negative_mining: hnm_rows (log-sum-exp of every row) + hnm_select')
+    params = hp.criterion.loss_params()
+    out3 = torch.empty((3,), dtype=torch.float32, device=device)
+    tgt2 = target.clone()
+    leg('multibox_loss_fwd', gpu_time_us(lambda: (tgt2.copy_(target), _lib.check(lib.ssdk_multibox_loss_fwd(
+        ctypes.byref(params), _lib.ptr(logits), _lib.ptr(locs), _lib.ptr(hp.anchors), _lib.ptr(tgt2), _lib.ptr(mask), B, A, C, 1, _lib.ptr(out3),
+        _lib.ptr(ws), ws.numel(), _lib.current_stream()), 'loss_fwd'))), (24.0 + 16.0 + 1.0 + 16.0 + 2 * 24.0) * A * B,
+        'ssdk_multibox_loss_fwd (+ the 2 x 24 A B copy that restores the target it mutates)')
+    dsc, dlo = torch.empty_like(logits), torch.empty_like(locs)
+    gout = torch.ones((2,), dtype=torch.float32, device=device)
+    leg('multibox_loss_bwd', gpu_time_us(lambda: _lib.check(lib.ssdk_multibox_loss_bwd(
+        ctypes.byref(params), _lib.ptr(logits), _lib.ptr(locs), _lib.ptr(hp.anchors), _lib.ptr(tgt2), _lib.ptr(mask), _lib.ptr(gout), B, A, C,
+        _lib.ptr(dsc), _lib.ptr(dlo), _lib.ptr(ws), ws.numel(), _lib.current_stream()), 'loss_bwd')), (4.0 * C + 16.0) * A * B,
+        'ssdk_multibox_loss_bwd: writes dscores + dlocs in full')
+    return {'workload': f'{cfg_name} batch {batch}, A={A}, C={C}', 'legs': legs}
+
+
+PER_CONFIG = (('ssd_300_vgg16_voc', 64), ('ssd_300_vgg16_voc_c21', 32), ('ssd_mb2_voc', 2), ('ssd_512_vgg16_coco', 16),
+              ('retina_rn50_500_coco', 32), ('m2det_512_vgg16_coco', 16))
+
+
+def per_config_legs(device, steps=4, warmup=2):
+    """The other BASELINE.json configs (parity-test cases, not the headline): a few train steps each."""
+    out = []
+    for name, batch in PER_CONFIG:
+        hp = HotPath(name, batch, device)
+        for _ in range(warmup):
+            hp.train_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            hp.train_step(timed=True)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in hp.fwd_events]))
+        tf = head_flops_per_image(hp.levels, hp.C) * batch / (fwd_ms * 1e-3) / 1e12
+        sc, lo = hp.forward_heads()
+        sc, lo = sc.detach(), lo.detach()
+        us = gpu_time_us(lambda: hp.post.postprocess_padded((sc, lo), hp.anchors), inner=3, reps=3)
+        out.append({'config': name, 'per_gpu_batch': batch, 'ms_per_step': dt * 1e3, 'images_per_sec': batch / dt, 'head_gemm_ms': fwd_ms,
+                    'head_gemm_tflops': tf, 'head_gemm_frac': tf / PEAK_FP32_MATRIX_TFLOPS,
+                    'postprocess_worst_case_images_per_sec': batch / (us * 1e-6)})
+        del hp, sc, lo
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -280,25 +392,46 @@ def main():
     ap.add_argument('--config', default='ssd_300_vgg16_voc')
     ap.add_argument('--batch', type=int, default=32, help='per-GPU batch (weak scaling)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra-legs', action='store_true', help='skip roofline_hbm / per_config (they run at N = 1 only)')
     ap.add_argument('--eval-steps', type=int, default=5)
+    ap.add_argument('--rendezvous-only', action='store_true',
+                    help='ranks form the process group, all-reduce their rank numbers, rank 0 prints a JSON line; no GPU work (launcher test)')
     args = ap.parse_args()
+
+    # --gpus N > 1 without an outer torchrun: start the N ranks ourselves (nothing above this line has touched a GPU)
+    _launch.self_launch_if_needed(args.gpus, __file__)
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})')
+    if args.gpus != world:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    backend = os.environ.get('SSDK_BENCH_BACKEND', 'nccl')   # nccl == RCCL on ROCm
+    if args.rendezvous_only:
+        import torch.distributed as dist
+        if world > 1:
+            dist.init_process_group(backend if backend != 'nccl' or torch.cuda.is_available() else 'gloo')
+        t = torch.tensor([float(rank)], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({'rendezvous_only': True, 'n_gpus': world, 'ranks': dist.get_world_size() if world > 1 else 1,
+                              'backend': dist.get_backend() if world > 1 else None, 'rank_sum': float(t.item())}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if os.environ.get('SSDK_BENCH_ONE_GPU'):   # rehearsal of the N > 1 code path on a one-GPU box (with SSDK_BENCH_BACKEND=gloo)
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
+    rccl_ranks = 1
     if world > 1:
         import torch.distributed as dist
-        backend = os.environ.get('SSDK_BENCH_BACKEND', 'nccl')   # nccl == RCCL on ROCm
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=device)
         else:
             dist.init_process_group(backend)
+        rccl_ranks = dist.get_world_size()
 
     def barrier():
         if world > 1:
@@ -374,6 +507,8 @@ def main():
                                    f'heads fwd+bwd (fp32 MFMA) + IoU-match + ' + ('HNM' if hp.cfg['loss'] == 'ce_hnm' else 'naive sampler') +
                                    f'/multibox loss fwd+bwd + SGD on the head-side params; backbone taps N(0,1) NHWC at the probed shapes, C={hp.C}, A={A}, G~U{{1..8}}',
                        'global_batch': world * args.batch, 'per_gpu_batch': args.batch, 'parallelism': f'dp{world}'},
+            'rccl_ranks': rccl_ranks, 'collective_backend': (backend if world > 1 else None),
+            'grad_bucket_bytes': {'heads': hp.bucket_heads.nbytes, 'rest': hp.bucket_rest.nbytes if hp.bucket_rest is not None else 0},
             'nms_boxes_per_sec': world * cand / dtp, 'postprocess_images_per_sec': world * args.batch / dtp,
             'eval_images_per_sec': world * args.batch / dte, 'nms_candidates_per_image': cand / args.batch,
             'postprocess_trained_like': {'images_per_sec': world * args.batch / dtp_tl, 'nms_boxes_per_sec': world * cand_tl / dtp_tl,
@@ -384,9 +519,14 @@ def main():
                          'traffic': measured_traffic(f'{args.config}:b{args.batch}:igemm_fwd_heads'),
                          'algorithmic_gflop_per_step': flops_step / 1e9, 'ms_per_step': fwd_ms},
         }
+        if world == 1 and not args.no_extra_legs:
+            del scores, locs, tl
+            torch.cuda.empty_cache()
+            out['roofline_hbm'] = hbm_legs(device)
+            out['per_config'] = per_config_legs(device)
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(hp)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

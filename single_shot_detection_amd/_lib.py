@@ -191,3 +191,19 @@ def require_cuda(*tensors):
         if t is not None and not t.is_cuda:
             raise SsdkError('libssdk kernels run on the GPU only; got a tensor on ' + str(t.device) +
                             ' (there is no CPU fallback)')
+
+
+_scratch = {}
+
+
+def scratch(nbytes, device, tag):
+    """A grow-only uint8 device buffer per (device, tag) for workspaces that live only for the duration of one library call.
+    Calls on one stream are ordered, so the next call may reuse the bytes; nothing that a backward pass reads later may live here.
+    (A torch.empty per call is cheap, but it makes the step allocate -- which is what broke HIP-graph capture of the step.)"""
+    import torch
+    key = (torch.device(device), tag, torch.cuda.current_stream(device).cuda_stream)
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=device)
+        _scratch[key] = buf
+    return buf

@@ -7,6 +7,7 @@ backward produces the source-map gradients, the weight gradients and the bias gr
 import torch
 
 from ... import _lib
+from ...distributed import grad_sink
 
 
 def to_nhwc(x):
@@ -48,11 +49,12 @@ class _HeadsFn(torch.autograd.Function):
     def forward(ctx, *args):
         lib = _lib.lib()
         L = len(args) // 5
-        levels = []
+        levels, saved, sinks = [], [], []
         s_off = l_off = 0
         for i in range(L):
             x, ws, bs, wl, bl = args[5 * i:5 * i + 5]
             _lib.require_cuda(x, ws, wl)
+            sinks.append((ws, bs, wl, bl))   # the parameters themselves: their bucket slots are looked up in the backward
             x, ws, wl = to_nhwc(x), weight_khwc(ws), weight_khwc(wl)
             B, cin, H, W = x.shape
             if ws.shape[1:] != (cin, 3, 3) or wl.shape[1:] != (cin, 3, 3):
@@ -70,7 +72,14 @@ class _HeadsFn(torch.autograd.Function):
         locs = torch.empty((B, l_off), dtype=torch.float32, device=dev)
         arr = _HeadsFn._level_array(levels)
         _lib.check(lib.ssdk_heads_fwd(arr, L, B, _dp(scores), s_off, _dp(locs), l_off, _lib.current_stream()), 'ssdk_heads_fwd')
+        # tensors go through save_for_backward (autograd's version counters then catch an in-place edit of a tapped source map
+        # between forward and backward, as they do for torch's own conv); ctx keeps only shapes and offsets
+        for lv in levels:
+            saved += [lv.pop('x'), lv.pop('ws'), lv.pop('wl')]
+            lv['has_bs'], lv['has_bl'] = lv.pop('bs') is not None, lv.pop('bl') is not None
+        ctx.save_for_backward(*saved)
         ctx.levels = levels
+        ctx.sinks = sinks
         ctx.totals = (s_off, l_off)
         return scores, locs
 
@@ -78,27 +87,35 @@ class _HeadsFn(torch.autograd.Function):
     def backward(ctx, dscores, dlocs):
         lib = _lib.lib()
         s_tot, l_tot = ctx.totals
-        levels = ctx.levels
+        saved = ctx.saved_tensors
+        levels = [dict(lv, x=saved[3 * i], ws=saved[3 * i + 1], wl=saved[3 * i + 2], bs=None, bl=None) for i, lv in enumerate(ctx.levels)]
         B = levels[0]['B']
-        dscores = dscores.float().contiguous()
-        dlocs = dlocs.float().contiguous()
+        dev = levels[0]['x'].device
+        dscores = (torch.zeros((B, s_tot), dtype=torch.float32, device=dev) if dscores is None else dscores.float().contiguous())
+        dlocs = (torch.zeros((B, l_tot), dtype=torch.float32, device=dev) if dlocs is None else dlocs.float().contiguous())
         grads, out = [], []
         for i, lv in enumerate(levels):
             need_x, need_ws, need_bs, need_wl, need_bl = ctx.needs_input_grad[5 * i:5 * i + 5]
             x = lv['x']
             need_w = need_ws or need_wl
-            need_b = (need_bs and lv['bs'] is not None) or (need_bl and lv['bl'] is not None)
+            need_b = (need_bs and lv['has_bs']) or (need_bl and lv['has_bl'])
+            k_ws, k_bs, k_wl, k_bl = (grad_sink(t) for t in ctx.sinks[i])   # slots of a flat gradient bucket (distributed.GradBucket), when attached
+
+            def dst(sink, like=None, n=None):
+                if sink is not None:
+                    return sink
+                return torch.empty_like(like, memory_format=torch.channels_last) if like is not None else torch.empty((n,), dtype=torch.float32, device=dev)
             gr = dict(dx=torch.empty_like(x, memory_format=torch.channels_last) if need_x else None,
-                      dws=torch.empty_like(lv['ws'], memory_format=torch.channels_last) if need_w else None,
-                      dwl=torch.empty_like(lv['wl'], memory_format=torch.channels_last) if need_w else None,
-                      dbs=torch.empty((lv['ns'],), dtype=torch.float32, device=x.device) if need_b else None,
-                      dbl=torch.empty((lv['nl'],), dtype=torch.float32, device=x.device) if need_b else None)
+                      dws=dst(k_ws, like=lv['ws']) if need_w else None,
+                      dwl=dst(k_wl, like=lv['wl']) if need_w else None,
+                      dbs=dst(k_bs if lv['has_bs'] else None, n=lv['ns']) if need_b else None,
+                      dbl=dst(k_bl if lv['has_bl'] else None, n=lv['nl']) if need_b else None)
             grads.append(gr)
-            out += [gr['dx'], gr['dws'] if need_ws else None, gr['dbs'] if (need_bs and lv['bs'] is not None) else None,
-                    gr['dwl'] if need_wl else None, gr['dbl'] if (need_bl and lv['bl'] is not None) else None]
+            out += [gr['dx'], gr['dws'] if need_ws else None, gr['dbs'] if (need_bs and lv['has_bs']) else None,
+                    gr['dwl'] if need_wl else None, gr['dbl'] if (need_bl and lv['has_bl']) else None]
         arr = _HeadsFn._level_array(levels, grads)
         need = lib.ssdk_heads_bwd_workspace_bytes(arr, len(levels), B)
-        ws = torch.empty((need,), dtype=torch.uint8, device=dscores.device)
+        ws = _lib.scratch(need, dev, 'heads_bwd')
         _lib.check(lib.ssdk_heads_bwd(arr, len(levels), B, _dp(dscores), s_tot, _dp(dlocs), l_tot, _dp(ws), need,
                                       _lib.current_stream()), 'ssdk_heads_bwd')
         return tuple(out)

@@ -51,7 +51,7 @@ class Postprocessor(object):
         cap = max_total if max_total > 0 else ncls * max_per_class
         dev = b_scores.device
         need = lib.ssdk_postprocess_workspace_bytes(batch_size, num_priors, num_classes, softmax, max_per_class, max_total)
-        ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+        ws = _lib.scratch(need, dev, 'postprocess')   # lives for this call only
         out = torch.empty((batch_size, cap, 6), dtype=torch.float32, device=dev)
         counts = torch.empty((batch_size,), dtype=torch.int32, device=dev)
         cand = torch.empty((batch_size,), dtype=torch.int64, device=dev)

@@ -8,46 +8,91 @@ import torch
 import torch.distributed as dist
 
 
+def grad_sink(param):
+    """A fresh alias of the bucket slot GradBucket.attach_() reserved for ``param`` (None when there is none, or when the parameter
+    already holds a gradient that this pass must be ADDED to).  Backward code that produces the parameter's whole gradient in one
+    launch (heads / conv weight gradients) writes it there and returns the alias, so that autograd's AccumulateGrad adopts it as
+    ``param.grad`` without a copy (it clones a gradient somebody else still references: hence a new alias per call).
+    Contract of an attached parameter: one autograd node per backward pass produces its gradient (true of every head / extras /
+    tower parameter: weights shared across pyramid levels are summed inside one grouped library call)."""
+    view = getattr(param, '_ssdk_grad_view', None) if param is not None else None
+    if view is None or param.grad is not None:
+        return None
+    return view.detach()
+
+
 class GradBucket(object):
+    """The gradients of ``params`` as ONE flat fp32 buffer: one collective per bucket instead of one per parameter.
+
+    ``attach_()`` gives every parameter a slot (a strided view with the parameter's own memory layout) and publishes it as
+    ``param._ssdk_grad_view``; producers that write there make ``param.grad`` a view of the bucket, and then ``start_`` / ``finish_``
+    move no data at all (a gradient found elsewhere is copied in and the parameter's ``.grad`` re-pointed at its slot).
+    The average is taken by the collective itself (ReduceOp.AVG) where the backend has it (nccl = RCCL); gloo sums, then one div_."""
+
     def __init__(self, params):
         self.params = [p for p in params]
         self.numel = sum(p.numel() for p in self.params)
         self.flat = None
+        self.views = None
+        self._work = None
+
+    @property
+    def nbytes(self):
+        return 4 * self.numel
+
+    def attach_(self, device=None):
+        dev = device if device is not None else self.params[0].device
+        if self.flat is not None and self.flat.device == torch.device(dev):
+            return self
+        self.flat = torch.zeros((self.numel,), dtype=torch.float32, device=dev)
+        self.views, off = [], 0
+        for p in self.params:
+            dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+            v = torch.as_strided(self.flat, tuple(p.shape), p.stride() if dense else torch.empty(p.shape).stride(), off)
+            self.views.append(v)
+            p._ssdk_grad_view = v
+            off += p.numel()
+        return self
 
     def allreduce_(self, group=None, average=True):
         """In-place all-reduce of ``p.grad`` for every parameter of the bucket."""
-        self.start_(group)
-        self.finish_(group, average)
+        self.start_(group, average)
+        self.finish_(group)
 
-    def start_(self, group=None):
-        """Packs the gradients into the flat bucket and STARTS the all-reduce (async): whatever the caller launches next
-        -- the backward of the layers in front of these parameters -- overlaps with the ring.  ``finish_`` waits and
-        writes the averaged gradients back."""
-        self._work, self._grads, self._views = None, None, None
+    def start_(self, group=None, average=True):
+        """STARTS the all-reduce (async): whatever the caller launches next -- the backward of the layers in front of these
+        parameters -- overlaps with the ring.  ``finish_`` waits for it."""
+        self._work = None
         if not dist.is_initialized() or dist.get_world_size(group) == 1:
             return
         grads = [p.grad for p in self.params]
         if any(g is None for g in grads):
             raise RuntimeError('GradBucket: a parameter has no gradient')
-        dev = grads[0].device
-        if self.flat is None or self.flat.device != dev:
-            self.flat = torch.empty((self.numel,), dtype=torch.float32, device=dev)
-        views, off = [], 0
-        for g in grads:
-            views.append(self.flat[off:off + g.numel()].view(g.shape))
-            off += g.numel()
-        torch._foreach_copy_(views, grads)   # strided (channels_last) grads are laid into the bucket logically
-        self._work = dist.all_reduce(self.flat, group=group, async_op=True)
-        self._grads, self._views = grads, views
+        self.attach_(grads[0].device)
+        stray = [(v, g, p) for v, g, p in zip(self.views, grads, self.params)
+                 if g.data_ptr() != v.data_ptr() or g.stride() != v.stride()]
+        if stray:   # gradients that were not produced in place (small ones: BatchNorm affine, biases): one batched copy
+            torch._foreach_copy_([v for v, _, _ in stray], [g for _, g, _ in stray])
+            for v, _, p in stray:
+                p.grad = v.detach()
+        self.copied_last = len(stray)
+        world = dist.get_world_size(group)
+        self._post_div = None
+        op = dist.ReduceOp.SUM
+        if average:
+            if dist.get_backend(group) == 'nccl':
+                op = dist.ReduceOp.AVG
+            else:
+                self._post_div = world
+        self._work = dist.all_reduce(self.flat, op=op, group=group, async_op=True)
 
     def finish_(self, group=None, average=True):
-        if getattr(self, '_work', None) is None:
+        if self._work is None:
             return
         self._work.wait()
-        if average:
-            self.flat.div_(dist.get_world_size(group))
-        torch._foreach_copy_(self._grads, self._views)
-        self._work, self._grads, self._views = None, None, None
+        if self._post_div:
+            self.flat.div_(self._post_div)
+        self._work = None
 
 
 def shard_batch(items, rank, world):

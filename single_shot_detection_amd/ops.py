@@ -6,6 +6,7 @@ Tensors are logical [B,C,H,W] with channels_last memory (= the NHWC buffers the 
 import torch
 
 from . import _lib
+from .distributed import grad_sink
 
 
 def _nhwc(x):
@@ -46,13 +47,14 @@ class _ConvFn(torch.autograd.Function):
             d.y = _dp(y)
         _lib.check(lib.ssdk_conv2d_fwd(arr, len(xs), B, _lib.current_stream()), 'ssdk_conv2d_fwd')
         ctx.save_for_backward(w, *xs, *(ys if relu else []))
-        ctx.meta = (stride, pad, bool(relu), len(xs), bias is not None)
+        ctx.meta = (stride, pad, bool(relu), len(xs), bias is not None, tuple(tuple(y.shape) for y in ys))
+        ctx.params = (weight, bias)   # leaves: their gradient-bucket slots (distributed.GradBucket) are looked up in the backward
         return tuple(ys)
 
     @staticmethod
     def backward(ctx, *dys):
         lib = _lib.lib()
-        stride, pad, relu, n, has_bias = ctx.meta
+        stride, pad, relu, n, has_bias, yshapes = ctx.meta
         saved = ctx.saved_tensors
         w, xs = saved[0], saved[1:1 + n]
         ys = saved[1 + n:] if relu else [None] * n
@@ -60,13 +62,21 @@ class _ConvFn(torch.autograd.Function):
         B = xs[0].shape[0]
         stream = _lib.current_stream()
         need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and has_bias
-        dw = torch.empty_like(w, memory_format=torch.channels_last) if need_w else None   # zeroed by the library
-        db = torch.empty((cout,), dtype=torch.float32, device=w.device) if need_b else None
+        dw = db = None
+        if need_w:   # zeroed by the library
+            dw = grad_sink(ctx.params[0])
+            if dw is None or dw.stride() != w.stride():
+                dw = torch.empty_like(w, memory_format=torch.channels_last)
+        if need_b:
+            db = grad_sink(ctx.params[1])
+            if db is None:
+                db = torch.empty((cout,), dtype=torch.float32, device=w.device)
         arr = (_lib.ConvDesc * n)()
         dxs, keep = [], []
         for i in range(n):
             x = xs[i]
-            dy = _nhwc(dys[i])
+            dy = dys[i]   # an output nobody used downstream arrives as None
+            dy = torch.zeros(yshapes[i], dtype=torch.float32, device=w.device).contiguous(memory_format=torch.channels_last) if dy is None else _nhwc(dy)
             if relu:  # undo the ReLU fused into the forward epilogue
                 g = torch.empty_like(dy, memory_format=torch.channels_last)
                 _lib.check(lib.ssdk_relu_bwd(_dp(ys[i]), _dp(dy), dy.numel(), _dp(g), stream), 'ssdk_relu_bwd')
@@ -79,7 +89,7 @@ class _ConvFn(torch.autograd.Function):
             d.w, d.bias, d.cout, d.ksize, d.stride, d.pad, d.relu = _dp(w), None, cout, k, stride, pad, 0
             d.dy, d.dx, d.dw, d.db = _dp(dy), _dp(dx), _dp(dw), _dp(db)
         need = lib.ssdk_conv2d_bwd_workspace_bytes(arr, n, B)
-        ws = torch.empty((max(need, 256),), dtype=torch.uint8, device=w.device)
+        ws = _lib.scratch(need, w.device, 'conv2d_bwd')
         _lib.check(lib.ssdk_conv2d_bwd(arr, n, B, 0, _dp(ws), ws.numel(), stream), 'ssdk_conv2d_bwd')
         return (dw, db, None, None, None) + tuple(dxs)
 
@@ -102,7 +112,7 @@ class _BatchNormFn(torch.autograd.Function):
         y = torch.empty_like(x, memory_format=torch.channels_last)
         mean = torch.empty((C,), dtype=torch.float32, device=x.device)
         rstd = torch.empty((C,), dtype=torch.float32, device=x.device)
-        ws = torch.empty((lib.ssdk_batchnorm_workspace_bytes(C),), dtype=torch.uint8, device=x.device)
+        ws = _lib.scratch(lib.ssdk_batchnorm_workspace_bytes(C), x.device, 'batchnorm')
         g = None if gamma is None else gamma.float().contiguous()
         b = None if beta is None else beta.float().contiguous()
         _lib.check(lib.ssdk_batchnorm_fwd(_dp(x), rows, C, _dp(g), _dp(b), _dp(running_mean), _dp(running_var),
@@ -123,7 +133,7 @@ class _BatchNormFn(torch.autograd.Function):
         dx = torch.empty_like(x, memory_format=torch.channels_last)
         dgamma = torch.empty((C,), dtype=torch.float32, device=x.device)
         dbeta = torch.empty((C,), dtype=torch.float32, device=x.device)
-        ws = torch.empty((lib.ssdk_batchnorm_workspace_bytes(C),), dtype=torch.uint8, device=x.device)
+        ws = _lib.scratch(lib.ssdk_batchnorm_workspace_bytes(C), x.device, 'batchnorm')
         _lib.check(lib.ssdk_batchnorm_bwd(_dp(x), _dp(y) if relu else None, _dp(dy), B * H * W, C, _dp(g) if has_g else None, _dp(mean),
                                           _dp(rstd), int(relu), int(training), _dp(dx), _dp(dgamma), _dp(dbeta), _dp(ws), ws.numel(),
                                           _lib.current_stream()), 'ssdk_batchnorm_bwd')

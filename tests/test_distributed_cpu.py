@@ -1,13 +1,20 @@
-"""CPU, world_size 2, gloo: the exchange step of the N > 1 path (flat head-gradient bucket all-reduce) and sharding."""
+"""CPU, world_size 2, gloo: the exchange step of the N > 1 path (flat head-gradient bucket all-reduce), sharding, and the
+self-starting launcher of `bench.py --gpus N` (bf/training/helpers.py:129-142)."""
+import json
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from single_shot_detection_amd.distributed import GradBucket, shard_batch
+from single_shot_detection_amd import launch
+from single_shot_detection_amd.distributed import GradBucket, grad_sink, shard_batch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
@@ -46,6 +53,28 @@ def _worker(rank, world, port, out_dir):
         want = sum(torch.from_numpy(gathered[r][i]) for r in range(world)) / world
         assert torch.allclose(p.grad, want, atol=1e-6), (rank, i)
         assert p.grad.stride() == local[i].stride()
+    assert all(b.copied_last == len(b.params) for b in buckets)       # gradients made elsewhere: copied into their slots once ...
+    assert all(p.grad.data_ptr() == p._ssdk_grad_view.data_ptr() for p in params)   # ... and .grad now IS the slot
+    # zero-copy step: a producer that writes its result into the slot (what the heads / conv backward do) -> nothing is moved
+    for p in params:
+        p.grad = None
+    local2 = []
+    for p in params:
+        sink = grad_sink(p)
+        assert sink is not None and sink.stride() == p.stride()
+        sink.copy_(torch.randn(p.shape, generator=g))
+        local2.append(sink.clone())
+        p.grad = sink
+        assert grad_sink(p) is None        # a parameter that already holds a gradient must be accumulated into, not overwritten
+    for b in buckets:
+        b.start_()
+    for b in buckets:
+        b.finish_()
+    assert all(b.copied_last == 0 for b in buckets)
+    dist.all_gather_object(gathered, [x.numpy() for x in local2])
+    for i, p in enumerate(params):
+        want = sum(torch.from_numpy(gathered[r][i]) for r in range(world)) / world
+        assert torch.allclose(p.grad, want, atol=1e-6), (rank, i)
     np.save(os.path.join(out_dir, f'ok{rank}.npy'), np.array([1]))
     dist.destroy_process_group()
 
@@ -68,3 +97,31 @@ def test_bucket_is_noop_without_process_group():
     p.grad = torch.full((3,), 2.0)
     GradBucket([p]).allreduce_()
     assert torch.equal(p.grad, torch.full((3,), 2.0))
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no torchrun around it: the parent spawns the two ranks, they rendezvous on 127.0.0.1 and rank 0's
+    JSON line comes back on the parent's stdout (--rendezvous-only: the hot path itself needs a GPU)."""
+    env = dict(os.environ, SSDK_BENCH_BACKEND='gloo')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--rendezvous-only'], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['ranks'] == 2 and out['rank_sum'] == 1.0
+
+
+def test_launcher_reports_a_failed_rank_and_stops_the_others(tmp_path):
+    script = tmp_path / 'child.py'
+    script.write_text('import os, sys, time\n'
+                      'rank = int(os.environ["RANK"])\n'
+                      'assert os.environ["WORLD_SIZE"] == "3" and os.environ["MASTER_ADDR"] == "127.0.0.1"\n'
+                      'if rank == 1:\n    sys.exit(7)\n'
+                      'time.sleep(120)\n')
+    import time
+    t0 = time.time()
+    code = launch.launch(3, [sys.executable, str(script)])
+    assert code == 7 and time.time() - t0 < 60

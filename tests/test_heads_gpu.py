@@ -56,17 +56,33 @@ def test_heads_layout_vs_reference_golden():
             np.testing.assert_allclose(heads[i][k].bias.grad.cpu().numpy(), g[f'db_{k}_{i}'], rtol=1e-4, atol=5e-5)
 
 
+SSD300_LEVELS = [(512, 37, 4), (512, 18, 6), (512, 9, 6), (256, 5, 6), (256, 3, 4), (256, 2, 4)]
+M2DET_LEVELS = [(1024, 64, 4), (1024, 32, 6), (1024, 16, 6), (1024, 8, 6), (1024, 4, 4), (1024, 2, 4)]   # samples/m2det_512_vgg16_coco.py
+
+
 @pytest.mark.parametrize('levels,C,B', [
-    ([(512, 37, 4), (512, 18, 6), (512, 9, 6), (256, 5, 6), (256, 3, 4), (256, 2, 4)], 81, 2),   # ssd_300_vgg16_voc
+    (SSD300_LEVELS, 81, 2),                                                                      # ssd_300_vgg16_voc
     ([(96, 19, 4), (1280, 10, 6), (512, 5, 6), (256, 3, 6), (256, 2, 4), (128, 1, 4)], 21, 2),   # ssd_mb2_voc
     ([(24, 7, 3), (40, 5, 5)], 7, 3),                                                            # Cin % 32 != 0, odd N
     ([(256, 8, 9)], 80, 1),                                                                      # retina level (nb=9, C=80)
+    (SSD300_LEVELS, 21, 2),                                                                      # ssd_300 with the VOC class count (N = 100 / 150)
 ])
 @pytest.mark.parametrize('pixel_density,mode', [(1.0, None), (0.05, None), (0.05, '1'), (0.05, '2'), (0.4, '0'), (0.4, '1'), (0.4, '2')])
 def test_heads_vs_torch_cpu_conv(levels, C, B, pixel_density, mode, monkeypatch):
     """pixel_density 1.0 exercises the dense backward kernels, < 1 the sparse ones: the device picks the path (0 dense, 1 rows =
     pixels with a gradient: compacted wgrad + scatter dgrad, 2 rows = single anchors with a gradient) from the densities;
     SSDK_HEADS_BWD_MODE forces one so that every form is checked on the same gradients."""
+    _heads_vs_torch_cpu_conv(levels, C, B, pixel_density, mode, monkeypatch)
+
+
+@pytest.mark.parametrize('B,pixel_density,mode', [(2, 1.0, None), (2, 0.05, None), (1, 0.05, '1'), (1, 0.05, '2'), (1, 0.4, '0')])
+def test_m2det_heads_vs_torch_cpu_conv(B, pixel_density, mode, monkeypatch):
+    """H1 at m2det_512_vgg16_coco's level shapes (Cin = 1024, 64^2 .. 2^2, C = 81; detection/detector.py:50-66 applied to the six
+    MLFPN outputs) against torch's fp32 CPU convolution: forward, dense and sampled-gradient backward."""
+    _heads_vs_torch_cpu_conv(M2DET_LEVELS, 81, B, pixel_density, mode, monkeypatch)
+
+
+def _heads_vs_torch_cpu_conv(levels, C, B, pixel_density, mode, monkeypatch):
     if mode is None:
         monkeypatch.delenv('SSDK_HEADS_BWD_MODE', raising=False)
     else:
@@ -155,7 +171,8 @@ def test_heads_accept_nchw_and_channels_last_sources():
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
-@pytest.mark.parametrize('cfg_name,batch', [('ssd_300_vgg16_voc', 32), ('ssd_512_vgg16_coco', 16), ('retina_rn50_500_coco', 8)])
+@pytest.mark.parametrize('cfg_name,batch', [('ssd_300_vgg16_voc', 32), ('ssd_512_vgg16_coco', 16), ('retina_rn50_500_coco', 8),
+                                            ('retina_rn50_500_coco', 32), ('m2det_512_vgg16_coco', 16)])
 @pytest.mark.parametrize('density', ['dense', 'sampled'])
 def test_heads_adjoint_identity_at_baseline_size(cfg_name, batch, density):
     """Size-independent property at BASELINE.json's full sizes (no CPU reference needed): the heads are bilinear in (x, w), so for any

@@ -114,7 +114,8 @@ def test_loss_matches_reference_golden(name, variant):
         assert np.array_equal(target[..., 4:].cpu().numpy(), g['match_target'][..., 4:])
 
 
-@pytest.mark.parametrize('name,batch', [('ssd_300_vgg16_voc', 32), ('ssd_512_vgg16_coco', 16), ('retina_rn50_500_coco', 8)])
+@pytest.mark.parametrize('name,batch', [('ssd_300_vgg16_voc', 32), ('ssd_512_vgg16_coco', 16), ('retina_rn50_500_coco', 8),
+                                        ('retina_rn50_500_coco', 32), ('m2det_512_vgg16_coco', 16)])
 def test_loss_full_size_vs_oracle(name, batch):
     cfg = syn.CONFIGS[name]
     g = load_golden(name)

@@ -65,7 +65,7 @@ def test_match_bit_exact_vs_reference_golden(name):
 
 
 @pytest.mark.parametrize('name,batch', [('ssd_300_vgg16_voc', 32), ('ssd_300_vgg16_voc', 64), ('ssd_512_vgg16_coco', 16),
-                                        ('retina_rn50_500_coco', 32)])
+                                        ('retina_rn50_500_coco', 32), ('m2det_512_vgg16_coco', 16)])
 def test_match_full_size_vs_oracle(name, batch):
     """BASELINE.json sizes; oracle finishes these in well under a second."""
     cfg = syn.CONFIGS[name]

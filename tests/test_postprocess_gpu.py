@@ -74,7 +74,9 @@ def test_postprocess_vs_golden(name, variant):
 
 
 @pytest.mark.parametrize('name,batch,variant', [('ssd_300_vgg16_voc', 32, 'rand'), ('ssd_300_vgg16_voc', 64, 'trained'),
-                                                ('ssd_512_vgg16_coco', 16, 'rand'), ('retina_rn50_500_coco', 8, 'trained')])
+                                                ('ssd_512_vgg16_coco', 16, 'rand'), ('retina_rn50_500_coco', 8, 'trained'),
+                                                ('retina_rn50_500_coco', 32, 'trained'), ('m2det_512_vgg16_coco', 16, 'rand'),
+                                                ('m2det_512_vgg16_coco', 16, 'trained')])
 def test_postprocess_full_size_vs_oracle(name, batch, variant):
     cfg, g, logits, locs, softmax = inputs(name, variant, batch=batch, seeds=(31, 32))
     post = make_post(cfg)
