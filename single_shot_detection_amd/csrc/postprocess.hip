@@ -18,6 +18,10 @@
 // Hard NMS follows torchvision.ops.nms's documented contract (bf/utils/box_utils.py:193 delegates to it):
 // IoU = inter / (a + b - inter) with areas (x2-x1)*(y2-y1), suppress when IoU > threshold.
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <type_traits>
 
 #include "common.h"
 
@@ -36,6 +40,8 @@ struct PostWs {
     float* pc_rows;   // [B*ncls][K][6] kept detections per (image, class), NMS order
     int* pc_count;    // [B*ncls]
     u64* merge_keys;  // [B][ncls*K]
+    float* pc_score;  // [B*ncls][K] scores of pc_rows, contiguous (the merge reads only these)
+    unsigned* tau;    // [B*ncls] per-(image, class) lower bound of the K-th score (score bits; 0 = none)
 };
 
 static PostWs carve_post_ws(void* ws, size_t B, size_t A, size_t ncls, size_t K, size_t* total) {
@@ -46,6 +52,8 @@ static PostWs carve_post_ws(void* ws, size_t B, size_t A, size_t ncls, size_t K,
     w.pc_rows = c.take<float>(B * ncls * K * 6);
     w.pc_count = c.take<int>(B * ncls);
     w.merge_keys = c.take<u64>(B * ncls * K);
+    w.pc_score = c.take<float>(B * ncls * K);
+    w.tau = c.take<unsigned>(B * ncls);
     if (total) *total = c.off;
     return w;
 }
@@ -259,8 +267,8 @@ __global__ void __launch_bounds__(kPostThreads) post_nms_kernel(const float4* __
                                                                 int A, int ncls, int K, float nms_thr, int soft, float sigma, float score_thr,
                                                                 float xy_scale, float wh_scale,
                                                                 const u64* __restrict__ cand, const int* __restrict__ cand_count,
-                                                                float* __restrict__ pc_rows, int* __restrict__ pc_count,
-                                                                u64* __restrict__ nms_candidates) {
+                                                                float* __restrict__ pc_rows, float* __restrict__ pc_score,
+                                                                int* __restrict__ pc_count, u64* __restrict__ nms_candidates) {
     __shared__ u64 s_keys[kSortCap];
     __shared__ unsigned s_hist[256];
     __shared__ u64 s_misc[4];
@@ -360,6 +368,7 @@ __global__ void __launch_bounds__(kPostThreads) post_nms_kernel(const float4* __
             o[0] = b.x; o[1] = b.y; o[2] = b.z; o[3] = b.w;
             o[4] = (float)(c + 1);
             o[5] = __uint_as_float((unsigned)(s_keys[src] >> 32));
+            pc_score[(size_t)pc * K + tid] = o[5];
         }
         if (tid == 0) {
             pc_count[pc] = np;
@@ -429,6 +438,7 @@ __global__ void __launch_bounds__(kPostThreads) post_nms_kernel(const float4* __
             o[0] = b.x; o[1] = b.y; o[2] = b.z; o[3] = b.w;
             o[4] = (float)(c + 1);  // postprocessor.py:66
             o[5] = __uint_as_float((unsigned)(s_keys[tid] >> 32));
+            pc_score[(size_t)pc * K + pos] = o[5];
         }
     }
     if (tid == 0) {
@@ -506,19 +516,774 @@ __global__ void __launch_bounds__(kPostThreads) post_merge_kernel(int ncls, int 
     if (tid == 0) counts[i] = nw;
 }
 
+
+// =====================================================================================================================
+// Round-2 pipeline (hard NMS, max_per_class <= 128, num_classes <= 96): the launches above remain the general fallback.
+//
+//   post_select2_kernel   the pass over the logits.  Its cost is vector arithmetic, not bytes (42 M exponentials at batch 64): the row
+//                         softmax keeps exp(x - max) in the LDS tile and does NOT divide -- a candidate is found by the conservative
+//                         test e > thr * (1 - 2^-21) * sum (one multiply per row, one compare per element) and only the survivors get
+//                         the exact IEEE e / sum and the exact `> thr` test, so the result set is the reference's.  exp itself is the
+//                         two-term product form (x*log2e split hi/lo around v_exp_f32: 7 instructions, same 1-ulp error as the
+//                         library's 13).  Per class one ballot pass; a wave gathers the hit masks of its <= 64 classes in its lanes and
+//                         reserves all of them with ONE returning atomic instruction, then stores class by class (contiguous bursts).
+//                         For even C (RetinaNet: 80) the tile is laid out with an odd row stride, otherwise the 64 rows of one class
+//                         column sit in two LDS banks.
+//   sample + tau          in the worst case (every (anchor, class) pair passes the score threshold) the candidate keys were 3x the
+//                         algorithmic traffic.  Now every 8th tile is selected first (mode 1), post_tau_kernel takes the K-th largest
+//                         key of each (image, class) list that already holds >= K candidates -- a rigorous LOWER bound of the final
+//                         K-th score, because the sample is a subset -- trims the list to those K, and the main pass (mode 2) only
+//                         emits pairs at or above that bound.  Nothing that can reach the top K is dropped; lists with < K sample
+//                         candidates (the trained-like case) are untouched.
+//   post_nms_wave_kernel  one WAVE per (image, class): radix narrowing by the wave, 128-slot bitonic sort in LDS, decode of the <= K
+//                         boxes, IoU rows in registers (lane l owns sorted entries l and 127-l: the triangle is balanced), the
+//                         division only when inter is within 2^-20 of thr * union, greedy sweep on scalars with v_readlane.
+//   post_merge2_kernel    1 024 threads per image, the <= 8 192 keys of an image in registers, radix select + rank-by-counting.
+
+constexpr int kSelMaxC = 96;
+constexpr int kSampleStride = 8;
+constexpr int kWaveK = 128;          // post_nms_wave_kernel: sorted slots (max_per_class <= this)
+constexpr int kMergeSlots = 8192;    // post_merge2_kernel: ncls * max_per_class <= this (8 keys per thread)
+constexpr int kMergeCap = 256;       // survivors of the merge's radix narrowing (>= max_total)
+constexpr int kTauCache = 1024;      // post_tau_kernel: keys of one sample list kept in LDS (8 KB per wave)
+constexpr int kNmsCache = 512;       // post_nms_wave_kernel: keys of one list kept in LDS (4 KB per wave: 20 waves per CU still fit)
+
+// exp(d) for d <= 0 (NaN stays NaN, -inf -> 0): t = d*log2e, r = the rounding error of that product + d*log2e_lo,
+// exp2(t) * (1 + r*ln2).  v_exp_f32 is 1 ulp over its whole range; the library's expf adds range checks this call site does not need.
+__device__ __forceinline__ float exp_nonpos(float d) {
+    const float L = 1.44269502162933349609375f, Llo = 1.925963033500011e-08f;
+    const float t = d * L;
+    float r = fmaf(d, L, -t);
+    r = fmaf(d, Llo, r);
+    const float e0 = __builtin_amdgcn_exp2f(t);
+    // d = -inf: e0 = 0 but r is NaN (inf - inf); the legacy multiply (0 * anything = 0) keeps the result 0 without a compare + select
+    float corr;
+    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(corr) : "v"(e0), "v"(r * 0.6931471805599453f));
+    return e0 + corr;
+}
+
+// the digit of one radix pass: the largest bin b with above + (keys in bins > b) + hist[b] >= K.  One wave; lane l owns bins 4l..4l+3.
+// Returns (all lanes): digit, cum = keys strictly above the digit's bin (incl. `above`), h = the bin's population.
+__device__ __forceinline__ void wave_find_digit(const unsigned* s_hist, unsigned above, unsigned K, int* digit, unsigned* cum_out, unsigned* h_out) {
+    const int l = lane_id();
+    const unsigned h0 = s_hist[4 * l], h1 = s_hist[4 * l + 1], h2 = s_hist[4 * l + 2], h3 = s_hist[4 * l + 3];
+    const unsigned mine = h0 + h1 + h2 + h3;
+    unsigned incl = mine;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const unsigned t = __shfl_down(incl, d, kWave);
+        if (l + d < kWave) incl += t;
+    }
+    unsigned cum = above + (incl - mine);
+    int found = -1;
+    unsigned cum_at = 0, h_at = 0;
+    const unsigned hq[4] = {h0, h1, h2, h3};
+#pragma unroll
+    for (int q = 3; q >= 0; --q) {
+        if (found < 0) {
+            if (cum + hq[q] >= K) { found = 4 * l + q; cum_at = cum; h_at = hq[q]; }
+            else cum += hq[q];
+        }
+    }
+    const unsigned long long hit = __ballot(found >= 0);
+    int src = 0;
+    if (hit) src = 63 - __clzll((long long)hit);
+    else { found = 0; cum_at = above + (incl - h0); h_at = h0; }   // fewer than K keys in range: bin 0 (lane 0's values)
+    *digit = __shfl(found, src, kWave);
+    *cum_out = __shfl(cum_at, src, kWave);
+    *h_out = __shfl(h_at, src, kWave);
+}
+
+// One workgroup of the select pass owns a run of `tiles_per_wg` consecutive tiles of one image AND a segment of every class list of
+// that image (capacity = its rows): a hit's slot is the class's running count inside the workgroup (an LDS atomic), so nothing is
+// reserved through global memory -- no returning global atomic sits on the critical path of a tile (it was 3-5 us of every tile's
+// ~8), no counter has to be zeroed before a call, and the order inside a list, which nothing depends on (keys are distinct and get
+// ranked later), is whatever the hardware made it.  At the end the workgroup publishes its per-class counts.
+struct SelArgs {
+    const float* scores;
+    int A, C, ncls, c_off;
+    float thr;
+    int mode;          // 0: every tile, 1: tiles with tile % kSampleStride == 0, 2: the others
+    int sel_tiles;     // tiles of this mode per image
+    int tiles_per_wg;  // T: workgroup g takes tiles g*T .. g*T + T - 1 of this mode
+    long long list_cap;   // keys per (image, class) list
+    int seg_off;       // first key of this pass's segment 0 inside a list; segment g starts at seg_off + g * T * 64
+    int nseg;          // segment counters per (image, class)
+    int seg0;          // index of this pass's segment 0 among them
+    const unsigned* tau;   // [B * ncls] score-bit lower bounds (0 = none) or NULL
+    u64* cand;         // [B * ncls][list_cap]
+    int* segcnt;       // [B * ncls][nseg]
+    int stop;          // debug (SSDK_POST_STOP): 1 = staging only, 2 = no threshold test
+};
+
+// JMAX = elements per thread of the row pass (4 threads per row): ceil(C / 4) <= JMAX
+template <bool SOFTMAX, bool PAD, int JMAX>
+__global__ void __launch_bounds__(kPostThreads) post_select2_kernel(SelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    const int C = a.C, Cp = PAD ? C + 1 : C, ncls = a.ncls;
+    float* s_tile = reinterpret_cast<float*>(s_raw);
+    float* s_pre = s_tile + align_up((size_t)kPostTileRows * Cp, 4);
+    unsigned* s_taub = reinterpret_cast<unsigned*>(s_pre + ncls);
+    int* s_ccnt = reinterpret_cast<int*>(s_taub + ncls);
+    const int i = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    const float thr = a.thr;
+    for (int c = tid; c < ncls; c += kPostThreads) {
+        const unsigned tb = a.tau ? a.tau[(size_t)i * ncls + c] : 0u;
+        const float teff = fmaxf(thr, __uint_as_float(tb));
+        // conservative pre-test levels: softmax e > pre * sum, sigmoid x > pre (logit of the level, minus a margin far above logf's error)
+        float pre;
+        if (SOFTMAX) pre = teff > 0.0f ? teff * (1.0f - 4.76837158203125e-07f) : teff * (1.0f + 4.76837158203125e-07f);
+        else pre = teff <= 0.0f ? -INFINITY : (teff >= 1.0f ? INFINITY : logf(teff / (1.0f - teff)) - 1e-3f);
+        s_pre[c] = pre;
+        s_taub[c] = tb;
+        s_ccnt[c] = 0;
+    }
+    __syncthreads();
+    float lvl_min = INFINITY;   // (every thread the same loop: ncls broadcast reads once per workgroup)
+    for (int c = 0; c < ncls; ++c) lvl_min = fminf(lvl_min, s_pre[c]);
+    u64* seg = a.cand + (size_t)i * ncls * a.list_cap + a.seg_off + (size_t)g * a.tiles_per_wg * kPostTileRows;
+    const unsigned cap32 = (unsigned)a.list_cap;   // (ncls * list_cap < 2^31: checked by the host)
+    const int u_end = min(a.sel_tiles, (g + 1) * a.tiles_per_wg);
+    for (int u = g * a.tiles_per_wg; u < u_end; ++u) {
+        const int tile = a.mode == 0 ? u : (a.mode == 1 ? u * kSampleStride : u + u / (kSampleStride - 1) + 1);
+        const int a0 = tile * kPostTileRows;
+        const int rows = min(kPostTileRows, a.A - a0);
+        const int nfloat = rows * C;
+        const float* src = a.scores + ((size_t)i * a.A + a0) * C;
+        __syncthreads();
+        const bool vec = (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+        if (!PAD) {
+            if (vec) {
+                if (nfloat >> 2) stage_tile_f4(reinterpret_cast<float4*>(s_tile), reinterpret_cast<const float4*>(src), nfloat >> 2);
+                for (int t = (nfloat & ~3) + tid; t < nfloat; t += kPostThreads) s_tile[t] = src[t];
+            } else {
+                for (int t = tid; t < nfloat; t += kPostThreads) s_tile[t] = src[t];
+            }
+        } else {
+            // odd row stride (even C: the four threads of a row, 16 rows per wave, would otherwise meet in 8 of the 32 banks):
+            // element e of the tile goes to e + e / C
+            const float invC = 1.0f / (float)C;
+            if (vec) {
+                const int n4 = nfloat >> 2;
+                for (int base = 0; base < n4; base += 4 * kPostThreads) {
+                    float4 v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = reinterpret_cast<const float4*>(src)[min(base + tid + k * kPostThreads, n4 - 1)];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int e = 4 * min(base + tid + k * kPostThreads, n4 - 1);
+                        int row = (int)(((float)e + 0.5f) * invC);
+                        int col = e - row * C;
+                        const float vv[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            s_tile[row * Cp + col] = vv[j];
+                            if (++col == C) { col = 0; ++row; }
+                        }
+                    }
+                }
+                for (int e = (nfloat & ~3) + tid; e < nfloat; e += kPostThreads) s_tile[e + e / C] = src[e];
+            } else {
+                for (int e = tid; e < nfloat; e += kPostThreads) s_tile[e + e / C] = src[e];
+            }
+        }
+        __syncthreads();
+        if (a.stop == 1) continue;
+        // --- row pass, 4 threads per row, the row's values in registers: softmax terms (written back to the tile), and a bit per
+        // element that passes the conservative test.  Then every thread walks ITS set bits: the exact probability, the exact tests,
+        // and the key straight into the class's segment.  (A wave-wide `if (any lane passes)` around the exact part per element ran it
+        // for nearly every element: at a few % of passing pairs some lane of 64 almost always has one.)
+        const int row = tid >> 2, q = tid & 3;
+        const bool live = row < rows;
+        float* x = s_tile + row * Cp;
+        float sum = 0.0f;
+        unsigned bits = 0;
+        {
+            float e[JMAX];
+            float m = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < JMAX; ++j) {
+                const int c = q + 4 * j;
+                e[j] = (live && c < C) ? x[c] : -INFINITY;
+                m = fmaxf(m, e[j]);
+            }
+            if (SOFTMAX) {   // postprocessor.py:43 F.softmax(dim=-1)
+                m = quad_max(m);
+#pragma unroll
+                for (int j = 0; j < JMAX; ++j) {
+                    e[j] = exp_nonpos(e[j] - m);
+                    sum += e[j];
+                }
+                sum = quad_sum(sum);
+            }
+            if (a.stop == 2) continue;
+            const float lvl = SOFTMAX ? lvl_min * sum : lvl_min;   // one level for the whole image: the lowest of its classes' bounds
+#pragma unroll
+            for (int j = 0; j < JMAX; ++j) {
+                const int c = q + 4 * j;
+                if (SOFTMAX && live && c < C) x[c] = e[j];
+                bits |= (e[j] > lvl) ? (1u << j) : 0u;
+            }
+        }
+        if (q == 0 && a.c_off) bits &= ~1u;   // postprocessor.py:46-48 drops the background column (c = 0 lives in q = 0, j = 0)
+        if (!live) bits = 0;
+        const u64 akey = (u64)(0xFFFFFFFFu - (unsigned)(a0 + row));
+        while (bits) {
+            const int j = __ffs(bits) - 1;
+            bits &= bits - 1;
+            const int c = q + 4 * j, cls = c - a.c_off;
+            if (c >= C) continue;   // (only when the level is negative: -inf padding never passes otherwise)
+            const float v = x[c];
+            const float p = SOFTMAX ? v / sum : 1.0f / (1.0f + expf(-v));   // the reference's value (:43), exactly
+            if (p > thr && __float_as_uint(p) >= s_taub[cls]) {               // :63
+                const int slot = atomicAdd(&s_ccnt[cls], 1);
+                if (a.stop != 3) seg[(unsigned)cls * cap32 + (unsigned)slot] = ((u64)__float_as_uint(p) << 32) | akey;
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < ncls; c += kPostThreads) a.segcnt[((size_t)i * ncls + c) * a.nseg + a.seg0 + g] = s_ccnt[c];
+}
+
+// The keys of one (image, class) as one index space 0 .. n-1: first the `ntop` keys of a contiguous list, then the segments the select
+// workgroups filled (s_pref = exclusive prefix of their counts, s_pref[nseg] = total; nseg <= 64).  load(p) finds its segment by a
+// binary search over the prefix (uniform trip count), so a wave fetches 64 keys per instruction whatever the segment sizes --
+// walking the segments one after the other cost a dependent memory round trip per segment (20-40 us per launch).
+struct KeySpace {
+    const u64* top;
+    int ntop;
+    const u64* segs;
+    int seg_cap, nseg, n;
+    const int* s_pref;
+    __device__ __forceinline__ u64 load(int p) const {
+        if (p < ntop) return top[p];
+        const int q = p - ntop;
+        int lo = 0, hi = nseg;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_pref[mid] <= q) lo = mid; else hi = mid;
+        }
+        return segs[(size_t)lo * seg_cap + (q - s_pref[lo])];
+    }
+};
+
+// builds s_pref from the per-lane counts (lane g = count of segment g) and returns the total; one wave
+__device__ __forceinline__ int wave_prefix_to_lds(int mycnt, int nseg, int* s_pref) {
+    const int lane = lane_id();
+    int incl = mycnt;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const int t = __shfl_up(incl, d, kWave);
+        if (lane >= d) incl += t;
+    }
+    s_pref[lane] = incl - mycnt;
+    const int total = __shfl(incl, kWave - 1, kWave);
+    if (lane == 0) s_pref[kWave] = total;
+    if (lane >= nseg) s_pref[lane] = total;   // (so that s_pref[nseg] = total for any nseg <= 64)
+    __syncthreads();
+    return total;
+}
+
+// All n keys into an LDS array with every fetch of the wave in flight at once (n <= cap): the radix passes and the collection then run
+// from LDS.  Fetching per pass made the launch as long as one wave's chain of dependent memory round trips (3 passes x 3 trips).
+template <int CAP>
+__device__ __forceinline__ void wave_cache_keys(const KeySpace& ks, u64* s_all) {
+    const int lane = lane_id();
+    u64 v[CAP / kWave];
+#pragma unroll
+    for (int k = 0; k < CAP / kWave; ++k) v[k] = (k * kWave < ks.n) ? ks.load(min(k * kWave + lane, ks.n - 1)) : 0ull;
+#pragma unroll
+    for (int k = 0; k < CAP / kWave; ++k)
+        if (k * kWave + lane < ks.n) s_all[k * kWave + lane] = v[k];
+    __syncthreads();
+}
+
+// Radix narrowing by one wave: the prefix such that at most `cap` and at least K of the keys are >= it (keys distinct).
+// s_all != NULL: the keys are in LDS (wave_cache_keys), else they are fetched through ks.
+__device__ __forceinline__ u64 wave_radix_prefix(unsigned* s_hist, int K, int cap, const KeySpace& ks, const u64* s_all) {
+    const int lane = lane_id();
+    u64 prefix = 0;
+    unsigned above = 0;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        for (int b = lane; b < 256; b += kWave) s_hist[b] = 0;
+        __syncthreads();
+        for (int p0 = 0; p0 < ks.n; p0 += 2 * kWave) {   // two independent fetches per trip
+            const int pa = p0 + lane, pb = p0 + kWave + lane;
+            const u64 ka = s_all ? s_all[min(pa, ks.n - 1)] : ks.load(min(pa, ks.n - 1));
+            const u64 kb = s_all ? s_all[min(pb, ks.n - 1)] : ks.load(min(pb, ks.n - 1));
+            if (pa < ks.n && (shift == 56 || (ka >> (shift + 8)) == (prefix >> (shift + 8)))) atomicAdd(&s_hist[(unsigned)(ka >> shift) & 255u], 1u);
+            if (pb < ks.n && (shift == 56 || (kb >> (shift + 8)) == (prefix >> (shift + 8)))) atomicAdd(&s_hist[(unsigned)(kb >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        int digit;
+        unsigned cum, h;
+        wave_find_digit(s_hist, above, (unsigned)K, &digit, &cum, &h);
+        prefix |= (u64)digit << shift;
+        above = cum;
+        __syncthreads();
+        if (cum + h <= (unsigned)cap) break;
+    }
+    return prefix;
+}
+
+// keys >= prefix -> out[0 ..) (any order), at most `cap` of them; returns the count.  One wave.
+template <class Out>
+__device__ __forceinline__ int wave_collect(const KeySpace& ks, const u64* s_all, u64 prefix, int cap, Out out) {
+    const int lane = lane_id();
+    int cnt = 0;   // (wave-uniform)
+    for (int p0 = 0; p0 < ks.n; p0 += kWave) {
+        const int p = p0 + lane;
+        const u64 key = s_all ? s_all[min(p, ks.n - 1)] : ks.load(min(p, ks.n - 1));
+        const bool keep = p < ks.n && key >= prefix;
+        const unsigned long long mk = __ballot(keep);
+        const int pos = cnt + __popcll(mk & ((1ull << lane) - 1ull));
+        if (keep && pos < cap) out(pos, key);   // (keys are distinct, so pos < cap always; the test keeps the buffer intact if they are not)
+        cnt = min(cnt + __popcll(mk), cap);
+    }
+    return cnt;
+}
+
+// The sample pass's candidates of every (image, class), gathered into one contiguous list top[pc][<= K]: all of them when there are
+// at most K, else the K largest -- and then tau = the K-th largest key's score, a rigorous lower bound of the final K-th score.
+__global__ void __launch_bounds__(kWave) post_tau_kernel(const u64* __restrict__ cand, long long list_cap, int seg_off, int seg_cap,
+                                                         const int* __restrict__ segcnt, int nseg_all, int seg0, int nseg, int K,
+                                                         u64* __restrict__ top, int* __restrict__ topcnt, unsigned* __restrict__ tau) {
+    __shared__ unsigned s_hist[256];
+    __shared__ int s_pref[kWave + 1];
+    __shared__ u64 s_cache[kTauCache];
+    const int pc = blockIdx.x, lane = threadIdx.x;
+    const int mycnt = lane < nseg ? segcnt[(size_t)pc * nseg_all + seg0 + lane] : 0;
+    KeySpace ks;
+    ks.top = nullptr; ks.ntop = 0; ks.segs = cand + (size_t)pc * list_cap + seg_off; ks.seg_cap = seg_cap; ks.nseg = nseg; ks.s_pref = s_pref;
+    ks.n = wave_prefix_to_lds(mycnt, nseg, s_pref);
+    u64* out = top + (size_t)pc * K;
+    u64 prefix = 0;
+    const u64* s_all = nullptr;
+    if (ks.n > K && ks.n <= kTauCache) {
+        wave_cache_keys<kTauCache>(ks, s_cache);
+        s_all = s_cache;
+    }
+    if (ks.n > K) prefix = wave_radix_prefix(s_hist, K, K, ks, s_all);   // exactly K keys are >= prefix
+    const int outn = ks.n ? wave_collect(ks, s_all, prefix, K, [&](int pos, u64 key) { out[pos] = key; }) : 0;
+    if (lane == 0) {
+        topcnt[pc] = outn;
+        tau[pc] = ks.n > K ? (unsigned)(prefix >> 32) : 0u;
+    }
+}
+
+// one wave per (image, class): top-K + decode + hard NMS.
+// Everything here is bound by instruction issue (5 120 independent problems, a few thousand instructions each), so the structure is
+// chosen for instruction count: survivors of the radix narrowing are ranked by counting (no sort network), lane l keeps sorted entries
+// l and l + 64 (box, area) in registers, and the greedy sweep computes the IoU row of entry i ONLY when i is still alive -- all 64
+// lanes test their two entries against box i (broadcast with v_readlane) and the two ballots are the row.  inter / union > thr is
+// decided exactly without a division: RN(q) > thr  <=>  q > mid (or >= when thr's last mantissa bit is odd: ties round to even),
+// mid = (thr + next float) / 2, and inter > mid * union is evaluated in fp64, where the 25 x 24-bit product is exact.
+struct NmsSrc {
+    const u64* cand;      // [npc][list_cap]
+    long long list_cap;
+    int seg_off, seg_cap; // the main pass's segments
+    const int* segcnt;    // [npc][nseg_all]
+    int nseg_all, seg0, nseg;
+    const u64* top;       // [npc][K] the sample pass's survivors (NULL: none)
+    const int* topcnt;
+};
+
+// single-instruction min / max (fminf / fmaxf canonicalise every operand that may be a signalling NaN: four extra v_max per IoU here)
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+template <bool TIE_UP>
+__global__ void __launch_bounds__(kWave) post_nms_wave_kernel(const float4* __restrict__ locs, const float4* __restrict__ priors, int A, int ncls,
+                                                              int K, double thr_mid, float xy_scale, float wh_scale, NmsSrc src,
+                                                              float* __restrict__ pc_rows, float* __restrict__ pc_score, int* __restrict__ pc_count,
+                                                              int* __restrict__ pc_m, int stop) {
+    __shared__ u64 s_keys[kWaveK];
+    __shared__ u64 s_sorted[kWaveK];
+    __shared__ unsigned s_hist[256];
+    __shared__ int s_pref[kWave + 1];
+    __shared__ u64 s_cache[kNmsCache];
+    const int pc = blockIdx.x, lane = threadIdx.x;
+    const int i = pc / ncls, c = pc % ncls;
+    const int mycnt = lane < src.nseg ? src.segcnt[(size_t)pc * src.nseg_all + src.seg0 + lane] : 0;
+    KeySpace ks;
+    ks.ntop = src.top ? src.topcnt[pc] : 0;
+    ks.top = src.top ? src.top + (size_t)pc * K : nullptr;
+    ks.segs = src.cand + (size_t)pc * src.list_cap + src.seg_off; ks.seg_cap = src.seg_cap; ks.nseg = src.nseg; ks.s_pref = s_pref;
+    ks.n = ks.ntop + wave_prefix_to_lds(mycnt, src.nseg, s_pref);
+    const int n = ks.n;
+    if (n == 0) {
+        if (lane == 0) { pc_count[pc] = 0; pc_m[pc] = 0; }
+        return;
+    }
+    // --- the (up to 128) largest keys, unordered, into s_keys
+    u64 prefix = 0;
+    const u64* s_all = nullptr;
+    if (n > kWaveK && n <= kNmsCache) {
+        wave_cache_keys<kNmsCache>(ks, s_cache);
+        s_all = s_cache;
+    }
+    if (n > kWaveK) prefix = wave_radix_prefix(s_hist, K, kWaveK, ks, s_all);
+    s_keys[lane] = 0ull;
+    s_keys[lane + 64] = 0ull;
+    __syncthreads();
+    const int cnt = wave_collect(ks, s_all, prefix, kWaveK, [&](int pos, u64 key) { s_keys[pos] = key; });
+    __syncthreads();
+    // --- rank by counting (keys are distinct): rank = number of larger keys; s_sorted[rank] = key
+    const u64 kA = s_keys[lane], kB = s_keys[lane + 64];
+    s_sorted[lane] = 0ull;
+    s_sorted[lane + 64] = 0ull;
+    __syncthreads();
+    {
+        int rA = 0, rB = 0;
+        const int c4 = (cnt + 3) & ~3;
+        for (int j = 0; j < c4; j += 4) {
+            const u64 k0 = s_keys[j], k1 = s_keys[j + 1], k2 = s_keys[j + 2], k3 = s_keys[j + 3];   // (slots past cnt hold 0: never larger)
+            rA += (k0 > kA) + (k1 > kA) + (k2 > kA) + (k3 > kA);
+            rB += (k0 > kB) + (k1 > kB) + (k2 > kB) + (k3 > kB);
+        }
+        if (lane < cnt) s_sorted[rA] = kA;
+        if (lane + 64 < cnt) s_sorted[rB] = kB;
+    }
+    __syncthreads();
+    const int m = min(cnt, K);   // box_utils.py:186-188
+    if (stop == 1) { if (lane == 0) { pc_count[pc] = 0; pc_m[pc] = (int)(s_sorted[0] & 1); } return; }
+    // --- decode: lane l holds sorted entries l and l + 64
+    float4 boxA = make_float4(0.f, 0.f, 0.f, 0.f), boxB = boxA;
+    float areaA = 0.f, areaB = 0.f, scoreA = 0.f, scoreB = 0.f;
+    auto decode = [&](int e, float4& b, float& ar, float& sc) {
+        const u64 key = s_sorted[e];
+        const unsigned an = min(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull), (unsigned)(A - 1));
+        const float4 t = locs[(size_t)i * A + an], p = priors[an];
+        // box_coder.py:55-57 decode_box, then box_utils.py:16-23 to_corners (postprocessor.py:52-53)
+        const float4 cen = make_float4(p.x + p.z * t.x / xy_scale, p.y + p.w * t.y / xy_scale, p.z * expf(t.z / wh_scale), p.w * expf(t.w / wh_scale));
+        b = to_corners(cen);
+        ar = (b.z - b.x) * (b.w - b.y);
+        sc = __uint_as_float((unsigned)(key >> 32));
+    };
+    if (lane < m) decode(lane, boxA, areaA, scoreA);
+    if (lane + 64 < m) decode(lane + 64, boxB, areaB, scoreB);
+    if (stop == 2) { if (lane == 0) { pc_count[pc] = 0; pc_m[pc] = (int)(boxA.x > 0.f); } return; }
+    // --- greedy sweep with the IoU row of every surviving entry computed on the spot
+    auto suppressed = [&](float bx1, float by1, float bx2, float by2, float barea, const float4& bj, float aj) -> bool {
+        const float iw = vmax(vmin(bx2, bj.z) - vmax(bx1, bj.x), 0.0f);
+        const float ih = vmax(vmin(by2, bj.w) - vmax(by1, bj.y), 0.0f);
+        const float inter = iw * ih;
+        const float uni = barea + aj - inter;
+        const double lhs = (double)inter, rhs = thr_mid * (double)uni;
+        const bool over = TIE_UP ? lhs >= rhs : lhs > rhs;
+        return over & (uni > 0.0f);   // (& not &&: no branch)
+    };
+    u64 rem_lo = 0, rem_hi = 0, keep_lo = 0, keep_hi = 0;
+    const bool liveA = lane < m, liveB = lane + 64 < m;
+    const int mA = min(m, 64);
+    for (int e = 0; e < mA; ++e) {
+        if ((rem_lo >> e) & 1ull) continue;
+        keep_lo |= 1ull << e;
+        const float bx1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(boxA.x), e)), by1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(boxA.y), e));
+        const float bx2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(boxA.z), e)), by2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(boxA.w), e));
+        const float ba = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(areaA), e));
+        rem_lo |= __ballot(liveA & suppressed(bx1, by1, bx2, by2, ba, boxA, areaA));
+        if (m > 64) rem_hi |= __ballot(liveB & suppressed(bx1, by1, bx2, by2, ba, boxB, areaB));
+    }
+    for (int e = 64; e < m; ++e) {
+        if ((rem_hi >> (e - 64)) & 1ull) continue;
+        keep_hi |= 1ull << (e - 64);
+        const float bx1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(boxB.x), e - 64)), by1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(boxB.y), e - 64));
+        const float bx2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(boxB.z), e - 64)), by2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(boxB.w), e - 64));
+        const float ba = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(areaB), e - 64));
+        rem_hi |= __ballot(liveB & suppressed(bx1, by1, bx2, by2, ba, boxB, areaB));
+    }
+    if (stop == 3) { if (lane == 0) { pc_count[pc] = 0; pc_m[pc] = (int)(keep_lo & 1); } return; }
+    // --- rows out, in sorted order
+    const int nlo = __popcll(keep_lo);
+    auto emit = [&](const float4& b, float sc, int pos) {
+        float* o = pc_rows + ((size_t)pc * K + pos) * 6;
+        o[0] = b.x; o[1] = b.y; o[2] = b.z; o[3] = b.w;
+        o[4] = (float)(c + 1);   // postprocessor.py:66
+        o[5] = sc;
+        pc_score[(size_t)pc * K + pos] = sc;
+    };
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (liveA && ((keep_lo >> lane) & 1ull)) emit(boxA, scoreA, __popcll(keep_lo & below));
+    if (liveB && ((keep_hi >> lane) & 1ull)) emit(boxB, scoreB, nlo + __popcll(keep_hi & below));
+    if (lane == 0) {
+        pc_count[pc] = nlo + __popcll(keep_hi);
+        pc_m[pc] = m;   // boxes that entered NMS
+    }
+}
+
+// per-image merge with the image's keys in registers (ncls * K <= kMergeSlots)
+__global__ void __launch_bounds__(1024) post_merge2_kernel(int ncls, int K, int max_total, const float* __restrict__ pc_rows,
+                                                           const float* __restrict__ pc_score, const int* __restrict__ pc_count,
+                                                           const int* __restrict__ pc_m, float* __restrict__ out, int out_cap,
+                                                           int* __restrict__ counts, long long* __restrict__ nms_candidates) {
+    __shared__ u64 s_keys[kMergeCap];
+    __shared__ unsigned s_hist[256];
+    __shared__ u64 s_misc[4];
+    __shared__ int s_n;
+    extern __shared__ int s_prefix[];  // [ncls + 1]
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const int* cnt = pc_count + (size_t)i * ncls;
+    if (tid < kWave) {
+        const int per = (ncls + kWave - 1) / kWave;
+        const int c0 = min(tid * per, ncls), c1 = min(c0 + per, ncls);
+        int run = 0;
+        for (int c = c0; c < c1; ++c) run += cnt[c];
+        int incl = run;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const int t = __shfl_up(incl, d, kWave);
+            if (tid >= d) incl += t;
+        }
+        int acc = incl - run;
+        for (int c = c0; c < c1; ++c) { s_prefix[c] = acc; acc += cnt[c]; }
+        if (tid == kWave - 1) s_prefix[ncls] = incl;
+    } else if (tid < 2 * kWave && nms_candidates) {   // boxes that entered NMS, summed over the image's classes
+        long long run = 0;
+        for (int c = tid - kWave; c < ncls; c += kWave) run += pc_m[(size_t)i * ncls + c];
+        struct AddLL { __device__ __forceinline__ long long operator()(long long a, long long b) const { return a + b; } };
+        run = wave_allreduce(run, AddLL());
+        if (tid == kWave) nms_candidates[i] = run;
+    }
+    __syncthreads();
+    const int T = s_prefix[ncls];
+    float* o = out + (size_t)i * out_cap * 6;
+    const float* rows = pc_rows + (size_t)i * ncls * K * 6;
+    if (max_total <= 0 || T <= max_total) {   // postprocessor.py:68-70: concatenation in class order
+        const int nw = min(T, out_cap);
+        for (int c = tid >> 6; c < ncls; c += 1024 / kWave) {
+            const int base = s_prefix[c], nc = s_prefix[c + 1] - base;
+            for (int e = lane_id(); e < nc * 6; e += kWave) {
+                const int dst = base * 6 + e;
+                if (dst < nw * 6) o[dst] = rows[(size_t)c * K * 6 + e];
+            }
+        }
+        if (tid == 0) counts[i] = nw;
+        return;
+    }
+    // :72-74 topk(max_total, sorted=True): key = (score bits, ~flat position); thread t holds slots t, t + 1024, ...
+    const float* sc = pc_score + (size_t)i * ncls * K;
+    u64 key[kMergeSlots / 1024];
+    const int slots = ncls * K;
+#pragma unroll
+    for (int k = 0; k < kMergeSlots / 1024; ++k) {
+        const int s = tid + k * 1024;
+        key[k] = 0ull;
+        if (s < slots) {
+            const int c = s / K, r = s - c * K;
+            const int base = s_prefix[c];
+            if (r < s_prefix[c + 1] - base) key[k] = ((u64)__float_as_uint(sc[s]) << 32) | (u64)(0xFFFFFFFFu - (unsigned)(base + r));
+        }
+    }
+    u64 prefix = 0;
+    unsigned above = 0;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        for (int b = tid; b < 256; b += 1024) s_hist[b] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kMergeSlots / 1024; ++k)
+            if (key[k] != 0ull && (shift == 56 || (key[k] >> (shift + 8)) == (prefix >> (shift + 8))))
+                atomicAdd(&s_hist[(unsigned)(key[k] >> shift) & 255u], 1u);
+        __syncthreads();
+        if (tid < kWave) {
+            int digit;
+            unsigned cum, h;
+            wave_find_digit(s_hist, above, (unsigned)max_total, &digit, &cum, &h);
+            if (tid == 0) { s_misc[0] = prefix | ((u64)digit << shift); s_misc[1] = cum; s_misc[2] = cum + h; }
+        }
+        __syncthreads();
+        prefix = s_misc[0];
+        above = (unsigned)s_misc[1];
+        const unsigned count_ge = (unsigned)s_misc[2];
+        __syncthreads();
+        if (count_ge <= (unsigned)kMergeCap) break;
+    }
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kMergeSlots / 1024; ++k)
+        if (key[k] != 0ull && key[k] >= prefix) {
+            const int slot = atomicAdd(&s_n, 1);
+            if (slot < kMergeCap) s_keys[slot] = key[k];
+        }
+    __syncthreads();
+    const int m = min(s_n, kMergeCap);
+    // rank by counting: 4 threads per survivor, each compares with a quarter of the others
+    {
+        const int e = tid >> 2, q = tid & 3;
+        int rank = 0;
+        const u64 mine = e < m ? s_keys[e] : 0ull;
+        if (e < m)
+            for (int j = q; j < m; j += 4) rank += s_keys[j] > mine;
+        rank += __shfl_xor(rank, 1, kWave);
+        rank += __shfl_xor(rank, 2, kWave);
+        const int nw = min(min(m, max_total), out_cap);
+        if (e < m && q == 0 && rank < nw) {
+            const int flat = (int)(0xFFFFFFFFu - (unsigned)(mine & 0xFFFFFFFFull));
+            int lo = 0, hi = ncls;  // class c with s_prefix[c] <= flat < s_prefix[c+1]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_prefix[mid] <= flat) lo = mid; else hi = mid;
+            }
+            const float* r = rows + ((size_t)lo * K + (flat - s_prefix[lo])) * 6;
+            float* d = o + (size_t)rank * 6;
+            d[0] = r[0]; d[1] = r[1]; d[2] = r[2]; d[3] = r[3]; d[4] = r[4]; d[5] = r[5];
+        }
+        if (tid == 0) counts[i] = nw;
+    }
+}
+
 }  // namespace ssdk
 
 using namespace ssdk;
 
 static inline int ncls_of(int C, int softmax) { return softmax ? C - 1 : C; }
 
+// ---- plan of the round-2 pipeline: who owns which tiles and which segment of the class lists -------------------------------------
+struct PostPlan {
+    bool ok;            // shapes inside the pipeline's limits (hard NMS is checked by the caller)
+    int tiles, ns;      // 64-row tiles per image; sample tiles (0: no sample pass)
+    int Gs, Ts, Gm, Tm; // workgroups per image and tiles per workgroup of the sample / main pass
+    long long list_cap; // keys per (image, class) list
+    int nseg;
+};
+
+static PostPlan make_plan(int batch, int A, int C, int softmax, int K, int max_total) {
+    PostPlan p;
+    memset(&p, 0, sizeof(p));
+    const int ncls = ncls_of(C, softmax);
+    p.ok = C <= kSelMaxC && K <= kWaveK && (long long)ncls * K <= kMergeSlots && max_total <= kMergeCap && !getenv("SSDK_POST_OLD");
+    p.tiles = cdiv(A, kPostTileRows);
+    const int ns = cdiv(p.tiles, kSampleStride);
+    // sample pass + per-class bound only where the sample can hold well over max_per_class candidates
+    p.ns = ((long long)ns * kPostTileRows >= 4LL * K && p.tiles - ns > 0 && !getenv("SSDK_POST_NO_SAMPLE")) ? ns : 0;
+    const int target_wgs = getenv("SSDK_POST_WGS") ? atoi(getenv("SSDK_POST_WGS")) : 1280;
+    int per_image = cdiv(target_wgs, batch);   // about five resident workgroups per CU over the whole grid ...
+    per_image = per_image < 1 ? 1 : (per_image > kWave ? kWave : per_image);   // ... and at most one segment counter per lane of the consumer
+    const int tm = p.tiles - p.ns;
+    p.Gm = tm < per_image ? tm : per_image;
+    p.Tm = cdiv(tm, p.Gm);
+    p.Gm = cdiv(tm, p.Tm);
+    if (p.ns) {
+        p.Gs = p.ns < per_image ? p.ns : per_image;
+        p.Ts = cdiv(p.ns, p.Gs);
+        p.Gs = cdiv(p.ns, p.Ts);
+    }
+    p.list_cap = ((long long)p.Gs * p.Ts + (long long)p.Gm * p.Tm) * kPostTileRows;
+    p.nseg = p.Gs + p.Gm;
+    if ((long long)ncls * p.list_cap >= (1LL << 31)) p.ok = false;   // 32-bit key indices inside one image's lists
+    return p;
+}
+
+struct PostWs2 {
+    u64* cand;        // [npc][list_cap]
+    int* segcnt;      // [npc][nseg]
+    u64* top;         // [npc][K]
+    int* topcnt;      // [npc]
+    unsigned* tau;    // [npc]
+    float* pc_rows;   // [npc][K][6]
+    float* pc_score;  // [npc][K]
+    int* pc_count;    // [npc]
+    int* pc_m;        // [npc]
+};
+
+static PostWs2 carve_post_ws2(void* ws, size_t npc, size_t K, const PostPlan& p, size_t* total) {
+    Carver c(ws);
+    PostWs2 w;
+    w.cand = c.take<u64>(npc * (size_t)p.list_cap);
+    w.segcnt = c.take<int>(npc * (size_t)p.nseg);
+    w.top = c.take<u64>(npc * K);
+    w.topcnt = c.take<int>(npc);
+    w.tau = c.take<unsigned>(npc);
+    w.pc_rows = c.take<float>(npc * K * 6);
+    w.pc_score = c.take<float>(npc * K);
+    w.pc_count = c.take<int>(npc);
+    w.pc_m = c.take<int>(npc);
+    if (total) *total = c.off;
+    return w;
+}
+
 extern "C" size_t ssdk_postprocess_workspace_bytes(int batch, int num_anchors, int num_classes, int softmax, int max_per_class,
                                                    int max_total) {
-    (void)max_total;
     if (batch <= 0 || num_anchors <= 0 || num_classes <= 0 || max_per_class <= 0) return 0;
-    size_t total = 0;
-    carve_post_ws(nullptr, (size_t)batch, (size_t)num_anchors, (size_t)ncls_of(num_classes, softmax), (size_t)max_per_class, &total);
-    return total;
+    const size_t ncls = (size_t)ncls_of(num_classes, softmax);
+    size_t total = 0, total2 = 0;
+    carve_post_ws(nullptr, (size_t)batch, (size_t)num_anchors, ncls, (size_t)max_per_class, &total);
+    const PostPlan p = make_plan(batch, num_anchors, num_classes, softmax, max_per_class, max_total);
+    if (p.ok) carve_post_ws2(nullptr, (size_t)batch * ncls, (size_t)max_per_class, p, &total2);
+    return total > total2 ? total : total2;   // (soft-NMS takes the general pipeline: the caller may ask for either)
+}
+
+static int postprocess_v2(const PostPlan& p, const float* scores, const float* locs, const float* priors, int batch, int num_anchors,
+                          int num_classes, int softmax, float score_threshold, int max_per_class, float nms_threshold, int max_total,
+                          float xy_scale, float wh_scale, float* out, int out_cap, int32_t* counts, int64_t* nms_candidates, void* workspace,
+                          hipStream_t s) {
+    const int ncls = ncls_of(num_classes, softmax), npc = batch * ncls;
+    const PostWs2 w = carve_post_ws2(workspace, (size_t)npc, (size_t)max_per_class, p, nullptr);
+    const bool pad = (num_classes & 1) == 0;
+    const int Cp = pad ? num_classes + 1 : num_classes;
+    const size_t lds = (align_up((size_t)kPostTileRows * Cp, 4) + 3 * (size_t)ncls) * 4;
+    SelArgs a;
+    a.scores = scores; a.A = num_anchors; a.C = num_classes; a.ncls = ncls; a.c_off = softmax ? 1 : 0; a.thr = score_threshold;
+    a.list_cap = p.list_cap; a.nseg = p.nseg; a.cand = w.cand; a.segcnt = w.segcnt;
+    a.stop = getenv("SSDK_POST_STOP") ? atoi(getenv("SSDK_POST_STOP")) : 0;
+    const int jneed = cdiv(num_classes, 4);
+    auto launch = [&](int mode, int sel_tiles, int G, int T, int seg_off, int seg0, const unsigned* tau) -> int {
+        a.mode = mode; a.sel_tiles = sel_tiles; a.tiles_per_wg = T; a.seg_off = seg_off; a.seg0 = seg0; a.tau = tau;
+        const dim3 grid(G, batch), block(kPostThreads);
+#define SSDK_SEL(SM, PD, J) hipLaunchKernelGGL((post_select2_kernel<SM, PD, J>), grid, block, lds, s, a)
+#define SSDK_SEL_J(SM, PD)                          \
+    do {                                            \
+        if (jneed <= 6) SSDK_SEL(SM, PD, 6);        \
+        else if (jneed <= 12) SSDK_SEL(SM, PD, 12); \
+        else if (jneed <= 21) SSDK_SEL(SM, PD, 21); \
+        else SSDK_SEL(SM, PD, 24);                  \
+    } while (0)
+        if (softmax && pad) SSDK_SEL_J(true, true);
+        else if (softmax) SSDK_SEL_J(true, false);
+        else if (pad) SSDK_SEL_J(false, true);
+        else SSDK_SEL_J(false, false);
+#undef SSDK_SEL_J
+#undef SSDK_SEL
+        SSDK_CHECK_LAUNCH("post_select2_kernel");
+        return SSDK_OK;
+    };
+    const int seg_off_main = p.Gs * p.Ts * kPostTileRows;
+    if (p.ns) {
+        int rc = launch(1, p.ns, p.Gs, p.Ts, 0, 0, nullptr);
+        if (rc) return rc;
+        hipLaunchKernelGGL(post_tau_kernel, dim3(npc), dim3(kWave), 0, s, w.cand, p.list_cap, 0, p.Ts * kPostTileRows, w.segcnt, p.nseg, 0, p.Gs,
+                           max_per_class, w.top, w.topcnt, w.tau);
+        SSDK_CHECK_LAUNCH("post_tau_kernel");
+        rc = launch(2, p.tiles - p.ns, p.Gm, p.Tm, seg_off_main, p.Gs, w.tau);
+        if (rc) return rc;
+    } else {
+        const int rc = launch(0, p.tiles, p.Gm, p.Tm, 0, 0, nullptr);
+        if (rc) return rc;
+    }
+    if (a.stop > 0) return SSDK_OK;   // debug: timing of the select stages alone (outputs are not written)
+    // RN(inter / union) > thr  <=>  inter / union > (or >=) the midpoint of thr and the next float above it
+    const float thr_next = nextafterf(nms_threshold, INFINITY);
+    const double thr_mid = 0.5 * ((double)nms_threshold + (double)thr_next);
+    unsigned thr_bits;
+    memcpy(&thr_bits, &nms_threshold, 4);
+    const int tie_up = (int)(thr_bits & 1u);   // a tie rounds to the even mantissa: up to thr_next when thr's is odd
+    NmsSrc src;
+    src.cand = w.cand; src.list_cap = p.list_cap; src.seg_off = p.ns ? seg_off_main : 0; src.seg_cap = p.Tm * kPostTileRows;
+    src.segcnt = w.segcnt; src.nseg_all = p.nseg; src.seg0 = p.Gs; src.nseg = p.Gm;
+    src.top = p.ns ? w.top : nullptr; src.topcnt = w.topcnt;
+    const int nms_stop = getenv("SSDK_NMS_STOP") ? atoi(getenv("SSDK_NMS_STOP")) : 0;
+    if (tie_up)
+        hipLaunchKernelGGL(post_nms_wave_kernel<true>, dim3(npc), dim3(kWave), 0, s, (const float4*)locs, (const float4*)priors, num_anchors, ncls,
+                           max_per_class, thr_mid, xy_scale, wh_scale, src, w.pc_rows, w.pc_score, w.pc_count, w.pc_m, nms_stop);
+    else
+        hipLaunchKernelGGL(post_nms_wave_kernel<false>, dim3(npc), dim3(kWave), 0, s, (const float4*)locs, (const float4*)priors, num_anchors, ncls,
+                           max_per_class, thr_mid, xy_scale, wh_scale, src, w.pc_rows, w.pc_score, w.pc_count, w.pc_m, nms_stop);
+    SSDK_CHECK_LAUNCH("post_nms_wave_kernel");
+    hipLaunchKernelGGL(post_merge2_kernel, dim3(batch), dim3(1024), sizeof(int) * (size_t)(ncls + 1), s, ncls, max_per_class, max_total,
+                       w.pc_rows, w.pc_score, w.pc_count, w.pc_m, out, out_cap, counts, (long long*)nms_candidates);
+    SSDK_CHECK_LAUNCH("post_merge2_kernel");
+    return SSDK_OK;
 }
 
 extern "C" int ssdk_postprocess(const float* scores, const float* locs, const float* priors, int batch, int num_anchors,
@@ -542,10 +1307,14 @@ extern "C" int ssdk_postprocess(const float* scores, const float* locs, const fl
                  SSDK_E_WORKSPACE, "ssdk_postprocess: workspace too small");
     SSDK_REQUIRE((long long)batch * ncls < 2147483647LL && batch <= 65535, SSDK_E_INVALID, "ssdk_postprocess: grid too large");
     hipStream_t s = (hipStream_t)stream;
+    const PostPlan plan = make_plan(batch, num_anchors, num_classes, softmax, max_per_class, max_total);
+    if (plan.ok && !soft_nms)
+        return postprocess_v2(plan, scores, locs, priors, batch, num_anchors, num_classes, softmax, score_threshold, max_per_class, nms_threshold,
+                              max_total, xy_scale, wh_scale, out, out_cap, counts, nms_candidates, workspace, s);
+    // ---- general pipeline: soft-NMS, max_per_class > 128, more than 96 classes
     PostWs w = carve_post_ws(workspace, (size_t)batch, (size_t)num_anchors, (size_t)ncls, (size_t)max_per_class, nullptr);
     SSDK_CHECK_HIP(hipMemsetAsync(w.cand_count, 0, sizeof(int) * (size_t)batch * ncls, s));
     if (nms_candidates) SSDK_CHECK_HIP(hipMemsetAsync(nms_candidates, 0, sizeof(int64_t) * (size_t)batch, s));
-
     const int tiles = cdiv(num_anchors, kPostTileRows);
     const size_t lds = align_up((size_t)kPostTileRows * num_classes * 4, 16) + (size_t)ncls * 4;
     SSDK_REQUIRE(lds <= 160 * 1024 - 1024, SSDK_E_UNSUPPORTED, "ssdk_postprocess: num_classes=%d needs %zu bytes of LDS", num_classes, lds);
@@ -556,8 +1325,7 @@ extern "C" int ssdk_postprocess(const float* scores, const float* locs, const fl
     SSDK_CHECK_LAUNCH("post_select_kernel");
     hipLaunchKernelGGL(post_nms_kernel, dim3(batch * ncls), dim3(kPostThreads), 0, s, (const float4*)locs, (const float4*)priors,
                        num_anchors, ncls, max_per_class, nms_threshold, soft_nms, soft_sigma, score_threshold, xy_scale, wh_scale, w.cand,
-                       w.cand_count, w.pc_rows, w.pc_count,
-                       (u64*)nms_candidates);
+                       w.cand_count, w.pc_rows, w.pc_score, w.pc_count, (u64*)nms_candidates);
     SSDK_CHECK_LAUNCH("post_nms_kernel");
     hipLaunchKernelGGL(post_merge_kernel, dim3(batch), dim3(kPostThreads), sizeof(int) * (size_t)(ncls + 1), s, ncls, max_per_class,
                        max_total, w.pc_rows, w.pc_count, w.merge_keys, out, out_cap, counts);
