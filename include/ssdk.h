@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SSDK_VERSION 101
+#define SSDK_VERSION 102
 
 #define SSDK_OK 0
 #define SSDK_E_INVALID (-1)   /* bad argument / shape */
@@ -266,7 +266,7 @@ int ssdk_conv2d_bwd(const ssdk_conv_desc* descs, int n, int batch, int accumulat
 /* dx = y > 0 ? dy : 0 (n floats, n % 4 == 0). */
 int ssdk_relu_bwd(const float* y, const float* dy, long long n, float* dx, void* stream);
 
-size_t ssdk_batchnorm_workspace_bytes(int channels);
+size_t ssdk_batchnorm_workspace_bytes(int channels); /* = the [2 * channels + 1] doubles of a `sums` buffer (below), 256-byte rounded */
 /*
  * torch.nn.BatchNorm2d forward on [rows = batch*H*W][channels] (NHWC), optional fused ReLU after it (conv.py:33-35).
  * training != 0: batch statistics (biased variance), running_mean / running_var updated with `momentum` (unbiased
@@ -282,6 +282,29 @@ int ssdk_batchnorm_fwd(const float* x, long long rows, int channels, const float
 int ssdk_batchnorm_bwd(const float* x, const float* y, const float* dy, long long rows, int channels, const float* gamma,
                        const float* save_mean, const float* save_rstd, int relu, int training, float* dx, float* dgamma,
                        float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Synchronised BatchNorm (the reference converts every BatchNorm with apex `convert_syncbn_model`, detection/init.py:85, in
+ * --distributed mode): ssdk_batchnorm_fwd / _bwd cut in two, with the caller's all-reduce(sum) over the ranks in between.
+ *   sums DEV double [2 * channels + 1]: forward  = (sum x, sum x^2, rows); backward = (sum dy', sum dy' * xhat, rows), dy' = dy masked by
+ *   the fused ReLU.  One all-reduce(sum) of the whole buffer -- or of several layers' buffers laid back to back, e.g. the five
+ *   per-level norms of one RetinaNet tower layer -- makes them the statistics of the global batch.
+ *   ssdk_batchnorm_apply: training-mode forward from such sums (count_in_sums != 0: the row count is sums[2 * channels], else `rows`);
+ *     running statistics, num_batches_tracked, save_mean / save_rstd as ssdk_batchnorm_fwd.
+ *   ssdk_batchnorm_bwd_apply: dx from `sums` (global; total_rows = sums + 2 * channels or NULL for `rows`), dgamma / dbeta from
+ *     `sums_local` (this rank's own sums, NULL = sums): parameter gradients stay per-rank sums, the gradient exchange averages them
+ *     like every other parameter's (torch.nn.SyncBatchNorm does the same).
+ * With one rank the two halves are exactly ssdk_batchnorm_fwd / ssdk_batchnorm_bwd (which are implemented as their composition).
+ */
+int ssdk_batchnorm_stats(const float* x, long long rows, int channels, double* sums, void* stream);
+int ssdk_batchnorm_apply(const float* x, long long rows, int channels, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, int64_t* num_batches_tracked, float momentum, float eps, int relu, float* y,
+                         float* save_mean, float* save_rstd, const double* sums, int count_in_sums, void* stream);
+int ssdk_batchnorm_bwd_stats(const float* x, const float* y, const float* dy, long long rows, int channels, const float* save_mean,
+                             const float* save_rstd, int relu, double* sums, void* stream);
+int ssdk_batchnorm_bwd_apply(const float* x, const float* y, const float* dy, long long rows, int channels, const float* gamma,
+                             const float* save_mean, const float* save_rstd, int relu, int training, const double* sums,
+                             const double* sums_local, const double* total_rows, float* dx, float* dgamma, float* dbeta, void* stream);
 
 /* ---- FPN top-down step (next-row f1) -------------------------------------------------------------------------------- */
 

@@ -7,9 +7,9 @@ from ... import ops
 
 
 def _norm_act(x, bn, act):
-    """BatchNorm (+ ReLU) on libssdk for a plain nn.BatchNorm2d.  Anything else -- in particular the SyncBatchNorm that
-    detection.init(distributed=True) converts to (reference: apex convert_syncbn_model, detection/init.py:85), whose batch statistics
-    are all-reduced over the ranks -- keeps its own torch kernels, so that the distributed semantics are the reference's."""
+    """BatchNorm (+ ReLU) on libssdk for an nn.BatchNorm2d -- per process, or over all ranks when distributed.convert_sync_batchnorm
+    marked it (detection.init(distributed=True); reference: apex convert_syncbn_model, detection/init.py:85).  Any other norm module
+    (a torch.nn.SyncBatchNorm someone converted by hand, GroupNorm, ...) keeps its own torch kernels."""
     if type(bn) is nn.BatchNorm2d:
         return ops.batch_norm(x, bn, relu=act is not None)
     x = bn(x)

@@ -26,6 +26,7 @@ __global__ void __launch_bounds__(256) bn_reduce_kernel(const float* __restrict_
     const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C4 = C >> 2;
+    if (blockIdx.x == 0 && threadIdx.x == 0) sums[2 * C] = (double)rows;   // (slot 2C: the count behind the sums)
     for (int cbase = 0; cbase < C4; cbase += 64) {
         const int c4 = cbase + lane;
         float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
@@ -125,8 +126,9 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float4* __restrict_
                                                        const double* __restrict__ sums, long long rows, float eps, float momentum,
                                                        float* __restrict__ running_mean, float* __restrict__ running_var,
                                                        float* __restrict__ save_mean, float* __restrict__ save_rstd,
-                                                       long long* __restrict__ num_batches_tracked) {
+                                                       long long* __restrict__ num_batches_tracked, int count_on_device) {
     const int C = C4 * 4;
+    if (sums && count_on_device) rows = (long long)sums[2 * C];   // synchronised statistics: the row count of all ranks travels with the sums
     if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
     if (sums && blockIdx.x == 0) {
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -161,12 +163,15 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float4* __restrict_
 }
 
 // dx = gamma * rstd * (dy' - [training] (sum dy')/n - xhat * (sum dy' xhat)/n)
+// sums: the sums the statistics are taken over (all ranks' when synchronised) with their row count in sums[2C] when count_on_device;
+// sums_local: this rank's own sums -- the affine parameters' gradients (summed over ranks later by the gradient exchange, like any other).
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
                                                            long long rows, int C, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                           const float* __restrict__ gamma, const double* __restrict__ sums, int relu, int training,
+                                                           const float* __restrict__ gamma, const double* __restrict__ sums,
+                                                           const double* __restrict__ sums_local, int count_on_device, int relu, int training,
                                                            float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta) {
     const long long total = rows * C;
-    const double inv_n = 1.0 / (double)rows;
+    const double inv_n = 1.0 / (count_on_device ? sums[2 * C] : (double)rows);
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         float g = dy[i];
@@ -179,8 +184,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
     }
     if (blockIdx.x == 0)
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            if (dbeta) dbeta[c] = (float)sums[c];
-            if (dgamma) dgamma[c] = (float)sums[C + c];
+            if (dbeta) dbeta[c] = (float)sums_local[c];
+            if (dgamma) dgamma[c] = (float)sums_local[C + c];
         }
 }
 
@@ -193,7 +198,34 @@ static inline int stream_blocks(long long items, int per_block) {
 
 using namespace ssdk;
 
-extern "C" size_t ssdk_batchnorm_workspace_bytes(int channels) { return align_up((size_t)2 * channels * sizeof(double), 256); }
+extern "C" size_t ssdk_batchnorm_workspace_bytes(int channels) { return align_up(((size_t)2 * channels + 1) * sizeof(double), 256); }
+
+extern "C" int ssdk_batchnorm_stats(const float* x, long long rows, int channels, double* sums, void* stream) {
+    SSDK_REQUIRE(x && sums && rows > 0 && channels > 0, SSDK_E_INVALID, "ssdk_batchnorm_stats: bad arguments");
+    SSDK_REQUIRE(channels % 4 == 0 && ((uintptr_t)x & 15) == 0, SSDK_E_UNSUPPORTED, "ssdk_batchnorm_stats: channels %% 4 != 0 or x not 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    SSDK_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * (2 * (size_t)channels + 1), s));
+    const int rpb = kBnRows;
+    hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, s, x, (const float*)nullptr,
+                       (const float*)nullptr, rows, rpb, channels, (const float*)nullptr, (const float*)nullptr, 0, sums);
+    SSDK_CHECK_LAUNCH("bn_reduce_kernel");
+    return SSDK_OK;
+}
+
+extern "C" int ssdk_batchnorm_apply(const float* x, long long rows, int channels, const float* gamma, const float* beta,
+                                    float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
+                                    int relu, float* y, float* save_mean, float* save_rstd, const double* sums, int count_in_sums,
+                                    void* stream) {
+    SSDK_REQUIRE(x && y && save_mean && save_rstd && sums && rows > 0 && channels > 0, SSDK_E_INVALID, "ssdk_batchnorm_apply: bad arguments");
+    SSDK_REQUIRE(channels % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, SSDK_E_UNSUPPORTED,
+                 "ssdk_batchnorm_apply: channels %% 4 != 0 or buffers not 16-byte aligned");
+    const long long n4 = rows * channels / 4;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_blocks(n4, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)x, n4, channels / 4,
+                       (const float4*)save_mean, (const float4*)save_rstd, (const float4*)gamma, (const float4*)beta, relu, (float4*)y, sums, rows,
+                       eps, momentum, running_mean, running_var, save_mean, save_rstd, (long long*)num_batches_tracked, count_in_sums);
+    SSDK_CHECK_LAUNCH("bn_apply_kernel");
+    return SSDK_OK;
+}
 
 extern "C" int ssdk_batchnorm_fwd(const float* x, long long rows, int channels, const float* gamma, const float* beta,
                                   float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
@@ -204,24 +236,47 @@ extern "C" int ssdk_batchnorm_fwd(const float* x, long long rows, int channels, 
                  "ssdk_batchnorm_fwd: channels %% 4 != 0 or buffers not 16-byte aligned");
     SSDK_REQUIRE(training || (running_mean && running_var), SSDK_E_INVALID, "ssdk_batchnorm_fwd: eval mode needs running statistics");
     hipStream_t s = (hipStream_t)stream;
-    if (training) {
+    if (training) {   // = ssdk_batchnorm_stats + ssdk_batchnorm_apply on this process's rows alone
         SSDK_REQUIRE(workspace && workspace_bytes >= ssdk_batchnorm_workspace_bytes(channels), SSDK_E_WORKSPACE, "ssdk_batchnorm_fwd: workspace too small");
-        double* sums = (double*)workspace;
-        SSDK_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)channels, s));
-        const int rpb = kBnRows;
-        hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, s, x, (const float*)nullptr,
-                           (const float*)nullptr, rows, rpb, channels, (const float*)nullptr, (const float*)nullptr, 0, sums);
-        SSDK_CHECK_LAUNCH("bn_reduce_kernel");
-    } else {
-        hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(channels, 256)), dim3(256), 0, s, running_mean, running_var, channels, eps, save_mean, save_rstd);
-        SSDK_CHECK_LAUNCH("bn_eval_stats_kernel");
+        const int rc = ssdk_batchnorm_stats(x, rows, channels, (double*)workspace, stream);
+        if (rc) return rc;
+        return ssdk_batchnorm_apply(x, rows, channels, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, relu, y,
+                                    save_mean, save_rstd, (const double*)workspace, 0, stream);
     }
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(channels, 256)), dim3(256), 0, s, running_mean, running_var, channels, eps, save_mean, save_rstd);
+    SSDK_CHECK_LAUNCH("bn_eval_stats_kernel");
     const long long n4 = rows * channels / 4;
     hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_blocks(n4, 256)), dim3(256), 0, s, (const float4*)x, n4, channels / 4, (const float4*)save_mean,
-                       (const float4*)save_rstd, (const float4*)gamma, (const float4*)beta, relu, (float4*)y,
-                       training ? (const double*)workspace : (const double*)nullptr, rows, eps, momentum, running_mean, running_var, save_mean,
-                       save_rstd, training ? (long long*)num_batches_tracked : (long long*)nullptr);
+                       (const float4*)save_rstd, (const float4*)gamma, (const float4*)beta, relu, (float4*)y, (const double*)nullptr, rows, eps,
+                       momentum, running_mean, running_var, save_mean, save_rstd, (long long*)nullptr, 0);
     SSDK_CHECK_LAUNCH("bn_apply_kernel");
+    return SSDK_OK;
+}
+
+extern "C" int ssdk_batchnorm_bwd_stats(const float* x, const float* y, const float* dy, long long rows, int channels, const float* save_mean,
+                                        const float* save_rstd, int relu, double* sums, void* stream) {
+    SSDK_REQUIRE(x && dy && sums && save_mean && save_rstd && rows > 0 && channels > 0 && (!relu || y), SSDK_E_INVALID,
+                 "ssdk_batchnorm_bwd_stats: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    SSDK_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * (2 * (size_t)channels + 1), s));
+    const int rpb = kBnRows;
+    hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, s, x, y, dy, rows, rpb, channels, save_mean,
+                       save_rstd, relu, sums);
+    SSDK_CHECK_LAUNCH("bn_reduce_kernel");
+    return SSDK_OK;
+}
+
+extern "C" int ssdk_batchnorm_bwd_apply(const float* x, const float* y, const float* dy, long long rows, int channels, const float* gamma,
+                                        const float* save_mean, const float* save_rstd, int relu, int training, const double* sums,
+                                        const double* sums_local, const double* total_rows, float* dx, float* dgamma, float* dbeta,
+                                        void* stream) {
+    SSDK_REQUIRE(x && dy && dx && sums && save_mean && save_rstd && rows > 0 && channels > 0 && (!relu || y), SSDK_E_INVALID,
+                 "ssdk_batchnorm_bwd_apply: bad arguments");
+    SSDK_REQUIRE(!total_rows || total_rows == sums + 2 * (size_t)channels, SSDK_E_INVALID,
+                 "ssdk_batchnorm_bwd_apply: total_rows must be the slot behind the sums (sums + 2 * channels) or NULL");
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_blocks(rows * channels, 256)), dim3(256), 0, (hipStream_t)stream, x, y, dy, rows, channels,
+                       save_mean, save_rstd, gamma, sums, sums_local ? sums_local : sums, total_rows ? 1 : 0, relu, training, dx, dgamma, dbeta);
+    SSDK_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return SSDK_OK;
 }
 
@@ -230,17 +285,10 @@ extern "C" int ssdk_batchnorm_bwd(const float* x, const float* y, const float* d
                                   float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
     SSDK_REQUIRE(x && dy && dx && save_mean && save_rstd && rows > 0 && channels > 0 && (!relu || y), SSDK_E_INVALID, "ssdk_batchnorm_bwd: bad arguments");
     SSDK_REQUIRE(workspace && workspace_bytes >= ssdk_batchnorm_workspace_bytes(channels), SSDK_E_WORKSPACE, "ssdk_batchnorm_bwd: workspace too small");
-    hipStream_t s = (hipStream_t)stream;
-    double* sums = (double*)workspace;
-    SSDK_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)channels, s));
-    const int rpb = kBnRows;
-    hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, s, x, y, dy, rows, rpb, channels, save_mean,
-                       save_rstd, relu, sums);
-    SSDK_CHECK_LAUNCH("bn_reduce_kernel");
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_blocks(rows * channels, 256)), dim3(256), 0, s, x, y, dy, rows, channels, save_mean,
-                       save_rstd, gamma, sums, relu, training, dx, dgamma, dbeta);
-    SSDK_CHECK_LAUNCH("bn_bwd_apply_kernel");
-    return SSDK_OK;
+    const int rc = ssdk_batchnorm_bwd_stats(x, y, dy, rows, channels, save_mean, save_rstd, relu, (double*)workspace, stream);
+    if (rc) return rc;
+    return ssdk_batchnorm_bwd_apply(x, y, dy, rows, channels, gamma, save_mean, save_rstd, relu, training, (const double*)workspace, nullptr, nullptr,
+                                    dx, dgamma, dbeta, stream);
 }
 
 // dx = (y > 0) ? dy : 0  -- undoes a ReLU that was fused into a convolution epilogue (predictors.py:67-68)

@@ -33,9 +33,13 @@ def init(device, model_args, box_coder_args, postprocess_args, loss_args, sample
             detector.load_state_dict(state.pop('model_dict'))
     detector = detector.to(device).to(memory_format=torch.channels_last)
     if distributed:
-        # one process per GPU; gradients of the predictor are averaged over RCCL/xGMI (init.py:80-86 used apex DDP)
-        detector = torch.nn.SyncBatchNorm.convert_sync_batchnorm(detector)
-        detector.predictor = torch.nn.parallel.DistributedDataParallel(detector.predictor, device_ids=[torch.device(device).index])
+        # one process per GPU; gradients of the predictor are averaged over RCCL/xGMI (init.py:80-86 used apex DDP + SyncBN).
+        # Hot-path BatchNorms stay on libssdk with their statistics all-reduced (distributed.convert_sync_batchnorm).
+        from ..distributed import convert_sync_batchnorm
+        detector = convert_sync_batchnorm(detector)
+        dev = torch.device(device)
+        index = dev.index if dev.index is not None else (torch.cuda.current_device() if dev.type == 'cuda' else None)
+        detector.predictor = torch.nn.parallel.DistributedDataParallel(detector.predictor, device_ids=None if index is None else [index])
     logging.info(detector)
 
     sampler = getattr(_sampler_mod, sampler_args['name'])

@@ -45,7 +45,9 @@ class SharedConvPredictor(nn.Module):
         if isinstance(block, conv.Conv2dBn) and isinstance(self.activation, nn.ReLU) and block._hip_ok():
             c = block.conv
             ys = ops.conv2d(list(xs), c.weight, c.bias, stride=c.stride[0], padding=c.padding[0], relu=True)
-            # (a SyncBatchNorm -- detection.init(distributed=True) -- keeps torch's kernels: its statistics are all-reduced over the ranks)
+            if all(type(norm) is nn.BatchNorm2d for norm in norms):
+                # per-level norms; marked for synchronisation (detection.init(distributed=True)) the five share ONE all-reduce
+                return ops.batch_norm_levels(ys, list(norms))
             return [ops.batch_norm(y, norm) if type(norm) is nn.BatchNorm2d else norm(y) for norm, y in zip(norms, ys)]
         return [norm(self.activation(block(x))) for norm, x in zip(norms, xs)]   # depthwise towers: stock ops
 

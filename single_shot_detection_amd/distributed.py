@@ -100,3 +100,28 @@ def shard_batch(items, rank, world):
     n = len(items)
     per = (n + world - 1) // world
     return items[rank * per:min(n, (rank + 1) * per)]
+
+
+def convert_sync_batchnorm(module, process_group=None):
+    """The role of apex `convert_syncbn_model` (detection/init.py:85): every BatchNorm of the detector gets batch statistics over all
+    ranks.  BatchNorm2d layers inside the hot-path blocks (Conv2dBn / DepthwiseConv2dBn pyramid tail and necks, the RetinaNet tower's
+    per-level norms) stay nn.BatchNorm2d -- same parameters, same state_dict keys -- and are MARKED: libssdk computes their partial
+    sums, torch.distributed all-reduces one packed buffer per layer (per tower layer across the levels), libssdk applies.  Everything
+    else (the PyTorch backbone) is converted to torch.nn.SyncBatchNorm."""
+    import torch.nn as nn
+    from .bf.modules.conv import Conv2dBn, DepthwiseConv2dBn
+    from .detection.modules.predictors import SharedConvPredictor
+    hot = (Conv2dBn, DepthwiseConv2dBn, SharedConvPredictor)
+
+    def walk(m, in_hot):
+        for name, child in list(m.named_children()):
+            h = in_hot or isinstance(child, hot)
+            if isinstance(child, nn.modules.batchnorm._BatchNorm):
+                if h and type(child) is nn.BatchNorm2d:
+                    child._ssdk_sync_group = (process_group,)
+                else:
+                    setattr(m, name, nn.SyncBatchNorm.convert_sync_batchnorm(child, process_group))
+            else:
+                walk(child, h)
+    walk(module, isinstance(module, hot))
+    return module

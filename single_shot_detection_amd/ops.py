@@ -145,10 +145,120 @@ def batch_norm(x, bn, relu=False):
     if bn.momentum is None or not bn.track_running_stats:
         raise NotImplementedError('BatchNorm2d with momentum=None / track_running_stats=False is not on the GPU path')
     training = bn.training
+    mark = sync_group_of(bn)
+    if mark is not None and training:   # statistics over all ranks (detection.init(distributed=True))
+        return sync_batch_norm([x], [bn], relu, mark[0])[0]
     nbt = bn.num_batches_tracked   # incremented inside the library's launch (torch: a launch of its own per layer)
     if nbt is not None:
         assert nbt.dtype == torch.int64 and nbt.is_cuda
     return _BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, nbt, bn.momentum, bn.eps, training, relu)
+
+
+def sync_group_of(bn):
+    """The process group a BatchNorm2d was marked with by distributed.convert_sync_batchnorm (detection.init(distributed=True)), as a
+    1-tuple -- (None,) is the default group -- or None for a plain, per-process BatchNorm."""
+    return getattr(bn, '_ssdk_sync_group', None)
+
+
+def allreduce_sums_(buf, group=None):
+    """The one exchange step of synchronised BatchNorm: all-reduce(sum) of a packed fp64 buffer [sum_i (2 C_i + 1)] holding, per
+    norm layer, (sum, sum of squares / products, row count).  No-op without an initialised process group or with one rank."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(buf, group=group)
+    return buf
+
+
+class _SyncBatchNormFn(torch.autograd.Function):
+    """Training-mode BatchNorm2d (+ fused ReLU) over the GLOBAL batch for n layers at once (e.g. the five per-level norms of one
+    RetinaNet tower layer): per-layer partial sums on libssdk -> ONE all-reduce of the packed buffer -> per-layer apply.
+    apply(group, relu, n, x_0, gamma_0, beta_0, running_mean_0, running_var_0, nbt_0, momentum_0, eps_0, x_1, ...) -> y_0, y_1, ...
+    (apex convert_syncbn_model in the reference, detection/init.py:85)."""
+
+    @staticmethod
+    def forward(ctx, group, relu, n, *args):
+        lib = _lib.lib()
+        stream = _lib.current_stream()
+        layers = []
+        for i in range(n):
+            x, gamma, beta, rm, rv, nbt, momentum, eps = args[8 * i:8 * i + 8]
+            _lib.require_cuda(x)
+            x = _nhwc(x)
+            layers.append(dict(x=x, C=x.shape[1], rows=x.shape[0] * x.shape[2] * x.shape[3],
+                               g=None if gamma is None else gamma.float().contiguous(), b=None if beta is None else beta.float().contiguous(),
+                               rm=rm, rv=rv, nbt=nbt, momentum=float(momentum), eps=float(eps)))
+        dev = layers[0]['x'].device
+        offs, tot = [], 0
+        for lv in layers:
+            offs.append(tot)
+            tot += 2 * lv['C'] + 1
+        sums = torch.empty((tot,), dtype=torch.float64, device=dev)
+        for lv, off in zip(layers, offs):
+            _lib.check(lib.ssdk_batchnorm_stats(_dp(lv['x']), lv['rows'], lv['C'], sums[off:].data_ptr(), stream), 'ssdk_batchnorm_stats')
+        allreduce_sums_(sums, group)
+        ys, saved = [], []
+        for lv, off in zip(layers, offs):
+            x, C = lv['x'], lv['C']
+            y = torch.empty_like(x, memory_format=torch.channels_last)
+            mean = torch.empty((C,), dtype=torch.float32, device=dev)
+            rstd = torch.empty((C,), dtype=torch.float32, device=dev)
+            _lib.check(lib.ssdk_batchnorm_apply(_dp(x), lv['rows'], C, _dp(lv['g']), _dp(lv['b']), _dp(lv['rm']), _dp(lv['rv']), _dp(lv['nbt']),
+                                                lv['momentum'], lv['eps'], int(relu), _dp(y), _dp(mean), _dp(rstd), sums[off:].data_ptr(), 1, stream),
+                       'ssdk_batchnorm_apply')
+            ys.append(y)
+            saved += [x, y if relu else x.new_empty(0), lv['g'] if lv['g'] is not None else x.new_empty(0), mean, rstd]
+        ctx.save_for_backward(*saved)
+        ctx.meta = (group, bool(relu), n, [(lv['C'], lv['rows'], lv['g'] is not None, lv['b'] is not None) for lv in layers], offs, tot)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        lib = _lib.lib()
+        stream = _lib.current_stream()
+        group, relu, n, shapes, offs, tot = ctx.meta
+        saved = ctx.saved_tensors
+        dev = saved[0].device
+        sums = torch.empty((tot,), dtype=torch.float64, device=dev)
+        dys = [torch.zeros_like(saved[5 * i], memory_format=torch.channels_last) if dy is None else _nhwc(dy) for i, dy in enumerate(dys)]
+        for i in range(n):
+            x, y, g, mean, rstd = saved[5 * i:5 * i + 5]
+            C, rows, _, _ = shapes[i]
+            _lib.check(lib.ssdk_batchnorm_bwd_stats(_dp(x), _dp(y) if relu else None, _dp(dys[i]), rows, C, _dp(mean), _dp(rstd), int(relu),
+                                                    sums[offs[i]:].data_ptr(), stream), 'ssdk_batchnorm_bwd_stats')
+        local = sums.clone()   # the affine parameters' gradients are this rank's own sums (the gradient exchange averages them later)
+        allreduce_sums_(sums, group)
+        out = [None, None, None]
+        for i in range(n):
+            x, y, g, mean, rstd = saved[5 * i:5 * i + 5]
+            C, rows, has_g, has_b = shapes[i]
+            dx = torch.empty_like(x, memory_format=torch.channels_last)
+            dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
+            dbeta = torch.empty((C,), dtype=torch.float32, device=dev)
+            base = sums[offs[i]:].data_ptr()
+            _lib.check(lib.ssdk_batchnorm_bwd_apply(_dp(x), _dp(y) if relu else None, _dp(dys[i]), rows, C, _dp(g) if has_g else None, _dp(mean),
+                                                    _dp(rstd), int(relu), 1, base, local[offs[i]:].data_ptr(), base + 16 * C, _dp(dx), _dp(dgamma),
+                                                    _dp(dbeta), stream), 'ssdk_batchnorm_bwd_apply')
+            out += [dx, dgamma if has_g else None, dbeta if has_b else None, None, None, None, None, None]
+        return tuple(out)
+
+
+def sync_batch_norm(xs, bns, relu=False, group=None):
+    """Synchronised training-mode BatchNorm of several maps with their own norm layers, one exchange for all of them."""
+    args = []
+    for x, bn in zip(xs, bns):
+        if bn.momentum is None or not bn.track_running_stats:
+            raise NotImplementedError('BatchNorm2d with momentum=None / track_running_stats=False is not on the GPU path')
+        args += [x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum, bn.eps]
+    return list(_SyncBatchNormFn.apply(group, bool(relu), len(bns), *args))
+
+
+def batch_norm_levels(xs, bns, relu=False):
+    """One BatchNorm2d per map (the per-level norms of a RetinaNet tower layer, detection/modules/predictors.py:39-42,69-70).  Layers
+    marked for synchronisation share ONE packed all-reduce in training mode; otherwise each runs on its own."""
+    marks = [sync_group_of(bn) for bn in bns]
+    if all(m is not None for m in marks) and all(bn.training for bn in bns) and len({id(m[0]) for m in marks}) == 1:
+        return sync_batch_norm(xs, bns, relu, marks[0][0])
+    return [batch_norm(x, bn, relu) for x, bn in zip(xs, bns)]
 
 
 class _UpsampleAddFn(torch.autograd.Function):

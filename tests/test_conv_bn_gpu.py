@@ -323,3 +323,109 @@ def test_conv2dbn_with_syncbatchnorm_keeps_torch_norm():
         yg = gpu(torch.from_numpy(x).cuda())
         yr = ref(torch.from_numpy(x))
         np.testing.assert_allclose(yg.detach().cpu().numpy(), yr.detach().numpy(), rtol=1e-3, atol=1e-3)
+
+
+def test_sync_batchnorm_with_one_rank_is_the_local_batchnorm_bit_for_bit():
+    """distributed.convert_sync_batchnorm marks the hot-path BatchNorm2d layers; with a single rank the split path
+    (ssdk_batchnorm_stats -> [all-reduce] -> ssdk_batchnorm_apply, and the same in the backward) must reproduce the local
+    ssdk_batchnorm_fwd / _bwd exactly: outputs, running statistics, all gradients.  (Compared on the norm alone: the convolution's
+    backward in front of it sums with atomics, so a whole block is not bit-reproducible from run to run.)"""
+    import copy
+    from single_shot_detection_amd import ops
+    from single_shot_detection_amd.distributed import convert_sync_batchnorm
+    rng = np.random.default_rng(11)
+    blk = conv.Conv2dBn(32, 64, kernel_size=3, stride=2, padding=1, bias=False)
+    _randomize(blk, rng)
+    marked = convert_sync_batchnorm(copy.deepcopy(blk))
+    assert type(marked.bn) is nn.BatchNorm2d and ops.sync_group_of(marked.bn) == (None,) and ops.sync_group_of(blk.bn) is None
+    for relu in (True, False):
+        a, b = copy.deepcopy(blk.bn).cuda().train(), copy.deepcopy(marked.bn).cuda().train()
+        b._ssdk_sync_group = (None,)
+        x = torch.from_numpy(rng.standard_normal((4, 64, 9, 9), dtype=np.float32)).cuda().contiguous(memory_format=torch.channels_last)
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        ya, yb = ops.batch_norm(xa, a, relu=relu), ops.batch_norm(xb, b, relu=relu)
+        assert torch.equal(ya, yb)
+        g = torch.from_numpy(rng.standard_normal(tuple(ya.shape), dtype=np.float32)).cuda().contiguous(memory_format=torch.channels_last)
+        (ya * g).sum().backward()
+        (yb * g).sum().backward()
+        assert torch.equal(xa.grad, xb.grad)
+        for (n1, p1), (n2, p2) in zip(sorted(a.named_parameters()), sorted(b.named_parameters())):
+            assert n1 == n2 and torch.equal(p1.grad, p2.grad), n1
+        for (n1, t1), (n2, t2) in zip(sorted(a.named_buffers()), sorted(b.named_buffers())):
+            assert n1 == n2 and torch.equal(t1, t2), n1
+
+
+def _sync_bn_rank(rank, world, port, out_dir):
+    import os
+    import torch.distributed as dist
+    from single_shot_detection_amd.distributed import convert_sync_batchnorm
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    d = np.load(os.path.join(out_dir, 'in.npz'))
+    from single_shot_detection_amd.detection.modules.predictors import SharedConvPredictor
+    torch.manual_seed(0)
+    tower = SharedConvPredictor([16, 16], [3, 3], 5, False, num_layers=2, num_channels=16)
+    tower.load_state_dict({k: torch.from_numpy(v) for k, v in np.load(os.path.join(out_dir, 'state.npz')).items()})
+    tower = convert_sync_batchnorm(tower).cuda().train()
+    half = slice(rank * 2, rank * 2 + 2)
+    xs = [torch.from_numpy(d[f'x{i}'][half]).cuda().requires_grad_(True) for i in range(2)]
+    s, l = tower(xs)
+    gs = [torch.from_numpy(d[f'g{i}'][half]).cuda() for i in range(4)]
+    loss = sum((y * g).sum() for y, g in zip(list(s) + list(l), gs))
+    loss.backward()
+    out = {f'y{i}': y.detach().cpu().numpy() for i, y in enumerate(list(s) + list(l))}
+    out.update({f'dx{i}': x.grad.cpu().numpy() for i, x in enumerate(xs)})
+    out.update({'p_' + n: p.grad.cpu().numpy() for n, p in tower.named_parameters()})
+    out.update({'b_' + n: b.cpu().numpy() for n, b in tower.named_buffers()})
+    np.savez(os.path.join(out_dir, f'out{rank}.npz'), **out)
+    dist.destroy_process_group()
+
+
+def test_sync_batchnorm_two_ranks_equal_one_process_on_the_whole_batch(tmp_path):
+    """Two ranks (both on this one GPU, gloo between them), half the batch each, through a RetinaNet tower whose per-level norms are
+    synchronised (one packed all-reduce per tower layer) == the same tower in ONE process on the whole batch with torch's own
+    BatchNorm2d on the CPU: outputs, running statistics, input gradients; parameter gradients sum over the ranks."""
+    import socket
+    import torch.multiprocessing as mp
+    from single_shot_detection_amd.detection.modules.predictors import SharedConvPredictor
+    rng = np.random.default_rng(5)
+    torch.manual_seed(0)
+    tower = SharedConvPredictor([16, 16], [3, 3], 5, False, num_layers=2, num_channels=16)
+    with torch.no_grad():
+        for n, p in tower.named_parameters():
+            p.copy_(torch.from_numpy(rng.standard_normal(tuple(p.shape), dtype=np.float32) * (0.2 if p.dim() > 1 else 0.5)) + (1.0 if n.endswith('weight') and p.dim() == 1 else 0.0))
+    np.savez(tmp_path / 'state.npz', **{k: v.numpy() for k, v in tower.state_dict().items()})
+    data = {'x0': rng.standard_normal((4, 16, 6, 6), dtype=np.float32), 'x1': rng.standard_normal((4, 16, 3, 3), dtype=np.float32)}
+    for i, hw in enumerate((6, 3, 6, 3)):
+        data[f'g{i}'] = rng.standard_normal((4, 16, hw, hw), dtype=np.float32)
+    np.savez(tmp_path / 'in.npz', **data)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_sync_bn_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    # reference: stock torch modules on the CPU, whole batch (predictors.py:60-76: conv -> ReLU -> per-level BatchNorm2d)
+    ref = SharedConvPredictor([16, 16], [3, 3], 5, False, num_layers=2, num_channels=16)
+    ref.load_state_dict(tower.state_dict())
+    ref.train()
+    xs = [torch.from_numpy(data[f'x{i}']).requires_grad_(True) for i in range(2)]
+    ss, ls = list(xs), list(xs)
+    for sc, lc, sn, ln in zip(ref.convs['score'], ref.convs['loc'], ref.norms['score'], ref.norms['loc']):
+        ss = [n(torch.relu(sc.conv(x))) for n, x in zip(sn, ss)]
+        ls = [n(torch.relu(lc.conv(x))) for n, x in zip(ln, ls)]
+    sum((y * torch.from_numpy(data[f'g{i}'])).sum() for i, y in enumerate(ss + ls)).backward()
+    outs = [np.load(tmp_path / f'out{r}.npz') for r in range(2)]
+    for i, y in enumerate(ss + ls):
+        got = np.concatenate([outs[0][f'y{i}'], outs[1][f'y{i}']], 0)
+        np.testing.assert_allclose(got, y.detach().numpy(), rtol=2e-4, atol=2e-4)
+    for i, x in enumerate(xs):
+        got = np.concatenate([outs[0][f'dx{i}'], outs[1][f'dx{i}']], 0)
+        np.testing.assert_allclose(got, x.grad.numpy(), rtol=2e-3, atol=2e-4 * (1 + float(x.grad.abs().max())))
+    for n, p in ref.named_parameters():
+        got = outs[0]['p_' + n] + outs[1]['p_' + n]
+        np.testing.assert_allclose(got, p.grad.numpy(), rtol=2e-3, atol=2e-4 * (1 + float(p.grad.abs().max())), err_msg=n)
+    for n, b in ref.named_buffers():
+        for r in range(2):
+            np.testing.assert_allclose(outs[r]['b_' + n], b.numpy(), rtol=1e-4, atol=1e-5, err_msg=n)

@@ -125,3 +125,31 @@ def test_launcher_reports_a_failed_rank_and_stops_the_others(tmp_path):
     t0 = time.time()
     code = launch.launch(3, [sys.executable, str(script)])
     assert code == 7 and time.time() - t0 < 60
+
+
+def _sums_worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from single_shot_detection_amd.ops import allreduce_sums_
+    # the packed buffer of a tower layer: per level (2 C + 1) doubles = (sum, sum of squares, rows)
+    C, levels = 8, 3
+    buf = torch.zeros((levels * (2 * C + 1),), dtype=torch.float64)
+    for lv in range(levels):
+        off = lv * (2 * C + 1)
+        buf[off:off + 2 * C] = torch.arange(2 * C, dtype=torch.float64) + 100 * lv + 1000 * rank
+        buf[off + 2 * C] = 10 * (lv + 1) + rank          # rows of this rank at this level
+    allreduce_sums_(buf)
+    for lv in range(levels):
+        off = lv * (2 * C + 1)
+        want = 2 * (torch.arange(2 * C, dtype=torch.float64) + 100 * lv) + 1000
+        assert torch.equal(buf[off:off + 2 * C], want)
+        assert buf[off + 2 * C].item() == 20 * (lv + 1) + 1
+    np.save(os.path.join(out_dir, f'sums{rank}.npy'), np.array([1]))
+    dist.destroy_process_group()
+
+
+def test_sync_batchnorm_packed_sums_allreduce_gloo_world2(tmp_path):
+    """The exchange step of synchronised BatchNorm: one all-reduce(sum) of the packed per-level (sum, sum^2, rows) buffers."""
+    mp.spawn(_sums_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert all(os.path.exists(tmp_path / f'sums{r}.npy') for r in range(2))

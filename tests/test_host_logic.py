@@ -91,3 +91,21 @@ def test_synthetic_inputs_are_deterministic():
     assert all(x.shape[1] == 6 and (x[:, 2] <= 299).all() and (x[:, 4] >= 1).all() and (x[:, 4] <= 80).all() for x in a)
     from conftest import CONFIG_NAMES
     assert [syn.num_anchors(syn.CONFIGS[n]) for n in CONFIG_NAMES] == [2268, 8108, 24564, 47961, 24528]
+
+
+def test_convert_sync_batchnorm_marks_hot_path_norms_and_converts_the_rest():
+    """distributed.convert_sync_batchnorm (the role of apex convert_syncbn_model, detection/init.py:85): BatchNorm2d inside the
+    hot-path blocks stays a BatchNorm2d (same state_dict keys) marked with the process group, anything else becomes SyncBatchNorm."""
+    import torch.nn as nn
+    from single_shot_detection_amd import ops
+    from single_shot_detection_amd.bf.modules.conv import Conv2dBn
+    from single_shot_detection_amd.detection.modules.predictors import SharedConvPredictor
+    from single_shot_detection_amd.distributed import convert_sync_batchnorm
+    m = nn.Sequential(nn.Sequential(nn.Conv2d(3, 8, 3), nn.BatchNorm2d(8)), Conv2dBn(8, 16, 1), SharedConvPredictor([16], [3], 4, False, num_layers=1, num_channels=16))
+    keys = sorted(m.state_dict())
+    convert_sync_batchnorm(m)
+    assert sorted(m.state_dict()) == keys
+    assert isinstance(m[0][1], nn.SyncBatchNorm)
+    assert type(m[1].bn) is nn.BatchNorm2d and ops.sync_group_of(m[1].bn) == (None,)
+    for head in ('score', 'loc'):
+        assert all(type(n) is nn.BatchNorm2d and ops.sync_group_of(n) == (None,) for n in m[2].norms[head][0])
