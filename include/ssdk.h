@@ -91,6 +91,17 @@ int ssdk_encode_ground_truth(const float* gt_rows, int gt_stride, const int32_t*
                              float unmatched_threshold, float* target, int32_t* box_idx, void* workspace,
                              size_t workspace_bytes, void* stream);
 
+size_t ssdk_match_per_prediction_workspace_bytes(int num_boxes);
+/*
+ * detection/matcher.py:33-56 match_per_prediction on a given weight matrix: weights DEV [num_boxes, num_anchors] (any values; NaN
+ * ranks above everything, as in torch.max / argmax); box_idx DEV int64 [num_anchors] = argmax over the boxes (first maximum),
+ * SSDK_NOT_MATCHED below unmatched_threshold, SSDK_IGNORE in [unmatched, matched); force_match_for_each_target != 0: every box's
+ * best anchor (first maximum) is given to it, the highest box index winning an anchor several boxes claim (:52-54).
+ */
+int ssdk_match_per_prediction(const float* weights, int num_boxes, int num_anchors, float matched_threshold,
+                              float unmatched_threshold, int force_match_for_each_target, int64_t* box_idx, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 /* ---- sampler + loss (S1 + L1 + L2 + L3) ----------------------------------------------------------------------- */
 
 size_t ssdk_multibox_loss_workspace_bytes(int batch, int num_anchors, int num_classes);

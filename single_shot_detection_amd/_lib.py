@@ -40,6 +40,9 @@ _SIGNATURES = {
     'ssdk_encode_ground_truth': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                            C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                            C.c_void_p]),
+    'ssdk_match_per_prediction_workspace_bytes': (C.c_size_t, [C.c_int]),
+    'ssdk_match_per_prediction': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+                                            C.c_void_p]),
     'ssdk_multibox_loss_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'ssdk_hard_negative_mining': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                             C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -87,7 +87,26 @@ _ZOO = {'torchvision_vgg16_bn': _Vgg16Bn, 'torchvision_resnet50': _ResNet50, 'to
 
 
 def create_base(name, weight=None, **model_args):
-    """bf/builders/base_builder.py:59-86 for the backbones the BASELINE configs name; no remote loaders."""
+    """bf/builders/base_builder.py:59-86 for the backbones the BASELINE configs name; no remote loaders.
+
+    ``weight``: a state_dict file is loaded like the reference does (:81-84); a path that does not exist raises (the reference skips
+    it silently and trains from whatever initialisation the constructor made).  ``pretrained=True`` -- every sample config passes
+    it -- meant a torchvision model-zoo download; there is no network and no torchvision here, so the backbone keeps its random
+    initialisation and says so once."""
     if name not in _ZOO:
         raise NotImplementedError(f'backbone {name!r} is outside the hot-path scope; available: {sorted(_ZOO)}')
-    return _ZOO[name](**model_args)
+    base = _ZOO[name](**model_args)
+    if weight == 'keras':
+        raise NotImplementedError("weight='keras' (init_from_keras of the reference's own MobileNets, bf/base/mobilenet*.py) is outside the hot-path scope")
+    if weight is not None:
+        import os
+        import torch
+        if not os.path.exists(weight):
+            raise FileNotFoundError(f'backbone weight file {weight!r} does not exist')
+        base.load_state_dict(torch.load(weight, map_location='cpu'))
+    elif model_args.get('pretrained'):
+        import logging
+        logging.getLogger(__name__).warning(
+            "create_base(%r, pretrained=True): no pretrained weights are available offline (torchvision's model zoo is a download); "
+            'the backbone is randomly initialised -- pass weight=<state_dict file> to load one', name)
+    return base

@@ -40,7 +40,8 @@ class BatchContainer(object):
         lam = np.random.beta(alpha, alpha)            # batch_container.py:26-28: the same draws, in the same order
         index = torch.randperm(self.imgs.size(0))
         roll = torch.rand(self.imgs.size(0)) < p
-        _lib.require_cuda(self.imgs)                   # the device path is the only path: call to_(device) first (callbacks.to_device)
+        _lib.require_cuda(self.imgs)                   # the device path is the only path: call to_(device) first (the reference's
+                                                       # trainer does: callbacks.to_device runs before callbacks.mixup, main.py:91)
         lib = _lib.lib()
         dev = self.imgs.device
         B = self.imgs.size(0)
@@ -53,10 +54,16 @@ class BatchContainer(object):
         self.imgs = out
         if self.target_type == TargetTypes.Boxes:
             from ...detection.target_assigner import pack_ground_truth
-            rows, offs, total = pack_ground_truth([t[:, :GT_ROW] if t.dim() == 2 else t for t in self.targets], dev)
-            rows_out = torch.empty((2 * max(total, 1), GT_ROW), dtype=torch.float32, device=dev)
+            # every attribute column travels (the reference clones whole rows, :37-41): e.g. `difficult` at column 6, which
+            # detection/metrics/mean_average_precision.py:22 reads when the rows are wider than 6
+            widths = {int(t.size(1)) for t in self.targets if t.dim() == 2 and t.size(0) > 0}
+            if len(widths) > 1:
+                raise ValueError(f'mixup_: ground-truth rows of different widths in one batch: {sorted(widths)}')
+            row = max(widths.pop() if widths else GT_ROW, GT_ROW)
+            rows, offs, total = pack_ground_truth(list(self.targets), dev, row=row)
+            rows_out = torch.empty((2 * max(total, 1), row), dtype=torch.float32, device=dev)
             offs_out = torch.empty((B + 1,), dtype=torch.int32, device=dev)
-            _lib.check(lib.ssdk_mixup_ground_truth(_lib.ptr(rows), GT_ROW, _lib.ptr(offs), B, _lib.ptr(index_d), _lib.ptr(roll_d), float(lam),
+            _lib.check(lib.ssdk_mixup_ground_truth(_lib.ptr(rows), row, _lib.ptr(offs), B, _lib.ptr(index_d), _lib.ptr(roll_d), float(lam),
                                                    _lib.ptr(rows_out), _lib.ptr(offs_out), _lib.current_stream()), 'ssdk_mixup_ground_truth')
             # per-image views of the packed buffer; the sizes are known on the host (no D2H sync)
             counts = [int(t.size(0)) if t.dim() == 2 else 0 for t in self.targets]

@@ -1,9 +1,22 @@
 """Conv blocks of the pyramid tail -- mirror of bf/modules/conv.py:4-85 (same submodule names, so state_dict keys
 ``conv``/``bn``/``activation`` and ``depthwise_*``/``pointwise_*`` line up with the reference's checkpoints)."""
+import logging
+
 import torch
 import torch.nn as nn
 
 from ... import ops
+
+_warned = set()
+
+
+def _warn_stock(kind, why):
+    """The blocks below run on libssdk for the shapes of the hot path; anything else falls back to the stock PyTorch-ROCm modules
+    (neck-side variants, out of scope as kernels).  Said once per reason, not silently."""
+    key = (kind, why)
+    if key not in _warned:
+        _warned.add(key)
+        logging.getLogger(__name__).warning('%s: %s -- this block runs on the stock PyTorch-ROCm modules, not on libssdk', kind, why)
 
 
 def _norm_act(x, bn, act):
@@ -29,12 +42,22 @@ class Conv2dBn(nn.Module):
         # [cout][ky][kx][cin] memory = the rows the implicit GEMM reads (no per-step permute copy); state_dict unchanged
         self.conv.weight.data = self.conv.weight.data.contiguous(memory_format=torch.channels_last)
 
-    def _hip_ok(self):
+    def _why_not_hip(self):
         c = self.conv
         act = self._modules.get('activation')
-        return (c.groups == 1 and c.kernel_size in ((1, 1), (3, 3)) and c.stride in ((1, 1), (2, 2)) and c.dilation == (1, 1)
-                and c.padding[0] == c.padding[1] and c.padding_mode == 'zeros' and c.in_channels % 4 == 0 and c.out_channels % 4 == 0
-                and (act is None or isinstance(act, nn.ReLU)))
+        if c.groups != 1:
+            return f'groups={c.groups}'
+        if c.kernel_size not in ((1, 1), (3, 3)) or c.stride not in ((1, 1), (2, 2)) or c.dilation != (1, 1) or c.padding[0] != c.padding[1] \
+                or c.padding_mode != 'zeros':
+            return f'kernel_size={c.kernel_size} stride={c.stride} dilation={c.dilation} padding={c.padding} ({c.padding_mode})'
+        if c.in_channels % 4 or c.out_channels % 4:
+            return f'channels {c.in_channels}->{c.out_channels} not multiples of 4'
+        if act is not None and not isinstance(act, nn.ReLU):
+            return f'activation {type(act).__name__}'
+        return None
+
+    def _hip_ok(self):
+        return self._why_not_hip() is None
 
     def forward(self, x):  # conv.py:30-36: conv -> BN -> activation
         if self._hip_ok():   # libssdk: implicit-GEMM conv (csrc/conv.hip) + BatchNorm/ReLU kernels (csrc/norm.hip)
@@ -44,7 +67,8 @@ class Conv2dBn(nn.Module):
             if has_bn:
                 x = _norm_act(x, self.bn, self._modules.get('activation'))
             return x
-        # grouped / depthwise / exotic variants (neck-side, out of the hot-path scope): stock PyTorch-ROCm modules
+        # grouped / exotic variants (neck-side, out of the hot-path scope): stock PyTorch-ROCm modules
+        _warn_stock('Conv2dBn', self._why_not_hip())
         x = self.conv(x)
         if 'bn' in self._modules:
             x = self.bn(x)
@@ -90,6 +114,7 @@ class DepthwiseConv2dBn(nn.Module):
             if has_bn:
                 x = _norm_act(x, self.pointwise_bn, self._modules.get('pointwise_activation'))
             return x
+        _warn_stock('DepthwiseConv2dBn', 'kernel / stride / padding / channel count / activation outside what the depthwise kernels take')
         for name in ('depthwise_conv', 'depthwise_bn', 'depthwise_activation', 'pointwise_conv', 'pointwise_bn',
                      'pointwise_activation'):
             if name in self._modules:

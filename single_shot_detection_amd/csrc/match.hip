@@ -115,9 +115,92 @@ __global__ void __launch_bounds__(kAssignThreads) assign_kernel(const float* __r
     for (int t = threadIdx.x; t < rows * 3; t += kAssignThreads) dst[t] = src[t];
 }
 
+// ---- detection/matcher.py:33-56 on a materialised weight matrix [G, A] (the API the reference exposes; the training path uses the
+// fused kernels above and never stores such a matrix) ------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) mpp_row_argmax_kernel(const float* __restrict__ w, int A, unsigned long long* __restrict__ best) {
+    const int g = blockIdx.y;
+    const int seg = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = lane_id();
+    const int a0 = seg * kSegAnchors;
+    if (a0 >= A) return;
+    const int a1 = min(A, a0 + kSegAnchors);
+    const float* row = w + (size_t)g * A;
+    float bv = 0.0f;
+    int bi = -1;
+    for (int a = a0 + lane; a < a1; a += kWave) {   // weights.argmax(dim=1): first maximum, NaN counts as the largest (matcher.py:52)
+        const float v = row[a];
+        if (bi < 0 || v > bv || (v != v && bv == bv)) { bv = v; bi = a; }
+    }
+    unsigned long long key = 0ull;
+    if (bi >= 0) {
+        // order-preserving bits for any sign: flip all bits of negatives, set the sign bit of the others; NaN above everything
+        unsigned u = __float_as_uint(bv);
+        u = (bv != bv) ? 0xFFFFFFFFu : ((u & 0x80000000u) ? ~u : (u | 0x80000000u));
+        key = ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)bi);
+    }
+    key = wave_allreduce(key, OpMaxU64());
+    if (lane == 0 && key) atomicMax(best + g, key);
+}
+
+__global__ void __launch_bounds__(kAssignThreads) mpp_assign_kernel(const float* __restrict__ w, int G, int A, float matched_thr, float unmatched_thr,
+                                                                    int force, const unsigned long long* __restrict__ best,
+                                                                    long long* __restrict__ box_idx) {
+    __shared__ int s_best_anchor[kGtChunk];
+    const int a = blockIdx.x * kAssignThreads + threadIdx.x;
+    float bv = 0.0f;
+    int bi = 0, forced = -1;
+    for (int base = 0; base < G; base += kGtChunk) {
+        const int n = min(kGtChunk, G - base);
+        __syncthreads();
+        if (threadIdx.x < n) s_best_anchor[threadIdx.x] = force ? (int)(0xFFFFFFFFu - (unsigned)(best[base + threadIdx.x] & 0xFFFFFFFFull)) : -1;
+        __syncthreads();
+        if (a < A)
+            for (int k = 0; k < n; ++k) {
+                const float v = w[(size_t)(base + k) * A + a];
+                if ((base + k) == 0 || v > bv || (v != v && bv == bv)) { bv = v; bi = base + k; }   // weights.max(dim=0), :45
+                if (s_best_anchor[k] == a) forced = base + k;                                            // :52-54, the highest box index wins
+            }
+    }
+    if (a >= A) return;
+    if (bv < unmatched_thr) bi = SSDK_NOT_MATCHED;        // :49
+    else if (bv < matched_thr) bi = SSDK_IGNORE;          // :50
+    if (forced >= 0) bi = forced;
+    box_idx[a] = bi;
+}
+
 }  // namespace ssdk
 
 using namespace ssdk;
+
+extern "C" size_t ssdk_match_per_prediction_workspace_bytes(int num_boxes) {
+    Carver c(nullptr);
+    c.take<unsigned long long>((size_t)(num_boxes > 0 ? num_boxes : 1));
+    return c.off;
+}
+
+extern "C" int ssdk_match_per_prediction(const float* weights, int num_boxes, int num_anchors, float matched_threshold,
+                                         float unmatched_threshold, int force_match_for_each_target, int64_t* box_idx, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+    SSDK_REQUIRE(weights && box_idx && num_boxes > 0 && num_anchors > 0, SSDK_E_INVALID,
+                 "ssdk_match_per_prediction: boxes=%d anchors=%d (weights.max(dim=0) of an empty matrix is an error in the reference too)",
+                 num_boxes, num_anchors);
+    SSDK_REQUIRE(num_boxes <= 65535, SSDK_E_INVALID, "ssdk_match_per_prediction: more than 65535 boxes");
+    SSDK_REQUIRE(matched_threshold >= unmatched_threshold, SSDK_E_INVALID,
+                 "ssdk_match_per_prediction: matched_threshold < unmatched_threshold (matcher.py:43)");
+    SSDK_REQUIRE(workspace && workspace_bytes >= ssdk_match_per_prediction_workspace_bytes(num_boxes), SSDK_E_WORKSPACE,
+                 "ssdk_match_per_prediction: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long* best = (unsigned long long*)workspace;
+    if (force_match_for_each_target) {
+        SSDK_CHECK_HIP(hipMemsetAsync(best, 0, sizeof(unsigned long long) * (size_t)num_boxes, s));
+        hipLaunchKernelGGL(mpp_row_argmax_kernel, dim3(cdiv(num_anchors, kSegAnchors * 4), num_boxes), dim3(256), 0, s, weights, num_anchors, best);
+        SSDK_CHECK_LAUNCH("mpp_row_argmax_kernel");
+    }
+    hipLaunchKernelGGL(mpp_assign_kernel, dim3(cdiv(num_anchors, kAssignThreads)), dim3(kAssignThreads), 0, s, weights, num_boxes, num_anchors,
+                       matched_threshold, unmatched_threshold, force_match_for_each_target, best, (long long*)box_idx);
+    SSDK_CHECK_LAUNCH("mpp_assign_kernel");
+    return SSDK_OK;
+}
 
 extern "C" size_t ssdk_encode_ground_truth_workspace_bytes(int batch, int total_gt) {
     (void)batch;

@@ -17,11 +17,13 @@ IGNORE_CLASS = -1
 GT_ROW = 6  # x1, y1, x2, y2, class, score (bf/datasets/detection_dataset.py:11-15); extra columns are dropped
 
 
-def pack_ground_truth(ground_truth, device):
-    """list[B] of [G_i, >=6] tensors (any device) -> (rows [sum G, 6] fp32, offsets int32 [B+1]) on ``device``.
+def pack_ground_truth(ground_truth, device, row=GT_ROW):
+    """list[B] of [G_i, >=row] tensors (any device) -> (rows [sum G, row] fp32, offsets int32 [B+1]) on ``device``.
 
     One pinned staging buffer and one async H2D copy per batch (the reference moves each image's tensor
-    separately, target_assigner.py:35)."""
+    separately, target_assigner.py:35).  ``row``: columns kept per box (6 for the target assigner; mixup keeps every
+    attribute, e.g. the `difficult` flag at column 6 that the evaluation metric reads)."""
+    GT_ROW = row   # (shadows the module constant below)
     counts = [int(g.size(0)) if g.dim() == 2 else 0 for g in ground_truth]
     total = sum(counts)
     if all((not g.is_cuda) for g in ground_truth):

@@ -101,3 +101,28 @@ def test_invalid_arguments_raise():
     from single_shot_detection_amd import _lib
     with pytest.raises(_lib.SsdkError):
         TargetAssigner(0.5, 0.5).encode_ground_truth([torch.zeros((1, 6))], anchors.cpu())
+
+
+def test_match_per_prediction_kats_and_oracle(kats):
+    """matcher.match_per_prediction(weights, ..., force_match_for_each_target) on a given matrix: the reference's own outputs
+    (kats.npz: with and without force-matching, ties, the ignore band) and the oracle on a large random matrix with ties and NaNs."""
+    from single_shot_detection_amd.detection import matcher
+    for key, mt, ut in (('kat1', 0.5, 0.5), ('kat5', 0.9, 0.3)):
+        w = torch.from_numpy(kats[f'{key}_iou']).cuda()
+        assert np.array_equal(matcher.match_per_prediction(w, mt, ut).cpu().numpy(), kats[f'{key}_idx'])
+        assert np.array_equal(matcher.match_per_prediction(w, mt, ut, force_match_for_each_target=False).cpu().numpy(), kats[f'{key}_idx_nf'])
+    w = torch.from_numpy(kats['kat4_w']).cuda()
+    assert np.array_equal(matcher.match_per_prediction(w, 0.5, 0.4).cpu().numpy(), kats['kat4_idx'])
+    assert np.array_equal(matcher.match_per_prediction(w, 0.5, 0.4, force_match_for_each_target=False).cpu().numpy(), kats['kat4_idx_nf'])
+    assert np.array_equal(matcher.match_per_prediction(torch.from_numpy(kats['kat3_iou']).cuda(), 0.5).cpu().numpy(), kats['kat3_idx'])
+    rng = np.random.default_rng(8)
+    w = rng.random((300, 8108), dtype=np.float32)
+    w[:, ::7] = np.round(w[:, ::7] * 8) / 8          # many exact ties down a column and along a row
+    w[5] = w[4]                                       # two boxes with identical rows: the later one wins their common best anchor
+    w[17, 100] = np.nan
+    for force in (True, False):
+        ref = oracle.match_per_prediction(w, 0.5, 0.4, force)
+        got = matcher.match_per_prediction(torch.from_numpy(w).cuda(), 0.5, 0.4, force).cpu().numpy()
+        assert np.array_equal(got, ref)
+    with pytest.raises(ValueError):
+        matcher.match_per_prediction(torch.zeros((0, 8), device='cuda'), 0.5)

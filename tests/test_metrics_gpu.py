@@ -89,3 +89,36 @@ def test_mixup_vs_reference_golden(case):
     target = TargetAssigner(0.5, 0.5).encode_ground_truth(list(out_t), anchors)
     ref = oracle.encode_ground_truth([t.cpu().numpy() for t in out_t], anchors.cpu().numpy(), 0.5, 0.5)
     assert np.array_equal(target.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+
+
+def test_mixup_keeps_every_attribute_column():
+    """Rows wider than 6 (the `difficult` flag of the VOC datasets at column 6, read by mean_average_precision.py:22) survive the
+    device mixup whole -- the reference clones and concatenates the full rows (batch_container.py:37-41)."""
+    from single_shot_detection_amd.bf.core.batch_container import BatchContainer, TargetTypes
+    rng = np.random.default_rng(2)
+    B = 6
+    gts = syn.make_ground_truth(B, 64, 9, seed=5)
+    gts7 = [np.concatenate([g, (rng.random((g.shape[0], 1)) < 0.5).astype(np.float32)], 1) for g in gts]
+    imgs = rng.standard_normal((B, 3, 8, 8)).astype(np.float32)
+    batch = BatchContainer([(torch.from_numpy(imgs[i]), torch.from_numpy(gts7[i])) for i in range(B)], TargetTypes.Boxes)
+    batch.to_(torch.device('cuda:0'))
+    np.random.seed(3)
+    torch.manual_seed(3)
+    batch.mixup_(1.5, 0.7)
+    np.random.seed(3)
+    torch.manual_seed(3)
+    lam = np.random.beta(1.5, 1.5)                 # the reference's draws (batch_container.py:26-28)
+    index = torch.randperm(B)
+    roll = torch.rand(B) < 0.7
+    assert bool(roll.any())
+    for i, t in enumerate(batch.get()[1]):
+        want = gts7[i]
+        if roll[i]:
+            a, b = gts7[i].copy(), gts7[int(index[i])].copy()
+            a[:, 5] *= np.float32(lam)
+            b[:, 5] *= np.float32(1.0 - lam)
+            want = np.concatenate([a, b], 0)
+        got = t.cpu().numpy()
+        assert got.shape == want.shape and got.shape[1] == 7
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=0)
+        assert np.array_equal(got[:, 6], want[:, 6])
