@@ -109,6 +109,35 @@ __device__ __forceinline__ T block_sum(T v, T* red) {
     return s;
 }
 
+// ---- scans ------------------------------------------------------------------------------------------------------------
+// inclusive scan over the 64 lanes of a wave
+template <typename T, typename Op>
+__device__ __forceinline__ T wave_inclusive_scan(T v, Op op) {
+    const int l = lane_id();
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const T t = __shfl_up(v, d, kWave);
+        if (l >= d) v = op(t, v);
+    }
+    return v;
+}
+// inclusive scan over a workgroup of up to 1024 threads (thread order); `tmp` = LDS T[17]; *agg = the total.  Every thread calls it.
+template <typename T, typename Op>
+__device__ __forceinline__ T block_inclusive_scan(T v, Op op, T* tmp, T* agg) {
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6, l = lane_id();
+    v = wave_inclusive_scan(v, op);
+    __syncthreads();
+    if (l == kWave - 1) tmp[w] = v;
+    __syncthreads();
+    T before = v;   // (value unused for wave 0)
+    bool have = false;
+    for (int i = 0; i < w; ++i) { before = have ? op(before, tmp[i]) : tmp[i]; have = true; }
+    T total = tmp[0];
+    for (int i = 1; i < nw; ++i) total = op(total, tmp[i]);
+    if (agg) *agg = total;
+    return have ? op(before, v) : v;
+}
+
 // Global -> LDS copy of n4 float4 (both 16-byte aligned) by a 256-thread workgroup with 8 loads per thread in flight.
 // Loads AND stores are branch-free: indices past the end are clamped to the last element, which is then written several
 // times with the same value.  (A `for (t < n4) lds[t] = src[t]` loop compiles to load / s_waitcnt vmcnt(0) / ds_write per

@@ -4,13 +4,12 @@
 // order (one box_utils.iou call, several .item() syncs and dict updates per prediction), then per class a Python loop for the
 // running maximum of the precision.  bf/eval.py:63-69 moves all predictions to the host first.
 //
-// Here: two stable radix sorts (rocPRIM through hipCUB) give the predictions in (class, score desc) order -- the order of the
+// Here: two stable radix sorts (radix_* kernels below: 8-bit digits, per-tile digit histograms -> row scans -> stable scatter with
+// wave-level ballot matching) give the predictions in (class, score desc) order -- the order of the
 // per-class cumulative counts -- and in (image, class, score desc) order, in which the greedy matching of :47-70 is
 // independent between (image, class) groups: one thread walks one group, against the <= G_i ground truths of that image.
 // A workgroup per class then does the cumulative sums, precision / recall, the reverse NaN-propagating running maximum and
-// the area / 11-point integration with block scans, in fp32 like the reference's tensors.
-#include <hipcub/hipcub.hpp>
-
+// the area / 11-point integration with block scans (common.h), in fp32 like the reference's tensors.
 #include "common.h"
 
 namespace ssdk {
@@ -29,12 +28,13 @@ struct MapWs {
     float* prec;                 // [n]  by (class, score) position
     float* rec;                  // [n]
     int* total_positive;         // [num_classes]
-    void* cub_temp;
-    size_t cub_bytes;
+    unsigned* table;             // [256][kSortMaxBlocks] per-tile digit counts, then their row-wise exclusive scans
+    unsigned* digit_total;       // [256]
     size_t total;
 };
 
-static size_t cub_temp_bound(long long n) { return (size_t)n * 32 + (16u << 20); }
+constexpr int kSortThreads = 256;
+constexpr int kSortMaxBlocks = 4096;   // tiles of a sort pass (the tile grows with n beyond 4096 * 4096 keys)
 
 static MapWs carve_map(void* base, long long n, long long total_gt, int num_classes) {
     Carver c(base);
@@ -51,8 +51,8 @@ static MapWs carve_map(void* base, long long n, long long total_gt, int num_clas
     w.prec = c.take<float>(nn);
     w.rec = c.take<float>(nn);
     w.total_positive = c.take<int>((size_t)num_classes);
-    w.cub_bytes = cub_temp_bound(n);
-    w.cub_temp = c.take<unsigned char>(w.cub_bytes);
+    w.table = c.take<unsigned>((size_t)256 * kSortMaxBlocks);
+    w.digit_total = c.take<unsigned>(256);
     w.total = c.off;
     return w;
 }
@@ -70,7 +70,8 @@ __global__ void map_prepare_kernel(const float* __restrict__ pred, long long n, 
     if (i < n) {
         const int c = (int)pred[i * 7 + 5];
         const bool ok = c >= 0 && c < num_classes;
-        key[i] = ok ? ((unsigned long long)(unsigned)c << 32) | desc_key(pred[i * 7 + 6]) : ~0ull;   // foreign classes sort last
+        key[i] = ok ? ((unsigned long long)(unsigned)c << 32) | desc_key(pred[i * 7 + 6])
+                    : ((unsigned long long)(unsigned)num_classes << 32) | 0xFFFFFFFFull;                        // foreign classes sort last
         val[i] = (unsigned)i;
     }
     if (i < total_gt) {
@@ -139,14 +140,8 @@ struct OpTmax { __device__ __forceinline__ float operator()(float a, float b) co
 __global__ void __launch_bounds__(kMapThreads) map_ap_kernel(const unsigned long long* __restrict__ key_b, const unsigned* __restrict__ perm_b, long long n,
                                                              const unsigned char* __restrict__ flag, const int* __restrict__ total_positive, int voc,
                                                              float* prec, float* rec, float* ap_out) {
-    typedef hipcub::BlockScan<int2, kMapThreads> ScanI2;
-    typedef hipcub::BlockScan<float, kMapThreads> ScanF;
-    typedef hipcub::BlockReduce<float, kMapThreads> ReduceF;
-    __shared__ union {
-        typename ScanI2::TempStorage si;
-        typename ScanF::TempStorage sf;
-        typename ReduceF::TempStorage rf;
-    } tmp;
+    __shared__ unsigned long long s_scan_i[17];   // (tp, fp) counts packed as two 32-bit halves
+    __shared__ float s_scan_f[17];
     __shared__ long long s_range[2];
     __shared__ int s_cnt[11];
     __shared__ float s_vocp[11];
@@ -184,16 +179,17 @@ __global__ void __launch_bounds__(kMapThreads) map_ap_kernel(const unsigned long
 
     // pass 1, forward: cumulative (tp, fp) -> precision, recall
     int2 carry = make_int2(0, 0);
-    struct AddI2 { __device__ __forceinline__ int2 operator()(const int2& a, const int2& b) const { return make_int2(a.x + b.x, a.y + b.y); } };
+    struct AddU64 { __device__ __forceinline__ unsigned long long operator()(unsigned long long a, unsigned long long b) const { return a + b; } };
     for (long long base = 0; base < m; base += kMapThreads) {
         const long long i = base + tid;
-        int2 v = make_int2(0, 0);
+        unsigned long long v = 0ull;   // tp in the low half, fp in the high half (a class has < 2^31 predictions: no carry between them)
         if (i < m) {
             const unsigned char f = flag[perm_b[begin + i]];
-            v = make_int2(f == 1, f == 2);
+            v = (unsigned long long)(f == 1) | ((unsigned long long)(f == 2) << 32);
         }
-        int2 incl, agg;
-        ScanI2(tmp.si).InclusiveScan(v, incl, AddI2(), agg);
+        unsigned long long aggv;
+        const unsigned long long inclv = block_inclusive_scan(v, AddU64(), s_scan_i, &aggv);
+        const int2 incl = make_int2((int)(unsigned)inclv, (int)(unsigned)(inclv >> 32)), agg = make_int2((int)(unsigned)aggv, (int)(unsigned)(aggv >> 32));
         __syncthreads();
         if (i < m) {
             const float tp = (float)(carry.x + incl.x), fp = (float)(carry.y + incl.y);
@@ -221,8 +217,7 @@ __global__ void __launch_bounds__(kMapThreads) map_ap_kernel(const unsigned long
         const long long i = ch * kMapThreads + (kMapThreads - 1 - tid);
         const float neg_inf = __uint_as_float(0xFF800000u);
         float v = i < m ? prec[begin + i] : neg_inf;
-        float incl;
-        ScanF(tmp.sf).InclusiveScan(v, incl, OpTmax());
+        const float incl = block_inclusive_scan(v, OpTmax(), s_scan_f, (float*)nullptr);
         const float carry_f = s_carry_f;
         __syncthreads();
         const float pm = tmaxf(incl, carry_f);
@@ -247,8 +242,100 @@ __global__ void __launch_bounds__(kMapThreads) map_ap_kernel(const unsigned long
         }
     } else {
         // the last term (1 - recall[m-1]) * precision[m] is (finite) * 0
-        const float sum = ReduceF(tmp.rf).Sum(acc);
+        const float sum = block_sum(acc, s_scan_f);
         if (tid == 0) ap_out[c] = sum;
+    }
+}
+
+// ---- stable LSD radix sort of (64-bit key, 32-bit value) pairs, 8 bits per pass ---------------------------------------------------
+// Pass = three launches.  radix_hist: every tile (a contiguous run of `tile` keys, one workgroup) counts its digits -> table[digit][tile].
+// radix_rowscan: one workgroup per digit turns its row into exclusive prefixes (and the row total).  radix_scatter: a tile's four waves
+// own four contiguous quarters of it; a key's slot = (keys with a smaller digit anywhere) + (same digit in earlier tiles) + (same digit
+// in earlier waves of the tile) + (same digit earlier in the wave's walk), the last found 64 keys at a time by ballot matching -- every
+// term follows input order, so the sort is stable (equal scores keep the lower prediction row first, like the oracle's stable sort).
+struct SortPass {
+    const unsigned long long* kin;
+    unsigned long long* kout;
+    const unsigned* vin;
+    unsigned* vout;
+    long long n;
+    int shift, tile, nblocks;
+    unsigned* table;        // [256][nblocks]
+    unsigned* digit_total;  // [256]
+};
+
+__global__ void __launch_bounds__(kSortThreads) radix_hist_kernel(SortPass a) {
+    __shared__ unsigned s_hist[256];
+    s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const long long b0 = (long long)blockIdx.x * a.tile, b1 = min(a.n, b0 + a.tile);
+    for (long long i = b0 + threadIdx.x; i < b1; i += kSortThreads) atomicAdd(&s_hist[(unsigned)(a.kin[i] >> a.shift) & 255u], 1u);
+    __syncthreads();
+    a.table[(size_t)threadIdx.x * a.nblocks + blockIdx.x] = s_hist[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(kSortThreads) radix_rowscan_kernel(SortPass a) {
+    __shared__ unsigned s_tmp[17];
+    unsigned* row = a.table + (size_t)blockIdx.x * a.nblocks;
+    struct AddU { __device__ __forceinline__ unsigned operator()(unsigned x, unsigned y) const { return x + y; } };
+    unsigned carry = 0;
+    for (int base = 0; base < a.nblocks; base += kSortThreads) {
+        const int i = base + threadIdx.x;
+        const unsigned v = i < a.nblocks ? row[i] : 0u;
+        unsigned agg;
+        const unsigned incl = block_inclusive_scan(v, AddU(), s_tmp, &agg);
+        if (i < a.nblocks) row[i] = carry + incl - v;
+        carry += agg;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.digit_total[blockIdx.x] = carry;
+}
+
+__global__ void __launch_bounds__(kSortThreads) radix_scatter_kernel(SortPass a) {
+    __shared__ unsigned s_base[256];        // keys with a smaller digit + same digit in earlier tiles
+    __shared__ volatile unsigned s_wcnt[4][256];   // per wave: its digit counts, then its running slots (volatile: lanes of a wave hand
+                                                   // the slot of a digit to each other through it from one 64-key round to the next)
+    __shared__ unsigned s_tmp[17];
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    struct AddU { __device__ __forceinline__ unsigned operator()(unsigned x, unsigned y) const { return x + y; } };
+    {
+        const unsigned t = a.digit_total[tid];
+        const unsigned incl = block_inclusive_scan(t, AddU(), s_tmp, (unsigned*)nullptr);
+        s_base[tid] = incl - t + a.table[(size_t)tid * a.nblocks + blockIdx.x];
+    }
+    for (int w = 0; w < 4; ++w) s_wcnt[w][tid] = 0;
+    __syncthreads();
+    const long long b0 = (long long)blockIdx.x * a.tile, b1 = min(a.n, b0 + a.tile);
+    const long long quarter = a.tile / 4;
+    const long long w0 = b0 + wave * quarter, w1 = min(b1, w0 + quarter);
+    for (long long i = w0 + lane; i < w1; i += kWave) atomicAdd(const_cast<unsigned*>(&s_wcnt[wave][(unsigned)(a.kin[i] >> a.shift) & 255u]), 1u);
+    __syncthreads();
+    {   // thread d: the four waves' starting slots for digit d
+        unsigned run = s_base[tid];
+        for (int w = 0; w < 4; ++w) { const unsigned c = s_wcnt[w][tid]; s_wcnt[w][tid] = run; run += c; }
+    }
+    __syncthreads();
+    for (long long i0 = w0; i0 < w1; i0 += kWave) {
+        const long long i = i0 + lane;
+        const bool valid = i < w1;
+        const unsigned long long key = valid ? a.kin[i] : 0ull;
+        const unsigned d = (unsigned)(key >> a.shift) & 255u;
+        unsigned long long m = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const bool one = (d >> bit) & 1u;
+            const unsigned long long bal = __ballot(one);
+            m &= one ? bal : ~bal;
+        }
+        const int rank = __popcll(m & ((1ull << lane) - 1ull)), cnt = __popcll(m);
+        if (valid) {
+            const unsigned pos = s_wcnt[wave][d] + (unsigned)rank;
+            a.kout[pos] = key;
+            a.vout[pos] = a.vin[i];
+        }
+        __builtin_amdgcn_wave_barrier();   // (every lane has read its digit's slot before the group's last lane moves it on)
+        if (valid && rank == cnt - 1) s_wcnt[wave][d] = s_wcnt[wave][d] + (unsigned)cnt;
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -264,6 +351,35 @@ __global__ void map_mean_kernel(const float* __restrict__ ap, const int* __restr
 }  // namespace ssdk
 
 using namespace ssdk;
+
+// stable sort of n (key, value) pairs on key bits [0, end_bit); the result lands in kb / vb.  ka / va are overwritten.
+static int radix_sort_pairs(unsigned long long* ka, unsigned long long* kb, unsigned* va, unsigned* vb, long long n, int end_bit, unsigned* table,
+                            unsigned* digit_total, hipStream_t s) {
+    SortPass a;
+    a.n = n;
+    long long tile = 4096;
+    while ((n + tile - 1) / tile > kSortMaxBlocks) tile *= 2;
+    a.tile = (int)tile;
+    a.nblocks = (int)((n + tile - 1) / tile);
+    a.table = table;
+    a.digit_total = digit_total;
+    const int digits = (end_bit + 7) / 8;
+    // pass p reads a (p even) or b (p odd) and writes the other: an odd number of passes ends in kb / vb.  With an even number of digits
+    // the most significant one is sorted once more -- a stable sort by a digit the data is already ordered by is a copy.
+    const int passes = (digits & 1) ? digits : digits + 1;
+    for (int p = 0; p < passes; ++p) {
+        a.shift = 8 * (p < digits ? p : digits - 1);
+        a.kin = (p & 1) ? kb : ka; a.kout = (p & 1) ? ka : kb;
+        a.vin = (p & 1) ? vb : va; a.vout = (p & 1) ? va : vb;
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(a.nblocks), dim3(kSortThreads), 0, s, a);
+        SSDK_CHECK_LAUNCH("radix_hist_kernel");
+        hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(kSortThreads), 0, s, a);
+        SSDK_CHECK_LAUNCH("radix_rowscan_kernel");
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(a.nblocks), dim3(kSortThreads), 0, s, a);
+        SSDK_CHECK_LAUNCH("radix_scatter_kernel");
+    }
+    return SSDK_OK;
+}
 
 extern "C" size_t ssdk_mean_average_precision_workspace_bytes(long long n_pred, long long total_gt, int num_classes) {
     if (n_pred < 0 || total_gt < 0 || num_classes <= 0) return 0;
@@ -291,17 +407,16 @@ extern "C" int ssdk_mean_average_precision(const float* predictions, long long n
     }
     if (n_pred > 0) {
         const int n = (int)n_pred;
-        size_t need = 0;
-        SSDK_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, need, w.key_a, w.key_b, w.val_a, w.perm_b, n, 0, 64, s));
-        SSDK_REQUIRE(need <= w.cub_bytes, SSDK_E_WORKSPACE, "ssdk_mean_average_precision: sort scratch %zu > %zu bytes", need, w.cub_bytes);
-        // (class, score desc): stable, so equal scores keep the lower row first.  All 64 bits: foreign classes carry ~0.
-        size_t bytes = w.cub_bytes;
-        SSDK_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(w.cub_temp, bytes, w.key_a, w.key_b, w.val_a, w.perm_b, n, 0, 64, s));
+        int class_bits = 1;
+        while ((1 << class_bits) <= num_classes) ++class_bits;   // keys go up to num_classes << 32 (foreign classes)
+        // (class, score desc): stable, so equal scores keep the lower row first
+        int rc = radix_sort_pairs(w.key_a, w.key_b, w.val_a, w.perm_b, n_pred, 32 + class_bits, w.table, w.digit_total, s);
+        if (rc) return rc;
         hipLaunchKernelGGL(map_image_key_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, predictions, n_pred, w.perm_b, w.key_a, w.val_a);
         SSDK_CHECK_LAUNCH("map_image_key_kernel");
         // stable sort by image on top: (image, class, score desc); val_b = prediction rows in that order
-        bytes = w.cub_bytes;
-        SSDK_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(w.cub_temp, bytes, w.key_a, w.key_c, w.val_a, w.val_b, n, 0, 32, s));
+        rc = radix_sort_pairs(w.key_a, w.key_c, w.val_a, w.val_b, n_pred, 32, w.table, w.digit_total, s);
+        if (rc) return rc;
         hipLaunchKernelGGL(map_match_kernel, dim3((unsigned)cdiv(n, 128)), dim3(128), 0, s, predictions, n_pred, w.val_b, gt_rows, gt_stride, gt_offsets, num_images,
                            num_classes, iou_threshold, w.matched, w.flag);
         SSDK_CHECK_LAUNCH("map_match_kernel");
