@@ -277,7 +277,7 @@ int ssdk_conv2d_bwd(const ssdk_conv_desc* descs, int n, int batch, int accumulat
 /* dx = y > 0 ? dy : 0 (n floats, n % 4 == 0). */
 int ssdk_relu_bwd(const float* y, const float* dy, long long n, float* dx, void* stream);
 
-size_t ssdk_batchnorm_workspace_bytes(int channels); /* = the [2 * channels + 1] doubles of a `sums` buffer (below), 256-byte rounded */
+size_t ssdk_batchnorm_workspace_bytes(int channels); /* = the [2 * channels + 2] doubles of a `sums` buffer (below), 256-byte rounded */
 /*
  * torch.nn.BatchNorm2d forward on [rows = batch*H*W][channels] (NHWC), optional fused ReLU after it (conv.py:33-35).
  * training != 0: batch statistics (biased variance), running_mean / running_var updated with `momentum` (unbiased
@@ -297,8 +297,8 @@ int ssdk_batchnorm_bwd(const float* x, const float* y, const float* dy, long lon
 /*
  * Synchronised BatchNorm (the reference converts every BatchNorm with apex `convert_syncbn_model`, detection/init.py:85, in
  * --distributed mode): ssdk_batchnorm_fwd / _bwd cut in two, with the caller's all-reduce(sum) over the ranks in between.
- *   sums DEV double [2 * channels + 1]: forward  = (sum x, sum x^2, rows); backward = (sum dy', sum dy' * xhat, rows), dy' = dy masked by
- *   the fused ReLU.  One all-reduce(sum) of the whole buffer -- or of several layers' buffers laid back to back, e.g. the five
+*   sums DEV double [2 * channels + 2]: forward  = (sum x, sum x^2, rows, 0); backward = (sum dy', sum dy' * xhat, rows, 0), dy' = dy masked
+ *   by the fused ReLU (the last double is padding: buffers are zero-filled in 16-byte units).  One all-reduce(sum) of the whole buffer -- or of several layers' buffers laid back to back, e.g. the five
  *   per-level norms of one RetinaNet tower layer -- makes them the statistics of the global batch.
  *   ssdk_batchnorm_apply: training-mode forward from such sums (count_in_sums != 0: the row count is sums[2 * channels], else `rows`);
  *     running statistics, num_batches_tracked, save_mean / save_rstd as ssdk_batchnorm_fwd.

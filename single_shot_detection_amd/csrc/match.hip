@@ -5,10 +5,10 @@
 // the CPU because anchors live there -- 331 ms per SSD-300 batch of 32.
 //
 // Here nothing [G,A]-shaped exists.  Two launches over the whole batch:
-//   1. gt_argmax_kernel   one wave per (ground-truth box, anchor segment): the wave sweeps its anchors (16-byte
-//                         coalesced loads, L2-resident: the anchor table is shared by every image) and folds the
-//                         box's best anchor into a 64-bit atomicMax key (iou bits << 32 | ~anchor), which is
-//                         argmax(dim=1) with torch's first-index tie rule (matcher.py:52).
+//   1. gt_argmax_kernel   one workgroup per ground-truth box: it sweeps the anchors (16-byte coalesced loads,
+//                         L2-resident: the anchor table is shared by every image) and reduces the box's best anchor as
+//                         a 64-bit key (iou bits << 32 | ~anchor): argmax(dim=1) with torch's first-index tie rule
+//                         (matcher.py:52).
 //   2. assign_kernel      one thread per (image, anchor): re-derives the anchor's IoU with the image's boxes from
 //                         LDS (cheaper than storing [G,A]), applies max(dim=0) with first-max ties, the two
 //                         thresholds, then the force-match (last writer = highest box index wins, matcher.py:53-54),
@@ -25,21 +25,21 @@ constexpr int kAssignThreads = 256;
 constexpr int kGtChunk = 128;
 constexpr int kSegAnchors = 512;  // anchors swept by one wave of gt_argmax_kernel
 
+// One workgroup per ground-truth box: its 256 threads sweep ALL anchors and the result is stored, not accumulated -- no atomics and
+// therefore no zero-fill launch in front (the first version folded (box, 512-anchor segment) partial results into a zeroed array with
+// atomicMax: a third launch, and a memset node costs as much as a small kernel).
 __global__ void __launch_bounds__(256) gt_argmax_kernel(const float* __restrict__ gt_rows, int gt_stride,
                                                         const float4* __restrict__ anchors, int A,
                                                         unsigned long long* __restrict__ gt_best) {
-    const int g = blockIdx.y;
-    const int seg = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = lane_id();
-    const int a0 = seg * kSegAnchors;
-    if (a0 >= A) return;
-    const int a1 = min(A, a0 + kSegAnchors);
+    __shared__ unsigned long long s_key[4];
+    const int g = blockIdx.x;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
     const float* r = gt_rows + (size_t)g * gt_stride;
     const float4 gb = make_float4(r[0], r[1], r[2], r[3]);
     const float garea = area4(gb.x, gb.y, gb.z, gb.w);
     float best = 0.0f;
     int bi = -1;
-    for (int a = a0 + lane; a < a1; a += kWave) {
+    for (int a = threadIdx.x; a < A; a += 256) {
         const float4 c = to_corners(anchors[a]);
         const float v = iou_corner(gb, garea, c, area4(c.x, c.y, c.z, c.w));
         if (bi < 0 || v > best || (v != v && best == best)) { best = v; bi = a; }
@@ -47,7 +47,13 @@ __global__ void __launch_bounds__(256) gt_argmax_kernel(const float* __restrict_
     unsigned long long key = 0ull;
     if (bi >= 0) key = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)bi);
     key = wave_allreduce(key, OpMaxU64());
-    if (lane == 0 && key) atomicMax(gt_best + g, key);
+    if (lane == 0) s_key[wave] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long k = s_key[0];
+        for (int w = 1; w < 4; ++w) k = s_key[w] > k ? s_key[w] : k;
+        gt_best[g] = k;
+    }
 }
 
 __global__ void __launch_bounds__(kAssignThreads) assign_kernel(const float* __restrict__ gt_rows, int gt_stride,
@@ -226,9 +232,7 @@ extern "C" int ssdk_encode_ground_truth(const float* gt_rows, int gt_stride, con
     Carver c(workspace);
     unsigned long long* gt_best = c.take<unsigned long long>((size_t)(total_gt > 0 ? total_gt : 1));
     if (total_gt > 0) {
-        SSDK_CHECK_HIP(hipMemsetAsync(gt_best, 0, sizeof(unsigned long long) * (size_t)total_gt, s));
-        dim3 grid(cdiv(num_anchors, kSegAnchors * 4), total_gt);
-        hipLaunchKernelGGL(gt_argmax_kernel, grid, dim3(256), 0, s, gt_rows, gt_stride, (const float4*)anchors, num_anchors, gt_best);
+        hipLaunchKernelGGL(gt_argmax_kernel, dim3(total_gt), dim3(256), 0, s, gt_rows, gt_stride, (const float4*)anchors, num_anchors, gt_best);
         SSDK_CHECK_LAUNCH("gt_argmax_kernel");
     }
     dim3 grid(cdiv(num_anchors, kAssignThreads), batch);

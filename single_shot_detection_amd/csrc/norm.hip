@@ -198,13 +198,15 @@ static inline int stream_blocks(long long items, int per_block) {
 
 using namespace ssdk;
 
-extern "C" size_t ssdk_batchnorm_workspace_bytes(int channels) { return align_up(((size_t)2 * channels + 1) * sizeof(double), 256); }
+// a `sums` buffer: 2C sums, the row count at [2C], one double of padding (an even number of doubles: the zero-fill of an odd number
+// is two fill kernels in the runtime, one for the 16-byte aligned part and one for the tail)
+extern "C" size_t ssdk_batchnorm_workspace_bytes(int channels) { return align_up(((size_t)2 * channels + 2) * sizeof(double), 256); }
 
 extern "C" int ssdk_batchnorm_stats(const float* x, long long rows, int channels, double* sums, void* stream) {
     SSDK_REQUIRE(x && sums && rows > 0 && channels > 0, SSDK_E_INVALID, "ssdk_batchnorm_stats: bad arguments");
     SSDK_REQUIRE(channels % 4 == 0 && ((uintptr_t)x & 15) == 0, SSDK_E_UNSUPPORTED, "ssdk_batchnorm_stats: channels %% 4 != 0 or x not 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    SSDK_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * (2 * (size_t)channels + 1), s));
+    SSDK_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * (2 * (size_t)channels + 2), s));
     const int rpb = kBnRows;
     hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, s, x, (const float*)nullptr,
                        (const float*)nullptr, rows, rpb, channels, (const float*)nullptr, (const float*)nullptr, 0, sums);
@@ -258,7 +260,7 @@ extern "C" int ssdk_batchnorm_bwd_stats(const float* x, const float* y, const fl
     SSDK_REQUIRE(x && dy && sums && save_mean && save_rstd && rows > 0 && channels > 0 && (!relu || y), SSDK_E_INVALID,
                  "ssdk_batchnorm_bwd_stats: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    SSDK_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * (2 * (size_t)channels + 1), s));
+    SSDK_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * (2 * (size_t)channels + 2), s));
     const int rpb = kBnRows;
     hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, s, x, y, dy, rows, rpb, channels, save_mean,
                        save_rstd, relu, sums);

@@ -161,8 +161,8 @@ def sync_group_of(bn):
 
 
 def allreduce_sums_(buf, group=None):
-    """The one exchange step of synchronised BatchNorm: all-reduce(sum) of a packed fp64 buffer [sum_i (2 C_i + 1)] holding, per
-    norm layer, (sum, sum of squares / products, row count).  No-op without an initialised process group or with one rank."""
+    """The one exchange step of synchronised BatchNorm: all-reduce(sum) of a packed fp64 buffer [sum_i (2 C_i + 2)] holding, per
+    norm layer, (sum, sum of squares / products, row count, padding).  No-op without an initialised process group or with one rank."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(buf, group=group)
@@ -191,7 +191,7 @@ class _SyncBatchNormFn(torch.autograd.Function):
         offs, tot = [], 0
         for lv in layers:
             offs.append(tot)
-            tot += 2 * lv['C'] + 1
+            tot += 2 * lv['C'] + 2   # (sum, sum of squares, rows, padding)
         sums = torch.empty((tot,), dtype=torch.float64, device=dev)
         for lv, off in zip(layers, offs):
             _lib.check(lib.ssdk_batchnorm_stats(_dp(lv['x']), lv['rows'], lv['C'], sums[off:].data_ptr(), stream), 'ssdk_batchnorm_stats')
