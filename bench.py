@@ -454,7 +454,7 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * args.batch * args.steps / dt
 
-    # forward head GEMMs (igemm_dma_kernel<false,false,false,4,32,4>, ONE grouped launch per step) timed with events inside the timed region
+    # forward head GEMMs (igemm_streamk_kernel, ONE grouped launch per step) timed with events inside the timed region
     fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in hp.fwd_events]))
     flops_step = head_flops_per_image(hp.levels, hp.C) * args.batch
     achieved = flops_step / (fwd_ms * 1e-3) / 1e12
@@ -513,7 +513,7 @@ def main():
             'eval_images_per_sec': world * args.batch / dte, 'nms_candidates_per_image': cand / args.batch,
             'postprocess_trained_like': {'images_per_sec': world * args.batch / dtp_tl, 'nms_boxes_per_sec': world * cand_tl / dtp_tl,
                                          'nms_candidates_per_image': cand_tl / args.batch, 'ms_per_batch': dtp_tl * 1e3},
-            'roofline': {'bound': 'mfma', 'kernel': 'igemm_dma_kernel<false,false,false,4,32,4> (forward head GEMMs, all pyramid levels in one grouped launch)',
+            'roofline': {'bound': 'mfma', 'kernel': 'igemm_streamk_kernel (forward head GEMMs, all pyramid levels in one grouped stream-K launch of 512 persistent workgroups)',
                          'achieved': achieved, 'peak': PEAK_FP32_MATRIX_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_FP32_MATRIX_TFLOPS,
                          'traffic': measured_traffic(f'{args.config}:b{args.batch}:igemm_fwd_heads'),

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SSDK_VERSION 102
+#define SSDK_VERSION 103
 
 #define SSDK_OK 0
 #define SSDK_E_INVALID (-1)   /* bad argument / shape */
@@ -233,8 +233,14 @@ typedef struct ssdk_head_level {
  * All levels of detector.py:50-66 in one grouped launch (n_levels <= 8): scores DEV [batch, scores_batch_stride],
  * locs DEV [batch, locs_batch_stride].  fp32 in, fp32 accumulate on the matrix cores (v_mfma_f32_32x32x2_f32).
  */
+/* workspace DEV (optional, NULL = none): ssdk_heads_fwd_workspace_bytes() bytes, ZERO-FILLED ONCE by the caller before its first use and then
+ * left to the library between calls (it holds parked partial tiles and their ready flags, told apart from call to call by a launch
+ * counter).  With it, a launch of a few rounds of whole tiles runs in stream-K form: the K slices of the whole launch are cut into equal
+ * ranges, one per resident workgroup, and a tile that straddles two ranges is summed through the workspace -- same results up to fp32
+ * summation order of that one K split. */
+size_t ssdk_heads_fwd_workspace_bytes(void);
 int ssdk_heads_fwd(const ssdk_head_level* levels, int n_levels, int batch, float* scores, long long scores_batch_stride,
-                   float* locs, long long locs_batch_stride, void* stream);
+                   float* locs, long long locs_batch_stride, void* workspace, size_t workspace_bytes, void* stream);
 
 size_t ssdk_heads_bwd_workspace_bytes(const ssdk_head_level* levels, int n_levels, int batch);
 

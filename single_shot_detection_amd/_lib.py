@@ -55,7 +55,8 @@ _SIGNATURES = {
                                   C.c_int, C.c_void_p]),
     'ssdk_decode_box': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
                                   C.c_void_p]),
-    'ssdk_heads_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_void_p]),
+    'ssdk_heads_fwd_workspace_bytes': (C.c_size_t, []),
+    'ssdk_heads_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_void_p, C.c_size_t, C.c_void_p]),
     'ssdk_heads_bwd_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     'ssdk_heads_bwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong,
                                  C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -206,14 +207,16 @@ def require_cuda(*tensors):
 _scratch = {}
 
 
-def scratch(nbytes, device, tag):
+def scratch(nbytes, device, tag, zeroed=False):
     """A grow-only uint8 device buffer per (device, tag) for workspaces that live only for the duration of one library call.
     Calls on one stream are ordered, so the next call may reuse the bytes; nothing that a backward pass reads later may live here.
-    (A torch.empty per call is cheap, but it makes the step allocate -- which is what broke HIP-graph capture of the step.)"""
+    (A torch.empty per call is cheap, but it makes the step allocate -- which is what broke HIP-graph capture of the step.)
+    ``zeroed``: zero-filled when it is created (workspaces whose state the library keeps from call to call, e.g. the ready flags of
+    ssdk_heads_fwd's stream-K form)."""
     import torch
     key = (torch.device(device), tag, torch.cuda.current_stream(device).cuda_stream)
     buf = _scratch.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=device)
+        buf = (torch.zeros if zeroed else torch.empty)((max(int(nbytes), 256),), dtype=torch.uint8, device=device)
         _scratch[key] = buf
     return buf

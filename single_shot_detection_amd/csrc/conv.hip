@@ -106,6 +106,21 @@ struct ConvGroup {
     ConvProblem p[kMaxProblems];
 };
 
+// Stream-K partition of a grouped forward launch (plain heads forward only): the launch's K slices -- every (M tile, column block,
+// K slice), weighted by the column tiles of the block -- are cut into `nwg` equal contiguous ranges, one per persistent workgroup, so
+// that all workgroups finish together instead of leaving the last of 2.9 rounds of whole tiles 10 % full.  A tile that straddles a
+// range boundary is computed in two K parts: the second part (start of the next workgroup's range, i.e. computed right after launch)
+// parks its accumulators in `partial`, the first part (END of the previous workgroup's range) adds them and runs the epilogue -- no
+// atomics on the outputs, no zero-fill, and by the time the owner looks the other half has been there for a millisecond.
+struct StreamK {
+    int nwg;
+    long long total_units;
+    long long unit_begin[kMaxProblems + 1];   // prefix over the problems in launch order; unit = one K slice of one 32-column tile
+    float* partial;                           // [nwg][4 waves][kMaxTN][4][64 lanes][4]: a workgroup's accumulators as they lie in registers
+    unsigned* flags;                          // [nwg + 1]: flags[s] == epoch <=> workgroup s parked its partial tile; flags[nwg] = timeouts
+    unsigned epoch;
+};
+
 template <int VEC>
 struct VecT;
 template <>
@@ -328,8 +343,12 @@ extern "C" int ssdk_debug_read_phase(unsigned long long* host) { return (int)hip
 #else
 #define PHASE(i)
 #endif
+// sk_mode (stream-K): 0 = a whole tile (or a split-K part `ksp`); 1 = K slices [sk_s0, sk_s1) of the tile, the accumulators are parked
+// in sk_buf and *sk_flag set to sk_epoch; 2 = K slices [sk_s0, sk_s1), then the accumulators parked by another workgroup are added
+// (once *sk_flag == sk_epoch) and the epilogue runs.
 template <bool MIRROR, bool GENERIC, bool SCATTER, int WAVES, int BK, int MAXTN>
-__device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_tile, int n_block, int ksp) {
+__device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_tile, int n_block, int ksp, int sk_mode = 0, int sk_s0 = 0, int sk_s1 = 0,
+                                         float* sk_buf = nullptr, unsigned* sk_flag = nullptr, unsigned sk_epoch = 0, unsigned* sk_timeouts = nullptr) {
     PHASE(0)
     // BK = K slice: 32 floats (128-byte rows, 8 rows per DMA piece, 64 KB of LDS: 2 workgroups per CU) or 16 floats (64-byte rows,
     // 16 rows per piece, 32 KB: 3 workgroups per CU at <= 170 VGPRs, a barrier every 32 MFMAs instead of 64)
@@ -354,8 +373,8 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
     const int chunks = Cc / kBK;
     const int n_slices_all = taps * chunks;
     const int per_split = (n_slices_all + g.k_splits - 1) / g.k_splits;
-    const int slice_begin = ksp * per_split;
-    const int n_slices = min(n_slices_all, slice_begin + per_split);
+    const int slice_begin = sk_mode ? sk_s0 : ksp * per_split;
+    const int n_slices = sk_mode ? sk_s1 : min(n_slices_all, slice_begin + per_split);
     if (slice_begin >= n_slices) return;
     const int K = taps * Cc;
     const int N = g.n0_pad + g.n1;
@@ -557,6 +576,38 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
         default: k_loop(std::integral_constant<int, 1>{}); break;
     }
     PHASE(2)
+    if (!MIRROR && !GENERIC && !SCATTER && WAVES == 4 && sk_mode) {
+        // accumulator image: [wave][column tile j][e / 4][lane] float4 -- every store / load instruction moves 1 KB contiguous
+        f32x4* img = reinterpret_cast<f32x4*>(sk_buf) + (size_t)wave * MAXTN * 4 * 64 + lane;
+        if (sk_mode == 1) {
+#pragma unroll
+            for (int j = 0; j < MAXTN; ++j)
+                if (j < tn)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) img[(j * 4 + q) * 64] = f32x4{acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // every wave: its stores have reached memory the other XCDs see ...
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(sk_flag, sk_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // ... before the flag does
+            return;
+        }
+        if (tid == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(sk_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != sk_epoch) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1u << 22)) { atomicAdd(sk_timeouts, 1u); break; }   // (never hangs: a lost partner costs the tile, not the GPU)
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (every wave: its reads below come from memory, not from lines cached earlier)
+#pragma unroll
+        for (int j = 0; j < MAXTN; ++j)
+            if (j < tn)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = img[(j * 4 + q) * 64];
+                    acc[j][4 * q] += v[0]; acc[j][4 * q + 1] += v[1]; acc[j][4 * q + 2] += v[2]; acc[j][4 * q + 3] += v[3];
+                }
+    }
     conv_epilogue<SCATTER>(g, acc, m_base, wave, r32, h, tn, n_begin, M, N, hw, ksp);
     PHASE(3)
 }
@@ -610,6 +661,61 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? (BK == 16 ? 3 : SSDK_
     const int n_block = within >> 3;
     if (m_tile >= (WAVES == 4 ? g.m_tiles : g.m_tiles256)) return;
     dma_tile<MIRROR, GENERIC, SCATTER, WAVES, BK, MAXTN>(g, pi, m_tile, n_block, ksp);
+}
+
+// Stream-K form of igemm_dma_kernel<false, false, false, 4> (see StreamK): `nwg` persistent workgroups, each walks its range of units.
+// Order inside a problem: M tile major, column block minor (a workgroup meets the column blocks of one M tile back to back: the A rows
+// it just streamed are still in its XCD's L2), K slice innermost.
+__global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_streamk_kernel(ConvGroup grp, StreamK sk) {
+    // (giving the workgroups of one XCD -- equal blockIdx % 8 -- neighbouring ranges measured the same within noise: 0.79-0.80 vs 0.80-0.81)
+    const int s = blockIdx.x;
+    // boundary b of the range split, snapped down to a whole K slice of the tile it falls in (both neighbours compute the same value)
+    auto locate = [&](long long u, int& pi, int& m_tile, int& n_block, int& slice, int& tn) -> long long {
+        pi = 0;
+#pragma unroll 1
+        for (int i = 1; i < grp.count; ++i)
+            if (u >= sk.unit_begin[i]) pi = i;
+        const ConvProblem& g = grp.p[pi];
+        const int slices = g.ksize * g.ksize * (g.Cc / kBK);
+        const long long local = u - sk.unit_begin[pi];
+        const long long per_m = (long long)slices * g.tiles_n;
+        m_tile = (int)(local / per_m);
+        int rem = (int)(local - (long long)m_tile * per_m);
+        const int base_t = g.tiles_n / g.n_blocks, rem_t = g.tiles_n % g.n_blocks;
+        int nb = 0, acc_u = 0;
+        tn = base_t + (0 < rem_t ? 1 : 0);
+        while (nb + 1 < g.n_blocks && rem >= acc_u + slices * tn) {
+            acc_u += slices * tn;
+            ++nb;
+            tn = base_t + (nb < rem_t ? 1 : 0);
+        }
+        n_block = nb;
+        slice = (rem - acc_u) / tn;
+        return sk.unit_begin[pi] + (long long)m_tile * per_m + acc_u + (long long)slice * tn;   // snapped position
+    };
+    int pi, m_tile, n_block, slice, tn;
+    long long u = s == 0 ? 0 : locate(sk.total_units * s / sk.nwg, pi, m_tile, n_block, slice, tn);
+    int pj, mj, nj, sj, tj;
+    const long long u_end = s + 1 == sk.nwg ? sk.total_units : locate(sk.total_units * (s + 1) / sk.nwg, pj, mj, nj, sj, tj);
+    float* const my_buf = sk.partial + (size_t)s * (4 * kMaxTN * 4 * 64 * 4);
+    float* const next_buf = my_buf + (size_t)(4 * kMaxTN * 4 * 64 * 4);
+    while (u < u_end) {
+        locate(u, pi, m_tile, n_block, slice, tn);
+        const ConvProblem& g = grp.p[pi];
+        const int slices = g.ksize * g.ksize * (g.Cc / kBK);
+        const long long left = (u_end - u) / tn;
+        const int s1 = (int)min((long long)slices, (long long)slice + left);
+        if (s1 <= slice) break;   // (cannot happen: boundaries are whole slices; a guard against walking on the spot)
+        if (slice == 0 && s1 == slices) {
+            dma_tile<false, false, false, 4, kBK, kMaxTN>(g, pi, m_tile, n_block, 0);
+        } else if (slice > 0) {   // second K part of a tile whose first part closes the previous workgroup's range: park the partial sums
+            dma_tile<false, false, false, 4, kBK, kMaxTN>(g, pi, m_tile, n_block, 0, 1, slice, s1, my_buf, sk.flags + s, sk.epoch, sk.flags + sk.nwg);
+        } else {                  // first K part: the rest was computed by the next workgroup right after launch
+            dma_tile<false, false, false, 4, kBK, kMaxTN>(g, pi, m_tile, n_block, 0, 2, 0, s1, next_buf, sk.flags + s + 1, sk.epoch, sk.flags + sk.nwg);
+        }
+        u += (long long)(s1 - slice) * tn;
+        __syncthreads();   // the next tile's first DMA overwrites LDS stage 0
+    }
 }
 
 // ---- forward / backward-data ------------------------------------------------------------------------------------
@@ -1622,7 +1728,15 @@ static void narrow_for_atomics(ConvProblem& g) {
 
 // decides the kernel (LDS-DMA or register staged; 128- or 256-pixel tiles), orders the problems by decreasing work per
 // workgroup (longest first), assigns block ranges, launches
-static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t s, bool generic = false, bool scatter = false, int* vtab = nullptr) {
+struct StreamKWs {
+    float* partial;
+    unsigned* flags;
+    int nwg;
+};
+static unsigned g_streamk_epoch = 0;   // (a launch counter: tells this launch's flags from an earlier launch's in the same workspace)
+
+static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t s, bool generic = false, bool scatter = false, int* vtab = nullptr,
+                        const StreamKWs* skws = nullptr) {
     bool vec4 = true, strided = false;
     for (int i = 0; i < count; ++i) {
         const ConvProblem& g = probs[i];
@@ -1696,6 +1810,31 @@ static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t 
         SSDK_CHECK_LAUNCH("build_vtab_kernel");
         grp.vtab = vtab;
         hipLaunchKernelGGL((igemm_dma_kernel<false, false, true, 4>), dim3(2048), dim3(kConvThreads), 0, s, grp);
+    } else if (dma && skws && !mirror && !generic && !scatter && !bk16 && !tn6 && !getenv("SSDK_CONV_NO_STREAMK")) {
+        // stream-K only where it pays: a launch of a few rounds of whole tiles (its last round is then a large share of the time), and
+        // every range at least as long as the longest tile (a tile is cut at most once)
+        StreamK sk{};
+        sk.nwg = skws->nwg;
+        long long max_tile = 0;
+        for (int i = 0; i < count; ++i) {
+            const ConvProblem& g = grp.p[i];
+            const long long slices = (long long)g.ksize * g.ksize * (g.Cc / kBK);
+            sk.unit_begin[i] = sk.total_units;
+            sk.total_units += (long long)g.m_tiles * slices * g.tiles_n;
+            max_tile = std::max(max_tile, slices * cdiv(g.tiles_n, g.n_blocks));
+            if (g.k_splits != 1 || g.mode) sk.nwg = 0;
+        }
+        sk.unit_begin[count] = sk.total_units;
+        const bool worth = sk.nwg > 0 && begin > sk.nwg && begin <= 16 * sk.nwg && sk.total_units / sk.nwg >= 2 * max_tile;
+        if (worth) {
+            sk.partial = skws->partial;
+            sk.flags = skws->flags;
+            sk.epoch = __atomic_add_fetch(&g_streamk_epoch, 1u, __ATOMIC_RELAXED);
+            if (sk.epoch == 0) sk.epoch = __atomic_add_fetch(&g_streamk_epoch, 1u, __ATOMIC_RELAXED);   // (0 is what a fresh workspace holds)
+            hipLaunchKernelGGL(igemm_streamk_kernel, dim3(sk.nwg), dim3(kConvThreads), 0, s, grp, sk);
+        } else {
+            hipLaunchKernelGGL((igemm_dma_kernel<false, false, false, 4>), dim3(begin), dim3(kConvThreads), 0, s, grp);
+        }
     } else if (dma) {
         if (scatter) hipLaunchKernelGGL((igemm_dma_kernel<false, false, true, 4>), dim3(begin), dim3(kConvThreads), 0, s, grp);
         else if (mirror) hipLaunchKernelGGL((igemm_dma_kernel<true, false, false, 4>), dim3(begin), dim3(kConvThreads), 0, s, grp);
@@ -1740,8 +1879,14 @@ static inline int anchor_types_of(const ssdk_head_level& lv) {
 }
 static inline int jpad_of(const ssdk_head_level& lv) { return cdiv(lv.n_score / (lv.n_loc / 4) + 4, 32) * 32; }
 
+constexpr int kStreamKWgs = 512;   // two 64 KB-LDS workgroups per CU x 256 CUs
+extern "C" size_t ssdk_heads_fwd_workspace_bytes(void) {
+    return align_up((size_t)(kStreamKWgs + 1) * (4 * kMaxTN * 4 * 64 * 4) * sizeof(float), 256) + align_up((size_t)(kStreamKWgs + 2) * sizeof(unsigned), 256);
+}
+
 extern "C" int ssdk_heads_fwd(const ssdk_head_level* levels, int n_levels, int batch, float* scores,
-                              long long scores_batch_stride, float* locs, long long locs_batch_stride, void* stream) {
+                              long long scores_batch_stride, float* locs, long long locs_batch_stride, void* workspace,
+                              size_t workspace_bytes, void* stream) {
     SSDK_REQUIRE(levels && n_levels > 0 && n_levels <= kMaxProblems, SSDK_E_INVALID, "ssdk_heads_fwd: n_levels=%d (1..%d)", n_levels, kMaxProblems);
     SSDK_REQUIRE(scores, SSDK_E_INVALID, "ssdk_heads_fwd: null scores");
     ConvProblem probs[kMaxProblems];
@@ -1760,7 +1905,14 @@ extern "C" int ssdk_heads_fwd(const ssdk_head_level* levels, int n_levels, int b
         finish_problem(g);
         probs[i] = g;
     }
-    return launch_group(probs, n_levels, false, (hipStream_t)stream);
+    StreamKWs sk{};
+    if (workspace && workspace_bytes >= ssdk_heads_fwd_workspace_bytes()) {
+        Carver c(workspace);
+        sk.partial = c.take<float>((size_t)(kStreamKWgs + 1) * (4 * kMaxTN * 4 * 64 * 4));
+        sk.flags = c.take<unsigned>((size_t)kStreamKWgs + 2);
+        sk.nwg = kStreamKWgs;
+    }
+    return launch_group(probs, n_levels, false, (hipStream_t)stream, false, false, nullptr, sk.nwg ? &sk : nullptr);
 }
 
 struct HeadsBwdWs {
