@@ -664,11 +664,12 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? (BK == 16 ? 3 : SSDK_
 }
 
 // Stream-K form of igemm_dma_kernel<false, false, false, 4> (see StreamK): `nwg` persistent workgroups, each walks its range of units.
-// Order inside a problem: M tile major, column block minor (a workgroup meets the column blocks of one M tile back to back: the A rows
-// it just streamed are still in its XCD's L2), K slice innermost.
+// Order inside a problem: column block major, M tile minor, K slice innermost; and the workgroups of one XCD (round-robin placement: equal
+// blockIdx % 8) take NEIGHBOURING ranges, so that at any moment an XCD works inside one or two column blocks: their weight rows
+// (2.3 MB per block of the 37 x 37 level) stay in its 4 MB L2 -- with M-tile-major order and ranges dealt out in blockIdx order every
+// XCD needed all of a level's weights at once and FETCH_SIZE tripled.
 __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_streamk_kernel(ConvGroup grp, StreamK sk) {
-    // (giving the workgroups of one XCD -- equal blockIdx % 8 -- neighbouring ranges measured the same within noise: 0.79-0.80 vs 0.80-0.81)
-    const int s = blockIdx.x;
+    const int s = (sk.nwg % 8 == 0) ? (int)(blockIdx.x % 8) * (sk.nwg / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
     // boundary b of the range split, snapped down to a whole K slice of the tile it falls in (both neighbours compute the same value)
     auto locate = [&](long long u, int& pi, int& m_tile, int& n_block, int& slice, int& tn) -> long long {
         pi = 0;
@@ -677,21 +678,21 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_streamk_k
             if (u >= sk.unit_begin[i]) pi = i;
         const ConvProblem& g = grp.p[pi];
         const int slices = g.ksize * g.ksize * (g.Cc / kBK);
-        const long long local = u - sk.unit_begin[pi];
-        const long long per_m = (long long)slices * g.tiles_n;
-        m_tile = (int)(local / per_m);
-        int rem = (int)(local - (long long)m_tile * per_m);
+        long long local = u - sk.unit_begin[pi];
         const int base_t = g.tiles_n / g.n_blocks, rem_t = g.tiles_n % g.n_blocks;
-        int nb = 0, acc_u = 0;
+        int nb = 0;
+        long long acc_u = 0;
         tn = base_t + (0 < rem_t ? 1 : 0);
-        while (nb + 1 < g.n_blocks && rem >= acc_u + slices * tn) {
-            acc_u += slices * tn;
+        while (nb + 1 < g.n_blocks && local >= acc_u + (long long)g.m_tiles * slices * tn) {
+            acc_u += (long long)g.m_tiles * slices * tn;
             ++nb;
             tn = base_t + (nb < rem_t ? 1 : 0);
         }
         n_block = nb;
-        slice = (rem - acc_u) / tn;
-        return sk.unit_begin[pi] + (long long)m_tile * per_m + acc_u + (long long)slice * tn;   // snapped position
+        local -= acc_u;
+        m_tile = (int)(local / ((long long)slices * tn));
+        slice = (int)(local - (long long)m_tile * slices * tn) / tn;
+        return sk.unit_begin[pi] + acc_u + ((long long)m_tile * slices + slice) * tn;   // snapped position
     };
     int pi, m_tile, n_block, slice, tn;
     long long u = s == 0 ? 0 : locate(sk.total_units * s / sk.nwg, pi, m_tile, n_block, slice, tn);

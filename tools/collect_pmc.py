@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel means of rocprofv3 --pmc passes -> profiles/r01_pmc.json.
+"""Per-kernel means of rocprofv3 --pmc passes -> profiles/rNN_pmc.json.
 
   python tools/collect_pmc.py <out.json> <config:bN> <dir-with-counter_collection-csvs>...
 
@@ -8,12 +8,13 @@ kernel (the first launch of each kernel, which includes cold caches, is dropped 
 import collections, csv, glob, json, sys
 
 KEYS = {   # json key suffix -> substring of the kernel name
-    'igemm_fwd_heads': 'igemm_dma_kernel<false, false, false, 4',
+    'igemm_fwd_heads': 'igemm_streamk_kernel',
+    'igemm_fwd_heads_tiles': 'igemm_dma_kernel<false, false, false, 4',
     'igemm_scatter_dgrad': 'igemm_dma_kernel<false, false, true, 4',
     'igemm_wgrad': 'igemm_wgrad_dma_kernel',
     'loss_bwd': 'loss_bwd_kernel', 'loss_fwd': 'loss_fwd_kernel', 'hnm_rows': 'hnm_rows_kernel', 'hnm_select': 'hnm_select_kernel',
     'pack_dy': 'pack_dy_kernel', 'assign': 'assign_kernel', 'gt_argmax': 'gt_argmax_kernel',
-    'post_select': 'post_select_kernel', 'post_nms': 'post_nms_kernel', 'post_merge': 'post_merge_kernel',
+    'post_select': 'post_select2_kernel', 'post_nms': 'post_nms_wave_kernel', 'post_merge': 'post_merge2_kernel', 'post_tau': 'post_tau_kernel',
 }
 out_path, tag, dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
