@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SSDK_VERSION 103
+#define SSDK_VERSION 104
 
 #define SSDK_OK 0
 #define SSDK_E_INVALID (-1)   /* bad argument / shape */
@@ -322,6 +322,19 @@ int ssdk_batchnorm_bwd_stats(const float* x, const float* y, const float* dy, lo
 int ssdk_batchnorm_bwd_apply(const float* x, const float* y, const float* dy, long long rows, int channels, const float* gamma,
                              const float* save_mean, const float* save_rstd, int relu, int training, const double* sums,
                              const double* sums_local, const double* total_rows, float* dx, float* dgamma, float* dbeta, void* stream);
+
+/*
+ * Chained form for a layer that keeps two `sums` buffers of its own (forward, backward), so that no zero-fill launch runs in front of
+ * the statistics: `sums` must hold zeros on entry; `zero_after` (NULL = none; a buffer of the same size that nothing else touches during
+ * the call) is zero-filled by the apply launch -- the forward call zeroes the layer's backward buffer, the backward call its forward
+ * buffer.  Training mode, statistics of this process's rows; otherwise exactly ssdk_batchnorm_fwd / ssdk_batchnorm_bwd.
+ */
+int ssdk_batchnorm_fwd_chained(const float* x, long long rows, int channels, const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, int64_t* num_batches_tracked, float momentum, float eps, int relu, float* y,
+                               float* save_mean, float* save_rstd, double* sums, double* zero_after, void* stream);
+int ssdk_batchnorm_bwd_chained(const float* x, const float* y, const float* dy, long long rows, int channels, const float* gamma,
+                               const float* save_mean, const float* save_rstd, int relu, float* dx, float* dgamma, float* dbeta,
+                               double* sums, double* zero_after, void* stream);
 
 /* ---- FPN top-down step (next-row f1) -------------------------------------------------------------------------------- */
 

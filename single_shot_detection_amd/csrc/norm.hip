@@ -126,8 +126,11 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float4* __restrict_
                                                        const double* __restrict__ sums, long long rows, float eps, float momentum,
                                                        float* __restrict__ running_mean, float* __restrict__ running_var,
                                                        float* __restrict__ save_mean, float* __restrict__ save_rstd,
-                                                       long long* __restrict__ num_batches_tracked, int count_on_device) {
+                                                       long long* __restrict__ num_batches_tracked, int count_on_device,
+                                                       double* __restrict__ zero_after) {
     const int C = C4 * 4;
+    if (zero_after && blockIdx.x == gridDim.x - 1)   // side job: zero-fill another sums buffer (nobody reads or writes it during this launch)
+        for (int c = threadIdx.x; c < 2 * C + 2; c += blockDim.x) zero_after[c] = 0.0;
     if (sums && count_on_device) rows = (long long)sums[2 * C];   // synchronised statistics: the row count of all ranks travels with the sums
     if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
     if (sums && blockIdx.x == 0) {
@@ -169,8 +172,11 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
                                                            long long rows, int C, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const double* __restrict__ sums,
                                                            const double* __restrict__ sums_local, int count_on_device, int relu, int training,
-                                                           float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                           float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           double* __restrict__ zero_after) {
     const long long total = rows * C;
+    if (zero_after && blockIdx.x == gridDim.x - 1)
+        for (int c = threadIdx.x; c < 2 * C + 2; c += blockDim.x) zero_after[c] = 0.0;
     const double inv_n = 1.0 / (count_on_device ? sums[2 * C] : (double)rows);
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
@@ -202,11 +208,11 @@ using namespace ssdk;
 // is two fill kernels in the runtime, one for the 16-byte aligned part and one for the tail)
 extern "C" size_t ssdk_batchnorm_workspace_bytes(int channels) { return align_up(((size_t)2 * channels + 2) * sizeof(double), 256); }
 
-extern "C" int ssdk_batchnorm_stats(const float* x, long long rows, int channels, double* sums, void* stream) {
+static int bn_stats(const float* x, long long rows, int channels, double* sums, bool zero_first, void* stream) {
     SSDK_REQUIRE(x && sums && rows > 0 && channels > 0, SSDK_E_INVALID, "ssdk_batchnorm_stats: bad arguments");
     SSDK_REQUIRE(channels % 4 == 0 && ((uintptr_t)x & 15) == 0, SSDK_E_UNSUPPORTED, "ssdk_batchnorm_stats: channels %% 4 != 0 or x not 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    SSDK_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * (2 * (size_t)channels + 2), s));
+    if (zero_first) SSDK_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * (2 * (size_t)channels + 2), s));
     const int rpb = kBnRows;
     hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, s, x, (const float*)nullptr,
                        (const float*)nullptr, rows, rpb, channels, (const float*)nullptr, (const float*)nullptr, 0, sums);
@@ -214,19 +220,43 @@ extern "C" int ssdk_batchnorm_stats(const float* x, long long rows, int channels
     return SSDK_OK;
 }
 
-extern "C" int ssdk_batchnorm_apply(const float* x, long long rows, int channels, const float* gamma, const float* beta,
-                                    float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
-                                    int relu, float* y, float* save_mean, float* save_rstd, const double* sums, int count_in_sums,
-                                    void* stream) {
+extern "C" int ssdk_batchnorm_stats(const float* x, long long rows, int channels, double* sums, void* stream) {
+    return bn_stats(x, rows, channels, sums, true, stream);
+}
+
+static int bn_apply(const float* x, long long rows, int channels, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, int64_t* num_batches_tracked, float momentum, float eps, int relu, float* y, float* save_mean,
+                    float* save_rstd, const double* sums, int count_in_sums, double* zero_after, void* stream) {
     SSDK_REQUIRE(x && y && save_mean && save_rstd && sums && rows > 0 && channels > 0, SSDK_E_INVALID, "ssdk_batchnorm_apply: bad arguments");
     SSDK_REQUIRE(channels % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, SSDK_E_UNSUPPORTED,
                  "ssdk_batchnorm_apply: channels %% 4 != 0 or buffers not 16-byte aligned");
     const long long n4 = rows * channels / 4;
     hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_blocks(n4, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)x, n4, channels / 4,
                        (const float4*)save_mean, (const float4*)save_rstd, (const float4*)gamma, (const float4*)beta, relu, (float4*)y, sums, rows,
-                       eps, momentum, running_mean, running_var, save_mean, save_rstd, (long long*)num_batches_tracked, count_in_sums);
+                       eps, momentum, running_mean, running_var, save_mean, save_rstd, (long long*)num_batches_tracked, count_in_sums, zero_after);
     SSDK_CHECK_LAUNCH("bn_apply_kernel");
     return SSDK_OK;
+}
+
+extern "C" int ssdk_batchnorm_apply(const float* x, long long rows, int channels, const float* gamma, const float* beta,
+                                    float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
+                                    int relu, float* y, float* save_mean, float* save_rstd, const double* sums, int count_in_sums,
+                                    void* stream) {
+    return bn_apply(x, rows, channels, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, relu, y, save_mean, save_rstd,
+                    sums, count_in_sums, nullptr, stream);
+}
+
+// The layer keeps two sums buffers of its own: `sums` holds zeros on entry (the layer's previous backward call zeroed it), `zero_after`
+// -- the buffer the backward will accumulate into -- is zero-filled by the apply launch.  No fill launch in front of the statistics.
+extern "C" int ssdk_batchnorm_fwd_chained(const float* x, long long rows, int channels, const float* gamma, const float* beta,
+                                          float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
+                                          int relu, float* y, float* save_mean, float* save_rstd, double* sums, double* zero_after,
+                                          void* stream) {
+    SSDK_REQUIRE(sums && sums != zero_after, SSDK_E_INVALID, "ssdk_batchnorm_fwd_chained: sums missing or equal to zero_after");
+    const int rc = bn_stats(x, rows, channels, sums, false, stream);
+    if (rc) return rc;
+    return bn_apply(x, rows, channels, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, relu, y, save_mean, save_rstd,
+                    sums, 0, zero_after, stream);
 }
 
 extern "C" int ssdk_batchnorm_fwd(const float* x, long long rows, int channels, const float* gamma, const float* beta,
@@ -250,17 +280,17 @@ extern "C" int ssdk_batchnorm_fwd(const float* x, long long rows, int channels, 
     const long long n4 = rows * channels / 4;
     hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_blocks(n4, 256)), dim3(256), 0, s, (const float4*)x, n4, channels / 4, (const float4*)save_mean,
                        (const float4*)save_rstd, (const float4*)gamma, (const float4*)beta, relu, (float4*)y, (const double*)nullptr, rows, eps,
-                       momentum, running_mean, running_var, save_mean, save_rstd, (long long*)nullptr, 0);
+                       momentum, running_mean, running_var, save_mean, save_rstd, (long long*)nullptr, 0, (double*)nullptr);
     SSDK_CHECK_LAUNCH("bn_apply_kernel");
     return SSDK_OK;
 }
 
-extern "C" int ssdk_batchnorm_bwd_stats(const float* x, const float* y, const float* dy, long long rows, int channels, const float* save_mean,
-                                        const float* save_rstd, int relu, double* sums, void* stream) {
+static int bn_bwd_stats(const float* x, const float* y, const float* dy, long long rows, int channels, const float* save_mean,
+                        const float* save_rstd, int relu, double* sums, bool zero_first, void* stream) {
     SSDK_REQUIRE(x && dy && sums && save_mean && save_rstd && rows > 0 && channels > 0 && (!relu || y), SSDK_E_INVALID,
                  "ssdk_batchnorm_bwd_stats: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    SSDK_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * (2 * (size_t)channels + 2), s));
+    if (zero_first) SSDK_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * (2 * (size_t)channels + 2), s));
     const int rpb = kBnRows;
     hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, s, x, y, dy, rows, rpb, channels, save_mean,
                        save_rstd, relu, sums);
@@ -268,18 +298,43 @@ extern "C" int ssdk_batchnorm_bwd_stats(const float* x, const float* y, const fl
     return SSDK_OK;
 }
 
-extern "C" int ssdk_batchnorm_bwd_apply(const float* x, const float* y, const float* dy, long long rows, int channels, const float* gamma,
-                                        const float* save_mean, const float* save_rstd, int relu, int training, const double* sums,
-                                        const double* sums_local, const double* total_rows, float* dx, float* dgamma, float* dbeta,
-                                        void* stream) {
+extern "C" int ssdk_batchnorm_bwd_stats(const float* x, const float* y, const float* dy, long long rows, int channels, const float* save_mean,
+                                        const float* save_rstd, int relu, double* sums, void* stream) {
+    return bn_bwd_stats(x, y, dy, rows, channels, save_mean, save_rstd, relu, sums, true, stream);
+}
+
+static int bn_bwd_apply(const float* x, const float* y, const float* dy, long long rows, int channels, const float* gamma,
+                        const float* save_mean, const float* save_rstd, int relu, int training, const double* sums,
+                        const double* sums_local, const double* total_rows, float* dx, float* dgamma, float* dbeta, double* zero_after,
+                        void* stream) {
     SSDK_REQUIRE(x && dy && dx && sums && save_mean && save_rstd && rows > 0 && channels > 0 && (!relu || y), SSDK_E_INVALID,
                  "ssdk_batchnorm_bwd_apply: bad arguments");
     SSDK_REQUIRE(!total_rows || total_rows == sums + 2 * (size_t)channels, SSDK_E_INVALID,
                  "ssdk_batchnorm_bwd_apply: total_rows must be the slot behind the sums (sums + 2 * channels) or NULL");
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_blocks(rows * channels, 256)), dim3(256), 0, (hipStream_t)stream, x, y, dy, rows, channels,
-                       save_mean, save_rstd, gamma, sums, sums_local ? sums_local : sums, total_rows ? 1 : 0, relu, training, dx, dgamma, dbeta);
+                       save_mean, save_rstd, gamma, sums, sums_local ? sums_local : sums, total_rows ? 1 : 0, relu, training, dx, dgamma, dbeta,
+                       zero_after);
     SSDK_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return SSDK_OK;
+}
+
+extern "C" int ssdk_batchnorm_bwd_apply(const float* x, const float* y, const float* dy, long long rows, int channels, const float* gamma,
+                                        const float* save_mean, const float* save_rstd, int relu, int training, const double* sums,
+                                        const double* sums_local, const double* total_rows, float* dx, float* dgamma, float* dbeta,
+                                        void* stream) {
+    return bn_bwd_apply(x, y, dy, rows, channels, gamma, save_mean, save_rstd, relu, training, sums, sums_local, total_rows, dx, dgamma, dbeta,
+                        nullptr, stream);
+}
+
+// backward of ssdk_batchnorm_fwd_chained: `sums` (zeroed by the forward's apply launch) takes the backward sums, `zero_after` -- the
+// layer's forward buffer -- is zero-filled for the next forward.
+extern "C" int ssdk_batchnorm_bwd_chained(const float* x, const float* y, const float* dy, long long rows, int channels, const float* gamma,
+                                          const float* save_mean, const float* save_rstd, int relu, float* dx, float* dgamma, float* dbeta,
+                                          double* sums, double* zero_after, void* stream) {
+    SSDK_REQUIRE(sums && sums != zero_after && dx, SSDK_E_INVALID, "ssdk_batchnorm_bwd_chained: bad arguments");
+    const int rc = bn_bwd_stats(x, y, dy, rows, channels, save_mean, save_rstd, relu, sums, false, stream);
+    if (rc) return rc;
+    return bn_bwd_apply(x, y, dy, rows, channels, gamma, save_mean, save_rstd, relu, 1, sums, nullptr, nullptr, dx, dgamma, dbeta, zero_after, stream);
 }
 
 extern "C" int ssdk_batchnorm_bwd(const float* x, const float* y, const float* dy, long long rows, int channels, const float* gamma,
