@@ -72,6 +72,10 @@ int ssdk_linspace_f32(float start, float end, int steps, float* out);
  */
 int ssdk_anchors_level(float* out, int layer_h, int layer_w, int nb, const float* hws_host, int img_w, int img_h,
                        void* stream);
+/* The same with the generator's `step` and `offset` given (ssd.py:111-118,138-139: step_w = step or img_w / layer_w; centres
+ * linspace(offset * step, (offset + n - 1) * step, n)); ssdk_anchors_level is step = img / n, offset = (.5, .5). */
+int ssdk_anchors_level_ex(float* out, int layer_h, int layer_w, int nb, const float* hws_host, double step_w, double step_h,
+                          double offset_x, double offset_y, void* stream);
 
 /* ---- target assignment (T1 + T2 + T3) ------------------------------------------------------------------------- */
 

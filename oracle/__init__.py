@@ -267,6 +267,46 @@ def anchors(cfg_anchor, size, levels, use_fma=True):
     return np.concatenate(outs, axis=0)
 
 
+def ssd_anchor_generator(img_wh, fmap_wh, aspect_ratios, min_scale=None, max_scale=None, min_size=None, max_size=None, step=None,
+                         offset=(.5, .5), num_branches=1, flip=True, use_fma=True):
+    """detection/anchor_generators/ssd.py:55-151 SsdAnchorGenerator(...).generate for one level, every constructor mode:
+    [H, W, num_boxes, 4] float32.  Arithmetic as the reference mixes it: fp32 linspace tables (ssd.py:102-104), fp32 products with
+    python scalars rounded to fp32 first (:125, :132-133), double square root of an fp32 product (:135-136), fp32 linspace of the
+    centres from python-float ends (:138-139)."""
+    import math
+    img_w, img_h = img_wh
+    W, H = fmap_wh
+    ars = []
+    for ar in aspect_ratios:                       # :86-92
+        ars.append(ar)
+        if ar > 1.0 and flip:
+            ars.append(1.0 / ar)
+    nr = len(ars) + 1
+    if min_size is not None and max_size is not None:
+        lin = linspace_f32(float(min_size), float(max_size), num_branches + 1, use_fma)
+        sizes = np.stack([lin, lin], 1)
+    else:
+        lin = linspace_f32(float(np.float32(min_scale)), float(np.float32(max_scale)), num_branches + 1, use_fma)
+        sizes = np.stack([lin * np.float32(img_w), lin * np.float32(img_h)], 1)
+    hws = np.empty((nr * num_branches, 2), np.float32)
+    for j in range(num_branches):
+        mn, mx = sizes[j], sizes[j + 1]
+        for i, r in enumerate(ars):
+            sr = np.float32(math.sqrt(r))
+            hws[j * nr + i] = (mn[0] * sr, mn[1] / sr)
+        hws[j * nr + nr - 1] = (np.float32(math.sqrt(float(np.float32(mn[0] * mx[0])))), np.float32(math.sqrt(float(np.float32(mn[1] * mx[1])))))
+    step_w = step if step is not None else img_w / W   # :111-118
+    step_h = step if step is not None else img_h / H
+    xs = linspace_f32(offset[0] * step_w, (offset[0] + W - 1) * step_w, W, use_fma)
+    ys = linspace_f32(offset[1] * step_h, (offset[1] + H - 1) * step_h, H, use_fma)
+    out = np.empty((H, W, nr * num_branches, 4), np.float32)
+    out[..., 0] = xs[None, :, None]
+    out[..., 1] = ys[:, None, None]
+    out[..., 2] = hws[None, None, :, 0]
+    out[..., 3] = hws[None, None, :, 1]
+    return out
+
+
 def mean_average_precision(pred, gt_list, num_classes, iou_threshold=0.5, voc=False):
     """detection/metrics/mean_average_precision.py:10-116 -> (mAP, ap[num_classes] with NaN for classes without ground truth)"""
     pred = _f32(np.asarray(pred, np.float32).reshape(-1, 7))

@@ -36,6 +36,7 @@ _SIGNATURES = {
     'ssdk_anchor_sizes_retina': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_int]),
     'ssdk_linspace_f32': (C.c_int, [C.c_float, C.c_float, C.c_int, C.c_void_p]),
     'ssdk_anchors_level': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'ssdk_anchors_level_ex': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     'ssdk_encode_ground_truth_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int]),
     'ssdk_encode_ground_truth': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                            C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,

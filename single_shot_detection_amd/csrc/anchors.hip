@@ -83,16 +83,16 @@ extern "C" int ssdk_anchor_sizes_retina(const double* ratios, int nratio, int le
     return nratio * scales_per_level;
 }
 
-extern "C" int ssdk_anchors_level(float* out, int layer_h, int layer_w, int nb, const float* hws_host, int img_w,
-                                  int img_h, void* stream) {
+extern "C" int ssdk_anchors_level_ex(float* out, int layer_h, int layer_w, int nb, const float* hws_host, double step_w, double step_h,
+                                     double offset_x, double offset_y, void* stream) {
     SSDK_REQUIRE(out && hws_host, SSDK_E_INVALID, "ssdk_anchors_level: null pointer");
     SSDK_REQUIRE(layer_h > 0 && layer_w > 0 && nb > 0 && nb <= kMaxBoxesPerCell, SSDK_E_INVALID,
                  "ssdk_anchors_level: bad shape H=%d W=%d nb=%d (nb <= %d)", layer_h, layer_w, nb, kMaxBoxesPerCell);
     HwTable hw;
     for (int k = 0; k < nb; ++k) { hw.w[k] = hws_host[2 * k]; hw.h[k] = hws_host[2 * k + 1]; }
-    const double step_w = (double)img_w / layer_w, step_h = (double)img_h / layer_h;  // ssd.py:117-118
-    const float xs = (float)(0.5 * step_w), xe = (float)((0.5 + layer_w - 1) * step_w);  // ssd.py:138
-    const float ys = (float)(0.5 * step_h), ye = (float)((0.5 + layer_h - 1) * step_h);  // ssd.py:139
+    // ssd.py:138-139: python-float products become the fp32 start / end of torch.linspace
+    const float xs = (float)(offset_x * step_w), xe = (float)((offset_x + layer_w - 1) * step_w);
+    const float ys = (float)(offset_y * step_h), ye = (float)((offset_y + layer_h - 1) * step_h);
     const float xstep = layer_w > 1 ? (xe - xs) / (float)(layer_w - 1) : 0.0f;
     const float ystep = layer_h > 1 ? (ye - ys) / (float)(layer_h - 1) : 0.0f;
     const int total = layer_h * layer_w * nb;
@@ -101,4 +101,11 @@ extern "C" int ssdk_anchors_level(float* out, int layer_h, int layer_w, int nb, 
                        nb, hw, xs, xe, xstep, ys, ye, ystep);
     SSDK_CHECK_LAUNCH("anchors_level_kernel");
     return SSDK_OK;
+}
+
+extern "C" int ssdk_anchors_level(float* out, int layer_h, int layer_w, int nb, const float* hws_host, int img_w,
+                                  int img_h, void* stream) {
+    SSDK_REQUIRE(layer_h > 0 && layer_w > 0, SSDK_E_INVALID, "ssdk_anchors_level: bad shape H=%d W=%d", layer_h, layer_w);
+    // ssd.py:117-118 step = img / n (python division), :138-139 offset .5
+    return ssdk_anchors_level_ex(out, layer_h, layer_w, nb, hws_host, (double)img_w / layer_w, (double)img_h / layer_h, 0.5, 0.5, stream);
 }

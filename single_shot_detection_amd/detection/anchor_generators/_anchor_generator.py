@@ -17,6 +17,10 @@ class _AnchorGenerator(object):
         """host float32 [num_boxes, 2] (w, h) table for an image size (w, h)."""
         raise NotImplementedError
 
+    def _grid(self, img_size, feature_map_size):
+        """(step_w, step_h, offset_x, offset_y) of the centre grid as python floats (ssd.py:111-118, :138-139)."""
+        return img_size[0] / feature_map_size[0], img_size[1] / feature_map_size[1], 0.5, 0.5
+
     def _generate_anchors(self, img_size, feature_map_size, device='cuda'):
         key = (tuple(img_size), tuple(feature_map_size), str(device))
         cache = self.__dict__.setdefault('_cache', {})
@@ -26,9 +30,10 @@ class _AnchorGenerator(object):
             hws = np.ascontiguousarray(self._box_sizes(img_size), dtype=np.float32)
             out = torch.empty((layer_h, layer_w, self.num_boxes, 4), dtype=torch.float32, device=device)
             _lib.require_cuda(out)
-            _lib.check(_lib.lib().ssdk_anchors_level(_lib.ptr(out), layer_h, layer_w, self.num_boxes,
-                                                     hws.ctypes.data_as(C.c_void_p), int(img_w), int(img_h),
-                                                     _lib.current_stream()), 'ssdk_anchors_level')
+            step_w, step_h, off_x, off_y = self._grid(img_size, feature_map_size)
+            _lib.check(_lib.lib().ssdk_anchors_level_ex(_lib.ptr(out), layer_h, layer_w, self.num_boxes,
+                                                        hws.ctypes.data_as(C.c_void_p), float(step_w), float(step_h), float(off_x), float(off_y),
+                                                        _lib.current_stream()), 'ssdk_anchors_level')
             cache[key] = out
         return cache[key]
 

@@ -483,6 +483,36 @@ def gen_mixup(out_dir):
     print(f'mixup -> {path} ({os.path.getsize(path) / 1e3:.1f} KB)')
 
 
+ANCHOR_OPTION_CASES = {
+    # name: (constructor kwargs of SsdAnchorGenerator, image (w, h), feature map (w, h))
+    'sizes_step': (dict(aspect_ratios=[1.0, 2.0], min_size=30, max_size=60, step=8), (300, 300), (38, 38)),
+    'branches_offset': (dict(aspect_ratios=[1.0, 2.0, 3.0], min_scale=0.2, max_scale=0.4, num_branches=2, offset=[0.3, 0.7]), (320, 256), (10, 8)),
+    'noflip_step': (dict(aspect_ratios=[1.5, 0.5, 2.0], min_scale=0.1, max_scale=0.3, flip=False, step=16), (512, 512), (32, 32)),
+    'sizes_branches3': (dict(aspect_ratios=[1.0], min_size=20.5, max_size=101.25, num_branches=3, step=4.5, offset=[0.0, 1.0]), (97, 131), (7, 5)),
+}
+ANCHOR_BUILDER_CASE = dict(num_scales=3, sizes=[30, 60, 111, 162], aspect_ratios=[[1.0, 2.0]] * 3, steps=[8, 16, 32], num_branches=[1, 2, 1])
+ANCHOR_BUILDER_MAPS = [(38, 38), (19, 19), (10, 10)]
+
+
+def gen_anchor_options(out_dir):
+    """SsdAnchorGenerator's other constructor modes (ssd.py:55-151: min_size / max_size, step, offset, num_branches, flip=False)
+    and build_anchor_generators with sizes / steps / num_branches (ssd.py:12-53), run through the reference."""
+    from detection.anchor_generators import ssd
+    res = {}
+    for name, (kw, img_wh, fmap_wh) in ANCHOR_OPTION_CASES.items():
+        gen = ssd.SsdAnchorGenerator(**kw)
+        img = torch.empty((1, 3, img_wh[1], img_wh[0]))
+        fmap = torch.empty((1, 8, fmap_wh[1], fmap_wh[0]))
+        res[name] = gen.generate(img, fmap).numpy().copy()
+        res[name + '_num_boxes'] = np.int64(gen.num_boxes)
+    gens = ssd.build_anchor_generators(**ANCHOR_BUILDER_CASE)
+    img = torch.empty((1, 3, 300, 300))
+    res['builder'] = torch.cat([g.generate(img, torch.empty((1, 8, h, w))).reshape(-1) for g, (w, h) in zip(gens, ANCHOR_BUILDER_MAPS)]).view(-1, 4).numpy()
+    path = os.path.join(out_dir, 'anchor_options.npz')
+    np.savez_compressed(path, **res)
+    print(f'anchor_options -> {path} ({os.path.getsize(path) / 1e3:.1f} KB)')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(REPO, 'tests', 'golden'))
@@ -501,6 +531,8 @@ def main():
         gen_map(args.out)
     if args.only in (None, 'mixup'):
         gen_mixup(args.out)
+    if args.only in (None, 'anchor_options'):
+        gen_anchor_options(args.out)
     for name, b in batches.items():
         if args.only in (None, name):
             gen_config(name, args.out, b)
