@@ -189,9 +189,11 @@ size_t ssdk_postprocess_workspace_bytes(int batch, int num_anchors, int num_clas
  * soft-NMS of box_utils.py:145-163 with sigma = soft_sigma) fused.
  *   scores DEV [batch, A, C] logits; locs DEV [batch, A, 4]; priors DEV [A, 4]
  *   softmax != 0: F.softmax and drop column 0 (classes 1..C-1); else sigmoid (classes 1..C)
- *   max_per_class in 1..256; max_total <= 0 means None
+ *   max_per_class: 1..256, or <= 0 for None (every candidate of a class enters NMS, box_utils.py:186), or > 256 -- the last two hard NMS
+ *   only, at most 131 072 anchors, a class then yields at most max_total rows (more can never reach the final top-max_total);
+ *   max_total <= 0 means None
  *   out    DEV [batch, out_cap, 6] rows (x1, y1, x2, y2, class, score); counts DEV int32 [batch];
- *          out_cap >= (max_total > 0 ? max_total : ncls * max_per_class)
+ *          out_cap >= (max_total > 0 ? max_total : ncls * max_per_class)   (max_per_class None: ncls * num_anchors)
  *   nms_candidates DEV int64 [batch] or NULL: number of boxes that entered NMS per image
  */
 int ssdk_postprocess(const float* scores, const float* locs, const float* priors, int batch, int num_anchors,

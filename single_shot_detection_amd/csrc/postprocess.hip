@@ -594,6 +594,123 @@ __device__ __forceinline__ void wave_find_digit(const unsigned* s_hist, unsigned
     *h_out = __shfl(h_at, src, kWave);
 }
 
+// ---- P2, any max_per_class (None, or more than the 256 the bit-matrix kernel holds): greedy selection ------------------------------
+// bf/utils/box_utils.py:166-194 with max_per_class=None lets every candidate of a class into NMS; a cap above 256 does not fit the
+// bit matrix of post_nms_kernel.  Here: boxes of an image decoded once (all classes share them), then one workgroup per (image, class)
+// repeats { best alive key -> keep it -> suppress the alive candidates it overlaps } with the alive set as a bit array in LDS.  The loop
+// stops after `cap` kept boxes: more than max_total boxes of one class can never reach the final top-max_total.
+__global__ void __launch_bounds__(kPostThreads) post_decode_kernel(const float4* __restrict__ locs, const float4* __restrict__ priors, int A, long long total,
+                                                                   float xy_scale, float wh_scale, float4* __restrict__ boxes) {
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const float4 l = locs[t], p = priors[t % A];
+        const float4 cen = make_float4(p.x + p.z * l.x / xy_scale, p.y + p.w * l.y / xy_scale, p.z * expf(l.z / wh_scale), p.w * expf(l.w / wh_scale));
+        boxes[t] = to_corners(cen);   // box_coder.py:55-57, box_utils.py:16-23
+    }
+}
+
+constexpr int kAnyMaxAnchors = 1 << 17;   // alive bits in LDS: 16 KB
+
+__global__ void __launch_bounds__(kPostThreads) post_nms_any_kernel(const float4* __restrict__ boxes, int A, int ncls, int K, int cap, float nms_thr,
+                                                                    const u64* __restrict__ cand, const int* __restrict__ cand_count,
+                                                                    float* __restrict__ pc_rows, float* __restrict__ pc_score, int* __restrict__ pc_count,
+                                                                    u64* __restrict__ nms_candidates) {
+    __shared__ unsigned s_dead[kAnyMaxAnchors / 32];   // bit k: candidate k of the list is cut off, kept already, or suppressed
+    __shared__ unsigned s_hist[256];
+    __shared__ u64 s_red[kPostThreads / kWave];
+    __shared__ u64 s_pick;
+    __shared__ u64 s_misc[2];
+    const int pc = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    const int i = pc / ncls, c = pc % ncls;
+    const int n = min(cand_count[pc], A);
+    if (n == 0) {
+        if (tid == 0) pc_count[pc] = 0;
+        return;
+    }
+    const u64* keys = cand + (size_t)pc * A;
+    const float4* ibox = boxes + (size_t)i * A;
+    for (int w = tid; w < (n + 31) / 32; w += kPostThreads) s_dead[w] = 0u;
+    __syncthreads();
+    int m = n;   // boxes that enter NMS
+    if (K > 0 && n > K) {   // box_utils.py:186-188: only the K best scores enter -- find the K-th largest key exactly (keys are distinct)
+        u64 prefix = 0;
+        unsigned above = 0;
+        for (int shift = 56; shift >= 0; shift -= 8) {
+            for (int b = tid; b < 256; b += kPostThreads) s_hist[b] = 0;
+            __syncthreads();
+            for (int k = tid; k < n; k += kPostThreads) {
+                const u64 key = keys[k];
+                if (shift == 56 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&s_hist[(unsigned)(key >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid < kWave) {
+                int digit;
+                unsigned cum, h;
+                wave_find_digit(s_hist, above, (unsigned)K, &digit, &cum, &h);
+                if (tid == 0) { s_misc[0] = prefix | ((u64)digit << shift); s_misc[1] = cum; }
+            }
+            __syncthreads();
+            prefix = s_misc[0];
+            above = (unsigned)s_misc[1];
+            __syncthreads();
+        }
+        for (int k = tid; k < n; k += kPostThreads)
+            if (keys[k] < prefix) atomicOr(&s_dead[k >> 5], 1u << (k & 31));
+        m = K;
+        __syncthreads();
+    }
+    int kept = 0;
+    while (kept < cap) {
+        // best alive key
+        u64 best = 0;
+        for (int k = tid; k < n; k += kPostThreads) {
+            if ((s_dead[k >> 5] >> (k & 31)) & 1u) continue;
+            const u64 key = keys[k];
+            best = key > best ? key : best;
+        }
+        best = wave_allreduce(best, OpMaxU64());
+        if (lane == 0) s_red[wave] = best;
+        __syncthreads();
+        if (tid == 0) {
+            u64 b = s_red[0];
+            for (int w = 1; w < kPostThreads / kWave; ++w) b = s_red[w] > b ? s_red[w] : b;
+            s_pick = b;
+        }
+        __syncthreads();
+        const u64 pick = s_pick;
+        if (pick == 0) break;
+        const unsigned pa = 0xFFFFFFFFu - (unsigned)(pick & 0xFFFFFFFFull);
+        const float4 pb = ibox[min(pa, (unsigned)(A - 1))];
+        const float parea = (pb.z - pb.x) * (pb.w - pb.y);
+        if (tid == 0) {
+            float* o = pc_rows + ((size_t)pc * cap + kept) * 6;
+            o[0] = pb.x; o[1] = pb.y; o[2] = pb.z; o[3] = pb.w;
+            o[4] = (float)(c + 1);   // postprocessor.py:66
+            o[5] = __uint_as_float((unsigned)(pick >> 32));
+            pc_score[(size_t)pc * cap + kept] = o[5];
+        }
+        // the pick itself and everything it overlaps leave the alive set (torchvision.ops.nms contract: IoU > threshold)
+        for (int k = tid; k < n; k += kPostThreads) {
+            if ((s_dead[k >> 5] >> (k & 31)) & 1u) continue;
+            const u64 key = keys[k];
+            bool kill = key == pick;
+            if (!kill) {
+                const float4 bj = ibox[min(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull), (unsigned)(A - 1))];
+                const float iw = clamp0(tminf(pb.z, bj.z) - tmaxf(pb.x, bj.x));
+                const float ih = clamp0(tminf(pb.w, bj.w) - tmaxf(pb.y, bj.y));
+                const float inter = iw * ih;
+                kill = inter / (parea + (bj.z - bj.x) * (bj.w - bj.y) - inter) > nms_thr;
+            }
+            if (kill) atomicOr(&s_dead[k >> 5], 1u << (k & 31));
+        }
+        ++kept;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        pc_count[pc] = kept;
+        if (nms_candidates) atomicAdd(nms_candidates + i, (u64)m);
+    }
+}
+
 // One workgroup of the select pass owns a run of `tiles_per_wg` consecutive tiles of one image AND a segment of every class list of
 // that image (capacity = its rows): a hit's slot is the class's running count inside the workgroup (an LDS atomic), so nothing is
 // reserved through global memory -- no returning global atomic sits on the critical path of a tile (it was 3-5 us of every tile's
@@ -1203,10 +1320,44 @@ static PostWs2 carve_post_ws2(void* ws, size_t npc, size_t K, const PostPlan& p,
     return w;
 }
 
+// per-class row capacity of the greedy path (max_per_class None or > 256): a class never contributes more than max_total rows
+static inline long long any_cap(int num_anchors, int max_per_class, int max_total) {
+    const long long per_class = max_per_class > 0 ? (max_per_class < num_anchors ? max_per_class : num_anchors) : num_anchors;
+    return max_total > 0 && max_total < per_class ? max_total : per_class;
+}
+
+struct PostWsAny {
+    u64* cand;
+    int* cand_count;
+    float4* boxes;
+    float* pc_rows;
+    float* pc_score;
+    int* pc_count;
+    u64* merge_keys;
+};
+static PostWsAny carve_post_any(void* ws, size_t B, size_t A, size_t ncls, size_t cap, size_t* total) {
+    Carver c(ws);
+    PostWsAny w;
+    w.cand = c.take<u64>(B * ncls * A);
+    w.cand_count = c.take<int>(B * ncls);
+    w.boxes = c.take<float4>(B * A);
+    w.pc_rows = c.take<float>(B * ncls * cap * 6);
+    w.pc_score = c.take<float>(B * ncls * cap);
+    w.pc_count = c.take<int>(B * ncls);
+    w.merge_keys = c.take<u64>(B * ncls * cap);
+    if (total) *total = c.off;
+    return w;
+}
+
 extern "C" size_t ssdk_postprocess_workspace_bytes(int batch, int num_anchors, int num_classes, int softmax, int max_per_class,
                                                    int max_total) {
-    if (batch <= 0 || num_anchors <= 0 || num_classes <= 0 || max_per_class <= 0) return 0;
+    if (batch <= 0 || num_anchors <= 0 || num_classes <= 0) return 0;
     const size_t ncls = (size_t)ncls_of(num_classes, softmax);
+    if (max_per_class <= 0 || max_per_class > kMaxPerClass) {   // None (<= 0) or beyond the bit-matrix kernel: the greedy path
+        size_t t = 0;
+        carve_post_any(nullptr, (size_t)batch, (size_t)num_anchors, ncls, (size_t)any_cap(num_anchors, max_per_class, max_total), &t);
+        return t;
+    }
     size_t total = 0, total2 = 0;
     carve_post_ws(nullptr, (size_t)batch, (size_t)num_anchors, ncls, (size_t)max_per_class, &total);
     const PostPlan p = make_plan(batch, num_anchors, num_classes, softmax, max_per_class, max_total);
@@ -1295,22 +1446,51 @@ extern "C" int ssdk_postprocess(const float* scores, const float* locs, const fl
                  "ssdk_postprocess: batch=%d anchors=%d classes=%d", batch, num_anchors, num_classes);
     SSDK_REQUIRE(scores && locs && priors && out && counts, SSDK_E_INVALID, "ssdk_postprocess: null pointer");
     SSDK_REQUIRE(((uintptr_t)locs & 15) == 0 && ((uintptr_t)priors & 15) == 0, SSDK_E_INVALID, "ssdk_postprocess: locs/priors must be 16-byte aligned");
-    SSDK_REQUIRE(max_per_class >= 1 && max_per_class <= kMaxPerClass, SSDK_E_UNSUPPORTED,
-                 "ssdk_postprocess: max_per_class=%d outside 1..%d (None is not supported on the GPU path)", max_per_class, kMaxPerClass);
+    const bool any_k = max_per_class <= 0 || max_per_class > kMaxPerClass;   // None, or beyond the bit-matrix kernel
+    SSDK_REQUIRE(!(any_k && soft_nms), SSDK_E_UNSUPPORTED, "ssdk_postprocess: soft-NMS takes max_per_class in 1..%d (got %d)", kMaxPerClass, max_per_class);
     SSDK_REQUIRE(max_total <= kSortCap, SSDK_E_UNSUPPORTED, "ssdk_postprocess: max_total=%d > %d", max_total, kSortCap);
     SSDK_REQUIRE(!soft_nms || soft_sigma > 0.0f, SSDK_E_INVALID, "ssdk_postprocess: soft-NMS sigma must be > 0");
     const int ncls = ncls_of(num_classes, softmax);
+    const long long per_class_cap = any_k ? any_cap(num_anchors, max_per_class, max_total) : max_per_class;
     SSDK_REQUIRE(out_cap >= (max_total > 0 ? max_total : 1), SSDK_E_INVALID, "ssdk_postprocess: out_cap=%d too small", out_cap);
-    SSDK_REQUIRE(max_total > 0 || (long long)out_cap >= (long long)ncls * max_per_class, SSDK_E_INVALID,
-                 "ssdk_postprocess: out_cap=%d < ncls*max_per_class with max_total=None", out_cap);
+    SSDK_REQUIRE(max_total > 0 || (long long)out_cap >= (long long)ncls * per_class_cap, SSDK_E_INVALID,
+                 "ssdk_postprocess: out_cap=%d < ncls * rows per class with max_total=None", out_cap);
     SSDK_REQUIRE(workspace && workspace_bytes >= ssdk_postprocess_workspace_bytes(batch, num_anchors, num_classes, softmax, max_per_class, max_total),
                  SSDK_E_WORKSPACE, "ssdk_postprocess: workspace too small");
     SSDK_REQUIRE((long long)batch * ncls < 2147483647LL && batch <= 65535, SSDK_E_INVALID, "ssdk_postprocess: grid too large");
     hipStream_t s = (hipStream_t)stream;
     const PostPlan plan = make_plan(batch, num_anchors, num_classes, softmax, max_per_class, max_total);
-    if (plan.ok && !soft_nms)
+    if (plan.ok && !soft_nms && !any_k)
         return postprocess_v2(plan, scores, locs, priors, batch, num_anchors, num_classes, softmax, score_threshold, max_per_class, nms_threshold,
                               max_total, xy_scale, wh_scale, out, out_cap, counts, nms_candidates, workspace, s);
+    if (any_k) {
+        // ---- greedy path: max_per_class None (every candidate enters NMS, box_utils.py:186 skipped) or > 256
+        SSDK_REQUIRE(num_anchors <= kAnyMaxAnchors, SSDK_E_UNSUPPORTED, "ssdk_postprocess: max_per_class=None / > %d takes at most %d anchors", kMaxPerClass,
+                     kAnyMaxAnchors);
+        const int cap = (int)per_class_cap;
+        PostWsAny w = carve_post_any(workspace, (size_t)batch, (size_t)num_anchors, (size_t)ncls, (size_t)cap, nullptr);
+        SSDK_CHECK_HIP(hipMemsetAsync(w.cand_count, 0, sizeof(int) * (size_t)batch * ncls, s));
+        if (nms_candidates) SSDK_CHECK_HIP(hipMemsetAsync(nms_candidates, 0, sizeof(int64_t) * (size_t)batch, s));
+        const int tiles = cdiv(num_anchors, kPostTileRows);
+        const size_t lds = align_up((size_t)kPostTileRows * num_classes * 4, 16) + (size_t)ncls * 4;
+        SSDK_REQUIRE(lds <= 160 * 1024 - 1024, SSDK_E_UNSUPPORTED, "ssdk_postprocess: num_classes=%d needs %zu bytes of LDS", num_classes, lds);
+        SSDK_CHECK_HIP(hipFuncSetAttribute((const void*)post_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(post_select_kernel, dim3(tiles < 1024 ? tiles : 1024, batch), dim3(kPostThreads), lds, s, scores, num_anchors, num_classes, softmax,
+                           score_threshold, tiles, w.cand, w.cand_count);
+        SSDK_CHECK_LAUNCH("post_select_kernel");
+        const long long total = (long long)batch * num_anchors;
+        hipLaunchKernelGGL(post_decode_kernel, dim3((unsigned)(cdiv((int)((total + 255) / 256), 1) < 4096 ? (total + 255) / 256 : 4096)), dim3(kPostThreads), 0, s,
+                           (const float4*)locs, (const float4*)priors, num_anchors, total, xy_scale, wh_scale, w.boxes);
+        SSDK_CHECK_LAUNCH("post_decode_kernel");
+        hipLaunchKernelGGL(post_nms_any_kernel, dim3(batch * ncls), dim3(kPostThreads), 0, s, (const float4*)w.boxes, num_anchors, ncls,
+                           max_per_class > 0 ? max_per_class : 0, cap, nms_threshold, w.cand, w.cand_count, w.pc_rows, w.pc_score, w.pc_count,
+                           (u64*)nms_candidates);
+        SSDK_CHECK_LAUNCH("post_nms_any_kernel");
+        hipLaunchKernelGGL(post_merge_kernel, dim3(batch), dim3(kPostThreads), sizeof(int) * (size_t)(ncls + 1), s, ncls, cap, max_total, w.pc_rows,
+                           w.pc_count, w.merge_keys, out, out_cap, counts);
+        SSDK_CHECK_LAUNCH("post_merge_kernel");
+        return SSDK_OK;
+    }
     // ---- general pipeline: soft-NMS, max_per_class > 128, more than 96 classes
     PostWs w = carve_post_ws(workspace, (size_t)batch, (size_t)num_anchors, (size_t)ncls, (size_t)max_per_class, nullptr);
     SSDK_CHECK_HIP(hipMemsetAsync(w.cand_count, 0, sizeof(int) * (size_t)batch * ncls, s));

@@ -15,8 +15,8 @@ class Postprocessor(object):
             raise ValueError(f'Wrong value for score_converter: {score_converter}')
         self.soft = bool(self.nms_args.get('soft', False))      # box_utils.py:166 `soft`, `sigma`
         self.sigma = float(self.nms_args.get('sigma', 0.5))
-        if self.nms_args.get('max_per_class') is None:
-            raise NotImplementedError('max_per_class=None is not supported on the GPU path (1..256)')
+        if self.nms_args.get('max_per_class') is None and self.soft:
+            raise NotImplementedError('soft-NMS takes max_per_class in 1..256 on the GPU path')
         self.last_nms_candidates = None
 
     def postprocess(self, prediction, priors):
@@ -46,9 +46,13 @@ class Postprocessor(object):
         num_classes = b_scores.numel() // (batch_size * num_priors)
         softmax = 1 if self.score_converter == 'SOFTMAX' else 0
         ncls = num_classes - 1 if softmax else num_classes
-        max_per_class = int(self.nms_args['max_per_class'])
+        mpc = self.nms_args.get('max_per_class')
+        max_per_class = int(mpc) if mpc is not None else 0          # box_utils.py:166 max_per_class=None: every candidate enters NMS
         max_total = int(self.max_total) if self.max_total is not None else 0
-        cap = max_total if max_total > 0 else ncls * max_per_class
+        cap = max_total if max_total > 0 else ncls * (min(max_per_class, num_priors) if max_per_class > 0 else num_priors)
+        if cap * batch_size * 24 > (8 << 30):
+            raise ValueError('postprocess without max_total and without max_per_class would return up to '
+                             f'{cap} rows per image: set max_total')
         dev = b_scores.device
         need = lib.ssdk_postprocess_workspace_bytes(batch_size, num_priors, num_classes, softmax, max_per_class, max_total)
         ws = _lib.scratch(need, dev, 'postprocess')   # lives for this call only

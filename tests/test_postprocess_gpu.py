@@ -131,6 +131,36 @@ def test_postprocess_ties_and_identical_boxes():
 def test_unsupported_options_raise():
     with pytest.raises(ValueError):
         Postprocessor(BoxCoder(10., 5.), 0.01, {'max_per_class': 100, 'overlap_threshold': .45}, 'TANH', 200)
-    p = Postprocessor(BoxCoder(10., 5.), 0.01, {'max_per_class': 1000, 'overlap_threshold': .45}, 'SOFTMAX', 200)
-    with pytest.raises(ValueError):
+    with pytest.raises(NotImplementedError):   # soft-NMS without a per-class cap
+        Postprocessor(BoxCoder(10., 5.), 0.01, {'overlap_threshold': .45, 'soft': True}, 'SOFTMAX', 200)
+    p = Postprocessor(BoxCoder(10., 5.), 0.01, {'max_per_class': 1000, 'overlap_threshold': .45, 'soft': True}, 'SOFTMAX', 200)
+    with pytest.raises(ValueError):            # soft-NMS beyond the 256-box kernel
         p.postprocess((torch.zeros((1, 8 * 3), device='cuda'), torch.zeros((1, 8 * 4), device='cuda')), torch.ones((8, 4), device='cuda'))
+
+
+@pytest.mark.parametrize('variant', ['rand', 'trained'])
+def test_postprocess_without_per_class_cap_vs_oracle(variant):
+    """nms(max_per_class=None) (bf/utils/box_utils.py:166-188: every candidate of a class enters NMS) and a cap above the 256 boxes of the
+    bit-matrix kernel: the greedy path, against the oracle (which skips the top-k for max_per_class=None like the reference)."""
+    cfg, g, logits, locs, softmax = inputs('ssd_mb2_voc', variant, batch=2, seeds=(51, 52))
+    anchors = torch.from_numpy(g['anchors']).cuda()
+    pred = (torch.from_numpy(logits).cuda(), torch.from_numpy(locs).cuda())
+    for mpc, mt in ((None, 200), (300, 200), (1000, 50)):
+        nms = {'overlap_threshold': cfg['nms_thr']}
+        if mpc is not None:
+            nms['max_per_class'] = mpc
+        post = Postprocessor(BoxCoder(10.0, 5.0), score_threshold=0.01, nms=nms, score_converter=cfg['score_converter'], max_total=mt)
+        out = post.postprocess(pred, anchors)
+        ref, cand = oracle.postprocess(logits, locs, g['anchors'], softmax=softmax, max_per_class=mpc, nms_thr=cfg['nms_thr'], max_total=mt, return_cand=True)
+        compare(out, ref)
+        assert np.array_equal(post.last_nms_candidates.cpu().numpy(), cand)
+    # neither cap: everything that survives NMS, in class order (postprocessor.py:68-70)
+    A, Cn = 400, 5
+    rng = np.random.default_rng(3)
+    pri = np.concatenate([rng.uniform(20, 280, (A, 2)), rng.uniform(10, 80, (A, 2))], 1).astype(np.float32)
+    lg = rng.standard_normal((2, A * Cn)).astype(np.float32)
+    lc = (rng.standard_normal((2, A * 4)) * 0.3).astype(np.float32)
+    post = Postprocessor(BoxCoder(10.0, 5.0), score_threshold=0.05, nms={'overlap_threshold': 0.45}, score_converter='SOFTMAX', max_total=None)
+    out = post.postprocess((torch.from_numpy(lg).cuda(), torch.from_numpy(lc).cuda()), torch.from_numpy(pri).cuda())
+    ref = oracle.postprocess(lg, lc, pri, softmax=True, score_thr=0.05, max_per_class=None, nms_thr=0.45, max_total=None)
+    compare(out, ref)
