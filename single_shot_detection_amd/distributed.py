@@ -21,6 +21,27 @@ def grad_sink(param):
     return view.detach()
 
 
+_avg_ok = {}
+
+
+def _avg_supported(group, device):
+    """ReduceOp.AVG exists in NCCL >= 2.10 / RCCL; gloo has no such op.  Probed once per (backend, group) with a one-element
+    all-reduce instead of assumed: an unsupported op must cost a division per step, not the run."""
+    key = (dist.get_backend(group), id(group))
+    if key not in _avg_ok:
+        ok = False
+        if key[0] == 'nccl':
+            try:
+                t = torch.full((1,), float(dist.get_rank(group) + 1), dtype=torch.float32, device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
+                n = dist.get_world_size(group)
+                ok = abs(float(t.item()) - (n + 1) / 2.0) < 1e-4
+            except Exception:
+                ok = False
+        _avg_ok[key] = ok
+    return _avg_ok[key]
+
+
 class GradBucket(object):
     """The gradients of ``params`` as ONE flat fp32 buffer: one collective per bucket instead of one per parameter.
 
@@ -85,7 +106,7 @@ class GradBucket(object):
         self._post_div = None
         op = dist.ReduceOp.SUM
         if average:
-            if dist.get_backend(group) == 'nccl':
+            if _avg_supported(group, self.flat.device):
                 op = dist.ReduceOp.AVG
             else:
                 self._post_div = world
