@@ -6,6 +6,7 @@ import itertools
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from ... import ops
 from ...utils import filter_kwargs
@@ -73,8 +74,6 @@ class FeaturePyramid(Features):
                  activation={'name': 'ReLU', 'args': {'inplace': True}}, initializer={'name': 'xavier_normal_'}, **kwargs):
         super(FeaturePyramid, self).__init__(base, out_layers, initializer=initializer, **kwargs)
         assert pyramid_layers >= len(out_layers)
-        if interpolation_mode != 'nearest':
-            raise NotImplementedError("FeaturePyramid: only interpolation_mode='nearest' is on the GPU path")
         self.pyramid_layers = pyramid_layers
         self.pyramid_channels = pyramid_channels
         self.interpolation_mode = interpolation_mode
@@ -100,7 +99,7 @@ class FeaturePyramid(Features):
         sources, _ = super(FeaturePyramid, self).forward(x)
         features = [ops.conv2d(s, lat.weight, lat.bias) for s, lat in zip(sources, self.pyramid_lateral)]   # features.py:104
         for i in reversed(range(len(features) - 1)):                                                       # :106-107
-            features[i] = ops.upsample_add(features[i], features[i + 1])
+            features[i] = _upsample_add(features[i], features[i + 1], self.interpolation_mode)
         outputs = []
         for output_layer, feature in itertools.zip_longest(self.pyramid_output, features):                 # :109-115
             outputs.append(output_layer(feature if feature is not None else outputs[-1]))
@@ -108,6 +107,16 @@ class FeaturePyramid(Features):
 
     def get_out_channels(self):
         return [self.pyramid_channels] * self.pyramid_layers
+
+
+def _upsample_add(fine, coarse, mode):
+    """fine + F.interpolate(coarse, size of fine, mode) (features.py:107-108, :264-265).  'nearest' -- the default and what every sample
+    config uses -- is the libssdk kernel; any other mode is torch's own interpolation (the neck is PyTorch-ROCm territory, SURVEY.md 2
+    row 16), said once."""
+    if mode == 'nearest':
+        return ops.upsample_add(fine, coarse)
+    conv._warn_stock('interpolate', f"interpolation_mode={mode!r}")
+    return fine + F.interpolate(coarse, size=fine.shape[2:], mode=mode)
 
 
 def update_existing(dict1, dict2):
@@ -124,8 +133,6 @@ class ThinnedUshapeModule(nn.Module):
     def __init__(self, in_channels, inner_channels, out_channels, num_scales, interpolation_mode='nearest', use_depthwise=False,
                  activation={'name': 'ReLU', 'args': {'inplace': True}}, initializer={'name': 'xavier_normal_'}):
         super(ThinnedUshapeModule, self).__init__()
-        if interpolation_mode != 'nearest':
-            raise NotImplementedError("ThinnedUshapeModule: only interpolation_mode='nearest' is on the GPU path")
         self.interpolation_mode = interpolation_mode
         self.down_layers = nn.ModuleList()
         self.up_layers = nn.ModuleList()
@@ -147,7 +154,7 @@ class ThinnedUshapeModule(nn.Module):
             down_path.append(x)
         up_path = [x]
         for down_x, layer in zip(reversed(down_path[:-1]), reversed(self.up_layers)):
-            x = ops.upsample_add(down_x, layer(x))   # features.py:263-265: interpolate to the skip's size, add the skip
+            x = _upsample_add(down_x, layer(x), self.interpolation_mode)   # features.py:263-265: interpolate to the skip's size, add the skip
             up_path.append(x)
         return [layer(x) for layer, x in zip(reversed(self.smooth_layers), up_path)]
 
