@@ -51,8 +51,9 @@ def test_multibox_loss_constructor_surface():
 def test_postprocessor_constructor_surface():
     with pytest.raises(ValueError):
         Postprocessor(BoxCoder(10., 5.), 0.01, {'max_per_class': 100, 'overlap_threshold': .45}, 'TANH')
-    with pytest.raises(NotImplementedError):
-        Postprocessor(BoxCoder(10., 5.), 0.01, {'overlap_threshold': .45}, 'SOFTMAX')
+    Postprocessor(BoxCoder(10., 5.), 0.01, {'overlap_threshold': .45}, 'SOFTMAX')            # max_per_class=None: every candidate enters NMS
+    with pytest.raises(NotImplementedError):                                                  # ... but not with soft-NMS
+        Postprocessor(BoxCoder(10., 5.), 0.01, {'overlap_threshold': .45, 'soft': True}, 'SOFTMAX')
 
 
 def test_product_path_refuses_cpu_tensors():
