@@ -62,12 +62,15 @@ class _ConvFn(torch.autograd.Function):
         B = xs[0].shape[0]
         stream = _lib.current_stream()
         need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and has_bias
+        # weight gradients of single-input convolutions can wait for the end of the backward pass: nothing in the chain depends on
+        # them, and eight small launches that each underfill the chip become one grouped launch (_flush_weight_gradients)
+        defer = _defer_wgrad and n == 1 and (need_w or need_b) and ctx.params[0].is_leaf and (ctx.params[1] is None or ctx.params[1].is_leaf)
         dw = db = None
-        if need_w:   # zeroed by the library
+        if need_w and not defer:   # zeroed by the library
             dw = grad_sink(ctx.params[0])
             if dw is None or dw.stride() != w.stride():
                 dw = torch.empty_like(w, memory_format=torch.channels_last)
-        if need_b:
+        if need_b and not defer:
             db = grad_sink(ctx.params[1])
             if db is None:
                 db = torch.empty((cout,), dtype=torch.float32, device=w.device)
@@ -88,10 +91,77 @@ class _ConvFn(torch.autograd.Function):
             d.x, d.hin, d.win, d.cin = _dp(x), x.shape[2], x.shape[3], cin
             d.w, d.bias, d.cout, d.ksize, d.stride, d.pad, d.relu = _dp(w), None, cout, k, stride, pad, 0
             d.dy, d.dx, d.dw, d.db = _dp(dy), _dp(dx), _dp(dw), _dp(db)
+        if defer:
+            _pending_wgrads.append(dict(x=xs[0], dy=keep[0], w=w, weight=ctx.params[0] if need_w else None, bias=ctx.params[1] if need_b else None,
+                                        stride=stride, pad=pad))
+            if len(_pending_wgrads) == 1:
+                torch.autograd.Variable._execution_engine.queue_callback(_flush_weight_gradients)
+            if all(dx is None for dx in dxs):
+                return (None, None, None, None, None) + tuple(dxs)
         need = lib.ssdk_conv2d_bwd_workspace_bytes(arr, n, B)
         ws = _lib.scratch(need, w.device, 'conv2d_bwd')
         _lib.check(lib.ssdk_conv2d_bwd(arr, n, B, 0, _dp(ws), ws.numel(), stream), 'ssdk_conv2d_bwd')
         return (dw, db, None, None, None) + tuple(dxs)
+
+
+_defer_wgrad = False
+_pending_wgrads = []
+
+
+def defer_weight_gradients(enabled=True):
+    """Weight (and bias) gradients of single-input ``conv2d`` calls are computed at the END of the backward pass, all in grouped
+    launches (up to eight convolutions each), and written into ``param.grad`` directly -- autograd's AccumulateGrad never sees them, so
+    do NOT enable this under a wrapper that hooks it (torch DistributedDataParallel); libssdk's own GradBucket path is fine (the flush
+    runs before ``backward()`` returns).  Returns the previous setting."""
+    global _defer_wgrad
+    prev = _defer_wgrad
+    _defer_wgrad = bool(enabled)
+    return prev
+
+
+def _flush_weight_gradients():
+    jobs = list(_pending_wgrads)
+    del _pending_wgrads[:]
+    lib = _lib.lib()
+    stream = _lib.current_stream()
+    for first in range(0, len(jobs), 8):
+        group = jobs[first:first + 8]
+        if len({j['x'].shape[0] for j in group}) != 1:
+            group_list = [[j] for j in group]   # (a grouped call shares the batch size)
+        else:
+            group_list = [group]
+        for grp in group_list:
+            arr = (_lib.ConvDesc * len(grp))()
+            outs = []
+            for i, j in enumerate(grp):
+                w, x = j['w'], j['x']
+                cout, cin, k, _ = w.shape
+                dw = db = None
+                if j['weight'] is not None:
+                    dw = grad_sink(j['weight'])
+                    if dw is None or dw.stride() != w.stride():
+                        dw = torch.empty_like(w, memory_format=torch.channels_last)
+                if j['bias'] is not None:
+                    db = grad_sink(j['bias'])
+                    if db is None:
+                        db = torch.empty((cout,), dtype=torch.float32, device=w.device)
+                d = arr[i]
+                d.x, d.hin, d.win, d.cin = _dp(x), x.shape[2], x.shape[3], cin
+                d.w, d.bias, d.cout, d.ksize, d.stride, d.pad, d.relu = _dp(w), None, cout, k, j['stride'], j['pad'], 0
+                d.dy, d.dx, d.dw, d.db = _dp(j['dy']), None, _dp(dw), _dp(db)
+                outs.append((j['weight'], dw, j['bias'], db))
+            B = grp[0]['x'].shape[0]
+            need = lib.ssdk_conv2d_bwd_workspace_bytes(arr, len(grp), B)
+            ws = _lib.scratch(need, grp[0]['w'].device, 'conv2d_bwd')
+            _lib.check(lib.ssdk_conv2d_bwd(arr, len(grp), B, 0, _dp(ws), ws.numel(), stream), 'ssdk_conv2d_bwd')
+            for weight, dw, bias, db in outs:
+                for p_, g_ in ((weight, dw), (bias, db)):
+                    if p_ is None:
+                        continue
+                    if p_.grad is None:
+                        p_.grad = g_
+                    else:
+                        p_.grad = p_.grad + g_
 
 
 def conv2d(xs, weight, bias=None, stride=1, padding=0, relu=False):

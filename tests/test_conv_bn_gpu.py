@@ -429,3 +429,36 @@ def test_sync_batchnorm_two_ranks_equal_one_process_on_the_whole_batch(tmp_path)
     for n, b in ref.named_buffers():
         for r in range(2):
             np.testing.assert_allclose(outs[r]['b_' + n], b.numpy(), rtol=1e-4, atol=1e-5, err_msg=n)
+
+
+def test_deferred_weight_gradients_equal_immediate_ones():
+    """ops.defer_weight_gradients: the pyramid tail's weight gradients computed in one grouped launch at the end of the backward pass
+    (written into param.grad directly) are the gradients of the immediate path; a second backward accumulates like autograd does."""
+    import copy
+    from single_shot_detection_amd import ops
+    rng = np.random.default_rng(21)
+    extras = detector_builder.get_extras([512], layers=(('s', 512), ('s', 256), ('s', 256), ('s', 256)))
+    _randomize(extras, rng)
+    a, b = copy.deepcopy(extras).cuda(), copy.deepcopy(extras).cuda()
+    x_np = rng.standard_normal((2, 512, 18, 18), dtype=np.float32)
+
+    def run(mod, defer, times=1):
+        prev = ops.defer_weight_gradients(defer)
+        try:
+            for _ in range(times):
+                x = torch.from_numpy(x_np).cuda().requires_grad_(True)
+                y, outs = x, []
+                for blk in mod:
+                    y = blk(y)
+                    outs.append(y)
+                sum((o * o).sum() for o in outs).backward()
+        finally:
+            ops.defer_weight_gradients(prev)
+        return x.grad
+
+    ga, gb = run(a, False, 2), run(b, True, 2)
+    np.testing.assert_allclose(gb.cpu().numpy(), ga.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(ga.abs().max()))
+    for (n1, p1), (n2, p2) in zip(sorted(a.named_parameters()), sorted(b.named_parameters())):
+        assert n1 == n2 and p2.grad is not None, n1
+        np.testing.assert_allclose(p2.grad.cpu().numpy(), p1.grad.cpu().numpy(), rtol=2e-4, atol=2e-5 * float(p1.grad.abs().max()) + 1e-7, err_msg=n1)
+    assert not ops._pending_wgrads
