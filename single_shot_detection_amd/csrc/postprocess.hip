@@ -525,8 +525,9 @@ __global__ void __launch_bounds__(kPostThreads) post_merge_kernel(int ncls, int 
 //                         test e > thr * (1 - 2^-21) * sum (one multiply per row, one compare per element) and only the survivors get
 //                         the exact IEEE e / sum and the exact `> thr` test, so the result set is the reference's.  exp itself is the
 //                         two-term product form (x*log2e split hi/lo around v_exp_f32: 7 instructions, same 1-ulp error as the
-//                         library's 13).  Per class one ballot pass; a wave gathers the hit masks of its <= 64 classes in its lanes and
-//                         reserves all of them with ONE returning atomic instruction, then stores class by class (contiguous bursts).
+//                         library's 13).  Every thread keeps a bit mask of its passing elements and walks its own set bits.  A
+//                         workgroup OWNS a run of tiles and a segment of every class list (capacity = its rows): a hit's slot is the
+//                         class's running count inside the workgroup (an LDS atomic) -- no global atomics, no counters to zero.
 //                         For even C (RetinaNet: 80) the tile is laid out with an odd row stride, otherwise the 64 rows of one class
 //                         column sit in two LDS banks.
 //   sample + tau          in the worst case (every (anchor, class) pair passes the score threshold) the candidate keys were 3x the
@@ -535,9 +536,11 @@ __global__ void __launch_bounds__(kPostThreads) post_merge_kernel(int ncls, int 
 //                         K-th score, because the sample is a subset -- trims the list to those K, and the main pass (mode 2) only
 //                         emits pairs at or above that bound.  Nothing that can reach the top K is dropped; lists with < K sample
 //                         candidates (the trained-like case) are untouched.
-//   post_nms_wave_kernel  one WAVE per (image, class): radix narrowing by the wave, 128-slot bitonic sort in LDS, decode of the <= K
-//                         boxes, IoU rows in registers (lane l owns sorted entries l and 127-l: the triangle is balanced), the
-//                         division only when inter is within 2^-20 of thr * union, greedy sweep on scalars with v_readlane.
+//   post_nms_wave_kernel  one WAVE per (image, class): radix narrowing by the wave, survivors ranked by counting, decode of the <= K
+//                         boxes into registers (lane l owns sorted entries l and l + 64), greedy sweep that computes the IoU row of an
+//                         entry only while it is alive (v_readlane broadcast + two ballots), inter / union > thr decided exactly
+//                         without a division.  With max_total set it runs twice (head of the best candidates per class ->
+//                         post_img_tau_kernel: image-level bound -> tail for the classes that can still matter; see the kernel).
 //   post_merge2_kernel    1 024 threads per image, the <= 8 192 keys of an image in registers, radix select + rank-by-counting.
 
 constexpr int kSelMaxC = 96;
@@ -1009,18 +1012,37 @@ struct NmsSrc {
 __device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
-template <bool TIE_UP>
+//
+// MODE 0: the whole list in one pass.  With max_total set, only an image's max_total best kept boxes leave the postprocessor
+// (postprocessor.py:72-74), so most of that work is for rows the merge drops.  Two passes instead:
+// MODE 1 (head): NMS of the Khead best candidates only -- greedy NMS of a prefix of the sorted list IS the prefix of the full result;
+//         head_last = score bits + 1 of the Khead-th candidate (0: the class has no candidate beyond the head).
+//         post_img_tau_kernel then takes the max_total-th largest score among an image's kept head boxes: a rigorous lower bound of the
+//         final max_total-th score, all of those boxes being truly kept (0 when there are not more than max_total of them).
+// MODE 2 (tail): a class whose Khead-th score is below the bound is done; any other one repeats the NMS on its candidates at or above
+//         the bound (all of them when it is 0) and overwrites the head's rows.  Exact: a kept box below the bound cannot be among the
+//         max_total best, and a box's fate depends only on better boxes of its class.
+template <bool TIE_UP, int MODE>
 __global__ void __launch_bounds__(kWave) post_nms_wave_kernel(const float4* __restrict__ locs, const float4* __restrict__ priors, int A, int ncls,
                                                               int K, double thr_mid, float xy_scale, float wh_scale, NmsSrc src,
                                                               float* __restrict__ pc_rows, float* __restrict__ pc_score, int* __restrict__ pc_count,
-                                                              int* __restrict__ pc_m, int stop) {
-    __shared__ u64 s_keys[kWaveK];
-    __shared__ u64 s_sorted[kWaveK];
+                                                              int* __restrict__ pc_m, int stop, int Khead, const unsigned* __restrict__ img_tau,
+                                                              unsigned* __restrict__ head_last) {
+    constexpr int kCap = MODE == 1 ? kWave : kWaveK;   // survivors of the radix narrowing (the head keeps one entry per lane)
+    __shared__ u64 s_keys[kCap];
+    __shared__ u64 s_sorted[kCap];
     __shared__ unsigned s_hist[256];
     __shared__ int s_pref[kWave + 1];
     __shared__ u64 s_cache[kNmsCache];
     const int pc = blockIdx.x, lane = threadIdx.x;
     const int i = pc / ncls, c = pc % ncls;
+    const int Kuse = MODE == 1 ? Khead : K;
+    unsigned floor_bits = 0;
+    if (MODE == 2) {
+        const unsigned hl = head_last[pc];
+        floor_bits = img_tau[i];
+        if (hl == 0u || hl <= floor_bits) return;   // (hl - 1 < floor: every further candidate of this class is below the bound)
+    }
     const int mycnt = lane < src.nseg ? src.segcnt[(size_t)pc * src.nseg_all + src.seg0 + lane] : 0;
     KeySpace ks;
     ks.ntop = src.top ? src.topcnt[pc] : 0;
@@ -1029,26 +1051,30 @@ __global__ void __launch_bounds__(kWave) post_nms_wave_kernel(const float4* __re
     ks.n = ks.ntop + wave_prefix_to_lds(mycnt, src.nseg, s_pref);
     const int n = ks.n;
     if (n == 0) {
-        if (lane == 0) { pc_count[pc] = 0; pc_m[pc] = 0; }
+        if (lane == 0) {
+            pc_count[pc] = 0;
+            pc_m[pc] = 0;
+            if (MODE == 1) head_last[pc] = 0u;
+        }
         return;
     }
-    // --- the (up to 128) largest keys, unordered, into s_keys
+    // --- the (up to kCap) largest keys, unordered, into s_keys
     u64 prefix = 0;
     const u64* s_all = nullptr;
-    if (n > kWaveK && n <= kNmsCache) {
+    if (n > kCap && n <= kNmsCache) {
         wave_cache_keys<kNmsCache>(ks, s_cache);
         s_all = s_cache;
     }
-    if (n > kWaveK) prefix = wave_radix_prefix(s_hist, K, kWaveK, ks, s_all);
+    if (n > kCap) prefix = wave_radix_prefix(s_hist, Kuse, kCap, ks, s_all);
     s_keys[lane] = 0ull;
-    s_keys[lane + 64] = 0ull;
+    if (MODE != 1) s_keys[lane + 64] = 0ull;
     __syncthreads();
-    const int cnt = wave_collect(ks, s_all, prefix, kWaveK, [&](int pos, u64 key) { s_keys[pos] = key; });
+    const int cnt = wave_collect(ks, s_all, prefix, kCap, [&](int pos, u64 key) { s_keys[pos] = key; });
     __syncthreads();
     // --- rank by counting (keys are distinct): rank = number of larger keys; s_sorted[rank] = key
-    const u64 kA = s_keys[lane], kB = s_keys[lane + 64];
+    const u64 kA = s_keys[lane], kB = MODE != 1 ? s_keys[lane + 64] : 0ull;
     s_sorted[lane] = 0ull;
-    s_sorted[lane + 64] = 0ull;
+    if (MODE != 1) s_sorted[lane + 64] = 0ull;
     __syncthreads();
     {
         int rA = 0, rB = 0;
@@ -1056,13 +1082,22 @@ __global__ void __launch_bounds__(kWave) post_nms_wave_kernel(const float4* __re
         for (int j = 0; j < c4; j += 4) {
             const u64 k0 = s_keys[j], k1 = s_keys[j + 1], k2 = s_keys[j + 2], k3 = s_keys[j + 3];   // (slots past cnt hold 0: never larger)
             rA += (k0 > kA) + (k1 > kA) + (k2 > kA) + (k3 > kA);
-            rB += (k0 > kB) + (k1 > kB) + (k2 > kB) + (k3 > kB);
+            if (MODE != 1) rB += (k0 > kB) + (k1 > kB) + (k2 > kB) + (k3 > kB);
         }
         if (lane < cnt) s_sorted[rA] = kA;
-        if (lane + 64 < cnt) s_sorted[rB] = kB;
+        if (MODE != 1 && lane + 64 < cnt) s_sorted[rB] = kB;
     }
     __syncthreads();
-    const int m = min(cnt, K);   // box_utils.py:186-188
+    int m = min(cnt, Kuse);   // box_utils.py:186-188
+    if (MODE == 1 && lane == 0) {
+        pc_m[pc] = min(n, K);   // boxes that enter NMS in the reference, whatever part of the work the bound spares
+        head_last[pc] = n > Khead ? (unsigned)(s_sorted[Khead - 1] >> 32) + 1u : 0u;
+    }
+    if (MODE == 2 && floor_bits) {   // the sorted entries at or above the image's bound are a prefix
+        const bool geA = lane < m && (unsigned)(s_sorted[lane] >> 32) >= floor_bits;
+        const bool geB = lane + 64 < m && (unsigned)(s_sorted[lane + 64] >> 32) >= floor_bits;
+        m = __popcll(__ballot(geA)) + __popcll(__ballot(geB));
+    }
     if (stop == 1) { if (lane == 0) { pc_count[pc] = 0; pc_m[pc] = (int)(s_sorted[0] & 1); } return; }
     // --- decode: lane l holds sorted entries l and l + 64
     float4 boxA = make_float4(0.f, 0.f, 0.f, 0.f), boxB = boxA;
@@ -1078,7 +1113,7 @@ __global__ void __launch_bounds__(kWave) post_nms_wave_kernel(const float4* __re
         sc = __uint_as_float((unsigned)(key >> 32));
     };
     if (lane < m) decode(lane, boxA, areaA, scoreA);
-    if (lane + 64 < m) decode(lane + 64, boxB, areaB, scoreB);
+    if (MODE != 1 && lane + 64 < m) decode(lane + 64, boxB, areaB, scoreB);
     if (stop == 2) { if (lane == 0) { pc_count[pc] = 0; pc_m[pc] = (int)(boxA.x > 0.f); } return; }
     // --- greedy sweep with the IoU row of every surviving entry computed on the spot
     auto suppressed = [&](float bx1, float by1, float bx2, float by2, float barea, const float4& bj, float aj) -> bool {
@@ -1100,9 +1135,9 @@ __global__ void __launch_bounds__(kWave) post_nms_wave_kernel(const float4* __re
         const float bx2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(boxA.z), e)), by2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(boxA.w), e));
         const float ba = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(areaA), e));
         rem_lo |= __ballot(liveA & suppressed(bx1, by1, bx2, by2, ba, boxA, areaA));
-        if (m > 64) rem_hi |= __ballot(liveB & suppressed(bx1, by1, bx2, by2, ba, boxB, areaB));
+        if (MODE != 1 && m > 64) rem_hi |= __ballot(liveB & suppressed(bx1, by1, bx2, by2, ba, boxB, areaB));
     }
-    for (int e = 64; e < m; ++e) {
+    for (int e = 64; MODE != 1 && e < m; ++e) {
         if ((rem_hi >> (e - 64)) & 1ull) continue;
         keep_hi |= 1ull << (e - 64);
         const float bx1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(boxB.x), e - 64)), by1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(boxB.y), e - 64));
@@ -1125,8 +1160,62 @@ __global__ void __launch_bounds__(kWave) post_nms_wave_kernel(const float4* __re
     if (liveB && ((keep_hi >> lane) & 1ull)) emit(boxB, scoreB, nlo + __popcll(keep_hi & below));
     if (lane == 0) {
         pc_count[pc] = nlo + __popcll(keep_hi);
-        pc_m[pc] = m;   // boxes that entered NMS
+        if (MODE == 0) pc_m[pc] = m;   // boxes that entered NMS
     }
+}
+
+// The max_total-th largest score among an image's kept head boxes (post_nms_wave_kernel MODE 1), as float bits; 0 when the image has
+// at most max_total of them (then nothing may be dropped: the merge concatenates when the total stays within max_total).
+constexpr int kImgTauPer = 24;   // values per thread: ncls * Khead <= 256 * 24
+__global__ void __launch_bounds__(256) post_img_tau_kernel(int ncls, int K, int Khead, int max_total, const float* __restrict__ pc_score,
+                                                           const int* __restrict__ pc_count, unsigned* __restrict__ img_tau) {
+    __shared__ unsigned s_hist[256];
+    __shared__ unsigned s_misc[2];
+    __shared__ int s_total;
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const int slots = ncls * Khead;
+    unsigned v[kImgTauPer];   // score bits + 1; 0 = no row
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < kImgTauPer; ++k) {
+        const int s = tid + k * 256;
+        v[k] = 0u;
+        if (s < slots) {
+            const int c = s / Khead, r = s - c * Khead;
+            const size_t pc = (size_t)i * ncls + c;
+            if (r < pc_count[pc]) { v[k] = __float_as_uint(pc_score[pc * K + r]) + 1u; ++mine; }
+        }
+    }
+    if (tid == 0) s_total = 0;
+    __syncthreads();
+    struct AddI { __device__ __forceinline__ int operator()(int a, int b) const { return a + b; } };
+    mine = wave_allreduce(mine, AddI());
+    if (lane_id() == 0) atomicAdd(&s_total, mine);
+    __syncthreads();
+    if (s_total <= max_total) {
+        if (tid == 0) img_tau[i] = 0u;
+        return;
+    }
+    unsigned prefix = 0, above = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        s_hist[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kImgTauPer; ++k)
+            if (v[k] != 0u && (shift == 24 || (v[k] >> (shift + 8)) == (prefix >> (shift + 8)))) atomicAdd(&s_hist[(v[k] >> shift) & 255u], 1u);
+        __syncthreads();
+        if (tid < kWave) {
+            int digit;
+            unsigned cum, h;
+            wave_find_digit(s_hist, above, (unsigned)max_total, &digit, &cum, &h);
+            if (tid == 0) { s_misc[0] = prefix | ((unsigned)digit << shift); s_misc[1] = cum; }
+        }
+        __syncthreads();
+        prefix = s_misc[0];
+        above = s_misc[1];
+        __syncthreads();
+    }
+    if (tid == 0) img_tau[i] = prefix - 1u;   // (prefix = the max_total-th largest stored value = score bits + 1)
 }
 
 // per-image merge with the image's keys in registers (ncls * K <= kMergeSlots)
@@ -1302,7 +1391,20 @@ struct PostWs2 {
     float* pc_score;  // [npc][K]
     int* pc_count;    // [npc]
     int* pc_m;        // [npc]
+    unsigned* head_last;  // [npc]   two-pass NMS (post_nms_wave_kernel MODE 1 / 2)
+    unsigned* img_tau;    // [batch]
 };
+
+// Head size of the two-pass NMS: about 2.5 x the share of max_total a class would get if the image's detections were spread evenly
+// (so that the kept head boxes of an image comfortably exceed max_total), a multiple of 8 in 16 .. 64; 0 = one pass (no max_total, or a
+// head that would not be much smaller than max_per_class).
+static int nms_head_size(int ncls, int K, int max_total) {
+    if (max_total <= 0 || getenv("SSDK_NMS_ONE_PASS")) return 0;
+    int h = (int)((5LL * max_total / (2LL * ncls) + 7) / 8 * 8);
+    h = h < 16 ? 16 : h;
+    if (h > kWave || 2 * h > K || (long long)ncls * h <= max_total || (long long)ncls * h > 256LL * kImgTauPer) return 0;
+    return h;
+}
 
 static PostWs2 carve_post_ws2(void* ws, size_t npc, size_t K, const PostPlan& p, size_t* total) {
     Carver c(ws);
@@ -1316,6 +1418,8 @@ static PostWs2 carve_post_ws2(void* ws, size_t npc, size_t K, const PostPlan& p,
     w.pc_score = c.take<float>(npc * K);
     w.pc_count = c.take<int>(npc);
     w.pc_m = c.take<int>(npc);
+    w.head_last = c.take<unsigned>(npc);
+    w.img_tau = c.take<unsigned>(npc);   // (one per image needed; npc >= batch)
     if (total) *total = c.off;
     return w;
 }
@@ -1424,13 +1528,24 @@ static int postprocess_v2(const PostPlan& p, const float* scores, const float* l
     src.segcnt = w.segcnt; src.nseg_all = p.nseg; src.seg0 = p.Gs; src.nseg = p.Gm;
     src.top = p.ns ? w.top : nullptr; src.topcnt = w.topcnt;
     const int nms_stop = getenv("SSDK_NMS_STOP") ? atoi(getenv("SSDK_NMS_STOP")) : 0;
-    if (tie_up)
-        hipLaunchKernelGGL(post_nms_wave_kernel<true>, dim3(npc), dim3(kWave), 0, s, (const float4*)locs, (const float4*)priors, num_anchors, ncls,
-                           max_per_class, thr_mid, xy_scale, wh_scale, src, w.pc_rows, w.pc_score, w.pc_count, w.pc_m, nms_stop);
-    else
-        hipLaunchKernelGGL(post_nms_wave_kernel<false>, dim3(npc), dim3(kWave), 0, s, (const float4*)locs, (const float4*)priors, num_anchors, ncls,
-                           max_per_class, thr_mid, xy_scale, wh_scale, src, w.pc_rows, w.pc_score, w.pc_count, w.pc_m, nms_stop);
-    SSDK_CHECK_LAUNCH("post_nms_wave_kernel");
+    const int khead = nms_stop ? 0 : nms_head_size(ncls, max_per_class, max_total);
+#define SSDK_NMS(TIE, MODE)                                                                                                                     \
+    hipLaunchKernelGGL((post_nms_wave_kernel<TIE, MODE>), dim3(npc), dim3(kWave), 0, s, (const float4*)locs, (const float4*)priors, num_anchors, \
+                       ncls, max_per_class, thr_mid, xy_scale, wh_scale, src, w.pc_rows, w.pc_score, w.pc_count, w.pc_m, nms_stop, khead,      \
+                       w.img_tau, w.head_last)
+    if (khead) {
+        if (tie_up) SSDK_NMS(true, 1); else SSDK_NMS(false, 1);
+        SSDK_CHECK_LAUNCH("post_nms_wave_kernel (head)");
+        hipLaunchKernelGGL(post_img_tau_kernel, dim3(batch), dim3(256), 0, s, ncls, max_per_class, khead, max_total, w.pc_score, w.pc_count,
+                           w.img_tau);
+        SSDK_CHECK_LAUNCH("post_img_tau_kernel");
+        if (tie_up) SSDK_NMS(true, 2); else SSDK_NMS(false, 2);
+        SSDK_CHECK_LAUNCH("post_nms_wave_kernel (tail)");
+    } else {
+        if (tie_up) SSDK_NMS(true, 0); else SSDK_NMS(false, 0);
+        SSDK_CHECK_LAUNCH("post_nms_wave_kernel");
+    }
+#undef SSDK_NMS
     hipLaunchKernelGGL(post_merge2_kernel, dim3(batch), dim3(1024), sizeof(int) * (size_t)(ncls + 1), s, ncls, max_per_class, max_total,
                        w.pc_rows, w.pc_score, w.pc_count, w.pc_m, out, out_cap, counts, (long long*)nms_candidates);
     SSDK_CHECK_LAUNCH("post_merge2_kernel");

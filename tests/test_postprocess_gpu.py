@@ -164,3 +164,31 @@ def test_postprocess_without_per_class_cap_vs_oracle(variant):
     out = post.postprocess((torch.from_numpy(lg).cuda(), torch.from_numpy(lc).cuda()), torch.from_numpy(pri).cuda())
     ref = oracle.postprocess(lg, lc, pri, softmax=True, score_thr=0.05, max_per_class=None, nms_thr=0.45, max_total=None)
     compare(out, ref)
+
+
+@pytest.mark.parametrize('name', ['ssd_300_vgg16_voc', 'ssd_mb2_voc'])
+def test_two_pass_nms_with_skewed_classes_vs_oracle(name):
+    """max_total lets the NMS stop early (a head of the best candidates per class, an image-level score bound, then only the classes
+    that can still matter): one class holding most of an image's best boxes (its tail is redone above the bound), three classes only
+    (fewer kept head boxes than max_total: no bound, everything redone), an ordinary image, and one with near-identical boxes."""
+    cfg, g, logits, locs, softmax = inputs(name, 'trained', batch=4, seeds=(61, 62))
+    A, Cn = g['anchors'].shape[0], cfg['num_classes']
+    assert softmax
+    lg = logits.reshape(4, A, Cn).copy()
+    rng = np.random.default_rng(9)
+    lg[0, rng.choice(A, min(A, 3000), replace=False), 3] += 5.0
+    lg[1, :, 0] += 12.0
+    for cls in (5, Cn - 4, Cn - 1):
+        lg[1, rng.choice(A, 400, replace=False), cls] += 14.0
+    lc = locs.reshape(4, A, 4).copy()
+    lc[3] = 0.0
+    lg[3, :, 1:4] += 3.0
+    lg, lc = lg.reshape(4, -1), lc.reshape(4, -1)
+    post = make_post(cfg)
+    out = post.postprocess((torch.from_numpy(lg).cuda(), torch.from_numpy(lc).cuda()), torch.from_numpy(g['anchors']).cuda())
+    ref, cand = oracle.postprocess(lg, lc, g['anchors'], softmax=True, nms_thr=cfg['nms_thr'], return_cand=True)
+    compare(out, ref)
+    assert np.array_equal(post.last_nms_candidates.cpu().numpy(), cand)
+    per_class = [np.bincount(r[:, 4].astype(int), minlength=Cn) for r in ref]
+    assert per_class[0].max() > 64   # image 0: one class holds more of the final rows than any head
+    assert (per_class[1] > 0).sum() <= 3 and ref[1].shape[0] == 200
