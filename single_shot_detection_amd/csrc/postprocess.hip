@@ -1164,7 +1164,8 @@ __global__ void __launch_bounds__(kWave) post_nms_wave_kernel(const float4* __re
     }
 }
 
-// The max_total-th largest score among an image's kept head boxes (post_nms_wave_kernel MODE 1), as float bits; 0 when the image has
+// The max_total-th largest score among an image's kept head boxes (post_nms_wave_kernel MODE 1), as float bits rounded down to 16
+// significant bits; 0 when the image has
 // at most max_total of them (then nothing may be dropped: the merge concatenates when the total stays within max_total).
 constexpr int kImgTauPer = 24;   // values per thread: ncls * Khead <= 256 * 24
 __global__ void __launch_bounds__(256) post_img_tau_kernel(int ncls, int K, int Khead, int max_total, const float* __restrict__ pc_score,
@@ -1180,10 +1181,12 @@ __global__ void __launch_bounds__(256) post_img_tau_kernel(int ncls, int K, int 
     for (int k = 0; k < kImgTauPer; ++k) {
         const int s = tid + k * 256;
         v[k] = 0u;
-        if (s < slots) {
+        if (s < slots) {   // (count and score fetched side by side: a slot past the count holds stale bits, never an invalid address)
             const int c = s / Khead, r = s - c * Khead;
             const size_t pc = (size_t)i * ncls + c;
-            if (r < pc_count[pc]) { v[k] = __float_as_uint(pc_score[pc * K + r]) + 1u; ++mine; }
+            const int have = pc_count[pc];
+            const unsigned bits = __float_as_uint(pc_score[pc * K + r]);
+            if (r < have) { v[k] = bits + 1u; ++mine; }
         }
     }
     if (tid == 0) s_total = 0;
@@ -1197,7 +1200,7 @@ __global__ void __launch_bounds__(256) post_img_tau_kernel(int ncls, int K, int 
         return;
     }
     unsigned prefix = 0, above = 0;
-    for (int shift = 24; shift >= 0; shift -= 8) {
+    for (int shift = 24; shift >= 16; shift -= 8) {   // the upper 16 bits of the value only: still a lower bound, half the passes
         s_hist[tid] = 0;
         __syncthreads();
 #pragma unroll
@@ -1215,7 +1218,7 @@ __global__ void __launch_bounds__(256) post_img_tau_kernel(int ncls, int K, int 
         above = s_misc[1];
         __syncthreads();
     }
-    if (tid == 0) img_tau[i] = prefix - 1u;   // (prefix = the max_total-th largest stored value = score bits + 1)
+    if (tid == 0) img_tau[i] = prefix ? prefix - 1u : 0u;   // (prefix <= the max_total-th largest stored value, which is score bits + 1)
 }
 
 // per-image merge with the image's keys in registers (ncls * K <= kMergeSlots)
