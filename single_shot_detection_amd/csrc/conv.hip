@@ -1906,6 +1906,45 @@ extern "C" int ssdk_heads_fwd(const ssdk_head_level* levels, int n_levels, int b
         finish_problem(g);
         probs[i] = g;
     }
+    // Small batches: a level has a handful of row tiles, each with a K chain of 9 * Cin / 32 slices (1.5 us apiece) -- ssd_mb2_voc at batch
+    // 2 spent 534 us in 24 workgroups.  While the launch is too small for stream-K (at most one workgroup per slot), the K slices of such
+    // a level are divided over several workgroups that add into the zeroed outputs, like the pyramid tail's convolutions.
+    long long blocks = 0;
+    for (int i = 0; i < n_levels; ++i) blocks += (long long)cdiv(probs[i].m_tiles, 8) * 8 * probs[i].n_blocks;
+    if (blocks <= kStreamKWgs && !getenv("SSDK_HEADS_NO_SPLITK")) {
+        bool any = false;
+        for (int i = 0; i < n_levels; ++i) any = maybe_split_k(probs[i]) || any;
+        if (any) {
+            ZeroList zl;
+            for (int which = 0; which < 2; ++which) {
+                // the split levels' segments of one image's row, merged where they touch (levels are usually laid out back to back)
+                long long off[kMaxProblems], len[kMaxProblems];
+                int ns = 0;
+                for (int i = 0; i < n_levels; ++i) {
+                    const ssdk_head_level& lv = levels[i];
+                    const long long n = (long long)lv.h * lv.w * (which ? lv.n_loc : lv.n_score);
+                    if (probs[i].k_splits > 1 && n > 0) { off[ns] = which ? lv.locs_offset : lv.scores_offset; len[ns] = n; ++ns; }
+                }
+                for (int a = 0; a < ns; ++a)
+                    for (int b = a + 1; b < ns; ++b)
+                        if (off[b] < off[a]) { std::swap(off[a], off[b]); std::swap(len[a], len[b]); }
+                int m = 0;
+                for (int a = 0; a < ns; ++a) {
+                    if (m && off[m - 1] + len[m - 1] == off[a]) len[m - 1] += len[a];
+                    else { off[m] = off[a]; len[m] = len[a]; ++m; }
+                }
+                float* const base = which ? locs : scores;
+                const long long stride = which ? locs_batch_stride : scores_batch_stride;
+                for (int b = 0; b < batch; ++b)
+                    for (int a = 0; a < m; ++a) {
+                        if (zl.a.count == kMaxZero) { const int rc = zl.launch((hipStream_t)stream); if (rc) return rc; }
+                        zl.add(base + (long long)b * stride + off[a], (size_t)len[a]);
+                    }
+            }
+            const int rc = zl.launch((hipStream_t)stream);
+            if (rc) return rc;
+        }
+    }
     StreamKWs sk{};
     if (workspace && workspace_bytes >= ssdk_heads_fwd_workspace_bytes()) {
         Carver c(workspace);

@@ -168,7 +168,8 @@ def test_heads_accept_nchw_and_channels_last_sources():
     x = torch.from_numpy(rng.standard_normal((B, 64, 6, 6), dtype=np.float32)).cuda()
     a = multi_level_heads([x], [x], heads)
     b = multi_level_heads([x.contiguous(memory_format=torch.channels_last)] * 1, [x.contiguous(memory_format=torch.channels_last)] * 1, heads)
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    # (not bit for bit: at this size the K slices are split over workgroups that add atomically, in any order)
+    assert torch.allclose(a[0], b[0], rtol=1e-5, atol=1e-5) and torch.allclose(a[1], b[1], rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize('cfg_name,batch', [('ssd_300_vgg16_voc', 32), ('ssd_512_vgg16_coco', 16), ('retina_rn50_500_coco', 8),
