@@ -117,7 +117,8 @@ struct StreamK {
     long long total_units;
     long long unit_begin[kMaxProblems + 1];   // prefix over the problems in launch order; unit = one K slice of one 32-column tile
     float* partial;                           // [nwg][4 waves][kMaxTN][4][64 lanes][4]: a workgroup's accumulators as they lie in registers
-    unsigned* flags;                          // [nwg + 1]: flags[s] == epoch <=> workgroup s parked its partial tile; flags[nwg] = timeouts
+    unsigned* flags;                          // [nwg]: flags[s] == epoch <=> workgroup s parked its partial tile
+    unsigned* timeouts;                       // partners given up on (stays 0)
     unsigned epoch;
 };
 
@@ -348,7 +349,8 @@ extern "C" int ssdk_debug_read_phase(unsigned long long* host) { return (int)hip
 // (once *sk_flag == sk_epoch) and the epilogue runs.
 template <bool MIRROR, bool GENERIC, bool SCATTER, int WAVES, int BK, int MAXTN>
 __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_tile, int n_block, int ksp, int sk_mode = 0, int sk_s0 = 0, int sk_s1 = 0,
-                                         float* sk_buf = nullptr, unsigned* sk_flag = nullptr, unsigned sk_epoch = 0, unsigned* sk_timeouts = nullptr) {
+                                         float* sk_buf = nullptr, unsigned* sk_flag = nullptr, unsigned sk_epoch = 0, unsigned* sk_timeouts = nullptr,
+                                         int sk_parts = 1) {
     PHASE(0)
     // BK = K slice: 32 floats (128-byte rows, 8 rows per DMA piece, 64 KB of LDS: 2 workgroups per CU) or 16 floats (64-byte rows,
     // 16 rows per piece, 32 KB: 3 workgroups per CU at <= 170 VGPRs, a barrier every 32 MFMAs instead of 64)
@@ -590,23 +592,29 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
             if (tid == 0) __hip_atomic_store(sk_flag, sk_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // ... before the flag does
             return;
         }
-        if (tid == 0) {
-            unsigned spins = 0;
-            while (__hip_atomic_load(sk_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != sk_epoch) {
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > (1u << 22)) { atomicAdd(sk_timeouts, 1u); break; }   // (never hangs: a lost partner costs the tile, not the GPU)
-            }
-        }
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (every wave: its reads below come from memory, not from lines cached earlier)
-#pragma unroll
-        for (int j = 0; j < MAXTN; ++j)
-            if (j < tn)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 v = img[(j * 4 + q) * 64];
-                    acc[j][4 * q] += v[0]; acc[j][4 * q + 1] += v[1]; acc[j][4 * q + 2] += v[2]; acc[j][4 * q + 3] += v[3];
+        // the rest of the tile was parked by the next sk_parts workgroups (one when a range is longer than a tile, several when a
+        // small launch cuts a long K chain into many ranges); they all parked first thing after launch
+#pragma unroll 1
+        for (int part = 0; part < sk_parts; ++part) {
+            if (tid == 0) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(sk_flag + part, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != sk_epoch) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > (1u << 22)) { atomicAdd(sk_timeouts, 1u); break; }   // (never hangs: a lost partner costs the tile, not the GPU)
                 }
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (every wave: its reads below come from memory, not from lines cached earlier)
+            const f32x4* pimg = img + (size_t)part * (4 * MAXTN * 4 * 64);
+#pragma unroll
+            for (int j = 0; j < MAXTN; ++j)
+                if (j < tn)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = pimg[(j * 4 + q) * 64];
+                        acc[j][4 * q] += v[0]; acc[j][4 * q + 1] += v[1]; acc[j][4 * q + 2] += v[2]; acc[j][4 * q + 3] += v[3];
+                    }
+        }
     }
     conv_epilogue<SCATTER>(g, acc, m_base, wave, r32, h, tn, n_begin, M, N, hw, ksp);
     PHASE(3)
@@ -710,9 +718,13 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_streamk_k
         if (slice == 0 && s1 == slices) {
             dma_tile<false, false, false, 4, kBK, kMaxTN>(g, pi, m_tile, n_block, 0);
         } else if (slice > 0) {   // second K part of a tile whose first part closes the previous workgroup's range: park the partial sums
-            dma_tile<false, false, false, 4, kBK, kMaxTN>(g, pi, m_tile, n_block, 0, 1, slice, s1, my_buf, sk.flags + s, sk.epoch, sk.flags + sk.nwg);
-        } else {                  // first K part: the rest was computed by the next workgroup right after launch
-            dma_tile<false, false, false, 4, kBK, kMaxTN>(g, pi, m_tile, n_block, 0, 2, 0, s1, next_buf, sk.flags + s + 1, sk.epoch, sk.flags + sk.nwg);
+            dma_tile<false, false, false, 4, kBK, kMaxTN>(g, pi, m_tile, n_block, 0, 1, slice, s1, my_buf, sk.flags + s, sk.epoch, sk.timeouts);
+        } else {                  // first K part: the rest was computed by the following workgroup(s) right after launch
+            const long long tile_end = u + (long long)slices * tn;
+            int parts = 1;
+            while (s + 1 + parts < sk.nwg && sk.total_units * (s + 1 + parts) / sk.nwg < tile_end) ++parts;
+            dma_tile<false, false, false, 4, kBK, kMaxTN>(g, pi, m_tile, n_block, 0, 2, 0, s1, next_buf, sk.flags + s + 1, sk.epoch, sk.timeouts,
+                                                          parts);
         }
         u += (long long)(s1 - slice) * tn;
         __syncthreads();   // the next tile's first DMA overwrites LDS stage 0
@@ -1734,6 +1746,8 @@ struct StreamKWs {
     unsigned* flags;
     int nwg;
 };
+constexpr long long kStreamKMinRange = 24 * kMaxTN;
+constexpr int kStreamKMinWgs = 256;
 static unsigned g_streamk_epoch = 0;   // (a launch counter: tells this launch's flags from an earlier launch's in the same workspace)
 
 static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t s, bool generic = false, bool scatter = false, int* vtab = nullptr,
@@ -1826,10 +1840,17 @@ static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t 
             if (g.k_splits != 1 || g.mode) sk.nwg = 0;
         }
         sk.unit_begin[count] = sk.total_units;
-        const bool worth = sk.nwg > 0 && begin > sk.nwg && begin <= 16 * sk.nwg && sk.total_units / sk.nwg >= 2 * max_tile;
+        // Not for launches of many rounds (the tail is then a small share and whole tiles need no fix-up).  Otherwise as many workgroups as
+        // leave each a range of at least kStreamKMinRange units (24 K slices of a 128-column block): a tile longer than a range is cut
+        // several times and its owner adds all the parked parts.  Below 256 workgroups the split-K path of the caller does as well (measured on ssd_mb2_voc).
+        if (sk.nwg > 0 && begin > 16 * sk.nwg) sk.nwg = 0;
+        if (sk.nwg > 0) sk.nwg = (int)std::min<long long>(sk.nwg, sk.total_units / kStreamKMinRange / 8 * 8);
+        (void)max_tile;
+        const bool worth = sk.nwg >= kStreamKMinWgs;
         if (worth) {
             sk.partial = skws->partial;
             sk.flags = skws->flags;
+            sk.timeouts = skws->flags + skws->nwg;   // (behind the flags of the largest launch)
             sk.epoch = __atomic_add_fetch(&g_streamk_epoch, 1u, __ATOMIC_RELAXED);
             if (sk.epoch == 0) sk.epoch = __atomic_add_fetch(&g_streamk_epoch, 1u, __ATOMIC_RELAXED);   // (0 is what a fresh workspace holds)
             hipLaunchKernelGGL(igemm_streamk_kernel, dim3(sk.nwg), dim3(kConvThreads), 0, s, grp, sk);
@@ -1911,7 +1932,15 @@ extern "C" int ssdk_heads_fwd(const ssdk_head_level* levels, int n_levels, int b
     // a level are divided over several workgroups that add into the zeroed outputs, like the pyramid tail's convolutions.
     long long blocks = 0;
     for (int i = 0; i < n_levels; ++i) blocks += (long long)cdiv(probs[i].m_tiles, 8) * 8 * probs[i].n_blocks;
-    if (blocks <= kStreamKWgs && !getenv("SSDK_HEADS_NO_SPLITK")) {
+    long long units = 0;
+    bool dma_ok = true;   // (what launch_group asks of its LDS-DMA kernel; stream-K is a form of it)
+    for (int i = 0; i < n_levels; ++i) {
+        units += (long long)probs[i].m_tiles * 9 * cdiv(probs[i].Cc, kBK) * probs[i].tiles_n;
+        dma_ok = dma_ok && probs[i].Cc % kBK == 0;
+    }
+    const bool have_ws = workspace && workspace_bytes >= ssdk_heads_fwd_workspace_bytes();
+    const bool streamk_takes_it = have_ws && dma_ok && units / kStreamKMinRange >= kStreamKMinWgs && !getenv("SSDK_CONV_NO_STREAMK");
+    if (blocks <= kStreamKWgs && !streamk_takes_it && !getenv("SSDK_HEADS_NO_SPLITK")) {
         bool any = false;
         for (int i = 0; i < n_levels; ++i) any = maybe_split_k(probs[i]) || any;
         if (any) {
