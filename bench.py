@@ -398,6 +398,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra-legs', action='store_true', help='skip roofline_hbm / per_config (they run at N = 1 only)')
     ap.add_argument('--eval-steps', type=int, default=5)
+    ap.add_argument('--sync-bn', action='store_true',
+                    help='N > 1: synchronise the pyramid tail\'s BatchNorm statistics over the ranks (detection/init.py:85 convert_syncbn_model); '
+                         'default is local statistics, the documented local-BN mode of SURVEY.md 8e')
     ap.add_argument('--rendezvous-only', action='store_true',
                     help='ranks form the process group, all-reduce their rank numbers, rank 0 prints a JSON line; no GPU work (launcher test)')
     args = ap.parse_args()
@@ -443,6 +446,12 @@ def main():
         torch.cuda.synchronize()
 
     hp = HotPath(args.config, args.batch, device)
+    bn_modules = [m for m in (hp.extras, hp.tower, hp.neck) if m is not None]
+    sync_bn = bool(args.sync_bn and world > 1 and bn_modules)
+    if sync_bn:
+        from single_shot_detection_amd.distributed import convert_sync_batchnorm
+        for m in bn_modules:
+            convert_sync_batchnorm(m)
     for _ in range(args.warmup):
         hp.train_step(world)
     barrier()
@@ -510,7 +519,7 @@ def main():
                                    ('extras conv-BN-ReLU + ' if hp.extras is not None else '') + ('shared-conv tower + ' if hp.tower is not None else '') +
                                    f'heads fwd+bwd (fp32 MFMA) + IoU-match + ' + ('HNM' if hp.cfg['loss'] == 'ce_hnm' else 'naive sampler') +
                                    f'/multibox loss fwd+bwd + SGD on the head-side params; backbone taps N(0,1) NHWC at the probed shapes, C={hp.C}, A={A}, G~U{{1..8}}',
-                       'global_batch': world * args.batch, 'per_gpu_batch': args.batch, 'parallelism': f'dp{world}'},
+                       'global_batch': world * args.batch, 'per_gpu_batch': args.batch, 'parallelism': f'dp{world}', 'sync_bn': sync_bn},
             'rccl_ranks': rccl_ranks, 'collective_backend': (backend if world > 1 else None),
             'grad_bucket_bytes': {'heads': hp.bucket_heads.nbytes, 'rest': hp.bucket_rest.nbytes if hp.bucket_rest is not None else 0},
             'nms_boxes_per_sec': world * cand / dtp, 'postprocess_images_per_sec': world * args.batch / dtp,
