@@ -1,0 +1,65 @@
+"""One rank of tests/test_end_to_end_gpu.py::test_detection_init_distributed_two_ranks: detection.init(distributed=True) (the role of
+detection/init.py:80-86: DistributedDataParallel around the predictor + synchronised BatchNorm), one training step on this rank's own
+images, then the cross-rank checks.  Both ranks share the one GPU of the box; the collectives run over gloo."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from single_shot_detection_amd import ops, synthetic as syn  # noqa: E402
+from single_shot_detection_amd.bf.modules.conv import Conv2dBn, DepthwiseConv2dBn  # noqa: E402
+from single_shot_detection_amd.detection import init as det_init  # noqa: E402
+from test_end_to_end_gpu import MB2  # noqa: E402
+
+
+def main():
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    out_dir = sys.argv[1]
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    torch.manual_seed(9)
+    wrapper, init_state, step_fn = det_init.init(
+        dev, MB2, {'xy_scale': 10.0, 'wh_scale': 5.0},
+        {'score_threshold': .01, 'max_total': 200, 'nms': {'max_per_class': 100, 'overlap_threshold': .45}, 'score_converter': 'SOFTMAX'},
+        {'classification_loss': {'name': 'CrossEntropyLoss'}, 'localization_loss': {'name': 'SmoothL1Loss'},
+         'classification_weight': 1.0, 'localization_weight': 1.0},
+        {'name': 'hard_negative_mining', 'negative_per_positive_ratio': 3, 'min_negative_per_image': 5},
+        {'matched_threshold': 0.5, 'unmatched_threshold': 0.5}, distributed=True)
+    detector = wrapper.model
+    assert isinstance(detector.predictor, torch.nn.parallel.DistributedDataParallel)
+    hot = [bn for m in detector.modules() if isinstance(m, (Conv2dBn, DepthwiseConv2dBn))
+           for bn in m.children() if type(bn) is torch.nn.BatchNorm2d]
+    assert hot and all(ops.sync_group_of(bn) is not None for bn in hot)           # the pyramid tail's norms stay on libssdk, marked
+    assert any(isinstance(m, torch.nn.SyncBatchNorm) for m in detector.modules())   # the backbone's became SyncBatchNorm
+    detector.train()
+    B = 2
+    imgs = torch.from_numpy(np.random.default_rng(31 + rank).standard_normal((B, 3, 300, 300), dtype=np.float32))
+    gt = [torch.from_numpy(g) for g in syn.make_ground_truth(B, 300, 21, seed=4 + rank)]
+    loss, (scores, locs), _ = step_fn(0, 'train', (imgs, gt), init_state())
+    loss.backward()
+    torch.cuda.synchronize()
+    params = [p for p in detector.parameters() if p.requires_grad]
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in params)
+    # DistributedDataParallel averaged the gradients: every rank holds the same ones, although the ranks saw different images
+    mine = torch.stack([p.grad.double().sum() for p in params] + [loss.detach().double()]).cpu()
+    both = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(both, mine)
+    assert torch.equal(both[0][:-1], both[1][:-1]), (both[0][:5], both[1][:5])
+    assert both[0][-1] != both[1][-1]                                             # ... and the losses are the ranks' own
+    # synchronised statistics: the running estimates of the hot-path norms agree over the ranks
+    stats = torch.cat([bn.running_mean.double().flatten() for bn in hot] + [bn.running_var.double().flatten() for bn in hot]).cpu()
+    both = [torch.zeros_like(stats) for _ in range(world)]
+    dist.all_gather(both, stats)
+    assert torch.equal(both[0], both[1])
+    np.save(os.path.join(out_dir, f'ok{rank}.npy'), np.array([1]))
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

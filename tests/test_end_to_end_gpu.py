@@ -317,3 +317,17 @@ def test_ssd512_step_fn_train():
     assert abs(loss.item() - vals[0]) <= 1e-4 + 1e-5 * abs(vals[0]), (loss.item(), vals)
     loss.backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in detector.parameters() if p.requires_grad)
+
+
+def test_detection_init_distributed_two_ranks(tmp_path):
+    """detection.init(distributed=True) with two ranks (detection/init.py:80-86): DistributedDataParallel around the predictor, the
+    hot-path BatchNorms on libssdk with their statistics all-reduced, the backbone's as SyncBatchNorm.  Both ranks use this box's one
+    GPU and gloo; tests/ddp_worker.py holds the per-rank body and its cross-rank checks (equal averaged gradients from different
+    images, equal running statistics)."""
+    import os
+    import sys
+    from single_shot_detection_amd import launch
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'ddp_worker.py')
+    rc = launch.launch(2, [sys.executable, worker, str(tmp_path)])
+    assert rc == 0
+    assert all(os.path.exists(os.path.join(str(tmp_path), f'ok{r}.npy')) for r in range(2))
