@@ -362,6 +362,38 @@ PER_CONFIG = (('ssd_300_vgg16_voc', 64), ('ssd_300_vgg16_voc_c21', 32), ('ssd_mb
               ('retina_rn50_500_coco', 32), ('m2det_512_vgg16_coco', 16))
 
 
+def serving_legs(device, cfg_name='ssd_300_vgg16_voc', batches=(1, 2, 8), reps=30):
+    """Evaluation step (pyramid tail + heads forward + postprocess) at serving batch sizes: enqueued launch by launch, and replayed from a
+    HIP graph (single_shot_detection_amd/graphs.py).  Images per second of both."""
+    from single_shot_detection_amd.graphs import GraphedCallable
+    out = []
+    for b in batches:
+        hp = HotPath(cfg_name, b, device)
+
+        def step(*taps):
+            hp.inputs = list(taps)
+            return hp.eval_step()
+
+        def rate(fn):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return b * reps / (time.perf_counter() - t0)
+
+        taps = [t.detach().clone() for t in hp.inputs]
+        eager = rate(lambda: step(*taps))
+        graphed = GraphedCallable(step, taps)
+        replay = rate(lambda: graphed(*taps))
+        out.append({'config': cfg_name, 'batch': b, 'eager_images_per_sec': eager, 'graph_images_per_sec': replay})
+        del hp, graphed
+        torch.cuda.empty_cache()
+    return out
+
+
 def per_config_legs(device, steps=4, warmup=2):
     """The other BASELINE.json configs (parity-test cases, not the headline): a few train steps each."""
     out = []
@@ -537,6 +569,7 @@ def main():
             torch.cuda.empty_cache()
             out['roofline_hbm'] = hbm_legs(device)
             out['per_config'] = per_config_legs(device)
+            out['serving'] = serving_legs(device)
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(hp)
         print(json.dumps(out), flush=True)

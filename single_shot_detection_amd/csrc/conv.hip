@@ -614,6 +614,9 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
                         const f32x4 v = pimg[(j * 4 + q) * 64];
                         acc[j][4 * q] += v[0]; acc[j][4 * q + 1] += v[1]; acc[j][4 * q + 2] += v[2]; acc[j][4 * q + 3] += v[3];
                     }
+            // the consumed flag goes back to 0: a launch replayed from a captured HIP graph carries the SAME epoch every time, and must
+            // not take the previous replay's flag for this one's (a partner writes its flag once per launch, so nothing races here)
+            if (tid == 0) __hip_atomic_store(sk_flag + part, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     conv_epilogue<SCATTER>(g, acc, m_base, wave, r32, h, tn, n_begin, M, N, hw, ksp);

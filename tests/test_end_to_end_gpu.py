@@ -331,3 +331,33 @@ def test_detection_init_distributed_two_ranks(tmp_path):
     rc = launch.launch(2, [sys.executable, worker, str(tmp_path)])
     assert rc == 0
     assert all(os.path.exists(os.path.join(str(tmp_path), f'ok{r}.npy')) for r in range(2))
+
+
+def test_graphed_eval_replays_match_the_eager_step():
+    """single_shot_detection_amd.graphs: the evaluation step (pyramid tail + heads forward + postprocess) captured in a HIP graph and
+    replayed on new inputs gives what the eagerly enqueued step gives.  Batch 2 of SSD-300: the head GEMM runs in its stream-K form,
+    whose flags must survive being replayed with the same launch arguments (they are reset by their consumer)."""
+    import bench
+    from single_shot_detection_amd.graphs import GraphedCallable
+    from test_postprocess_gpu import compare
+    dev = torch.device('cuda:0')
+    hp = bench.HotPath('ssd_300_vgg16_voc', 2, dev)
+    hp.heads.eval()
+    if hp.extras is not None:
+        hp.extras.eval()
+
+    def step(*taps):
+        hp.inputs = list(taps)
+        return hp.eval_step()
+
+    first = [t.detach().clone() for t in hp.inputs]
+    graphed = GraphedCallable(step, first)
+    gen = torch.Generator(device=dev).manual_seed(77)
+    for trial in range(3):   # the captured inputs again, then two new sets (the second replay would meet the first one's flags)
+        taps = first if trial == 0 else [torch.randn(t.shape, device=dev, generator=gen).contiguous(memory_format=torch.channels_last) for t in first]
+        rows, counts = graphed(*taps)
+        rows, counts = rows.clone(), counts.clone()
+        ref_rows, ref_counts = step(*taps)
+        n, m = counts.cpu().numpy(), ref_counts.cpu().numpy()
+        assert np.abs(n - m).max() <= 1
+        compare([rows[i, :n[i]] for i in range(len(n))], [ref_rows[i, :m[i]].cpu().numpy() for i in range(len(m))])

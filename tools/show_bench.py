@@ -10,3 +10,5 @@ for r in d.get('per_config', []):
     print('  %-24s b%-3d %7.3f ms/step %9.1f img/s  gemm %6.1f TF (%.3f)  post %9.0f img/s' % (r['config'], r['per_gpu_batch'], r['ms_per_step'], r['images_per_sec'], r['head_gemm_tflops'], r['head_gemm_frac'], r['postprocess_worst_case_images_per_sec']))
 if 'cpu_baseline' in d:
     print('cpu', d['cpu_baseline']['value'], d['cpu_baseline']['cores'])
+for r in d.get('serving', []):
+    print('  serving %-22s b%-3d eager %8.0f img/s   graph replay %8.0f img/s' % (r['config'], r['batch'], r['eager_images_per_sec'], r['graph_images_per_sec']))
