@@ -25,13 +25,14 @@ constexpr int kAssignThreads = 256;
 constexpr int kGtChunk = 128;
 constexpr int kSegAnchors = 512;  // anchors swept by one wave of gt_argmax_kernel
 
-// One workgroup per ground-truth box: its 256 threads sweep ALL anchors and the result is stored, not accumulated -- no atomics and
+// One workgroup per ground-truth box: its 1 024 threads sweep ALL anchors and the result is stored, not accumulated -- no atomics and
 // therefore no zero-fill launch in front (the first version folded (box, 512-anchor segment) partial results into a zeroed array with
 // atomicMax: a third launch, and a memset node costs as much as a small kernel).
-__global__ void __launch_bounds__(256) gt_argmax_kernel(const float* __restrict__ gt_rows, int gt_stride,
-                                                        const float4* __restrict__ anchors, int A,
-                                                        unsigned long long* __restrict__ gt_best) {
-    __shared__ unsigned long long s_key[4];
+constexpr int kArgmaxThreads = 1024;   // (a box's sweep is a chain of dependent L2 round trips per thread: 8 anchors per thread at A = 8 108, not 32)
+__global__ void __launch_bounds__(kArgmaxThreads) gt_argmax_kernel(const float* __restrict__ gt_rows, int gt_stride,
+                                                                   const float4* __restrict__ anchors, int A,
+                                                                   unsigned long long* __restrict__ gt_best) {
+    __shared__ unsigned long long s_key[kArgmaxThreads / kWave];
     const int g = blockIdx.x;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const float* r = gt_rows + (size_t)g * gt_stride;
@@ -39,20 +40,29 @@ __global__ void __launch_bounds__(256) gt_argmax_kernel(const float* __restrict_
     const float garea = area4(gb.x, gb.y, gb.z, gb.w);
     float best = 0.0f;
     int bi = -1;
-    for (int a = threadIdx.x; a < A; a += 256) {
-        const float4 c = to_corners(anchors[a]);
+    auto take = [&](int a, const float4& p) {
+        const float4 c = to_corners(p);
         const float v = iou_corner(gb, garea, c, area4(c.x, c.y, c.z, c.w));
         if (bi < 0 || v > best || (v != v && best == best)) { best = v; bi = a; }
+    };
+    int a = threadIdx.x;
+    for (; a + 3 * kArgmaxThreads < A; a += 4 * kArgmaxThreads) {   // four loads in flight, taken in ascending anchor order (first-index ties)
+        const float4 p0 = anchors[a], p1 = anchors[a + kArgmaxThreads], p2 = anchors[a + 2 * kArgmaxThreads], p3 = anchors[a + 3 * kArgmaxThreads];
+        take(a, p0);
+        take(a + kArgmaxThreads, p1);
+        take(a + 2 * kArgmaxThreads, p2);
+        take(a + 3 * kArgmaxThreads, p3);
     }
+    for (; a < A; a += kArgmaxThreads) take(a, anchors[a]);
     unsigned long long key = 0ull;
     if (bi >= 0) key = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)bi);
     key = wave_allreduce(key, OpMaxU64());
     if (lane == 0) s_key[wave] = key;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long k = s_key[0];
-        for (int w = 1; w < 4; ++w) k = s_key[w] > k ? s_key[w] : k;
-        gt_best[g] = k;
+    if (threadIdx.x < kWave) {
+        unsigned long long k = threadIdx.x < kArgmaxThreads / kWave ? s_key[threadIdx.x] : 0ull;
+        k = wave_allreduce(k, OpMaxU64());
+        if (threadIdx.x == 0) gt_best[g] = k;
     }
 }
 
@@ -232,7 +242,7 @@ extern "C" int ssdk_encode_ground_truth(const float* gt_rows, int gt_stride, con
     Carver c(workspace);
     unsigned long long* gt_best = c.take<unsigned long long>((size_t)(total_gt > 0 ? total_gt : 1));
     if (total_gt > 0) {
-        hipLaunchKernelGGL(gt_argmax_kernel, dim3(total_gt), dim3(256), 0, s, gt_rows, gt_stride, (const float4*)anchors, num_anchors, gt_best);
+        hipLaunchKernelGGL(gt_argmax_kernel, dim3(total_gt), dim3(kArgmaxThreads), 0, s, gt_rows, gt_stride, (const float4*)anchors, num_anchors, gt_best);
         SSDK_CHECK_LAUNCH("gt_argmax_kernel");
     }
     dim3 grid(cdiv(num_anchors, kAssignThreads), batch);
