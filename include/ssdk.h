@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SSDK_VERSION 104
+#define SSDK_VERSION 105
 
 #define SSDK_OK 0
 #define SSDK_E_INVALID (-1)   /* bad argument / shape */
@@ -277,6 +277,7 @@ typedef struct ssdk_conv_desc {
     float* dx;
     float* dw;
     float* db;
+    const float* w_t;   /* ssdk_conv2d_bwd: the weights as re-laid out by ssdk_conv2d_transpose_weights, or NULL (the call does it itself) */
 } ssdk_conv_desc;
 
 /* n <= 8 convolutions (e.g. the five pyramid levels of one shared tower layer) in one grouped launch. */
@@ -286,6 +287,11 @@ size_t ssdk_conv2d_bwd_workspace_bytes(const ssdk_conv_desc* descs, int n, int b
  * same dw / db -- weights shared across levels -- are summed into it). */
 int ssdk_conv2d_bwd(const ssdk_conv_desc* descs, int n, int batch, int accumulate, void* workspace, size_t workspace_bytes,
                     void* stream);
+/* The weights of n <= 24 convolutions in the layout ssdk_conv2d_bwd's backward-data GEMM reads (stride 1: [cin][tap][cout], else
+ * [tap][cin][cout]), outs[i] = cin * ksize^2 * cout floats, 16-byte aligned, ONE launch: called once per training step for all the
+ * layers of a chain, the results passed as ssdk_conv_desc::w_t (the reference has no counterpart: cuDNN re-lays weights out inside
+ * every backward call, bf/modules/conv.py:30-36 through torch.nn.Conv2d). */
+int ssdk_conv2d_transpose_weights(const ssdk_conv_desc* descs, int n, float* const* outs, void* stream);
 /* dx = y > 0 ? dy : 0 (n floats, n % 4 == 0). */
 int ssdk_relu_bwd(const float* y, const float* dy, long long n, float* dx, void* stream);
 

@@ -64,6 +64,7 @@ _SIGNATURES = {
     'ssdk_conv2d_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'ssdk_conv2d_bwd_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     'ssdk_conv2d_bwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'ssdk_conv2d_transpose_weights': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'ssdk_relu_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]),
     'ssdk_batchnorm_workspace_bytes': (C.c_size_t, [C.c_int]),
     'ssdk_batchnorm_fwd': (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -132,7 +133,7 @@ class ConvDesc(C.Structure):
     _fields_ = [('x', C.c_void_p), ('hin', C.c_int), ('win', C.c_int), ('cin', C.c_int), ('w', C.c_void_p),
                 ('bias', C.c_void_p), ('cout', C.c_int), ('ksize', C.c_int), ('stride', C.c_int), ('pad', C.c_int),
                 ('relu', C.c_int), ('y', C.c_void_p), ('dy', C.c_void_p), ('dx', C.c_void_p), ('dw', C.c_void_p),
-                ('db', C.c_void_p)]
+                ('db', C.c_void_p), ('w_t', C.c_void_p)]
 
 
 def exported_symbols():

@@ -1702,7 +1702,13 @@ struct ZeroList {
     int launch(hipStream_t s) {
         SSDK_REQUIRE(!overflow, SSDK_E_INVALID, "ZeroList: more than %d buffers queued for one zeroing launch", kMaxZero);
         if (!a.count) return SSDK_OK;
-        hipLaunchKernelGGL(zero_many_kernel, dim3(256, a.count), dim3(256), 0, s, a);
+        // workgroups per buffer sized to the largest one (four float4 stores per thread; the heads' 45 MB of weight gradients took
+        // 22 us at 256 workgroups), the small buffers' surplus workgroups find nothing to do
+        unsigned long long largest = 0;
+        for (int i = 0; i < a.count; ++i) largest = std::max(largest, a.n[i]);
+        const unsigned long long want = (largest / 4 + 256 * 4 - 1) / (256 * 4);
+        const unsigned gx = (unsigned)std::min<unsigned long long>(2048, std::max<unsigned long long>(32, want));
+        hipLaunchKernelGGL(zero_many_kernel, dim3(gx, a.count), dim3(256), 0, s, a);
         SSDK_CHECK_LAUNCH("zero_many_kernel");
         a.count = 0;
         return SSDK_OK;
@@ -2302,6 +2308,30 @@ extern "C" int ssdk_conv2d_fwd(const ssdk_conv_desc* descs, int n, int batch, vo
     return launch_group(probs, n, false, (hipStream_t)stream, true);
 }
 
+// The weights of n convolutions in the layout their backward-data GEMM reads (stride 1: [cin][tap][cout], mirrored-tap dgrad; strided:
+// [tap][cin][cout], scatter dgrad), cin * ksize^2 * cout floats each, in ONE launch.  A training step calls it once for all the layers of
+// a chain (the weights do not change between the forward and the backward pass) and hands the results to ssdk_conv2d_bwd as
+// ssdk_conv_desc::w_t -- the per-layer re-layout launches in front of every backward-data GEMM (8 per SSD-300 step, 40 per RetinaNet
+// tower step) disappear.
+extern "C" int ssdk_conv2d_transpose_weights(const ssdk_conv_desc* descs, int n, float* const* outs, void* stream) {
+    SSDK_REQUIRE(descs && outs && n > 0 && n <= kMaxTransposeJobs, SSDK_E_INVALID, "ssdk_conv2d_transpose_weights: n=%d (1..%d)", n, kMaxTransposeJobs);
+    TransposeGroup tg{};
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const ssdk_conv_desc& d = descs[i];
+        SSDK_REQUIRE(d.w && outs[i] && d.cin > 0 && d.cout > 0 && d.ksize > 0 && d.stride > 0, SSDK_E_INVALID,
+                     "ssdk_conv2d_transpose_weights: descriptor %d: null pointer or bad shape", i);
+        TransposeJob& J = tg.j[tg.count++];
+        J.w0 = d.w; J.w1 = nullptr; J.out = outs[i];
+        J.kind = d.stride == 1 ? 0 : 1; J.n0 = d.cout; J.n1 = 0; J.Npad = d.cout; J.taps = d.ksize * d.ksize; J.Cc = d.cin; J.mode = nullptr;
+        J.tiles_x = cdiv(d.cout, 32); J.tiles_y = cdiv(d.cin, 32); J.block_begin = blocks;
+        blocks += J.tiles_x * J.tiles_y * kTrDepth;
+    }
+    hipLaunchKernelGGL(transpose_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tg);
+    SSDK_CHECK_LAUNCH("transpose_group_kernel");
+    return SSDK_OK;
+}
+
 extern "C" size_t ssdk_conv2d_bwd_workspace_bytes(const ssdk_conv_desc* descs, int n, int batch) {
     (void)batch;
     size_t total = 0;
@@ -2334,11 +2364,18 @@ extern "C" int ssdk_conv2d_bwd(const ssdk_conv_desc* descs, int n, int batch, in
         const int ho = out_dim(d.hin, d.ksize, d.stride, d.pad), wo = out_dim(d.win, d.ksize, d.stride, d.pad);
         const int taps = d.ksize * d.ksize;
         float* wd = carve.take<float>((size_t)d.cin * taps * d.cout);
+        const bool have_wt = d.w_t != nullptr;   // re-laid out beforehand by ssdk_conv2d_transpose_weights (one launch for many layers)
+        if (have_wt) {
+            SSDK_REQUIRE(((uintptr_t)d.w_t & 15) == 0, SSDK_E_INVALID, "ssdk_conv2d_bwd: w_t must be 16-byte aligned");
+            wd = const_cast<float*>(d.w_t);
+        }
         if (d.dx && d.stride == 1) {
             // output stationary: rows are INPUT pixels, A = dy [ho*wo][cout] with mirrored taps, W = wd [cin][taps*cout]
-            hipLaunchKernelGGL(transpose_taps_kernel, dim3(cdiv(d.cout, 32), cdiv(d.cin, 32), taps), dim3(256), 0, s, d.w, (const float*)nullptr,
-                               d.cout, 0, d.cout, taps, d.cin, wd);
-            SSDK_CHECK_LAUNCH("transpose_taps_kernel");
+            if (!have_wt) {
+                hipLaunchKernelGGL(transpose_taps_kernel, dim3(cdiv(d.cout, 32), cdiv(d.cin, 32), taps), dim3(256), 0, s, d.w, (const float*)nullptr,
+                                   d.cout, 0, d.cout, taps, d.cin, wd);
+                SSDK_CHECK_LAUNCH("transpose_taps_kernel");
+            }
             ConvProblem g{};
             g.a = d.dy; g.a_bstride = (long long)ho * wo * d.cout; g.a_pstride = d.cout; g.Cc = d.cout;
             g.B = batch; g.Hout = d.hin; g.Wout = d.win; g.Hin = ho; g.Win = wo; g.ksize = d.ksize; g.stride = 1; g.pad = d.pad;
@@ -2350,9 +2387,11 @@ extern "C" int ssdk_conv2d_bwd(const ssdk_conv_desc* descs, int n, int batch, in
         } else if (d.dx) {
             // strided: input stationary.  T[out pixel][tap*cin + c] = dy[out pixel][:] . W[:, tap, c], scatter-added into
             // dx at (yo*stride - pad + ky, xo*stride - pad + kx): no multiply is spent on (pixel, tap) pairs that do not exist
-            hipLaunchKernelGGL(transpose_tapmajor_kernel, dim3(cdiv(d.cout, 32), cdiv(d.cin, 32), taps), dim3(256), 0, s, d.w, (const float*)nullptr,
-                               d.cout, 0, d.cout, taps, d.cin, wd);
-            SSDK_CHECK_LAUNCH("transpose_tapmajor_kernel");
+            if (!have_wt) {
+                hipLaunchKernelGGL(transpose_tapmajor_kernel, dim3(cdiv(d.cout, 32), cdiv(d.cin, 32), taps), dim3(256), 0, s, d.w, (const float*)nullptr,
+                                   d.cout, 0, d.cout, taps, d.cin, wd);
+                SSDK_CHECK_LAUNCH("transpose_tapmajor_kernel");
+            }
             zl.add(d.dx, (size_t)batch * d.hin * d.win * d.cin);
             ConvProblem g{};
             g.a = d.dy; g.a_bstride = (long long)ho * wo * d.cout; g.a_pstride = d.cout; g.Cc = d.cout;

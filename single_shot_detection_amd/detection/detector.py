@@ -8,6 +8,7 @@ cat (detector.py:50-66) run as libssdk implicit GEMMs (modules/heads.py) and the
 import torch
 import torch.nn as nn
 
+from .. import ops
 from .modules.heads import multi_level_heads
 
 
@@ -32,6 +33,8 @@ class Predictor(nn.Module):
         """
         sources, x = self.features(img)
         sources = list(sources)
+        if self.training and len(self.extras):
+            ops.prepare_weight_transposes(self.extras)   # one re-layout launch for the whole tail's backward instead of one per layer
         for layer in self.extras:
             x = layer(x)
             sources.append(x)

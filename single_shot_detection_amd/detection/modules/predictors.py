@@ -53,6 +53,8 @@ class SharedConvPredictor(nn.Module):
 
     def forward(self, sources):  # predictors.py:60-76: conv -> activation -> per-level norm
         score_sources = loc_sources = list(sources)
+        if self.training:
+            ops.prepare_weight_transposes(self.convs)   # (a shared tower weight is re-laid out once per step, not once per level and layer)
         for score_conv, loc_conv, score_norm, loc_norm in zip(self.convs['score'], self.convs['loc'], self.norms['score'],
                                                               self.norms['loc']):
             score_sources = self._layer(score_conv, score_norm, score_sources)

@@ -46,6 +46,7 @@ class _ConvFn(torch.autograd.Function):
             d.w, d.bias, d.cout, d.ksize, d.stride, d.pad, d.relu = _dp(w), _dp(b), cout, k, stride, pad, int(relu)
             d.y = _dp(y)
         _lib.check(lib.ssdk_conv2d_fwd(arr, len(xs), B, _lib.current_stream()), 'ssdk_conv2d_fwd')
+        ctx.w_t = _transposed_weights_of(weight, stride)   # (prepare_weight_transposes ran for this step: the backward skips its re-layout)
         ctx.save_for_backward(w, *xs, *(ys if relu else []))
         ctx.meta = (stride, pad, bool(relu), len(xs), bias is not None, tuple(tuple(y.shape) for y in ys))
         ctx.params = (weight, bias)   # leaves: their gradient-bucket slots (distributed.GradBucket) are looked up in the backward
@@ -91,6 +92,7 @@ class _ConvFn(torch.autograd.Function):
             d.x, d.hin, d.win, d.cin = _dp(x), x.shape[2], x.shape[3], cin
             d.w, d.bias, d.cout, d.ksize, d.stride, d.pad, d.relu = _dp(w), None, cout, k, stride, pad, 0
             d.dy, d.dx, d.dw, d.db = _dp(dy), _dp(dx), _dp(dw), _dp(db)
+            d.w_t = _dp(ctx.w_t)
         if defer:
             _pending_wgrads.append(dict(x=xs[0], dy=keep[0], w=w, weight=ctx.params[0] if need_w else None, bias=ctx.params[1] if need_b else None,
                                         stride=stride, pad=pad))
@@ -106,6 +108,62 @@ class _ConvFn(torch.autograd.Function):
 
 _defer_wgrad = False
 _pending_wgrads = []
+
+# weights re-laid out for the backward-data GEMMs, keyed by id(parameter): (weakref to it, its version, stride == 1, the layout)
+_wt_cache = {}
+
+
+def _transposed_weights_of(weight, stride):
+    ent = _wt_cache.get(id(weight))
+    if ent is None or ent[0]() is not weight or ent[1] != weight._version or ent[2] != (stride == 1):
+        return None
+    return ent[3]
+
+
+def prepare_weight_transposes(module):
+    """Call at the start of a training step's forward pass over a chain of libssdk convolutions (the pyramid tail, the RetinaNet
+    tower): the weights of every ``nn.Conv2d`` under ``module`` that the hot-path blocks run on libssdk are re-laid out for their
+    backward-data GEMMs in ONE launch (``ssdk_conv2d_transpose_weights``) instead of one small launch in front of every backward call
+    (8 per SSD-300 step, 40 per tower step: a shared tower weight was re-laid out once per level).  The layouts are keyed by parameter
+    identity and version, so a stale one is never used: after an optimizer step (or for a convolution that was not prepared) the
+    backward simply re-lays out its own weights as before.  No-op when gradients are off."""
+    import weakref
+    import ctypes
+    if not torch.is_grad_enabled():
+        return 0
+    convs = [m for m in module.modules() if isinstance(m, torch.nn.Conv2d) and m.groups == 1 and m.weight.is_cuda and m.weight.requires_grad
+             and m.weight.dtype == torch.float32 and m.weight.is_contiguous(memory_format=torch.channels_last)
+             and m.kernel_size[0] == m.kernel_size[1] and m.stride[0] == m.stride[1] and m.in_channels % 4 == 0 and m.out_channels % 4 == 0]
+    seen, todo = set(), []
+    for m in convs:
+        w = m.weight
+        if id(w) in seen or _transposed_weights_of(w, m.stride[0]) is not None:
+            continue
+        seen.add(id(w))
+        todo.append((w, m.kernel_size[0], m.stride[0]))
+    if not todo:
+        return 0
+    lib = _lib.lib()
+    dev = todo[0][0].device
+    sizes = [(w.numel() + 63) // 64 * 64 for w, _, _ in todo]   # (256-byte aligned slices of one arena)
+    arena = torch.empty((sum(sizes),), dtype=torch.float32, device=dev)
+    off = 0
+    for first in range(0, len(todo), 24):
+        group = todo[first:first + 24]
+        arr = (_lib.ConvDesc * len(group))()
+        outs = (ctypes.c_void_p * len(group))()
+        for i, (w, k, stride) in enumerate(group):
+            cout, cin = w.shape[0], w.shape[1]
+            d = arr[i]
+            d.w, d.cin, d.cout, d.ksize, d.stride = w.data_ptr(), cin, cout, k, stride
+            view = arena[off:off + w.numel()]
+            off += sizes[first + i]
+            outs[i] = view.data_ptr()
+            _wt_cache[id(w)] = (weakref.ref(w), w._version, stride == 1, view)
+        _lib.check(lib.ssdk_conv2d_transpose_weights(arr, len(group), outs, _lib.current_stream()), 'ssdk_conv2d_transpose_weights')
+    for key in [k_ for k_, v in _wt_cache.items() if v[0]() is None]:   # parameters that no longer exist
+        del _wt_cache[key]
+    return len(todo)
 
 
 def defer_weight_gradients(enabled=True):

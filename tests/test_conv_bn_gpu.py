@@ -462,3 +462,44 @@ def test_deferred_weight_gradients_equal_immediate_ones():
         assert n1 == n2 and p2.grad is not None, n1
         np.testing.assert_allclose(p2.grad.cpu().numpy(), p1.grad.cpu().numpy(), rtol=2e-4, atol=2e-5 * float(p1.grad.abs().max()) + 1e-7, err_msg=n1)
     assert not ops._pending_wgrads
+
+
+def test_prepared_weight_transposes_equal_the_per_call_ones_and_never_go_stale():
+    """ops.prepare_weight_transposes: one grouped re-layout launch for a chain's backward-data GEMMs (ssdk_conv2d_transpose_weights +
+    ssdk_conv_desc::w_t).  Same gradients as when every backward call re-lays out its own weights; and a layout prepared BEFORE the
+    weights changed (an optimizer step between two forward passes) is not used for the new weights."""
+    import copy
+    from single_shot_detection_amd import ops
+    rng = np.random.default_rng(33)
+    extras = detector_builder.get_extras([512], layers=(('s', 512), ('s', 256), ('s', 256)))
+    _randomize(extras, rng)
+    a, b = copy.deepcopy(extras).cuda(), copy.deepcopy(extras).cuda()
+    x_np = rng.standard_normal((2, 512, 18, 18), dtype=np.float32)
+
+    def run(mod, prepare):
+        x = torch.from_numpy(x_np).cuda().requires_grad_(True)
+        if prepare:
+            assert ops.prepare_weight_transposes(mod) == 6        # the six convolutions of the three blocks, one launch
+            assert ops.prepare_weight_transposes(mod) == 0        # ... all current: nothing to do
+        y, outs = x, []
+        for blk in mod:
+            y = blk(y)
+            outs.append(y)
+        sum((o * o).sum() for o in outs).backward()
+        return x.grad
+
+    ga, gb = run(a, False), run(b, True)
+    np.testing.assert_allclose(gb.cpu().numpy(), ga.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(ga.abs().max()))
+    # the weights change in place (what an optimizer step does): the prepared layouts are now those of OLD weights
+    with torch.no_grad():
+        for m in (a, b):
+            for p in m.parameters():
+                if p.dim() == 4:
+                    p.mul_(-0.5)
+    for m in (a, b):
+        m.zero_grad(set_to_none=True)
+    conv0 = b[0][0].conv
+    assert ops._transposed_weights_of(conv0.weight, conv0.stride[0]) is None
+    ga2, gb2 = run(a, False), run(b, False)   # b is NOT prepared again: its backward must re-lay out the new weights itself
+    np.testing.assert_allclose(gb2.cpu().numpy(), ga2.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(ga2.abs().max()))
+    assert not np.allclose(gb2.cpu().numpy(), gb.cpu().numpy(), rtol=1e-3, atol=1e-5 * float(ga.abs().max()))
