@@ -14,7 +14,15 @@
 namespace ssdk {
 
 constexpr int kBnRows = 64;
-// (rows per bn_reduce workgroup; 16-row workgroups on the small maps were slower: 4x the same-address fp64 atomics per channel)
+// Rows per bn_reduce workgroup.  Measured over the SSD-300 tail (rocprofv3, all eight layers; SSDK_BN_ROWS overrides): 64 rows is the best
+// single value (8.3 us per launch on average; 128: 10.0, 256: 14.3 -- fewer, longer chains of dependent loads; 32: 10.4, 16: 16.3 --
+// the big maps then queue 4x the same-address fp64 atomics per channel).  Picking 16 / 32 rows for the small maps only (2.7 - 2.9 us
+// against 4.1) did not move the step time beyond run-to-run noise and is not done.
+static inline int bn_rows_per_block(long long rows) {
+    (void)rows;
+    if (const char* e = getenv("SSDK_BN_ROWS")) return atoi(e);
+    return kBnRows;
+}
 
 // MODE 0: s0 = sum x, s1 = sum x^2.   MODE 1 (backward): s0 = sum dy', s1 = sum dy' * xhat, dy' = relu ? dy * (y > 0) : dy
 // Workgroup = 64 rows; wave w takes rows w, w+4, ...; lane l owns float4 columns l, l+64, ... (whole 1 KB lines per wave).
@@ -213,7 +221,7 @@ static int bn_stats(const float* x, long long rows, int channels, double* sums, 
     SSDK_REQUIRE(channels % 4 == 0 && ((uintptr_t)x & 15) == 0, SSDK_E_UNSUPPORTED, "ssdk_batchnorm_stats: channels %% 4 != 0 or x not 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     if (zero_first) SSDK_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * (2 * (size_t)channels + 2), s));
-    const int rpb = kBnRows;
+    const int rpb = bn_rows_per_block(rows);
     hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, s, x, (const float*)nullptr,
                        (const float*)nullptr, rows, rpb, channels, (const float*)nullptr, (const float*)nullptr, 0, sums);
     SSDK_CHECK_LAUNCH("bn_reduce_kernel");
@@ -291,7 +299,7 @@ static int bn_bwd_stats(const float* x, const float* y, const float* dy, long lo
                  "ssdk_batchnorm_bwd_stats: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     if (zero_first) SSDK_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * (2 * (size_t)channels + 2), s));
-    const int rpb = kBnRows;
+    const int rpb = bn_rows_per_block(rows);
     hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, s, x, y, dy, rows, rpb, channels, save_mean,
                        save_rstd, relu, sums);
     SSDK_CHECK_LAUNCH("bn_reduce_kernel");
