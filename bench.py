@@ -397,6 +397,36 @@ def serving_legs(device, cfg_name='ssd_300_vgg16_voc', batches=(1, 2, 8), reps=3
     return out
 
 
+def train_graph_legs(device, cases=(('ssd_300_vgg16_voc', 32), ('ssd_mb2_voc', 2), ('ssd_300_vgg16_voc', 2)), reps=30):
+    """The WHOLE training step (forward, match, sampler, loss, backward, fused SGD) captured in a HIP graph and replayed, against the
+    step enqueued launch by launch.  The ground truth sits in static device buffers (target_assigner.PackedGroundTruth); a training
+    loop would refill them between replays.  ms per step of both."""
+    from single_shot_detection_amd.detection.target_assigner import PackedGroundTruth
+    from single_shot_detection_amd.graphs import GraphedCallable
+    out = []
+    for cfg_name, b in cases:
+        hp = HotPath(cfg_name, b, device)
+        hp.gt = PackedGroundTruth.from_list(hp.gt, device)
+
+        def ms(fn):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / reps * 1e3
+
+        eager = ms(hp.train_step)
+        graphed = GraphedCallable(hp.train_step, [])
+        replay = ms(graphed)
+        out.append({'config': cfg_name, 'batch': b, 'eager_ms_per_step': eager, 'graph_ms_per_step': replay})
+        del hp, graphed
+        torch.cuda.empty_cache()
+    return out
+
+
 def per_config_legs(device, steps=4, warmup=2):
     """The other BASELINE.json configs (parity-test cases, not the headline): a few train steps each."""
     out = []
@@ -573,6 +603,7 @@ def main():
             out['roofline_hbm'] = hbm_legs(device)
             out['per_config'] = per_config_legs(device)
             out['serving'] = serving_legs(device)
+            out['train_graph'] = train_graph_legs(device)
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(hp)
         print(json.dumps(out), flush=True)

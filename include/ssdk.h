@@ -84,7 +84,8 @@ size_t ssdk_encode_ground_truth_workspace_bytes(int batch, int total_gt);
 /*
  * detection/target_assigner.py:22-63 TargetAssigner.encode_ground_truth, with bf/utils/box_utils.py:83-101 (iou)
  * and detection/matcher.py:33-56 (match_per_prediction, force_match_for_each_target=True) fused.
- *   gt_rows    DEV [total_gt, gt_stride] rows of all images back to back, gt_stride >= 6
+ *   gt_rows    DEV [total_gt, gt_stride] rows of all images back to back, gt_stride >= 6.  total_gt may be a fixed CAPACITY larger than
+ *              gt_offsets[batch] (static buffers of a captured HIP graph): rows past gt_offsets[batch] are padding and ignored
  *   gt_offsets DEV int32 [batch + 1], image i owns rows gt_offsets[i] .. gt_offsets[i+1]
  *   anchors    DEV [A, 4] centroid form
  *   target     DEV [batch, A, 6] (written in full)

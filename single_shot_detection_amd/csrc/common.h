@@ -152,6 +152,27 @@ __device__ __forceinline__ void stage_tile_f4(float4* __restrict__ lds, const fl
     }
 }
 
+// Zero-fill as a KERNEL.  hipMemsetAsync is not used anywhere in the library: captured into a HIP graph, its memset node left a 16-byte
+// counter block non-zero from the second replay on (ROCm 7.2, ssd_mb2_voc's loss workspace; the multibox loss came out divided by a
+// garbage positive count), and as a stream operation it costs a kernel launch anyway.
+static __global__ void __launch_bounds__(256) zero_fill_kernel(unsigned char* __restrict__ p, size_t n) {
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+    if (((uintptr_t)p & 15) == 0) {
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        for (size_t i = i0; i < (n >> 4); i += step) reinterpret_cast<uint4*>(p)[i] = z;
+        for (size_t i = (n & ~(size_t)15) + i0; i < n; i += step) p[i] = 0;
+    } else {
+        for (size_t i = i0; i < n; i += step) p[i] = 0;
+    }
+}
+static inline hipError_t zero_async(void* p, size_t bytes, hipStream_t s) {
+    if (!p || !bytes) return hipSuccess;
+    const size_t want = (bytes / 16 + 255) / 256;
+    const unsigned grid = (unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(grid), dim3(256), 0, s, (unsigned char*)p, bytes);
+    return hipGetLastError();
+}
+
 #endif  // __HIPCC__
 
 }  // namespace ssdk

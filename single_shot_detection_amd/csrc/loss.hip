@@ -811,7 +811,7 @@ extern "C" int ssdk_multibox_loss_fwd(const ssdk_loss_params* params, const floa
     hipStream_t s = (hipStream_t)stream;
     const long long n_rows = (long long)batch * num_anchors;
     LossWs w = carve_loss_ws(workspace, (size_t)n_rows, nullptr);
-    SSDK_CHECK_HIP(hipMemsetAsync(w.counters, 0, 4 * sizeof(int), s));
+    SSDK_CHECK_HIP(zero_async(w.counters, 4 * sizeof(int), s));   // (a kernel, never hipMemsetAsync: common.h)
     LossParams p = to_device_params(params, num_classes, lse_valid);
     const int grid = stream_grid(n_rows, kLossThreads);
     hipLaunchKernelGGL(loss_fwd_kernel, dim3(grid), dim3(kLossThreads), 0, s, p, scores, (const float4*)locs, (const float4*)anchors,

@@ -31,9 +31,11 @@ constexpr int kSegAnchors = 512;  // anchors swept by one wave of gt_argmax_kern
 constexpr int kArgmaxThreads = 1024;   // (a box's sweep is a chain of dependent L2 round trips per thread: 8 anchors per thread at A = 8 108, not 32)
 __global__ void __launch_bounds__(kArgmaxThreads) gt_argmax_kernel(const float* __restrict__ gt_rows, int gt_stride,
                                                                    const float4* __restrict__ anchors, int A,
-                                                                   unsigned long long* __restrict__ gt_best) {
+                                                                   unsigned long long* __restrict__ gt_best, const int32_t* __restrict__ gt_off,
+                                                                   int batch) {
     __shared__ unsigned long long s_key[kArgmaxThreads / kWave];
     const int g = blockIdx.x;
+    if (g >= gt_off[batch]) return;   // (a row buffer of fixed capacity, e.g. inside a captured HIP graph: rows past the last image's are padding)
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const float* r = gt_rows + (size_t)g * gt_stride;
     const float4 gb = make_float4(r[0], r[1], r[2], r[3]);
@@ -208,7 +210,7 @@ extern "C" int ssdk_match_per_prediction(const float* weights, int num_boxes, in
     hipStream_t s = (hipStream_t)stream;
     unsigned long long* best = (unsigned long long*)workspace;
     if (force_match_for_each_target) {
-        SSDK_CHECK_HIP(hipMemsetAsync(best, 0, sizeof(unsigned long long) * (size_t)num_boxes, s));
+        SSDK_CHECK_HIP(zero_async(best, sizeof(unsigned long long) * (size_t)num_boxes, s));
         hipLaunchKernelGGL(mpp_row_argmax_kernel, dim3(cdiv(num_anchors, kSegAnchors * 4), num_boxes), dim3(256), 0, s, weights, num_anchors, best);
         SSDK_CHECK_LAUNCH("mpp_row_argmax_kernel");
     }
@@ -242,7 +244,7 @@ extern "C" int ssdk_encode_ground_truth(const float* gt_rows, int gt_stride, con
     Carver c(workspace);
     unsigned long long* gt_best = c.take<unsigned long long>((size_t)(total_gt > 0 ? total_gt : 1));
     if (total_gt > 0) {
-        hipLaunchKernelGGL(gt_argmax_kernel, dim3(total_gt), dim3(kArgmaxThreads), 0, s, gt_rows, gt_stride, (const float4*)anchors, num_anchors, gt_best);
+        hipLaunchKernelGGL(gt_argmax_kernel, dim3(total_gt), dim3(kArgmaxThreads), 0, s, gt_rows, gt_stride, (const float4*)anchors, num_anchors, gt_best, gt_offsets, batch);
         SSDK_CHECK_LAUNCH("gt_argmax_kernel");
     }
     dim3 grid(cdiv(num_anchors, kAssignThreads), batch);

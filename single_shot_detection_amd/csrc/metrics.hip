@@ -397,8 +397,8 @@ extern "C" int ssdk_mean_average_precision(const float* predictions, long long n
     MapWs w = carve_map(workspace, n_pred, total_gt, num_classes);
     SSDK_REQUIRE(workspace && workspace_bytes >= w.total, SSDK_E_WORKSPACE, "ssdk_mean_average_precision: workspace %zu < %zu bytes", workspace_bytes, w.total);
     hipStream_t s = (hipStream_t)stream;
-    SSDK_CHECK_HIP(hipMemsetAsync(w.total_positive, 0, sizeof(int) * (size_t)num_classes, s));
-    SSDK_CHECK_HIP(hipMemsetAsync(w.matched, 0, (size_t)(total_gt > 0 ? total_gt : 1), s));
+    SSDK_CHECK_HIP(zero_async(w.total_positive, sizeof(int) * (size_t)num_classes, s));
+    SSDK_CHECK_HIP(zero_async(w.matched, (size_t)(total_gt > 0 ? total_gt : 1), s));
     const long long work = n_pred > total_gt ? n_pred : total_gt;
     if (work > 0) {
         hipLaunchKernelGGL(map_prepare_kernel, dim3((unsigned)cdiv((int)work, 256)), dim3(256), 0, s, predictions, n_pred, gt_rows, gt_stride, total_gt, num_classes,

@@ -220,7 +220,7 @@ static int bn_stats(const float* x, long long rows, int channels, double* sums, 
     SSDK_REQUIRE(x && sums && rows > 0 && channels > 0, SSDK_E_INVALID, "ssdk_batchnorm_stats: bad arguments");
     SSDK_REQUIRE(channels % 4 == 0 && ((uintptr_t)x & 15) == 0, SSDK_E_UNSUPPORTED, "ssdk_batchnorm_stats: channels %% 4 != 0 or x not 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    if (zero_first) SSDK_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * (2 * (size_t)channels + 2), s));
+    if (zero_first) SSDK_CHECK_HIP(zero_async(sums, sizeof(double) * (2 * (size_t)channels + 2), s));
     const int rpb = bn_rows_per_block(rows);
     hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, s, x, (const float*)nullptr,
                        (const float*)nullptr, rows, rpb, channels, (const float*)nullptr, (const float*)nullptr, 0, sums);
@@ -298,7 +298,7 @@ static int bn_bwd_stats(const float* x, const float* y, const float* dy, long lo
     SSDK_REQUIRE(x && dy && sums && save_mean && save_rstd && rows > 0 && channels > 0 && (!relu || y), SSDK_E_INVALID,
                  "ssdk_batchnorm_bwd_stats: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    if (zero_first) SSDK_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * (2 * (size_t)channels + 2), s));
+    if (zero_first) SSDK_CHECK_HIP(zero_async(sums, sizeof(double) * (2 * (size_t)channels + 2), s));
     const int rpb = bn_rows_per_block(rows);
     hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, s, x, y, dy, rows, rpb, channels, save_mean,
                        save_rstd, relu, sums);

@@ -1587,8 +1587,8 @@ extern "C" int ssdk_postprocess(const float* scores, const float* locs, const fl
                      kAnyMaxAnchors);
         const int cap = (int)per_class_cap;
         PostWsAny w = carve_post_any(workspace, (size_t)batch, (size_t)num_anchors, (size_t)ncls, (size_t)cap, nullptr);
-        SSDK_CHECK_HIP(hipMemsetAsync(w.cand_count, 0, sizeof(int) * (size_t)batch * ncls, s));
-        if (nms_candidates) SSDK_CHECK_HIP(hipMemsetAsync(nms_candidates, 0, sizeof(int64_t) * (size_t)batch, s));
+        SSDK_CHECK_HIP(zero_async(w.cand_count, sizeof(int) * (size_t)batch * ncls, s));
+        if (nms_candidates) SSDK_CHECK_HIP(zero_async(nms_candidates, sizeof(int64_t) * (size_t)batch, s));
         const int tiles = cdiv(num_anchors, kPostTileRows);
         const size_t lds = align_up((size_t)kPostTileRows * num_classes * 4, 16) + (size_t)ncls * 4;
         SSDK_REQUIRE(lds <= 160 * 1024 - 1024, SSDK_E_UNSUPPORTED, "ssdk_postprocess: num_classes=%d needs %zu bytes of LDS", num_classes, lds);
@@ -1611,8 +1611,8 @@ extern "C" int ssdk_postprocess(const float* scores, const float* locs, const fl
     }
     // ---- general pipeline: soft-NMS, max_per_class > 128, more than 96 classes
     PostWs w = carve_post_ws(workspace, (size_t)batch, (size_t)num_anchors, (size_t)ncls, (size_t)max_per_class, nullptr);
-    SSDK_CHECK_HIP(hipMemsetAsync(w.cand_count, 0, sizeof(int) * (size_t)batch * ncls, s));
-    if (nms_candidates) SSDK_CHECK_HIP(hipMemsetAsync(nms_candidates, 0, sizeof(int64_t) * (size_t)batch, s));
+    SSDK_CHECK_HIP(zero_async(w.cand_count, sizeof(int) * (size_t)batch * ncls, s));
+    if (nms_candidates) SSDK_CHECK_HIP(zero_async(nms_candidates, sizeof(int64_t) * (size_t)batch, s));
     const int tiles = cdiv(num_anchors, kPostTileRows);
     const size_t lds = align_up((size_t)kPostTileRows * num_classes * 4, 16) + (size_t)ncls * 4;
     SSDK_REQUIRE(lds <= 160 * 1024 - 1024, SSDK_E_UNSUPPORTED, "ssdk_postprocess: num_classes=%d needs %zu bytes of LDS", num_classes, lds);

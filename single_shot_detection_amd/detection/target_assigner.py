@@ -17,6 +17,40 @@ IGNORE_CLASS = -1
 GT_ROW = 6  # x1, y1, x2, y2, class, score (bf/datasets/detection_dataset.py:11-15); extra columns are dropped
 
 
+class PackedGroundTruth(object):
+    """A batch's ground truth already on the device in the library's layout: ``rows`` [capacity, 6] fp32 (boxes of all images back to
+    back, rows past ``offsets[-1]`` are padding), ``offsets`` int32 [B + 1].  ``TargetAssigner.encode_ground_truth`` takes it in place of
+    the list of per-image tensors -- with no host-side packing and no H2D copy in the call, the training step can be captured in a HIP
+    graph (graphs.py): keep ONE PackedGroundTruth of fixed capacity and ``update_`` it between replays."""
+
+    def __init__(self, rows, offsets):
+        assert rows.is_cuda and offsets.is_cuda and rows.dim() == 2 and rows.shape[1] == GT_ROW and rows.dtype == torch.float32
+        assert offsets.dtype == torch.int32 and offsets.dim() == 1
+        self.rows, self.offsets = rows.contiguous(), offsets.contiguous()
+
+    @classmethod
+    def from_list(cls, ground_truth, device, capacity=None):
+        rows, offs, total = pack_ground_truth(ground_truth, device)
+        cap = total if capacity is None else int(capacity)
+        if cap < total:
+            raise ValueError(f'PackedGroundTruth: {total} boxes do not fit the capacity of {cap}')
+        buf = torch.zeros((max(cap, 1), GT_ROW), dtype=torch.float32, device=device)
+        buf[:total] = rows
+        return cls(buf, offs.clone())
+
+    def update_(self, ground_truth):
+        """New boxes into the same buffers (same batch size, at most the capacity): what a training loop does between graph replays."""
+        rows, offs, total = pack_ground_truth(ground_truth, self.rows.device)
+        if total > self.rows.shape[0] or offs.numel() != self.offsets.numel():
+            raise ValueError('PackedGroundTruth.update_: batch size or capacity exceeded')
+        self.rows[:total].copy_(rows, non_blocking=True)
+        self.offsets.copy_(offs, non_blocking=True)
+        return self
+
+    def __len__(self):
+        return self.offsets.numel() - 1
+
+
 def pack_ground_truth(ground_truth, device, row=GT_ROW):
     """list[B] of [G_i, >=row] tensors (any device) -> (rows [sum G, row] fp32, offsets int32 [B+1]) on ``device``.
 
@@ -69,7 +103,10 @@ class TargetAssigner(object):
         batch_size = len(ground_truth)
         num_anchors = anchors.size(0)
         anchors = anchors.contiguous().float()
-        rows, offs, total = pack_ground_truth(ground_truth, device)
+        if isinstance(ground_truth, PackedGroundTruth):
+            rows, offs, total = ground_truth.rows, ground_truth.offsets, ground_truth.rows.shape[0]   # (total = capacity: padding is skipped on the device)
+        else:
+            rows, offs, total = pack_ground_truth(ground_truth, device)
         target = torch.empty((batch_size, num_anchors, TARGET_SIZE), dtype=torch.float32, device=device)
         box_idx = torch.empty((batch_size, num_anchors), dtype=torch.int32, device=device) if return_box_idx else None
         need = lib.ssdk_encode_ground_truth_workspace_bytes(batch_size, total)

@@ -11,6 +11,12 @@ flags of ``ssdk_heads_fwd`` are reset by their consumer, so a replay (same launc
 flags.  What the captured function itself must respect: fixed shapes, no ``.item()`` / ``.cpu()`` / host-side branching on device values
 (``Postprocessor.postprocess_padded`` returns padded rows + counts for exactly this reason; ``postprocess`` splits on the host and is not
 capturable), and its outputs are static buffers that the next call overwrites.
+
+The training step can be captured as well (forward, match, sampler, loss, backward, fused SGD: ``GraphedCallable(step, [])``) once the
+ground truth is a ``target_assigner.PackedGroundTruth`` -- static device buffers of fixed capacity refilled between replays -- instead of a
+list of host tensors packed and copied inside the step: ssd_mb2_voc at batch 2 goes from 0.78 ms (host bound) to 0.27 ms per step; at
+batch 32 the SSD-300 step is GPU bound and gains nothing.  Replays were checked against eager steps parameter by parameter
+(tests/test_end_to_end_gpu.py).
 """
 import torch
 

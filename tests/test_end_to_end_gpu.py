@@ -361,3 +361,31 @@ def test_graphed_eval_replays_match_the_eager_step():
         n, m = counts.cpu().numpy(), ref_counts.cpu().numpy()
         assert np.abs(n - m).max() <= 1
         compare([rows[i, :n[i]] for i in range(len(n))], [ref_rows[i, :m[i]].cpu().numpy() for i in range(len(m))])
+
+
+@pytest.mark.parametrize('cfg_name,batch', [('ssd_mb2_voc', 2), ('ssd_300_vgg16_voc', 2)])
+def test_graphed_training_steps_match_eager_ones(cfg_name, batch):
+    """The whole training step (pyramid tail + heads forward, match, sampler, loss, backward, fused SGD) captured in a HIP graph with the
+    ground truth in a PackedGroundTruth: every replay moves the parameters like the eagerly enqueued step does.  (Found with this
+    check: a hipMemsetAsync node that stopped zeroing the loss counters from the second replay on -- the library zero-fills with kernels.)"""
+    import bench
+    from single_shot_detection_amd.detection.target_assigner import PackedGroundTruth
+    from single_shot_detection_amd.graphs import GraphedCallable
+    dev = torch.device('cuda:0')
+    eager, graphed = bench.HotPath(cfg_name, batch, dev), bench.HotPath(cfg_name, batch, dev)
+    graphed.gt = PackedGroundTruth.from_list(graphed.gt, dev, capacity=sum(len(g) for g in graphed.gt) + 7)   # (padding rows are skipped)
+
+    def params(hp):
+        return [p for g in hp.opt.param_groups for p in g['params']]
+
+    step = GraphedCallable(graphed.train_step, [], warmup=3)
+    for _ in range(3):
+        eager.train_step()
+    for k in range(4):
+        loss_e = eager.train_step()
+        loss_g = step()
+        torch.cuda.synchronize()
+        assert abs(float(loss_e.detach()) - float(loss_g.detach())) <= 2e-4 * abs(float(loss_e.detach())), (k, float(loss_e.detach()), float(loss_g.detach()))
+        for p, q in zip(params(graphed), params(eager)):
+            scale = float(q.detach().abs().max()) + 1e-12
+            assert float((p.detach() - q.detach()).abs().max()) <= 2e-3 * scale, k

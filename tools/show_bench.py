@@ -12,3 +12,5 @@ if 'cpu_baseline' in d:
     print('cpu', d['cpu_baseline']['value'], d['cpu_baseline']['cores'])
 for r in d.get('serving', []):
     print('  serving %-22s b%-3d eager %8.0f img/s   graph replay %8.0f img/s' % (r['config'], r['batch'], r['eager_images_per_sec'], r['graph_images_per_sec']))
+for r in d.get('train_graph', []):
+    print('  train step %-22s b%-3d eager %7.3f ms   graph replay %7.3f ms' % (r['config'], r['batch'], r['eager_ms_per_step'], r['graph_ms_per_step']))
