@@ -148,3 +148,28 @@ def test_ssd_anchor_generator_options_bit_exact_vs_reference():
     assert np.array_equal(got.view(np.uint32), g['builder'].view(np.uint32))
     with pytest.raises(NotImplementedError):
         ssd.SsdAnchorGenerator([1.0, 2.0], min_scale=0.2)     # no maximum: the reference's own code fails on it (ssd.py:135)
+
+
+def test_packed_ground_truth_with_padding_equals_the_list_form():
+    """target_assigner.PackedGroundTruth (static buffers of fixed capacity for a captured HIP graph): rows past the last image's are padding
+    -- NaNs here -- and change nothing; update_ refills the same buffers with another batch (an empty image included)."""
+    from single_shot_detection_amd.detection.target_assigner import PackedGroundTruth
+    cfg = syn.CONFIGS['ssd_300_vgg16_voc']
+    anchors = torch.from_numpy(load_golden('ssd_300_vgg16_voc')['anchors']).cuda()
+    ta = TargetAssigner(cfg['matched'], cfg['unmatched'])
+    gt_a = [torch.from_numpy(x) for x in syn.make_ground_truth(4, cfg['size'], cfg['num_classes'], seed=4)]
+    gt_b = [torch.from_numpy(x) for x in syn.make_ground_truth(4, cfg['size'], cfg['num_classes'], seed=5)]
+    gt_b[2] = torch.zeros((0, 6))
+    cap = max(sum(len(g) for g in gt_a), sum(len(g) for g in gt_b)) + 5
+    packed = PackedGroundTruth.from_list(gt_a, anchors.device, capacity=cap)
+    packed.rows[int(packed.offsets[-1]):] = float('nan')
+    assert len(packed) == 4
+    for gt in (gt_a, gt_b):
+        if gt is gt_b:
+            packed.update_(gt_b)
+            packed.rows[int(packed.offsets[-1]):] = float('nan')
+        ref_t, ref_idx = ta.encode_ground_truth(gt, anchors, return_box_idx=True)
+        t, idx = ta.encode_ground_truth(packed, anchors, return_box_idx=True)
+        assert torch.equal(idx, ref_idx) and np.array_equal(bits(t), bits(ref_t))
+    with pytest.raises(ValueError):
+        PackedGroundTruth.from_list(gt_a, anchors.device, capacity=1)
