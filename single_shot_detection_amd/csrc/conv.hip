@@ -1542,7 +1542,15 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ d
     const long long m0 = (long long)blockIdx.x * rows_per_block, m1 = min(M, m0 + rows_per_block);
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
         float s = 0.0f;
-        for (long long m = m0; m < m1; ++m) s += dy[m * N + n];
+        long long m = m0;
+        for (; m + 8 <= m1; m += 8) {   // eight loads in flight (a row per trip is one memory round trip per row)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = dy[(m + u) * N + n];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; m < m1; ++m) s += dy[m * N + n];
         atomicAdd(db + n, s);
     }
 }
@@ -2427,7 +2435,9 @@ extern "C" int ssdk_conv2d_bwd(const ssdk_conv_desc* descs, int n, int batch, in
         if (!d.db) continue;
         const int ho = out_dim(d.hin, d.ksize, d.stride, d.pad), wo = out_dim(d.win, d.ksize, d.stride, d.pad);
         const long long M = (long long)batch * ho * wo;
-        const int rows_per_block = 64;
+        // (64 rows per workgroup until the launch has 256 of them, then more rows: every workgroup ends with an atomic per column on the
+        // same cout addresses -- the rule measured for the BatchNorm statistics, norm.hip)
+        const int rows_per_block = (int)std::max<long long>(64, (M + 255) / 256);
         hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((M + rows_per_block - 1) / rows_per_block)), dim3(256), 0, s, d.dy, M, d.cout,
                            d.db, rows_per_block);
         SSDK_CHECK_LAUNCH("colsum_kernel");

@@ -19,9 +19,16 @@ constexpr int kBnRows = 64;
 // the big maps then queue 4x the same-address fp64 atomics per channel).  Picking 16 / 32 rows for the small maps only (2.7 - 2.9 us
 // against 4.1) did not move the step time beyond run-to-run noise and is not done.
 static inline int bn_rows_per_block(long long rows) {
-    (void)rows;
     if (const char* e = getenv("SSDK_BN_ROWS")) return atoi(e);
-    return kBnRows;
+    // Large maps (RetinaNet's 63 x 63 level at batch 32: 127 k rows): every workgroup ends with one fp64 atomic per channel and sum, all on
+    // the same 2C addresses, and with 64 rows 1 984 workgroups queue there.  bn_reduce<0> per launch, averaged over the tower's five levels
+    // (rocprofv3, tools/bnrows_retina.sh): 64 rows everywhere 53.4 us; 256 rows everywhere 30.2 (the small levels then take 17 instead of
+    // 6 us); 64 rows until the launch has N workgroups, then more rows per workgroup: N = 1536: 42.3, 1024: 36.6, 768: 32.3, 512: 29.1,
+    // 384: 24.8, 256: 23.0, 192: 23.1 (backward statistics alike: 60.7 -> 28.9).  retina_rn50_500_coco step 52.97 -> 50.17 ms.
+    const long long target = getenv("SSDK_BN_WGS") ? atoll(getenv("SSDK_BN_WGS")) : 256;
+    long long r = (rows + target - 1) / target;
+    r = (r + 15) / 16 * 16;
+    return (int)(r < kBnRows ? kBnRows : (r > 4096 ? 4096 : r));
 }
 
 // MODE 0: s0 = sum x, s1 = sum x^2.   MODE 1 (backward): s0 = sum dy', s1 = sum dy' * xhat, dy' = relu ? dy * (y > 0) : dy
