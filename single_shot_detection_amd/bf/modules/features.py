@@ -97,6 +97,9 @@ class FeaturePyramid(Features):
 
     def forward(self, x):
         sources, _ = super(FeaturePyramid, self).forward(x)
+        if self.training:
+            ops.prepare_weight_transposes(self.pyramid_lateral)
+            ops.prepare_weight_transposes(self.pyramid_output)
         features = [ops.conv2d(s, lat.weight, lat.bias) for s, lat in zip(sources, self.pyramid_lateral)]   # features.py:104
         for i in reversed(range(len(features) - 1)):                                                       # :106-107
             features[i] = _upsample_add(features[i], features[i + 1], self.interpolation_mode)
@@ -224,6 +227,9 @@ class MultilevelFeaturePyramid(Features):
     def neck(self, sources):
         """Everything behind the backbone taps (features.py:363-393); separate so that a caller that already holds the taps
         (bench.py) can drive the libssdk part alone."""
+        if self.training:   # one re-layout launch for the backward-data GEMMs of the ~90 convolutions below instead of one each
+            for group in (self.base_reducers, self.tums, self.reducers, self.sfam):
+                ops.prepare_weight_transposes(group)
         base_reduced = [reducer(source) for reducer, source in zip(self.base_reducers, sources)]
         size = base_reduced[0].shape[2:]
         upscaled = [base_reduced[0]] + [ops.upsample_nearest(f, size) for f in base_reduced[1:]]   # features.py:369-371
