@@ -109,14 +109,14 @@ class _ConvFn(torch.autograd.Function):
 _defer_wgrad = False
 _pending_wgrads = []
 
-# weights re-laid out for the backward-data GEMMs, keyed by id(parameter): (weakref to it, its version, stride == 1, the layout)
+# weights re-laid out for the backward-data GEMMs, keyed by id(parameter): (weakref to it, (version, data_ptr), stride == 1, the layout)
 _wt_cache = {}
 
 
 def _transposed_weights_of(weight, stride):
     ent = _wt_cache.get(id(weight))
-    if ent is None or ent[0]() is not weight or ent[1] != weight._version or ent[2] != (stride == 1):
-        return None
+    if ent is None or ent[0]() is not weight or ent[1] != (weight._version, weight.data_ptr()) or ent[2] != (stride == 1):
+        return None   # (another tensor, changed in place, or its storage swapped through .data since the layout was made)
     return ent[3]
 
 
@@ -159,7 +159,7 @@ def prepare_weight_transposes(module):
             view = arena[off:off + w.numel()]
             off += sizes[first + i]
             outs[i] = view.data_ptr()
-            _wt_cache[id(w)] = (weakref.ref(w), w._version, stride == 1, view)
+            _wt_cache[id(w)] = (weakref.ref(w), (w._version, w.data_ptr()), stride == 1, view)
         _lib.check(lib.ssdk_conv2d_transpose_weights(arr, len(group), outs, _lib.current_stream()), 'ssdk_conv2d_transpose_weights')
     for key in [k_ for k_, v in _wt_cache.items() if v[0]() is None]:   # parameters that no longer exist
         del _wt_cache[key]
