@@ -389,3 +389,22 @@ def test_graphed_training_steps_match_eager_ones(cfg_name, batch):
         for p, q in zip(params(graphed), params(eager)):
             scale = float(q.detach().abs().max()) + 1e-12
             assert float((p.detach() - q.detach()).abs().max()) <= 2e-3 * scale, k
+
+
+def test_bench_n2_path_on_one_gpu_over_gloo():
+    """`python bench.py --gpus 2` end to end (self-launched ranks, two-phase backward, zero-copy gradient buckets, synchronised BatchNorm
+    statistics): both ranks share this box's GPU and the collectives run over gloo (SSDK_BENCH_ONE_GPU / SSDK_BENCH_BACKEND) -- the timing
+    means nothing, the N > 1 code path is what is exercised; on a multi-GPU node the same command runs one rank per GPU over RCCL."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SSDK_BENCH_ONE_GPU='1', SSDK_BENCH_BACKEND='gloo')
+    out = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--no-cpu-baseline',
+                          '--sync-bn', '--eval-steps', '1'], env=env, cwd=repo, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2 and line['collective_backend'] == 'gloo'
+    assert line['config']['parallelism'] == 'dp2' and line['config']['sync_bn'] is True and line['config']['global_batch'] == 64
+    assert line['scaling'] == 'weak' and line['value'] > 0 and line['grad_bucket_bytes']['heads'] == 36046848
