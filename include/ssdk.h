@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SSDK_VERSION 105
+#define SSDK_VERSION 106
 
 #define SSDK_OK 0
 #define SSDK_E_INVALID (-1)   /* bad argument / shape */
@@ -279,6 +279,10 @@ typedef struct ssdk_conv_desc {
     float* dw;
     float* db;
     const float* w_t;   /* ssdk_conv2d_bwd: the weights as re-laid out by ssdk_conv2d_transpose_weights, or NULL (the call does it itself) */
+    double* stats;      /* ssdk_conv2d_fwd: NULL, or a BatchNorm `sums` buffer [2 * cout + 2] (fp64) into which the per-channel sums of the
+                           output and of its squares are ADDED (the values stored, i.e. after bias and ReLU), [2 * cout] = rows: the
+                           statistics half of the BatchNorm that follows (bf/modules/conv.py:33-35), taken in the GEMM epilogue when the
+                           convolution is not split over K, else by a pass over the output; cout % 4 == 0 */
 } ssdk_conv_desc;
 
 /* n <= 8 convolutions (e.g. the five pyramid levels of one shared tower layer) in one grouped launch. */
@@ -348,6 +352,13 @@ int ssdk_batchnorm_fwd_chained(const float* x, long long rows, int channels, con
 int ssdk_batchnorm_bwd_chained(const float* x, const float* y, const float* dy, long long rows, int channels, const float* gamma,
                                const float* save_mean, const float* save_rstd, int relu, float* dx, float* dgamma, float* dbeta,
                                double* sums, double* zero_after, void* stream);
+/* The statistics half alone, ADDING into `sums` (no zero-fill; sums[2 * channels] = rows), and the apply half of the chained form for sums
+ * that are already complete -- accumulated by the producing convolution's epilogue (ssdk_conv_desc::stats): conv -> BatchNorm then costs one
+ * launch for the norm instead of two, and the statistics pass over the activation is gone (bf/modules/conv.py:30-36). */
+int ssdk_batchnorm_stats_accumulate(const float* x, long long rows, int channels, double* sums, void* stream);
+int ssdk_batchnorm_apply_chained(const float* x, long long rows, int channels, const float* gamma, const float* beta, float* running_mean,
+                                 float* running_var, int64_t* num_batches_tracked, float momentum, float eps, int relu, float* y,
+                                 float* save_mean, float* save_rstd, const double* sums, double* zero_after, void* stream);
 
 /* ---- FPN top-down step (next-row f1) -------------------------------------------------------------------------------- */
 

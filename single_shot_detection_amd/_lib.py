@@ -84,6 +84,9 @@ _SIGNATURES = {
                                              C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'ssdk_batchnorm_bwd_chained': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ssdk_batchnorm_stats_accumulate': (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p]),
+    'ssdk_batchnorm_apply_chained': (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                               C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'ssdk_upsample_nearest_add_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                 C.c_void_p, C.c_void_p]),
     'ssdk_upsample_nearest_add_bwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
@@ -133,7 +136,7 @@ class ConvDesc(C.Structure):
     _fields_ = [('x', C.c_void_p), ('hin', C.c_int), ('win', C.c_int), ('cin', C.c_int), ('w', C.c_void_p),
                 ('bias', C.c_void_p), ('cout', C.c_int), ('ksize', C.c_int), ('stride', C.c_int), ('pad', C.c_int),
                 ('relu', C.c_int), ('y', C.c_void_p), ('dy', C.c_void_p), ('dx', C.c_void_p), ('dw', C.c_void_p),
-                ('db', C.c_void_p), ('w_t', C.c_void_p)]
+                ('db', C.c_void_p), ('w_t', C.c_void_p), ('stats', C.c_void_p)]
 
 
 def exported_symbols():

@@ -63,6 +63,8 @@ class Conv2dBn(nn.Module):
         if self._hip_ok():   # libssdk: implicit-GEMM conv (csrc/conv.hip) + BatchNorm/ReLU kernels (csrc/norm.hip)
             has_bn, has_act = 'bn' in self._modules, 'activation' in self._modules
             c = self.conv
+            if has_bn and type(self.bn) is nn.BatchNorm2d:   # (statistics in the convolution's epilogue where they can be: ops.conv2d_batch_norm)
+                return ops.conv2d_batch_norm(x, c.weight, c.bias, c.stride[0], c.padding[0], self.bn, conv_relu=False, bn_relu=has_act)
             x = ops.conv2d(x, c.weight, c.bias, stride=c.stride[0], padding=c.padding[0], relu=has_act and not has_bn)
             if has_bn:
                 x = _norm_act(x, self.bn, self._modules.get('activation'))

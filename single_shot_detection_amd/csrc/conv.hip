@@ -97,6 +97,9 @@ struct ConvProblem {
     // the LDS-DMA kernel, which rounds it up to 8 so that every 8-row DMA piece reads ONE weight tensor (one descriptor)
     int n0_pad;
     unsigned w0_bytes, w1_bytes;   // LDS-DMA kernel: sizes of the two weight tensors (buffer descriptors)
+    // BatchNorm statistics of the output, fused into the epilogue (forward, one output, not split over K): per-column sums of the
+    // stored values and of their squares are ADDED into stats[0 .. n0) / stats[n0 .. 2 n0) (fp64), stats[2 n0] = rows.  NULL: none.
+    double* stats;
 };
 
 struct ConvGroup {
@@ -157,7 +160,7 @@ struct GVecT<1> { typedef const float __attribute__((address_space(1))) * type; 
 // Epilogue shared by the GEMM kernels: bias, optional ReLU, store (or atomic add for split-K / scatter).
 template <bool SCATTER, int NT>
 __device__ __forceinline__ void conv_epilogue(const ConvProblem& g, const f32x16 (&acc)[NT], int m_base, int wave, int r32, int h, int tn,
-                                              int n_begin, int M, int N, int hw, int ksp) {
+                                              int n_begin, int M, int N, int hw, int ksp, float* s_red = nullptr, int waves = 4) {
     // epilogue: C/D map of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
     if (SCATTER) {
         // row = a pixel (or one anchor of a pixel) with a non-zero output gradient; column n = tap * Cin + c: add the product into
@@ -277,6 +280,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvProblem& g, const f32x16
     }
     const unsigned lo0 = (unsigned)(unsigned long long)off0, hi0 = (unsigned)((unsigned long long)off0 >> 32);
     const unsigned lo1 = (unsigned)(unsigned long long)off1, hi1 = (unsigned)((unsigned long long)off1 >> 32);
+    double* const stats = (!split && s_red) ? g.stats : nullptr;   // (uniform over the workgroup)
+    float cs1[NT], cs2[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) cs1[j] = cs2[j] = 0.0f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int src = (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -290,9 +297,45 @@ __device__ __forceinline__ void conv_epilogue(const ConvProblem& g, const f32x16
             if (!((valid >> j) & 1u)) continue;
             float* const dst = (((is1 >> j) & 1u) ? p1 : p0) + colj[j];
             const float v = acc[j][e] + biasj[j];
-            if (split) atomicAdd(dst, v);
-            else *dst = relu ? fmaxf(v, 0.0f) : v;
+            if (split) {
+                atomicAdd(dst, v);
+            } else {
+                const float out = relu ? fmaxf(v, 0.0f) : v;
+                *dst = out;
+                cs1[j] += out;
+                cs2[j] += out * out;
+            }
         }
+    }
+    if (stats) {
+        // BatchNorm statistics of what was just stored: a lane holds the sums of its column over 16 rows of the wave's 32; the two lane
+        // halves together are the wave's 32 rows; the waves meet in LDS (the K loop's staging buffers are free by now), then ONE fp64
+        // atomic per column and sum for the whole 32 * waves rows of the tile
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            cs1[j] += __shfl_xor(cs1[j], 32, kWave);
+            cs2[j] += __shfl_xor(cs2[j], 32, kWave);
+        }
+        __syncthreads();
+        if (h == 0) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                s_red[((wave * NT + j) * 32 + r32) * 2 + 0] = cs1[j];
+                s_red[((wave * NT + j) * 32 + r32) * 2 + 1] = cs2[j];
+            }
+        }
+        __syncthreads();
+        const int t = wave * 64 + h * 32 + r32;   // thread id inside the workgroup
+        for (int q = t; q < NT * 32; q += waves * 64) {
+            const int j = q >> 5, c = q & 31, n = n_begin + j * 32 + c;
+            if (j < tn && n < n0) {
+                float a = 0.0f, b = 0.0f;
+                for (int w = 0; w < waves; ++w) { a += s_red[((w * NT + j) * 32 + c) * 2 + 0]; b += s_red[((w * NT + j) * 32 + c) * 2 + 1]; }
+                atomicAdd(stats + n, (double)a);
+                atomicAdd(stats + n0 + n, (double)b);
+            }
+        }
+        if (m_base == 0 && n_begin == 0 && t == 0) stats[2 * n0] = (double)M;
     }
 }
 
@@ -619,7 +662,7 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
             if (tid == 0) __hip_atomic_store(sk_flag + part, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    conv_epilogue<SCATTER>(g, acc, m_base, wave, r32, h, tn, n_begin, M, N, hw, ksp);
+    conv_epilogue<SCATTER>(g, acc, m_base, wave, r32, h, tn, n_begin, M, N, hw, ksp, (!MIRROR && !SCATTER && !sk_mode) ? s_a0 : nullptr, WAVES);
     PHASE(3)
 }
 
@@ -976,7 +1019,7 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_fwd_kerne
         default: k_loop(std::integral_constant<int, 1>{}); break;
     }
 
-    conv_epilogue<SCATTER>(g, acc, m_tile * kBM, wave, r32, h, tn, n_begin, M, N, hw, ksp);
+    conv_epilogue<SCATTER>(g, acc, m_tile * kBM, wave, r32, h, tn, n_begin, M, N, hw, ksp, (!MIRROR && !SCATTER) ? &s_a[0][0] : nullptr, 4);
 }
 
 // ---- backward-weights ------------------------------------------------------------------------------------------
@@ -2308,12 +2351,26 @@ extern "C" int ssdk_conv2d_fwd(const ssdk_conv_desc* descs, int n, int batch, vo
         g.o0 = d.y; g.ob0 = (long long)ho * wo * d.cout; g.os0 = d.cout; g.o1 = nullptr; g.ob1 = 0; g.os1 = 0;
         g.relu = d.relu;
         finish_problem(g);
-        if (maybe_split_k(g)) zl.add(d.y, (size_t)batch * ho * wo * d.cout);
+        const bool split = maybe_split_k(g);
+        if (split) zl.add(d.y, (size_t)batch * ho * wo * d.cout);
+        if (d.stats) {
+            SSDK_REQUIRE(d.cout % 4 == 0 && ((uintptr_t)d.y & 15) == 0, SSDK_E_UNSUPPORTED, "ssdk_conv2d_fwd: stats need cout %% 4 == 0 and a 16-byte aligned output");
+            if (!split) g.stats = d.stats;   // in the epilogue; a split-K output is only complete after the launch: a pass of its own below
+        }
         probs[i] = g;
     }
     int rc = zl.launch((hipStream_t)stream);
     if (rc) return rc;
-    return launch_group(probs, n, false, (hipStream_t)stream, true);
+    rc = launch_group(probs, n, false, (hipStream_t)stream, true);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) {
+        const ssdk_conv_desc& d = descs[i];
+        if (!d.stats || probs[i].stats) continue;
+        const long long rows = (long long)batch * out_dim(d.hin, d.ksize, d.stride, d.pad) * out_dim(d.win, d.ksize, d.stride, d.pad);
+        rc = ssdk_batchnorm_stats_accumulate(d.y, rows, d.cout, d.stats, stream);
+        if (rc) return rc;
+    }
+    return SSDK_OK;
 }
 
 // The weights of n convolutions in the layout their backward-data GEMM reads (stride 1: [cin][tap][cout], mirrored-tap dgrad; strided:

@@ -239,6 +239,11 @@ extern "C" int ssdk_batchnorm_stats(const float* x, long long rows, int channels
     return bn_stats(x, rows, channels, sums, true, stream);
 }
 
+// sums += this call's partial sums (the caller holds a buffer of zeros, or is accumulating over several calls); sums[2C] = rows
+extern "C" int ssdk_batchnorm_stats_accumulate(const float* x, long long rows, int channels, double* sums, void* stream) {
+    return bn_stats(x, rows, channels, sums, false, stream);
+}
+
 static int bn_apply(const float* x, long long rows, int channels, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, int64_t* num_batches_tracked, float momentum, float eps, int relu, float* y, float* save_mean,
                     float* save_rstd, const double* sums, int count_in_sums, double* zero_after, void* stream) {
@@ -270,6 +275,17 @@ extern "C" int ssdk_batchnorm_fwd_chained(const float* x, long long rows, int ch
     SSDK_REQUIRE(sums && sums != zero_after, SSDK_E_INVALID, "ssdk_batchnorm_fwd_chained: sums missing or equal to zero_after");
     const int rc = bn_stats(x, rows, channels, sums, false, stream);
     if (rc) return rc;
+    return bn_apply(x, rows, channels, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, relu, y, save_mean, save_rstd,
+                    sums, 0, zero_after, stream);
+}
+
+// ... and when the statistics are already in `sums` (accumulated by the producing convolution's epilogue, ssdk_conv_desc::stats): the apply
+// half alone, with the same side job of zero-filling the layer's other buffer.
+extern "C" int ssdk_batchnorm_apply_chained(const float* x, long long rows, int channels, const float* gamma, const float* beta,
+                                            float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
+                                            int relu, float* y, float* save_mean, float* save_rstd, const double* sums, double* zero_after,
+                                            void* stream) {
+    SSDK_REQUIRE(sums && sums != zero_after, SSDK_E_INVALID, "ssdk_batchnorm_apply_chained: sums missing or equal to zero_after");
     return bn_apply(x, rows, channels, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, relu, y, save_mean, save_rstd,
                     sums, 0, zero_after, stream);
 }

@@ -44,6 +44,9 @@ class SharedConvPredictor(nn.Module):
     def _layer(self, block, norms, xs):
         if isinstance(block, conv.Conv2dBn) and isinstance(self.activation, nn.ReLU) and block._hip_ok():
             c = block.conv
+            if all(type(norm) is nn.BatchNorm2d and norm.training and ops.sync_group_of(norm) is None for norm in norms):
+                # per-process statistics: taken in the shared convolution's epilogue, level by level (ops.conv2d_batch_norm)
+                return ops.conv2d_batch_norm(list(xs), c.weight, c.bias, c.stride[0], c.padding[0], list(norms), conv_relu=True, bn_relu=False)
             ys = ops.conv2d(list(xs), c.weight, c.bias, stride=c.stride[0], padding=c.padding[0], relu=True)
             if all(type(norm) is nn.BatchNorm2d for norm in norms):
                 # per-level norms; marked for synchronisation (detection.init(distributed=True)) the five share ONE all-reduce

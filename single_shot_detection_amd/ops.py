@@ -22,10 +22,11 @@ def _out_dim(n, k, s, p):
 
 
 class _ConvFn(torch.autograd.Function):
-    """apply(weight, bias, stride, pad, relu, *xs) -> tuple of outputs; the n inputs share `weight` (one grouped launch)."""
+    """apply(weight, bias, stride, pad, relu, stats, *xs) -> tuple of outputs; the n inputs share `weight` (one grouped launch).
+    stats: None, or one fp64 `sums` buffer address (or None) per input: the BatchNorm statistics of that output are accumulated into it."""
 
     @staticmethod
-    def forward(ctx, weight, bias, stride, pad, relu, *xs):
+    def forward(ctx, weight, bias, stride, pad, relu, stats, *xs):
         lib = _lib.lib()
         _lib.require_cuda(weight, *xs)
         w = weight.float().contiguous(memory_format=torch.channels_last)
@@ -45,6 +46,7 @@ class _ConvFn(torch.autograd.Function):
             d.x, d.hin, d.win, d.cin = _dp(x), x.shape[2], x.shape[3], cin
             d.w, d.bias, d.cout, d.ksize, d.stride, d.pad, d.relu = _dp(w), _dp(b), cout, k, stride, pad, int(relu)
             d.y = _dp(y)
+            d.stats = None if stats is None else stats[i]
         _lib.check(lib.ssdk_conv2d_fwd(arr, len(xs), B, _lib.current_stream()), 'ssdk_conv2d_fwd')
         ctx.w_t = _transposed_weights_of(weight, stride)   # (prepare_weight_transposes ran for this step: the backward skips its re-layout)
         ctx.save_for_backward(w, *xs, *(ys if relu else []))
@@ -86,7 +88,7 @@ class _ConvFn(torch.autograd.Function):
                 _lib.check(lib.ssdk_relu_bwd(_dp(ys[i]), _dp(dy), dy.numel(), _dp(g), stream), 'ssdk_relu_bwd')
                 dy = g
             keep.append(dy)
-            dx = torch.empty_like(x, memory_format=torch.channels_last) if ctx.needs_input_grad[5 + i] else None
+            dx = torch.empty_like(x, memory_format=torch.channels_last) if ctx.needs_input_grad[6 + i] else None
             dxs.append(dx)
             d = arr[i]
             d.x, d.hin, d.win, d.cin = _dp(x), x.shape[2], x.shape[3], cin
@@ -99,11 +101,11 @@ class _ConvFn(torch.autograd.Function):
             if len(_pending_wgrads) == 1:
                 torch.autograd.Variable._execution_engine.queue_callback(_flush_weight_gradients)
             if all(dx is None for dx in dxs):
-                return (None, None, None, None, None) + tuple(dxs)
+                return (None, None, None, None, None, None) + tuple(dxs)
         need = lib.ssdk_conv2d_bwd_workspace_bytes(arr, n, B)
         ws = _lib.scratch(need, w.device, 'conv2d_bwd')
         _lib.check(lib.ssdk_conv2d_bwd(arr, n, B, 0, _dp(ws), ws.numel(), stream), 'ssdk_conv2d_bwd')
-        return (dw, db, None, None, None) + tuple(dxs)
+        return (dw, db, None, None, None, None) + tuple(dxs)
 
 
 _defer_wgrad = False
@@ -225,8 +227,54 @@ def _flush_weight_gradients():
 def conv2d(xs, weight, bias=None, stride=1, padding=0, relu=False):
     """Conv2d on a list of maps that share the weights (one grouped GEMM launch); returns a list."""
     single = isinstance(xs, torch.Tensor)
-    out = _ConvFn.apply(weight, bias, int(stride), int(padding), bool(relu), *([xs] if single else list(xs)))
+    out = _ConvFn.apply(weight, bias, int(stride), int(padding), bool(relu), None, *([xs] if single else list(xs)))
     return out[0] if single else list(out)
+
+
+_NO_FUSED_STATS = bool(__import__('os').environ.get('SSDK_NO_FUSED_STATS'))   # (measurement knob)
+fused_stats_calls = 0   # (norm layers whose forward statistics were handed to a convolution's epilogue; tests read it)
+
+
+def _local_training_chain(bn, device):
+    """The layer's `sums` chain when its forward statistics can be taken by the producing convolution's epilogue: a plain BatchNorm2d in
+    training mode, per-process statistics, its forward buffer known to hold zeros.  None otherwise."""
+    if _NO_FUSED_STATS or type(bn) is not torch.nn.BatchNorm2d or not bn.training or bn.momentum is None or not bn.track_running_stats or sync_group_of(bn) is not None:
+        return None
+    chain = getattr(bn, '_ssdk_sums_chain', None)
+    if chain is None or chain.buf.device != device or chain.buf.shape[1] != 2 * bn.num_features + 2:
+        chain = bn._ssdk_sums_chain = _SumsChain(bn.num_features, device)
+    return chain if chain.usable(0, device) else None
+
+
+def conv2d_batch_norm(xs, weight, bias, stride, padding, bns, conv_relu=False, bn_relu=False):
+    """conv (-> ReLU) -> BatchNorm (-> ReLU) on a list of maps that share the convolution's weights and have a norm layer each
+    (bf/modules/conv.py:30-36; the per-level norms of a RetinaNet tower layer, detection/modules/predictors.py:60-76).  Where a norm is a
+    training-mode BatchNorm2d with per-process statistics, the convolution's epilogue accumulates its statistics (ssdk_conv_desc::stats)
+    and the norm is ONE launch (apply) instead of two -- and the statistics pass over the activation is gone; anywhere else this is
+    conv2d followed by batch_norm."""
+    single = isinstance(xs, torch.Tensor)
+    xs = [xs] if single else list(xs)
+    bns = [bns] if single else list(bns)
+    chains = [_local_training_chain(bn, x.device) if x.is_cuda and torch.is_grad_enabled() else None for x, bn in zip(xs, bns)]
+    if not any(c is not None for c in chains) or weight.shape[0] % 4:
+        ys = conv2d(xs, weight, bias, stride, padding, relu=conv_relu)
+        out = [batch_norm(y, bn, relu=bn_relu) for y, bn in zip(ys, bns)]
+        return out[0] if single else out
+    for c in chains:
+        if c is not None:
+            c.clean[0] = False   # (handed to the convolution: whatever happens next, it no longer holds zeros)
+    global fused_stats_calls
+    fused_stats_calls += sum(c is not None for c in chains)
+    stats = tuple(None if c is None else c.buf[0].data_ptr() for c in chains)
+    ys = _ConvFn.apply(weight, bias, int(stride), int(padding), bool(conv_relu), stats, *xs)
+    out = []
+    for y, bn, c in zip(ys, bns, chains):
+        if c is None:
+            out.append(batch_norm(y, bn, relu=bn_relu))
+        else:
+            out.append(_BatchNormFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum, bn.eps,
+                                          True, bn_relu, c, True))
+    return out[0] if single else out
 
 
 class _SumsChain(object):
@@ -247,7 +295,7 @@ class _SumsChain(object):
 
 class _BatchNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, training, relu, chain):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, training, relu, chain, sums_ready=False):
         lib = _lib.lib()
         _lib.require_cuda(x)
         x = _nhwc(x)
@@ -258,7 +306,12 @@ class _BatchNormFn(torch.autograd.Function):
         rstd = torch.empty((C,), dtype=torch.float32, device=x.device)
         g = None if gamma is None else gamma.float().contiguous()
         b = None if beta is None else beta.float().contiguous()
-        if training and chain is not None and chain.usable(0, x.device):
+        if sums_ready:   # the producing convolution's epilogue left the statistics in chain.buf[0] (conv2d_batch_norm)
+            _lib.check(lib.ssdk_batchnorm_apply_chained(_dp(x), rows, C, _dp(g), _dp(b), _dp(running_mean), _dp(running_var), _dp(num_batches_tracked),
+                                                        float(momentum), float(eps), int(relu), _dp(y), _dp(mean), _dp(rstd), chain.buf[0].data_ptr(),
+                                                        chain.buf[1].data_ptr(), _lib.current_stream()), 'ssdk_batchnorm_apply_chained')
+            chain.clean = [False, True]
+        elif training and chain is not None and chain.usable(0, x.device):
             _lib.check(lib.ssdk_batchnorm_fwd_chained(_dp(x), rows, C, _dp(g), _dp(b), _dp(running_mean), _dp(running_var), _dp(num_batches_tracked),
                                                       float(momentum), float(eps), int(relu), _dp(y), _dp(mean), _dp(rstd), chain.buf[0].data_ptr(),
                                                       chain.buf[1].data_ptr(), _lib.current_stream()), 'ssdk_batchnorm_fwd_chained')
@@ -295,7 +348,7 @@ class _BatchNormFn(torch.autograd.Function):
             _lib.check(lib.ssdk_batchnorm_bwd(_dp(x), _dp(y) if relu else None, _dp(dy), B * H * W, C, _dp(g) if has_g else None, _dp(mean),
                                               _dp(rstd), int(relu), int(training), _dp(dx), _dp(dgamma), _dp(dbeta), _dp(ws), ws.numel(),
                                               _lib.current_stream()), 'ssdk_batchnorm_bwd')
-        return dx, dgamma if has_g else None, dbeta if has_b else None, None, None, None, None, None, None, None, None
+        return dx, dgamma if has_g else None, dbeta if has_b else None, None, None, None, None, None, None, None, None, None
 
 
 def batch_norm(x, bn, relu=False):
@@ -314,7 +367,7 @@ def batch_norm(x, bn, relu=False):
         chain = getattr(bn, '_ssdk_sums_chain', None)
         if chain is None or chain.buf.device != x.device or chain.buf.shape[1] != 2 * bn.num_features + 2:
             chain = bn._ssdk_sums_chain = _SumsChain(bn.num_features, x.device)
-    return _BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, nbt, bn.momentum, bn.eps, training, relu, chain)
+    return _BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, nbt, bn.momentum, bn.eps, training, relu, chain, False)
 
 
 def sync_group_of(bn):

@@ -503,3 +503,41 @@ def test_prepared_weight_transposes_equal_the_per_call_ones_and_never_go_stale()
     ga2, gb2 = run(a, False), run(b, False)   # b is NOT prepared again: its backward must re-lay out the new weights itself
     np.testing.assert_allclose(gb2.cpu().numpy(), ga2.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(ga2.abs().max()))
     assert not np.allclose(gb2.cpu().numpy(), gb.cpu().numpy(), rtol=1e-3, atol=1e-5 * float(ga.abs().max()))
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,pad,hw,batch', [(64, 128, 3, 1, 1, 64, 8),     # 256 row tiles: not split over K -> statistics in the epilogue
+                                                             (32, 256, 1, 1, 0, 48, 16),    # two column blocks, 1 x 1
+                                                             (64, 64, 3, 2, 1, 9, 2)])      # small map: split over K -> the pass of its own
+def test_batchnorm_statistics_from_the_conv_epilogue_equal_the_separate_pass(cin, cout, k, stride, pad, hw, batch, monkeypatch):
+    """ssdk_conv_desc::stats / ops.conv2d_batch_norm: Conv2dBn whose BatchNorm statistics are accumulated by the convolution's epilogue
+    (or, for a split-K convolution, by the library's own pass after it) against the same block with conv and norm run apart: outputs,
+    running statistics, and every gradient."""
+    import copy
+    from single_shot_detection_amd import ops
+    rng = np.random.default_rng(5)
+    blk = conv.Conv2dBn(cin, cout, k, stride=stride, padding=pad, bias=True)
+    _randomize(blk, rng)
+    a, b = copy.deepcopy(blk).cuda().train(), copy.deepcopy(blk).cuda().train()
+    x_np = rng.standard_normal((batch, cin, hw, hw), dtype=np.float32)
+
+    def run(mod):
+        x = torch.from_numpy(x_np).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        y = mod(x)
+        (y * y).sum().backward()
+        return y.detach(), x.grad
+
+    before = ops.fused_stats_calls
+    ya, ga = run(a)
+    assert ops.fused_stats_calls == before + 1
+    monkeypatch.setattr(ops, '_local_training_chain', lambda bn, device: None)
+    yb, gb = run(b)
+    assert ops.fused_stats_calls == before + 1
+    scale = float(yb.abs().max())
+    np.testing.assert_allclose(ya.cpu().numpy(), yb.cpu().numpy(), rtol=1e-4, atol=2e-5 * scale)
+    np.testing.assert_allclose(ga.cpu().numpy(), gb.cpu().numpy(), rtol=1e-3, atol=2e-4 * float(gb.abs().max()))
+    for name in ('running_mean', 'running_var'):
+        np.testing.assert_allclose(getattr(a.bn, name).cpu().numpy(), getattr(b.bn, name).cpu().numpy(), rtol=1e-5, atol=1e-6)
+    assert int(a.bn.num_batches_tracked) == int(b.bn.num_batches_tracked) == 1
+    gmax = max(float(p.grad.abs().max()) for p in b.parameters())   # (the conv bias' gradient through a BatchNorm is zero up to rounding: one scale for all)
+    for (n1, p1), (n2, p2) in zip(sorted(a.named_parameters()), sorted(b.named_parameters())):
+        np.testing.assert_allclose(p1.grad.cpu().numpy(), p2.grad.cpu().numpy(), rtol=2e-3, atol=2e-4 * gmax, err_msg=n1)
