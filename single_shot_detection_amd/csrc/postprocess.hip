@@ -1569,7 +1569,7 @@ extern "C" int ssdk_postprocess(const float* scores, const float* locs, const fl
     SSDK_REQUIRE(max_total <= kSortCap, SSDK_E_UNSUPPORTED, "ssdk_postprocess: max_total=%d > %d", max_total, kSortCap);
     SSDK_REQUIRE(!soft_nms || soft_sigma > 0.0f, SSDK_E_INVALID, "ssdk_postprocess: soft-NMS sigma must be > 0");
     const int ncls = ncls_of(num_classes, softmax);
-    const long long per_class_cap = any_k ? any_cap(num_anchors, max_per_class, max_total) : max_per_class;
+    const long long per_class_cap = any_k ? any_cap(num_anchors, max_per_class, max_total) : (max_per_class < num_anchors ? max_per_class : num_anchors);   // (a class never holds more rows than there are anchors)
     SSDK_REQUIRE(out_cap >= (max_total > 0 ? max_total : 1), SSDK_E_INVALID, "ssdk_postprocess: out_cap=%d too small", out_cap);
     SSDK_REQUIRE(max_total > 0 || (long long)out_cap >= (long long)ncls * per_class_cap, SSDK_E_INVALID,
                  "ssdk_postprocess: out_cap=%d < ncls * rows per class with max_total=None", out_cap);

@@ -192,3 +192,18 @@ def test_two_pass_nms_with_skewed_classes_vs_oracle(name):
     per_class = [np.bincount(r[:, 4].astype(int), minlength=Cn) for r in ref]
     assert per_class[0].max() > 64   # image 0: one class holds more of the final rows than any head
     assert (per_class[1] > 0).sum() <= 3 and ref[1].shape[0] == 200
+
+
+def test_fewer_anchors_than_max_per_class_without_max_total():
+    """A = 37 anchors, max_per_class = 64, max_total = None (found by tools/stress_post.py): the output holds ncls * min(max_per_class, A)
+    rows at most, and the library accepts a buffer of that size."""
+    rng = np.random.default_rng(8)
+    A, C, B = 37, 20, 2
+    pri = np.concatenate([rng.uniform(20, 280, (A, 2)), rng.uniform(8, 120, (A, 2))], 1).astype(np.float32)
+    lg = (rng.standard_normal((B, A * C)) - 2.0).astype(np.float32)
+    lc = (rng.standard_normal((B, A * 4)) * 0.2).astype(np.float32)
+    post = Postprocessor(BoxCoder(10.0, 5.0), score_threshold=0.01, nms={'max_per_class': 64, 'overlap_threshold': 0.5}, score_converter='SIGMOID',
+                         max_total=None)
+    out = post.postprocess((torch.from_numpy(lg).cuda(), torch.from_numpy(lc).cuda()), torch.from_numpy(pri).cuda())
+    ref = oracle.postprocess(lg, lc, pri, softmax=False, score_thr=0.01, max_per_class=64, nms_thr=0.5, max_total=None)
+    compare(out, ref)

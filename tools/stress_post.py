@@ -1,0 +1,61 @@
+"""Randomised differential check of Postprocessor against the oracle (many small shapes and option combinations: class counts, caps,
+thresholds, score converters, skewed / sparse / dense score distributions).   python3 tools/stress_post.py [cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import oracle  # noqa: E402
+from single_shot_detection_amd.detection.box_coder import BoxCoder  # noqa: E402
+from single_shot_detection_amd.detection.postprocessor import Postprocessor  # noqa: E402
+from test_postprocess_gpu import compare  # noqa: E402
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+for case in range(cases):
+    B = int(rng.integers(1, 5))
+    A = int(rng.choice([37, 200, 777, 1500, 3100, 6000]))
+    softmax = bool(rng.integers(0, 2))
+    C = int(rng.choice([2, 3, 5, 21, 40, 81, 91])) if softmax else int(rng.choice([1, 3, 20, 80, 90]))
+    mpc = rng.choice([1, 7, 16, 31, 32, 33, 64, 100, 128, 200, None])
+    mpc = None if mpc is None else int(mpc)
+    mt = rng.choice([1, 10, 50, 100, 200, 256, None])
+    mt = None if mt is None else int(mt)
+    thr = float(rng.choice([0.01, 0.05, 0.3, 0.6]))
+    nms_thr = float(rng.choice([0.3, 0.45, 0.5, 0.7]))
+    pri = np.concatenate([rng.uniform(20, 280, (A, 2)), rng.uniform(8, 120, (A, 2))], 1).astype(np.float32)
+    kind = int(rng.integers(0, 4))
+    lg = rng.standard_normal((B, A, C)).astype(np.float32)
+    if kind == 1:      # trained-like: background / negative bias
+        if softmax:
+            lg[..., 0] += 5.0
+        else:
+            lg -= 4.0
+    elif kind == 2:    # one class dominates
+        lg[..., min(C - 1, 1)] += 4.0
+    elif kind == 3:    # clustered boxes (heavy suppression)
+        pri[:, :2] = pri[rng.integers(0, 6, A), :2] + rng.normal(0, 2.0, (A, 2)).astype(np.float32)
+    lc = (rng.standard_normal((B, A, 4)) * float(rng.choice([0.0, 0.2, 0.6]))).astype(np.float32)
+    if mt is None and (mpc is None or mpc > 256):
+        mt = 200   # (neither cap: huge outputs; covered by a dedicated test)
+    nms = {'overlap_threshold': nms_thr}
+    if mpc is not None:
+        nms['max_per_class'] = mpc
+    tag = dict(case=case, B=B, A=A, C=C, softmax=softmax, mpc=mpc, mt=mt, thr=thr, nms_thr=nms_thr, kind=kind)
+    try:
+        post = Postprocessor(BoxCoder(10.0, 5.0), score_threshold=thr, nms=nms, score_converter='SOFTMAX' if softmax else 'SIGMOID', max_total=mt)
+        out = post.postprocess((torch.from_numpy(lg.reshape(B, -1)).cuda(), torch.from_numpy(lc.reshape(B, -1)).cuda()), torch.from_numpy(pri).cuda())
+        ref, cand = oracle.postprocess(lg.reshape(B, -1), lc.reshape(B, -1), pri, softmax=softmax, score_thr=thr, max_per_class=mpc, nms_thr=nms_thr,
+                                       max_total=mt, return_cand=True)
+        compare(out, ref)
+        assert np.array_equal(post.last_nms_candidates.cpu().numpy(), cand), (post.last_nms_candidates.cpu().numpy(), cand)
+    except Exception as e:   # noqa: BLE001
+        bad += 1
+        print('FAIL', tag, type(e).__name__, str(e)[:300], flush=True)
+print('%d cases, %d failures' % (cases, bad))
+sys.exit(1 if bad else 0)
