@@ -47,6 +47,9 @@ def _compare_module(gpu_m, ref_m, x_np, train, rtol=2e-4, atol=2e-4):
     (yg * g.cuda()).sum().backward()
     np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=rtol, atol=atol)
     for (n1, p1), (n2, p2) in zip(sorted(gpu_m.named_parameters()), sorted(ref_m.named_parameters())):
+        if p2.grad is None:
+            assert p1.grad is None or not p1.requires_grad
+            continue
         scale = float(p2.grad.abs().max()) + 1e-6
         np.testing.assert_allclose(p1.grad.cpu().numpy(), p2.grad.numpy(), rtol=rtol, atol=atol * scale + 1e-5, err_msg=n1)
     for (n1, b1), (n2, b2) in zip(sorted(gpu_m.named_buffers()), sorted(ref_m.named_buffers())):

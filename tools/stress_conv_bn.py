@@ -1,0 +1,56 @@
+"""Randomised differential check of Conv2dBn (conv -> BatchNorm -> ReLU on libssdk: split-K and whole-tile convolutions, statistics in the
+epilogue or by the separate pass, with / without bias, BatchNorm, activation) against the same block on torch's CPU kernels, training and
+evaluation mode, forward and backward.   python3 tools/stress_conv_bn.py [cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from single_shot_detection_amd.bf.modules import conv  # noqa: E402
+from test_conv_bn_gpu import _RefConv2dBn, _compare_module, _randomize  # noqa: E402
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 80
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+for case in range(cases):
+    cin = int(rng.choice([4, 32, 36, 64, 128, 256]))
+    cout = int(rng.choice([4, 32, 44, 128, 256]))
+    k = int(rng.choice([1, 3]))
+    stride = int(rng.choice([1, 2]))
+    pad = int(rng.choice([0, 1])) if k == 3 else 0
+    hw = int(rng.choice([1, 2, 3, 5, 9, 17, 32, 48]))
+    if k == 3 and pad == 0 and hw < 3:
+        hw = 3
+    B = int(rng.choice([1, 2, 4, 8]))
+    if B * hw * hw * cin * cout * k * k > 3e9:
+        B, hw = 2, min(hw, 32)
+    use_bn, bias = bool(rng.integers(0, 4)), bool(rng.integers(0, 2))
+    act = {'name': 'ReLU', 'args': {'inplace': True}} if rng.integers(0, 3) else None
+    train = bool(rng.integers(0, 3))
+    tag = dict(case=case, cin=cin, cout=cout, k=k, stride=stride, pad=pad, hw=hw, B=B, use_bn=use_bn, bias=bias, act=act is not None, train=train)
+    try:
+        m = conv.Conv2dBn(cin, cout, kernel_size=k, stride=stride, padding=pad, bias=bias, use_bn=use_bn, activation_params=act)
+        _randomize(m, rng)
+        if use_bn:
+            with torch.no_grad():
+                m.bn.running_mean.copy_(torch.from_numpy(rng.standard_normal(cout, dtype=np.float32) * 0.1))
+                m.bn.running_var.copy_(torch.from_numpy(rng.uniform(0.5, 2.0, cout).astype(np.float32)))
+        ref = _RefConv2dBn(m)
+        x = rng.standard_normal((B, cin, hw, hw), dtype=np.float32)
+        ho = (hw + 2 * pad - k) // stride + 1
+        if use_bn and train and B * ho * ho < 16:
+            continue   # (a handful of values per channel: torch raises for one, and 1 / std amplifies rounding for a few)
+        if use_bn and train and bias:
+            # the gradient of a convolution bias in front of a training-mode BatchNorm is zero up to rounding: nothing to compare
+            m.conv.bias.requires_grad_(False)
+            ref.conv.bias.requires_grad_(False)
+        _compare_module(m.cuda(), ref, x, train, rtol=5e-4, atol=5e-4)
+    except Exception as e:   # noqa: BLE001
+        bad += 1
+        print('FAIL', tag, type(e).__name__, str(e)[:400].replace('\n', ' | '), flush=True)
+print('%d cases, %d failures' % (cases, bad))
+sys.exit(1 if bad else 0)

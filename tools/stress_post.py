@@ -46,12 +46,15 @@ for case in range(cases):
     nms = {'overlap_threshold': nms_thr}
     if mpc is not None:
         nms['max_per_class'] = mpc
-    tag = dict(case=case, B=B, A=A, C=C, softmax=softmax, mpc=mpc, mt=mt, thr=thr, nms_thr=nms_thr, kind=kind)
+    soft = mpc is not None and mpc <= 256 and rng.integers(0, 6) == 0
+    if soft:
+        nms.update(soft=True, sigma=0.5)
+    tag = dict(case=case, B=B, A=A, C=C, softmax=softmax, mpc=mpc, mt=mt, thr=thr, nms_thr=nms_thr, kind=kind, soft=bool(soft))
     try:
         post = Postprocessor(BoxCoder(10.0, 5.0), score_threshold=thr, nms=nms, score_converter='SOFTMAX' if softmax else 'SIGMOID', max_total=mt)
         out = post.postprocess((torch.from_numpy(lg.reshape(B, -1)).cuda(), torch.from_numpy(lc.reshape(B, -1)).cuda()), torch.from_numpy(pri).cuda())
         ref, cand = oracle.postprocess(lg.reshape(B, -1), lc.reshape(B, -1), pri, softmax=softmax, score_thr=thr, max_per_class=mpc, nms_thr=nms_thr,
-                                       max_total=mt, return_cand=True)
+                                       max_total=mt, return_cand=True, **(dict(soft=True, sigma=0.5) if soft else {}))
         compare(out, ref)
         assert np.array_equal(post.last_nms_candidates.cpu().numpy(), cand), (post.last_nms_candidates.cpu().numpy(), cand)
     except Exception as e:   # noqa: BLE001
