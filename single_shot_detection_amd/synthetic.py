@@ -129,8 +129,14 @@ def make_map_case(seed, num_images=12, num_classes=6, with_difficult=True, max_g
         pass                                                  # raw scores: a few accidental ties (large benchmark inputs)
     elif unique_scores and pred.shape[0]:
         s = pred[:, 6]
-        while np.unique(s).size != s.size:
+        for _ in range(20):
+            if np.unique(s).size == s.size:
+                break
             s += rng.uniform(0, 1e-4, s.size).astype(np.float32)
+        while np.unique(s).size != s.size:   # tens of thousands of fp32 scores: re-drawing all of them keeps colliding -- move the repeats only
+            order = np.argsort(s, kind='stable')
+            rep = order[1:][s[order[1:]] == s[order[:-1]]]
+            s[rep] = np.nextafter(s[rep], np.float32(2.0))
     elif pred.shape[0]:
         pred[:, 6] = np.round(pred[:, 6] * 20) / 20          # many exact ties
     pred = pred[rng.permutation(pred.shape[0])]

@@ -35,4 +35,34 @@ for case in range(cases):
         bad += 1
         print('FAIL', dict(case=case, voc=voc, **kw), type(e).__name__, str(e)[:300].replace('\n', ' | '), flush=True)
 print('%d mAP cases, %d failures' % (cases, bad))
-sys.exit(1 if bad else 0)
+
+# ---- SSD anchor generator: every constructor mode, bit for bit against the oracle's restatement (itself pinned by the reference's goldens)
+from single_shot_detection_amd.detection.anchor_generators import ssd  # noqa: E402
+abad = 0
+for case in range(cases):
+    ars = [[1.0], [1.0, 2.0], [1.0, 2.0, 3.0], [2.0, 0.5], [1.5, 1.0, 3.0]][int(rng.integers(0, 5))]
+    kw = dict(aspect_ratios=ars, flip=bool(rng.integers(0, 2)) and min(ars) >= 1.0, num_branches=int(rng.choice([1, 2, 3])))   # (ratios < 1 with flip: the constructor asserts, like the reference's)
+    if rng.integers(0, 2):
+        lo = float(rng.uniform(0.05, 0.5))
+        kw.update(min_scale=lo, max_scale=lo + float(rng.uniform(0.05, 0.5)))
+    else:
+        lo = float(rng.uniform(10, 100))
+        kw.update(min_size=lo, max_size=lo + float(rng.uniform(5, 150)))
+    if rng.integers(0, 2):
+        kw['step'] = int(rng.choice([8, 16, 30, 64]))
+    if rng.integers(0, 2):
+        kw['offset'] = (float(rng.choice([0.0, 0.25, 0.5])), float(rng.choice([0.5, 0.75])))
+    img_wh = (int(rng.choice([300, 512, 321])), int(rng.choice([300, 512, 287])))
+    fmap_wh = (int(rng.choice([1, 3, 10, 19, 38, 64])), int(rng.choice([1, 2, 10, 19, 38])))
+    try:
+        gen = ssd.SsdAnchorGenerator(**kw)
+        img = torch.empty((1, 3, img_wh[1], img_wh[0]), device='cuda')
+        got = gen.generate(img, (fmap_wh[1], fmap_wh[0])).cpu().numpy()
+        okw = {k: v for k, v in kw.items() if k != 'aspect_ratios'}
+        ref = oracle.ssd_anchor_generator(img_wh, fmap_wh, ars, **okw)
+        assert got.shape == ref.shape and np.array_equal(got.view(np.uint32), ref.view(np.uint32)), float(np.abs(got - ref).max())
+    except Exception as e:   # noqa: BLE001
+        abad += 1
+        print('FAIL', dict(case=case, img=img_wh, fmap=fmap_wh, **kw), type(e).__name__, str(e)[:300].replace('\n', ' | '), flush=True)
+print('%d anchor cases, %d failures' % (cases, abad))
+sys.exit(1 if bad or abad else 0)
