@@ -235,6 +235,12 @@ class HotPath(object):
         self.opt.step()
         return loss
 
+    def set_training(self, training):
+        """model.train() / model.eval() of the path's modules (the reference evaluates under model.eval(): BatchNorm on running statistics)."""
+        for m in (self.extras, self.tower, self.neck, self.heads):
+            if m is not None:
+                m.train(training)
+
     def eval_step(self):
         with torch.no_grad():
             scores, locs = self.forward_heads()
@@ -372,6 +378,7 @@ def serving_legs(device, cfg_name='ssd_300_vgg16_voc', batches=(1, 2, 8), reps=3
     out = []
     for b in batches:
         hp = HotPath(cfg_name, b, device)
+        hp.set_training(False)
 
         def step(*taps):
             hp.inputs = list(taps)
@@ -538,6 +545,7 @@ def main():
     achieved = flops_step / (fwd_ms * 1e-3) / 1e12
 
     # eval leg: heads forward + postprocess (NMS boxes/s = candidates entering NMS per second)
+    hp.set_training(False)
     for _ in range(2):
         hp.eval_step()
     barrier()

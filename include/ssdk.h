@@ -312,7 +312,9 @@ int ssdk_batchnorm_fwd(const float* x, long long rows, int channels, const float
                        float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
                        int training, int relu, float* y, float* save_mean, float* save_rstd, void* workspace,
                        size_t workspace_bytes, void* stream);
-/* y is the forward output (needed only when relu != 0, for the mask). */
+/* y is the forward output (needed only when relu bit 0 is set, for the mask).  Backward entry points read `relu` as two bits: bit 0 = the
+ * norm's own fused ReLU; bit 1 = the norm's INPUT x is the output of a ReLU (conv -> ReLU -> BatchNorm, detection/modules/predictors.py:60-76)
+ * whose gradient is taken in the same pass: dx = 0 where x <= 0, and the producer skips its own ReLU-gradient pass. */
 int ssdk_batchnorm_bwd(const float* x, const float* y, const float* dy, long long rows, int channels, const float* gamma,
                        const float* save_mean, const float* save_rstd, int relu, int training, float* dx, float* dgamma,
                        float* dbeta, void* workspace, size_t workspace_bytes, void* stream);

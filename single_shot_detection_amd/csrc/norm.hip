@@ -189,19 +189,51 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
                                                            const double* __restrict__ sums_local, int count_on_device, int relu, int training,
                                                            float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                            double* __restrict__ zero_after) {
-    const long long total = rows * C;
+    // relu bit 0: the norm's own fused ReLU (dy counts where y > 0); bit 1: the norm's INPUT is the output of a ReLU whose gradient is
+    // taken here as well (dx = 0 where x <= 0: conv -> ReLU -> BatchNorm of the RetinaNet tower, the producing convolution then skips its
+    // own ReLU-gradient pass)
+    const bool own_relu = (relu & 1) != 0, mask_input = (relu & 2) != 0;
+    const long long total4 = rows * C / 4;   // (C % 4 == 0, 16-byte aligned buffers: checked by the host)
+    const int C4 = C >> 2;
     if (zero_after && blockIdx.x == gridDim.x - 1)
         for (int c = threadIdx.x; c < 2 * C + 2; c += blockDim.x) zero_after[c] = 0.0;
     const double inv_n = 1.0 / (count_on_device ? sums[2 * C] : (double)rows);
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        float g = dy[i];
-        if (relu && !(y[i] > 0.0f)) g = 0.0f;
-        const float rs = rstd[c], xhat = (x[i] - mean[c]) * rs;
-        const float ga = gamma ? gamma[c] : 1.0f;
-        float v = g;
-        if (training) v -= (float)(sums[c] * inv_n) + xhat * (float)(sums[C + c] * inv_n);
-        dx[i] = ga * rs * v;
+    // A thread's four channels stay the same over its grid-stride trips whenever the stride is a multiple of the row length (C / 4 divides
+    // 256 * gridDim for every power-of-two C): their five per-channel constants are then loaded and converted ONCE.  (Per element they
+    // were five scattered loads and two fp64 multiplies: the float4 form of this kernel was slower than the scalar one until they moved.)
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const bool fixed_c = stride % C4 == 0;
+    float k_mean[4], k_rs[4], k_ga[4], k_m1[4], k_m2[4];
+    auto load_consts = [&](int c) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            k_mean[k] = mean[c + k];
+            k_rs[k] = rstd[c + k];
+            k_ga[k] = gamma ? gamma[c + k] : 1.0f;
+            k_m1[k] = training ? (float)(sums[c + k] * inv_n) : 0.0f;
+            k_m2[k] = training ? (float)(sums[C + c + k] * inv_n) : 0.0f;
+        }
+    };
+    const long long i0 = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (fixed_c && i0 < total4) load_consts((int)(i0 % C4) * 4);
+    for (long long i = i0; i < total4; i += stride) {
+        if (!fixed_c) load_consts((int)(i % C4) * 4);
+        const float4 g4 = reinterpret_cast<const float4*>(dy)[i];
+        const float4 x4 = reinterpret_cast<const float4*>(x)[i];
+        float4 y4 = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (own_relu) y4 = reinterpret_cast<const float4*>(y)[i];
+        const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, xx[4] = {x4.x, x4.y, x4.z, x4.w}, yy[4] = {y4.x, y4.y, y4.z, y4.w};
+        float out[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float g = gg[k];
+            if (own_relu && !(yy[k] > 0.0f)) g = 0.0f;
+            const float xhat = (xx[k] - k_mean[k]) * k_rs[k];
+            float v = g;
+            if (training) v -= k_m1[k] + xhat * k_m2[k];
+            out[k] = (mask_input && !(xx[k] > 0.0f)) ? 0.0f : k_ga[k] * k_rs[k] * v;
+        }
+        reinterpret_cast<float4*>(dx)[i] = make_float4(out[0], out[1], out[2], out[3]);
     }
     if (blockIdx.x == 0)
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -318,6 +350,7 @@ extern "C" int ssdk_batchnorm_fwd(const float* x, long long rows, int channels, 
 
 static int bn_bwd_stats(const float* x, const float* y, const float* dy, long long rows, int channels, const float* save_mean,
                         const float* save_rstd, int relu, double* sums, bool zero_first, void* stream) {
+    relu &= 1;   // (bit 1 -- the norm's input is a ReLU output -- concerns dx only: the sums are over the gradient of the norm's OUTPUT)
     SSDK_REQUIRE(x && dy && sums && save_mean && save_rstd && rows > 0 && channels > 0 && (!relu || y), SSDK_E_INVALID,
                  "ssdk_batchnorm_bwd_stats: bad arguments");
     hipStream_t s = (hipStream_t)stream;
@@ -338,11 +371,13 @@ static int bn_bwd_apply(const float* x, const float* y, const float* dy, long lo
                         const float* save_mean, const float* save_rstd, int relu, int training, const double* sums,
                         const double* sums_local, const double* total_rows, float* dx, float* dgamma, float* dbeta, double* zero_after,
                         void* stream) {
-    SSDK_REQUIRE(x && dy && dx && sums && save_mean && save_rstd && rows > 0 && channels > 0 && (!relu || y), SSDK_E_INVALID,
+    SSDK_REQUIRE(x && dy && dx && sums && save_mean && save_rstd && rows > 0 && channels > 0 && (!(relu & 1) || y), SSDK_E_INVALID,
                  "ssdk_batchnorm_bwd_apply: bad arguments");
+    SSDK_REQUIRE(channels % 4 == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)y) & 15) == 0, SSDK_E_UNSUPPORTED,
+                 "ssdk_batchnorm_bwd_apply: channels %% 4 != 0 or buffers not 16-byte aligned");
     SSDK_REQUIRE(!total_rows || total_rows == sums + 2 * (size_t)channels, SSDK_E_INVALID,
                  "ssdk_batchnorm_bwd_apply: total_rows must be the slot behind the sums (sums + 2 * channels) or NULL");
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_blocks(rows * channels, 256)), dim3(256), 0, (hipStream_t)stream, x, y, dy, rows, channels,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_blocks(rows * channels / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, y, dy, rows, channels,
                        save_mean, save_rstd, gamma, sums, sums_local ? sums_local : sums, total_rows ? 1 : 0, relu, training, dx, dgamma, dbeta,
                        zero_after);
     SSDK_CHECK_LAUNCH("bn_bwd_apply_kernel");
@@ -371,7 +406,7 @@ extern "C" int ssdk_batchnorm_bwd_chained(const float* x, const float* y, const 
 extern "C" int ssdk_batchnorm_bwd(const float* x, const float* y, const float* dy, long long rows, int channels, const float* gamma,
                                   const float* save_mean, const float* save_rstd, int relu, int training, float* dx, float* dgamma,
                                   float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
-    SSDK_REQUIRE(x && dy && dx && save_mean && save_rstd && rows > 0 && channels > 0 && (!relu || y), SSDK_E_INVALID, "ssdk_batchnorm_bwd: bad arguments");
+    SSDK_REQUIRE(x && dy && dx && save_mean && save_rstd && rows > 0 && channels > 0 && (!(relu & 1) || y), SSDK_E_INVALID, "ssdk_batchnorm_bwd: bad arguments");
     SSDK_REQUIRE(workspace && workspace_bytes >= ssdk_batchnorm_workspace_bytes(channels), SSDK_E_WORKSPACE, "ssdk_batchnorm_bwd: workspace too small");
     const int rc = ssdk_batchnorm_bwd_stats(x, y, dy, rows, channels, save_mean, save_rstd, relu, (double*)workspace, stream);
     if (rc) return rc;

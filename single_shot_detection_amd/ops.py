@@ -44,13 +44,15 @@ class _ConvFn(torch.autograd.Function):
             ys.append(y)
             d = arr[i]
             d.x, d.hin, d.win, d.cin = _dp(x), x.shape[2], x.shape[3], cin
-            d.w, d.bias, d.cout, d.ksize, d.stride, d.pad, d.relu = _dp(w), _dp(b), cout, k, stride, pad, int(relu)
+            d.w, d.bias, d.cout, d.ksize, d.stride, d.pad, d.relu = _dp(w), _dp(b), cout, k, stride, pad, int(bool(relu))
             d.y = _dp(y)
             d.stats = None if stats is None else stats[i]
         _lib.check(lib.ssdk_conv2d_fwd(arr, len(xs), B, _lib.current_stream()), 'ssdk_conv2d_fwd')
         ctx.w_t = _transposed_weights_of(weight, stride)   # (prepare_weight_transposes ran for this step: the backward skips its re-layout)
-        ctx.save_for_backward(w, *xs, *(ys if relu else []))
-        ctx.meta = (stride, pad, bool(relu), len(xs), bias is not None, tuple(tuple(y.shape) for y in ys))
+        ctx.save_for_backward(w, *xs, *(ys if relu == 1 else []))
+        # relu == 2: ReLU in the forward epilogue as usual, but its gradient is taken by the consumer (a BatchNorm that masks its dx where
+        # its input is not positive, conv2d_batch_norm): the backward gets dy already masked and skips its own pass over it
+        ctx.meta = (stride, pad, relu == 1, len(xs), bias is not None, tuple(tuple(y.shape) for y in ys))
         ctx.params = (weight, bias)   # leaves: their gradient-bucket slots (distributed.GradBucket) are looked up in the backward
         return tuple(ys)
 
@@ -232,6 +234,7 @@ def conv2d(xs, weight, bias=None, stride=1, padding=0, relu=False):
 
 
 _NO_FUSED_STATS = bool(__import__('os').environ.get('SSDK_NO_FUSED_STATS'))   # (measurement knob)
+_NO_RELU_BY_NORM = bool(__import__('os').environ.get('SSDK_NO_RELU_BY_NORM'))   # (measurement knob)
 fused_stats_calls = 0   # (norm layers whose forward statistics were handed to a convolution's epilogue; tests read it)
 
 
@@ -266,14 +269,17 @@ def conv2d_batch_norm(xs, weight, bias, stride, padding, bns, conv_relu=False, b
     global fused_stats_calls
     fused_stats_calls += sum(c is not None for c in chains)
     stats = tuple(None if c is None else c.buf[0].data_ptr() for c in chains)
-    ys = _ConvFn.apply(weight, bias, int(stride), int(padding), bool(conv_relu), stats, *xs)
+    # conv -> ReLU -> norm with every norm on this path: the norms' backward also takes the ReLU's gradient (dx = 0 where the norm's input
+    # is not positive), and the convolution's backward skips its own pass over dy
+    relu_by_norm = bool(conv_relu) and all(c is not None for c in chains) and not _NO_RELU_BY_NORM
+    ys = _ConvFn.apply(weight, bias, int(stride), int(padding), 2 if relu_by_norm else int(bool(conv_relu)), stats, *xs)
     out = []
     for y, bn, c in zip(ys, bns, chains):
         if c is None:
             out.append(batch_norm(y, bn, relu=bn_relu))
         else:
             out.append(_BatchNormFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum, bn.eps,
-                                          True, bn_relu, c, True))
+                                          True, int(bool(bn_relu)) | (2 if relu_by_norm else 0), c, True))
     return out[0] if single else out
 
 
@@ -306,23 +312,25 @@ class _BatchNormFn(torch.autograd.Function):
         rstd = torch.empty((C,), dtype=torch.float32, device=x.device)
         g = None if gamma is None else gamma.float().contiguous()
         b = None if beta is None else beta.float().contiguous()
+        relu = int(relu)      # bit 0: the norm's own fused ReLU; bit 1 (backward only): the input is a ReLU output, its gradient is taken here too
+        own = relu & 1
         if sums_ready:   # the producing convolution's epilogue left the statistics in chain.buf[0] (conv2d_batch_norm)
             _lib.check(lib.ssdk_batchnorm_apply_chained(_dp(x), rows, C, _dp(g), _dp(b), _dp(running_mean), _dp(running_var), _dp(num_batches_tracked),
-                                                        float(momentum), float(eps), int(relu), _dp(y), _dp(mean), _dp(rstd), chain.buf[0].data_ptr(),
+                                                        float(momentum), float(eps), own, _dp(y), _dp(mean), _dp(rstd), chain.buf[0].data_ptr(),
                                                         chain.buf[1].data_ptr(), _lib.current_stream()), 'ssdk_batchnorm_apply_chained')
             chain.clean = [False, True]
         elif training and chain is not None and chain.usable(0, x.device):
             _lib.check(lib.ssdk_batchnorm_fwd_chained(_dp(x), rows, C, _dp(g), _dp(b), _dp(running_mean), _dp(running_var), _dp(num_batches_tracked),
-                                                      float(momentum), float(eps), int(relu), _dp(y), _dp(mean), _dp(rstd), chain.buf[0].data_ptr(),
+                                                      float(momentum), float(eps), own, _dp(y), _dp(mean), _dp(rstd), chain.buf[0].data_ptr(),
                                                       chain.buf[1].data_ptr(), _lib.current_stream()), 'ssdk_batchnorm_fwd_chained')
             chain.clean = [False, True]
         else:
             ws = _lib.scratch(lib.ssdk_batchnorm_workspace_bytes(C), x.device, 'batchnorm')
             _lib.check(lib.ssdk_batchnorm_fwd(_dp(x), rows, C, _dp(g), _dp(b), _dp(running_mean), _dp(running_var),
-                                              _dp(num_batches_tracked) if training else None, float(momentum), float(eps), int(training), int(relu), _dp(y), _dp(mean), _dp(rstd), _dp(ws), ws.numel(),
+                                              _dp(num_batches_tracked) if training else None, float(momentum), float(eps), int(training), own, _dp(y), _dp(mean), _dp(rstd), _dp(ws), ws.numel(),
                                               _lib.current_stream()), 'ssdk_batchnorm_fwd')
-        ctx.save_for_backward(x, y if relu else x.new_empty(0), g if g is not None else x.new_empty(0), mean, rstd)
-        ctx.meta = (bool(relu), bool(training), gamma is not None, beta is not None)
+        ctx.save_for_backward(x, y if own else x.new_empty(0), g if g is not None else x.new_empty(0), mean, rstd)
+        ctx.meta = (relu, bool(training), gamma is not None, beta is not None)
         ctx.chain = chain
         ctx.mark_non_differentiable(mean, rstd)
         return y
@@ -339,14 +347,14 @@ class _BatchNormFn(torch.autograd.Function):
         dgamma = torch.empty((C,), dtype=torch.float32, device=x.device)
         dbeta = torch.empty((C,), dtype=torch.float32, device=x.device)
         if training and chain is not None and chain.usable(1, x.device):
-            _lib.check(lib.ssdk_batchnorm_bwd_chained(_dp(x), _dp(y) if relu else None, _dp(dy), B * H * W, C, _dp(g) if has_g else None, _dp(mean),
-                                                      _dp(rstd), int(relu), _dp(dx), _dp(dgamma), _dp(dbeta), chain.buf[1].data_ptr(),
+            _lib.check(lib.ssdk_batchnorm_bwd_chained(_dp(x), _dp(y) if relu & 1 else None, _dp(dy), B * H * W, C, _dp(g) if has_g else None, _dp(mean),
+                                                      _dp(rstd), relu, _dp(dx), _dp(dgamma), _dp(dbeta), chain.buf[1].data_ptr(),
                                                       chain.buf[0].data_ptr(), _lib.current_stream()), 'ssdk_batchnorm_bwd_chained')
             chain.clean = [True, False]
         else:
             ws = _lib.scratch(lib.ssdk_batchnorm_workspace_bytes(C), x.device, 'batchnorm')
-            _lib.check(lib.ssdk_batchnorm_bwd(_dp(x), _dp(y) if relu else None, _dp(dy), B * H * W, C, _dp(g) if has_g else None, _dp(mean),
-                                              _dp(rstd), int(relu), int(training), _dp(dx), _dp(dgamma), _dp(dbeta), _dp(ws), ws.numel(),
+            _lib.check(lib.ssdk_batchnorm_bwd(_dp(x), _dp(y) if relu & 1 else None, _dp(dy), B * H * W, C, _dp(g) if has_g else None, _dp(mean),
+                                              _dp(rstd), relu, int(training), _dp(dx), _dp(dgamma), _dp(dbeta), _dp(ws), ws.numel(),
                                               _lib.current_stream()), 'ssdk_batchnorm_bwd')
         return dx, dgamma if has_g else None, dbeta if has_b else None, None, None, None, None, None, None, None, None, None
 
