@@ -158,10 +158,13 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float4* __restrict_
             if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * uv;
         }
     }
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C4);
-        const float4 v = x[i];
-        float4 m, rs;
+    // A thread's four channels do not change over its grid-stride trips when the stride is a multiple of the row length (always for
+    // power-of-two C): mean / rstd -- four fp64 divisions and square roots from the sums -- gamma and beta are then worked out ONCE per
+    // thread, not once per float4.
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const bool fixed_c = stride % C4 == 0;
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f), rs = m, ga = m, be = m;
+    auto load_consts = [&](int c) {
         if (sums) {
             float uv;
             stats_from_sums(sums, rows, C, 4 * c + 0, eps, m.x, rs.x, uv);
@@ -172,7 +175,14 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float4* __restrict_
             m = mean[c];
             rs = rstd[c];
         }
-        const float4 ga = gamma ? gamma[c] : make_float4(1.f, 1.f, 1.f, 1.f), be = beta ? beta[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        ga = gamma ? gamma[c] : make_float4(1.f, 1.f, 1.f, 1.f);
+        be = beta ? beta[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    const long long i0 = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (fixed_c && i0 < n4) load_consts((int)(i0 % C4));
+    for (long long i = i0; i < n4; i += stride) {
+        if (!fixed_c) load_consts((int)(i % C4));
+        const float4 v = x[i];
         float4 o = make_float4((v.x - m.x) * rs.x * ga.x + be.x, (v.y - m.y) * rs.y * ga.y + be.y, (v.z - m.z) * rs.z * ga.z + be.z,
                                (v.w - m.w) * rs.w * ga.w + be.w);
         if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
