@@ -48,9 +48,28 @@ for case in range(cases):
             # the gradient of a convolution bias in front of a training-mode BatchNorm is zero up to rounding: nothing to compare
             m.conv.bias.requires_grad_(False)
             ref.conv.bias.requires_grad_(False)
+        if act is not None:
+            # an output within rounding of the ReLU's kink may land on the other side of it on the GPU: its whole gradient (9 * cin input
+            # elements) then differs legitimately.  Such a draw says nothing: take another input.
+            import copy
+            probe = copy.deepcopy(ref).train(train)
+            with torch.no_grad():
+                pre = probe.conv(torch.from_numpy(x))
+                pre = probe.bn(pre) if probe.bn is not None else pre
+            if float(pre.abs().min()) < 2e-5:
+                continue
         _compare_module(m.cuda(), ref, x, train, rtol=5e-4, atol=5e-4)
     except Exception as e:   # noqa: BLE001
         bad += 1
         print('FAIL', tag, type(e).__name__, str(e)[:400].replace('\n', ' | '), flush=True)
+        try:   # the same data once more: does it fail again (data dependent) or not (state left by earlier cases / a race)?
+            m2 = conv.Conv2dBn(cin, cout, kernel_size=k, stride=stride, padding=pad, bias=bias, use_bn=use_bn, activation_params=act)
+            m2.load_state_dict(ref.state_dict() if False else {kk: vv.detach().clone() for kk, vv in m.state_dict().items()})
+            for trial in range(3):
+                ref2 = _RefConv2dBn(m2.cpu())
+                _compare_module(m2.cuda(), ref2, x, train, rtol=5e-4, atol=5e-4)
+            print('   ... the same case passes three times when repeated', flush=True)
+        except Exception as e2:   # noqa: BLE001
+            print('   ... and fails again when repeated:', str(e2)[:200].replace('\n', ' | '), flush=True)
 print('%d cases, %d failures' % (cases, bad))
 sys.exit(1 if bad else 0)
