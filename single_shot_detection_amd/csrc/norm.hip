@@ -7,7 +7,7 @@
 //
 // All three kernels are HBM-bound streams over a [rows = B*H*W][C] matrix (channels contiguous, so a wave reads whole
 // lines): bn_reduce_kernel accumulates two per-channel sums (64 rows per workgroup in registers, then one fp64 atomic
-// per channel), bn_finalize_kernel turns them into mean / rstd (and the running-stat update), bn_apply_kernel /
+// per channel), bn_apply_kernel turns them into mean / rstd itself (and updates the running statistics), bn_apply_kernel /
 // bn_bwd_apply_kernel are the elementwise passes with the ReLU fused.
 #include "common.h"
 
@@ -99,30 +99,6 @@ __global__ void __launch_bounds__(256) bn_reduce_kernel(const float* __restrict_
     }
 }
 
-__global__ void __launch_bounds__(256) bn_finalize_kernel(const double* __restrict__ sums, long long rows, int C, float eps, float momentum,
-                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                          float* __restrict__ save_mean, float* __restrict__ save_rstd) {
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
-        const double n = (double)rows;
-        const double m = sums[c] / n;
-        double var = sums[C + c] / n - m * m;
-        if (var < 0.0) var = 0.0;
-        save_mean[c] = (float)m;
-        save_rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-        if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)m;
-        if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(rows > 1 ? var * n / (n - 1.0) : var);
-    }
-}
-
-// eval mode: mean = running_mean, rstd = 1/sqrt(running_var + eps)
-__global__ void __launch_bounds__(256) bn_eval_stats_kernel(const float* __restrict__ running_mean, const float* __restrict__ running_var,
-                                                            int C, float eps, float* __restrict__ save_mean, float* __restrict__ save_rstd) {
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
-        save_mean[c] = running_mean[c];
-        save_rstd[c] = 1.0f / sqrtf(running_var[c] + eps);
-    }
-}
-
 // sums != NULL (training): mean / rstd come straight from the fp64 sums of bn_reduce_kernel<0> (no separate finalize
 // launch); workgroup 0 also publishes save_mean / save_rstd for the backward and updates the running statistics.
 __device__ __forceinline__ void stats_from_sums(const double* sums, long long rows, int C, int c, float eps, float& m, float& rs, float& var_out) {
@@ -158,6 +134,11 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float4* __restrict_
             if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * uv;
         }
     }
+    if (!sums && !mean && blockIdx.x == 0)   // evaluation mode: what the backward of a frozen norm needs
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            save_mean[c] = running_mean[c];
+            save_rstd[c] = 1.0f / sqrtf(running_var[c] + eps);
+        }
     // A thread's four channels do not change over its grid-stride trips when the stride is a multiple of the row length (always for
     // power-of-two C): mean / rstd -- four fp64 divisions and square roots from the sums -- gamma and beta are then worked out ONCE per
     // thread, not once per float4.
@@ -171,9 +152,13 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float4* __restrict_
             stats_from_sums(sums, rows, C, 4 * c + 1, eps, m.y, rs.y, uv);
             stats_from_sums(sums, rows, C, 4 * c + 2, eps, m.z, rs.z, uv);
             stats_from_sums(sums, rows, C, 4 * c + 3, eps, m.w, rs.w, uv);
-        } else {
+        } else if (mean) {
             m = mean[c];
             rs = rstd[c];
+        } else {   // evaluation mode: the running statistics (torch: 1 / sqrt(running_var + eps))
+            m = reinterpret_cast<const float4*>(running_mean)[c];
+            const float4 rv = reinterpret_cast<const float4*>(running_var)[c];
+            rs = make_float4(1.0f / sqrtf(rv.x + eps), 1.0f / sqrtf(rv.y + eps), 1.0f / sqrtf(rv.z + eps), 1.0f / sqrtf(rv.w + eps));
         }
         ga = gamma ? gamma[c] : make_float4(1.f, 1.f, 1.f, 1.f);
         be = beta ? beta[c] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -348,11 +333,12 @@ extern "C" int ssdk_batchnorm_fwd(const float* x, long long rows, int channels, 
         return ssdk_batchnorm_apply(x, rows, channels, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, relu, y,
                                     save_mean, save_rstd, (const double*)workspace, 0, stream);
     }
-    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(channels, 256)), dim3(256), 0, s, running_mean, running_var, channels, eps, save_mean, save_rstd);
-    SSDK_CHECK_LAUNCH("bn_eval_stats_kernel");
+    // evaluation mode: ONE launch -- the apply kernel takes mean / rstd from the running statistics itself (mean == NULL) and leaves
+    // save_mean / save_rstd for a backward through the frozen norm (a launch of their own before: 8 per SSD-300 evaluation step)
+    SSDK_REQUIRE((((uintptr_t)running_mean | (uintptr_t)running_var) & 15) == 0, SSDK_E_UNSUPPORTED, "ssdk_batchnorm_fwd: running statistics not 16-byte aligned");
     const long long n4 = rows * channels / 4;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_blocks(n4, 256)), dim3(256), 0, s, (const float4*)x, n4, channels / 4, (const float4*)save_mean,
-                       (const float4*)save_rstd, (const float4*)gamma, (const float4*)beta, relu, (float4*)y, (const double*)nullptr, rows, eps,
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_blocks(n4, 256)), dim3(256), 0, s, (const float4*)x, n4, channels / 4, (const float4*)nullptr,
+                       (const float4*)nullptr, (const float4*)gamma, (const float4*)beta, relu, (float4*)y, (const double*)nullptr, rows, eps,
                        momentum, running_mean, running_var, save_mean, save_rstd, (long long*)nullptr, 0, (double*)nullptr);
     SSDK_CHECK_LAUNCH("bn_apply_kernel");
     return SSDK_OK;
