@@ -581,6 +581,16 @@ def main():
     barrier()
     dtp_tl = (time.perf_counter() - t0) / args.eval_steps
 
+    # a stream-K owner that gave up on a parked partial tile fills the tile with NaN and counts here: never reported as a result
+    from single_shot_detection_amd import _lib as _ssdk_lib
+    sk_timeouts = _ssdk_lib.streamk_timeouts()
+    if world > 1:
+        t = torch.tensor([float(sk_timeouts)], dtype=torch.float64, device=device)
+        dist.all_reduce(t)
+        sk_timeouts = int(t.item())
+    if sk_timeouts:
+        raise SystemExit(f'bench.py: {sk_timeouts} stream-K fix-up wait(s) timed out -- the head GEMM output is invalid, no line is printed')
+
     if rank == 0:
         A = hp.anchors.shape[0]
         out = {
@@ -593,7 +603,7 @@ def main():
                                    f'heads fwd+bwd (fp32 MFMA) + IoU-match + ' + ('HNM' if hp.cfg['loss'] == 'ce_hnm' else 'naive sampler') +
                                    f'/multibox loss fwd+bwd + SGD on the head-side params; backbone taps N(0,1) NHWC at the probed shapes, C={hp.C}, A={A}, G~U{{1..8}}',
                        'global_batch': world * args.batch, 'per_gpu_batch': args.batch, 'parallelism': f'dp{world}', 'sync_bn': sync_bn},
-            'rccl_ranks': rccl_ranks, 'collective_backend': (backend if world > 1 else None),
+            'rccl_ranks': rccl_ranks, 'collective_backend': (backend if world > 1 else None), 'streamk_timeouts': sk_timeouts,
             'grad_bucket_bytes': {'heads': hp.bucket_heads.nbytes, 'rest': hp.bucket_rest.nbytes if hp.bucket_rest is not None else 0},
             'nms_boxes_per_sec': world * cand / dtp, 'postprocess_images_per_sec': world * args.batch / dtp,
             'eval_images_per_sec': world * args.batch / dte, 'nms_candidates_per_image': cand / args.batch,

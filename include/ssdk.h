@@ -24,12 +24,13 @@
 extern "C" {
 #endif
 
-#define SSDK_VERSION 106
+#define SSDK_VERSION 107
 
 #define SSDK_OK 0
 #define SSDK_E_INVALID (-1)   /* bad argument / shape */
 #define SSDK_E_WORKSPACE (-2) /* workspace missing or too small */
 #define SSDK_E_UNSUPPORTED (-3)
+#define SSDK_E_STREAMK_TIMEOUT (-4) /* a stream-K head GEMM gave up on a parked partial tile (see ssdk_heads_fwd_timeouts) */
 
 /* detection/matcher.py:4-5 */
 #define SSDK_NOT_MATCHED (-2)
@@ -245,7 +246,13 @@ typedef struct ssdk_head_level {
  * counter).  With it, a launch of a few rounds of whole tiles runs in stream-K form: the K slices of the whole launch are cut into equal
  * ranges, one per resident workgroup, and a tile that straddles two ranges is summed through the workspace -- same results up to fp32
  * summation order of that one K split. */
+/* The stream-K fix-up wait is bounded (a workgroup that never runs must not hang the GPU), and a wait that runs out is LOUD: the owner fills
+ * its output tile with NaN instead of storing an incomplete sum, counts the event in the workspace, and sets a sticky word in pinned host
+ * memory that makes this and every later ssdk_heads_fwd of the process return SSDK_E_STREAMK_TIMEOUT.  ssdk_heads_fwd_timeouts reads the
+ * workspace's counter back (it SYNCHRONISES `stream`: a test / end-of-run check, not a hot-path call); *timeouts_host == 0 is the only
+ * healthy value.  (Reference: none -- torch.nn.Conv2d has no such failure mode; detection/detector.py:50-63.) */
 size_t ssdk_heads_fwd_workspace_bytes(void);
+int ssdk_heads_fwd_timeouts(const void* workspace, size_t workspace_bytes, void* stream, unsigned* timeouts_host);
 int ssdk_heads_fwd(const ssdk_head_level* levels, int n_levels, int batch, float* scores, long long scores_batch_stride,
                    float* locs, long long locs_batch_stride, void* workspace, size_t workspace_bytes, void* stream);
 

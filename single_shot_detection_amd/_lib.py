@@ -58,6 +58,7 @@ _SIGNATURES = {
                                   C.c_void_p]),
     'ssdk_heads_fwd_workspace_bytes': (C.c_size_t, []),
     'ssdk_heads_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'ssdk_heads_fwd_timeouts': (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     'ssdk_heads_bwd_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     'ssdk_heads_bwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong,
                                  C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -229,3 +230,21 @@ def scratch(nbytes, device, tag, zeroed=False):
         buf = (torch.zeros if zeroed else torch.empty)((max(int(nbytes), 256),), dtype=torch.uint8, device=device)
         _scratch[key] = buf
     return buf
+
+
+STREAMK_TAG = 'heads_fwd_streamk'
+
+
+def streamk_timeouts():
+    """Stream-K fix-up waits that ran out, summed over every ssdk_heads_fwd workspace this process made (synchronises their streams).
+    0 is the only healthy value: a non-zero count means an output tile was filled with NaN and ssdk_heads_fwd now refuses to run."""
+    import torch
+    total = 0
+    word = C.c_uint(0)
+    for (dev, tag, stream), buf in list(_scratch.items()):
+        if tag != STREAMK_TAG:
+            continue
+        with torch.cuda.device(dev):
+            check(lib().ssdk_heads_fwd_timeouts(C.c_void_p(buf.data_ptr()), buf.numel(), C.c_void_p(stream), C.byref(word)), 'ssdk_heads_fwd_timeouts')
+        total += int(word.value)
+    return total

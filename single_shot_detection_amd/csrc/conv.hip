@@ -40,6 +40,8 @@
 
 #include <type_traits>
 
+#include <mutex>
+
 #include "common.h"
 
 namespace ssdk {
@@ -121,7 +123,8 @@ struct StreamK {
     long long unit_begin[kMaxProblems + 1];   // prefix over the problems in launch order; unit = one K slice of one 32-column tile
     float* partial;                           // [nwg][4 waves][kMaxTN][4][64 lanes][4]: a workgroup's accumulators as they lie in registers
     unsigned* flags;                          // [nwg]: flags[s] == epoch <=> workgroup s parked its partial tile
-    unsigned* timeouts;                       // partners given up on (stays 0)
+    unsigned* timeouts;                       // DEV counter of partners given up on (stays 0; ssdk_heads_fwd_timeouts reads it)
+    unsigned* host_err;                       // the same event as a sticky word in pinned HOST memory (NULL: none): the next ssdk_heads_fwd fails
     unsigned epoch;
 };
 
@@ -393,7 +396,7 @@ extern "C" int ssdk_debug_read_phase(unsigned long long* host) { return (int)hip
 template <bool MIRROR, bool GENERIC, bool SCATTER, int WAVES, int BK, int MAXTN>
 __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_tile, int n_block, int ksp, int sk_mode = 0, int sk_s0 = 0, int sk_s1 = 0,
                                          float* sk_buf = nullptr, unsigned* sk_flag = nullptr, unsigned sk_epoch = 0, unsigned* sk_timeouts = nullptr,
-                                         int sk_parts = 1) {
+                                         int sk_parts = 1, unsigned* sk_host_err = nullptr) {
     PHASE(0)
     // BK = K slice: 32 floats (128-byte rows, 8 rows per DMA piece, 64 KB of LDS: 2 workgroups per CU) or 16 floats (64-byte rows,
     // 16 rows per piece, 32 KB: 3 workgroups per CU at <= 170 VGPRs, a barrier every 32 MFMAs instead of 64)
@@ -641,13 +644,22 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
         for (int part = 0; part < sk_parts; ++part) {
             if (tid == 0) {
                 unsigned spins = 0;
+                bool lost = false;
                 while (__hip_atomic_load(sk_flag + part, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != sk_epoch) {
                     __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1u << 22)) { atomicAdd(sk_timeouts, 1u); break; }   // (never hangs: a lost partner costs the tile, not the GPU)
+                    if (++spins > (1u << 22)) { lost = true; break; }   // (never hangs: a lost partner costs the tile, not the GPU)
                 }
+                if (lost) {
+                    // LOUD: the device counter (ssdk_heads_fwd_timeouts), a sticky word in pinned host memory that makes every later
+                    // ssdk_heads_fwd on this process fail, and the tile itself is poisoned below -- an incomplete sum is never stored
+                    atomicAdd(sk_timeouts, 1u);
+                    if (sk_host_err) __hip_atomic_store(sk_host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                s_a0[0] = lost ? __builtin_nanf("") : 0.0f;   // (the staging LDS is free: the K loop ended behind a barrier)
             }
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (every wave: its reads below come from memory, not from lines cached earlier)
+            const float poison = s_a0[0];
             const f32x4* pimg = img + (size_t)part * (4 * MAXTN * 4 * 64);
 #pragma unroll
             for (int j = 0; j < MAXTN; ++j)
@@ -657,9 +669,17 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
                         const f32x4 v = pimg[(j * 4 + q) * 64];
                         acc[j][4 * q] += v[0]; acc[j][4 * q + 1] += v[1]; acc[j][4 * q + 2] += v[2]; acc[j][4 * q + 3] += v[3];
                     }
+            if (poison != poison) {
+#pragma unroll
+                for (int j = 0; j < MAXTN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[j][e] = poison;
+            }
+            __syncthreads();   // (s_a0[0] is rewritten for the next part)
             // the consumed flag goes back to 0: a launch replayed from a captured HIP graph carries the SAME epoch every time, and must
-            // not take the previous replay's flag for this one's (a partner writes its flag once per launch, so nothing races here)
-            if (tid == 0) __hip_atomic_store(sk_flag + part, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // not take the previous replay's flag for this one's (a partner writes its flag once per launch, so nothing races here).
+            // A flag that was NOT consumed (timeout) is left alone: the late partner may still be writing it.
+            if (tid == 0 && poison == poison) __hip_atomic_store(sk_flag + part, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     conv_epilogue<SCATTER>(g, acc, m_base, wave, r32, h, tn, n_begin, M, N, hw, ksp, (!MIRROR && !SCATTER && !sk_mode) ? s_a0 : nullptr, WAVES);
@@ -770,7 +790,7 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_streamk_k
             int parts = 1;
             while (s + 1 + parts < sk.nwg && sk.total_units * (s + 1 + parts) / sk.nwg < tile_end) ++parts;
             dma_tile<false, false, false, 4, kBK, kMaxTN>(g, pi, m_tile, n_block, 0, 2, 0, s1, next_buf, sk.flags + s + 1, sk.epoch, sk.timeouts,
-                                                          parts);
+                                                          parts, sk.host_err);
         }
         u += (long long)(s1 - slice) * tn;
         __syncthreads();   // the next tile's first DMA overwrites LDS stage 0
@@ -1809,6 +1829,31 @@ struct StreamKWs {
 constexpr long long kStreamKMinRange = 24 * kMaxTN;
 constexpr int kStreamKMinWgs = 256;
 static unsigned g_streamk_epoch = 0;   // (a launch counter: tells this launch's flags from an earlier launch's in the same workspace)
+// A stream-K owner that gave up on a parked partner says so in a word of pinned, device-visible HOST memory (one per process, allocated
+// on first use outside stream capture, never freed): reading it costs the host nothing, so every ssdk_heads_fwd checks it first and fails
+// from then on.  The kernel also poisons the tile with NaN and counts the event in the workspace (ssdk_heads_fwd_timeouts).
+static unsigned* g_sk_host_err = nullptr;
+static bool g_sk_host_err_tried = false;
+static unsigned* streamk_host_err_word(hipStream_t s) {
+    if (!g_sk_host_err && !__atomic_load_n(&g_sk_host_err_tried, __ATOMIC_ACQUIRE)) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (st != hipStreamCaptureStatusNone) return nullptr;   // (an allocation is not capturable; the warm-up calls in front of a capture made it)
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lock(mu);
+        if (!g_sk_host_err && !g_sk_host_err_tried) {
+            void* p = nullptr;
+            if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && p) {
+                *static_cast<volatile unsigned*>(p) = 0u;
+                g_sk_host_err = static_cast<unsigned*>(p);
+            } else {
+                (void)hipGetLastError();
+            }
+            __atomic_store_n(&g_sk_host_err_tried, true, __ATOMIC_RELEASE);
+        }
+    }
+    return g_sk_host_err;
+}
 
 static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t s, bool generic = false, bool scatter = false, int* vtab = nullptr,
                         const StreamKWs* skws = nullptr) {
@@ -1911,6 +1956,7 @@ static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t 
             sk.partial = skws->partial;
             sk.flags = skws->flags;
             sk.timeouts = skws->flags + skws->nwg;   // (behind the flags of the largest launch)
+            sk.host_err = streamk_host_err_word(s);
             sk.epoch = __atomic_add_fetch(&g_streamk_epoch, 1u, __ATOMIC_RELAXED);
             if (sk.epoch == 0) sk.epoch = __atomic_add_fetch(&g_streamk_epoch, 1u, __ATOMIC_RELAXED);   // (0 is what a fresh workspace holds)
             hipLaunchKernelGGL(igemm_streamk_kernel, dim3(sk.nwg), dim3(kConvThreads), 0, s, grp, sk);
@@ -1971,6 +2017,9 @@ extern "C" int ssdk_heads_fwd(const ssdk_head_level* levels, int n_levels, int b
                               size_t workspace_bytes, void* stream) {
     SSDK_REQUIRE(levels && n_levels > 0 && n_levels <= kMaxProblems, SSDK_E_INVALID, "ssdk_heads_fwd: n_levels=%d (1..%d)", n_levels, kMaxProblems);
     SSDK_REQUIRE(scores, SSDK_E_INVALID, "ssdk_heads_fwd: null scores");
+    SSDK_REQUIRE(!g_sk_host_err || *static_cast<volatile unsigned*>(g_sk_host_err) == 0u, SSDK_E_STREAMK_TIMEOUT,
+                 "ssdk_heads_fwd: an earlier stream-K launch of this process gave up waiting for a parked partial tile (its output tile "
+                 "was filled with NaN); the card is oversubscribed or a workgroup never ran -- see ssdk_heads_fwd_timeouts");
     ConvProblem probs[kMaxProblems];
     for (int i = 0; i < n_levels; ++i) {
         const ssdk_head_level& lv = levels[i];
@@ -2042,6 +2091,18 @@ extern "C" int ssdk_heads_fwd(const ssdk_head_level* levels, int n_levels, int b
         sk.nwg = kStreamKWgs;
     }
     return launch_group(probs, n_levels, false, (hipStream_t)stream, false, false, nullptr, sk.nwg ? &sk : nullptr);
+}
+
+extern "C" int ssdk_heads_fwd_timeouts(const void* workspace, size_t workspace_bytes, void* stream, unsigned* timeouts_host) {
+    SSDK_REQUIRE(workspace && timeouts_host && workspace_bytes >= ssdk_heads_fwd_workspace_bytes(), SSDK_E_WORKSPACE,
+                 "ssdk_heads_fwd_timeouts: workspace of ssdk_heads_fwd_workspace_bytes() bytes and a host word are required");
+    Carver c(const_cast<void*>(workspace));
+    c.take<float>((size_t)(kStreamKWgs + 1) * (4 * kMaxTN * 4 * 64 * 4));
+    const unsigned* flags = c.take<unsigned>((size_t)kStreamKWgs + 2);
+    SSDK_CHECK_HIP(hipMemcpyAsync(timeouts_host, flags + kStreamKWgs, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    SSDK_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (g_sk_host_err && *static_cast<volatile unsigned*>(g_sk_host_err) && *timeouts_host == 0u) *timeouts_host = 1u;   // (another workspace's)
+    return SSDK_OK;
 }
 
 struct HeadsBwdWs {

@@ -71,7 +71,7 @@ class _HeadsFn(torch.autograd.Function):
         scores = torch.empty((B, s_off), dtype=torch.float32, device=dev)
         locs = torch.empty((B, l_off), dtype=torch.float32, device=dev)
         arr = _HeadsFn._level_array(levels)
-        sk = _lib.scratch(lib.ssdk_heads_fwd_workspace_bytes(), dev, 'heads_fwd_streamk', zeroed=True)   # (state kept by the library between calls)
+        sk = _lib.scratch(lib.ssdk_heads_fwd_workspace_bytes(), dev, _lib.STREAMK_TAG, zeroed=True)   # (state kept by the library between calls)
         _lib.check(lib.ssdk_heads_fwd(arr, L, B, _dp(scores), s_off, _dp(locs), l_off, _dp(sk), sk.numel(), _lib.current_stream()), 'ssdk_heads_fwd')
         # tensors go through save_for_backward (autograd's version counters then catch an in-place edit of a tapped source map
         # between forward and backward, as they do for torch's own conv); ctx keeps only shapes and offsets

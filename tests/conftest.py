@@ -50,3 +50,14 @@ def has_gpu():
         return torch.cuda.is_available()
     except Exception:
         return False
+
+
+@pytest.fixture(autouse=True)
+def _streamk_waits_never_ran_out(request):
+    """After every GPU test: no stream-K owner of ssdk_heads_fwd gave up on a parked partial tile (csrc/conv.hip; a timeout fills the
+    tile with NaN, counts here and makes the next ssdk_heads_fwd fail -- it must never pass silently)."""
+    yield
+    if request.node.get_closest_marker('gpu') is None or not has_gpu():
+        return
+    from single_shot_detection_amd import _lib
+    assert _lib.streamk_timeouts() == 0, 'a stream-K fix-up wait timed out during this test'

@@ -11,7 +11,7 @@ import torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
-from single_shot_detection_amd import ops, synthetic as syn  # noqa: E402
+from single_shot_detection_amd import _lib, ops, synthetic as syn  # noqa: E402
 from single_shot_detection_amd.bf.modules.conv import Conv2dBn, DepthwiseConv2dBn  # noqa: E402
 from single_shot_detection_amd.detection import init as det_init  # noqa: E402
 from test_end_to_end_gpu import MB2  # noqa: E402
@@ -57,6 +57,7 @@ def main():
     both = [torch.zeros_like(stats) for _ in range(world)]
     dist.all_gather(both, stats)
     assert torch.equal(both[0], both[1])
+    assert _lib.streamk_timeouts() == 0   # (two ranks time-slice the card: no stream-K owner may have given up on a partner)
     np.save(os.path.join(out_dir, f'ok{rank}.npy'), np.array([1]))
     dist.destroy_process_group()
 

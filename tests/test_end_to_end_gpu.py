@@ -408,3 +408,4 @@ def test_bench_n2_path_on_one_gpu_over_gloo():
     assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2 and line['collective_backend'] == 'gloo'
     assert line['config']['parallelism'] == 'dp2' and line['config']['sync_bn'] is True and line['config']['global_batch'] == 64
     assert line['scaling'] == 'weak' and line['value'] > 0 and line['grad_bucket_bytes']['heads'] == 36046848
+    assert line['streamk_timeouts'] == 0   # two ranks time-slicing one card: every stream-K partner still arrived
