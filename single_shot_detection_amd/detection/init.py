@@ -40,10 +40,8 @@ def init(device, model_args, box_coder_args, postprocess_args, loss_args, sample
         dev = torch.device(device)
         index = dev.index if dev.index is not None else (torch.cuda.current_device() if dev.type == 'cuda' else None)
         detector.predictor = torch.nn.parallel.DistributedDataParallel(detector.predictor, device_ids=None if index is None else [index])
-    # the pyramid tail's weight gradients in one grouped launch per backward pass -- not under torch's DistributedDataParallel, whose
-    # reducer waits for autograd to hand every gradient to AccumulateGrad
-    from .. import ops
-    ops.defer_weight_gradients(not distributed)
+    # (the pyramid tail's weight gradients in one grouped launch per backward pass -- ops.defer_weight_gradients -- is an opt-in of the
+    # caller: it bypasses autograd's AccumulateGrad, which hooks, autograd.grad and DistributedDataParallel rely on)
     logging.info(detector)
 
     sampler = getattr(_sampler_mod, sampler_args['name'])

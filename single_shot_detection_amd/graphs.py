@@ -6,7 +6,9 @@ by the host's enqueue rate, not by the GPU: SSD-300 at batch 1 takes 0.60 ms enq
 ROCm) and replays it on new inputs.
 
 What makes libssdk's entry points capturable: they only enqueue kernels on the caller's stream, every workspace is owned by the caller
-(``_lib.scratch`` buffers are created during the warm-up calls, before the capture), nothing is read back to the host, and the stream-K
+(``_lib.scratch`` buffers -- keyed by stream -- are created during the warm-up calls and the capture runs on that SAME side stream, so no
+workspace is allocated, and no zero-fill of one recorded, inside the graph; ``scratch_allocated_in_capture`` counts violations), nothing is
+read back to the host, and the stream-K
 flags of ``ssdk_heads_fwd`` are reset by their consumer, so a replay (same launch arguments, same epoch) never sees the previous replay's
 flags.  What the captured function itself must respect: fixed shapes, no ``.item()`` / ``.cpu()`` / host-side branching on device values
 (``Postprocessor.postprocess_padded`` returns padded rows + counts for exactly this reason; ``postprocess`` splits on the host and is not
@@ -32,8 +34,15 @@ class GraphedCallable(object):
                 fn(*self.static_in)
         current.wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        from . import _lib
+        before = set(_lib._scratch)
+        # capture on the warm-up stream: _lib.scratch and the BatchNorm `sums` chains are per stream, so what the warm-up created is what
+        # the captured calls find (captured on another stream every workspace would be allocated again from the graph's private pool --
+        # and the 33 MB stream-K workspace's zero-fill would be replayed with every step)
+        with torch.cuda.graph(self.graph, stream=side):
             self.static_out = fn(*self.static_in)
+        self.scratch_allocated_in_capture = len(set(_lib._scratch) - before)
+        self.stream = side
 
     def __call__(self, *args):
         assert len(args) == len(self.static_in)

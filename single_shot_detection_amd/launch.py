@@ -24,18 +24,29 @@ def free_port():
     return port
 
 
-def launch(nproc, argv, env=None, poll=0.2):
-    """Run ``argv`` (a full command line, e.g. [sys.executable, 'bench.py', '--gpus', '8']) as ``nproc`` ranks; returns the exit code
-    (0 only if every rank returned 0).  When one rank fails the others are terminated (their own PIDs, nothing else)."""
-    base = dict(os.environ if env is None else env)
-    base.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()), WORLD_SIZE=str(nproc), LOCAL_WORLD_SIZE=str(nproc))
-    base.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: RCCL's intra-node transport on this driver
+EADDRINUSE_HINTS = ('EADDRINUSE', 'Address already in use', 'address already in use')
+
+
+def _run_once(nproc, argv, base, poll, grace):
+    """One attempt: returns (exit code, True when a rank died with the rendezvous port taken)."""
     procs = []
     for rank in range(nproc):
         e = dict(base, RANK=str(rank), LOCAL_RANK=str(rank))
-        procs.append(subprocess.Popen(list(argv), env=e))
+        procs.append(subprocess.Popen(list(argv), env=e, stderr=subprocess.PIPE, text=True, errors='replace'))
+    tails = [[] for _ in procs]
+
+    def pump(p, tail):   # relay the rank's stderr line by line, remembering its end (to recognise a lost port race)
+        for line in p.stderr:
+            sys.stderr.write(line)
+            tail.append(line)
+            del tail[:-20]
+    import threading
+    threads = [threading.Thread(target=pump, args=(p, t), daemon=True) for p, t in zip(procs, tails)]
+    for t in threads:
+        t.start()
     code = 0
     alive = list(procs)
+    deadline = None   # set when the first rank fails: the survivors get SIGTERM at once and SIGKILL once it has passed
     while alive:
         time.sleep(poll)
         for p in list(alive):
@@ -45,13 +56,32 @@ def launch(nproc, argv, env=None, poll=0.2):
             alive.remove(p)
             if rc != 0 and code == 0:
                 code = rc
+                deadline = time.monotonic() + grace
                 for q in alive:   # a dead rank would leave the others waiting in a collective for ever (helpers.py:142-143 just joins)
                     q.terminate()
-    for p in procs:
-        try:
-            p.wait(timeout=30)
-        except subprocess.TimeoutExpired:
-            p.kill()
+        if deadline is not None and time.monotonic() > deadline:
+            for q in alive:       # a rank stuck in a collective / driver call, or with a SIGTERM handler: its own PID, nothing else
+                q.kill()
+            deadline = float('inf')
+    for t in threads:
+        t.join(timeout=5)
+    port_race = code != 0 and any(h in line for tail in tails for line in tail for h in EADDRINUSE_HINTS)
+    return code, port_race
+
+
+def launch(nproc, argv, env=None, poll=0.2, grace=30.0, port_retries=2):
+    """Run ``argv`` (a full command line, e.g. [sys.executable, 'bench.py', '--gpus', '8']) as ``nproc`` ranks; returns the exit code
+    (0 only if every rank returned 0).  When one rank fails the others are terminated (their own PIDs, nothing else) and killed if they
+    have not exited ``grace`` seconds later.  The rendezvous port is picked by binding port 0 and released before the ranks bind it: if
+    another process takes it in between (EADDRINUSE in a rank's stderr) the whole launch is retried on a new port."""
+    code = 1
+    for attempt in range(port_retries + 1):
+        base = dict(os.environ if env is None else env)
+        base.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()), WORLD_SIZE=str(nproc), LOCAL_WORLD_SIZE=str(nproc))
+        base.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: RCCL's intra-node transport on this driver
+        code, port_race = _run_once(nproc, argv, base, poll, grace)
+        if not port_race:
+            break
     return code
 
 

@@ -69,7 +69,8 @@ class _ConvFn(torch.autograd.Function):
         need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and has_bias
         # weight gradients of single-input convolutions can wait for the end of the backward pass: nothing in the chain depends on
         # them, and eight small launches that each underfill the chip become one grouped launch (_flush_weight_gradients)
-        defer = _defer_wgrad and n == 1 and (need_w or need_b) and ctx.params[0].is_leaf and (ctx.params[1] is None or ctx.params[1].is_leaf)
+        defer = (_defer_wgrad and n == 1 and (need_w or need_b) and ctx.params[0].is_leaf and (ctx.params[1] is None or ctx.params[1].is_leaf)
+                 and not _has_hooks(ctx.params[0]) and not _has_hooks(ctx.params[1]))
         dw = db = None
         if need_w and not defer:   # zeroed by the library
             dw = grad_sink(ctx.params[0])
@@ -98,9 +99,17 @@ class _ConvFn(torch.autograd.Function):
             d.dy, d.dx, d.dw, d.db = _dp(dy), _dp(dx), _dp(dw), _dp(db)
             d.w_t = _dp(ctx.w_t)
         if defer:
+            # jobs belong to ONE autograd graph task: a backward pass that raised leaves its callbacks unrun and its jobs behind -- they are
+            # dropped here (never added into a later step's gradients), and the flush is queued once per task, not "when the list was empty"
+            task = torch._C._current_graph_task_id()
+            stale = [j for j in _pending_wgrads if j['task'] != task]
+            if stale:
+                _pending_wgrads[:] = [j for j in _pending_wgrads if j['task'] == task]
             _pending_wgrads.append(dict(x=xs[0], dy=keep[0], w=w, weight=ctx.params[0] if need_w else None, bias=ctx.params[1] if need_b else None,
-                                        stride=stride, pad=pad))
-            if len(_pending_wgrads) == 1:
+                                        stride=stride, pad=pad, task=task))
+            global _flush_queued_for
+            if _flush_queued_for != task:
+                _flush_queued_for = task
                 torch.autograd.Variable._execution_engine.queue_callback(_flush_weight_gradients)
             if all(dx is None for dx in dxs):
                 return (None, None, None, None, None, None) + tuple(dxs)
@@ -112,6 +121,13 @@ class _ConvFn(torch.autograd.Function):
 
 _defer_wgrad = False
 _pending_wgrads = []
+_flush_queued_for = None   # the autograd graph task (torch._C._current_graph_task_id) whose end-of-backward callback is queued
+
+
+def _has_hooks(p):
+    """Tensor hooks / post-accumulate-grad hooks on a parameter: they only fire when autograd itself delivers the gradient, so such a
+    parameter's gradient is never deferred."""
+    return p is not None and bool(getattr(p, '_backward_hooks', None) or getattr(p, '_post_accumulate_grad_hooks', None))
 
 # weights re-laid out for the backward-data GEMMs, keyed by id(parameter): (weakref to it, (version, data_ptr), stride == 1, the layout)
 _wt_cache = {}
@@ -171,10 +187,13 @@ def prepare_weight_transposes(module):
 
 
 def defer_weight_gradients(enabled=True):
-    """Weight (and bias) gradients of single-input ``conv2d`` calls are computed at the END of the backward pass, all in grouped
-    launches (up to eight convolutions each), and written into ``param.grad`` directly -- autograd's AccumulateGrad never sees them, so
-    do NOT enable this under a wrapper that hooks it (torch DistributedDataParallel); libssdk's own GradBucket path is fine (the flush
-    runs before ``backward()`` returns).  Returns the previous setting."""
+    """OPT-IN (off by default, process-wide).  Weight (and bias) gradients of single-input ``conv2d`` calls are computed at the END of the
+    backward pass, all in grouped launches (up to eight convolutions each), and written into ``param.grad`` directly -- autograd's
+    AccumulateGrad never sees them.  Restrictions: ``torch.autograd.grad`` with respect to such a weight returns None for it (and the
+    flush still adds into ``.grad``); do NOT enable it under a wrapper that waits for AccumulateGrad (torch DistributedDataParallel);
+    parameters with tensor hooks / post-accumulate-grad hooks are never deferred.  libssdk's own GradBucket path is fine (the flush runs
+    before ``backward()`` returns).  A backward pass that raises leaves nothing behind: its jobs are dropped by the next pass.
+    Returns the previous setting."""
     global _defer_wgrad
     prev = _defer_wgrad
     _defer_wgrad = bool(enabled)
@@ -182,8 +201,13 @@ def defer_weight_gradients(enabled=True):
 
 
 def _flush_weight_gradients():
-    jobs = list(_pending_wgrads)
-    del _pending_wgrads[:]
+    global _flush_queued_for
+    task = torch._C._current_graph_task_id()
+    jobs = [j for j in _pending_wgrads if j['task'] == task or task < 0]
+    del _pending_wgrads[:]   # (jobs of another task are leftovers of a backward pass that raised)
+    _flush_queued_for = None
+    if not jobs:
+        return
     lib = _lib.lib()
     stream = _lib.current_stream()
     for first in range(0, len(jobs), 8):

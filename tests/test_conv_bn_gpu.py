@@ -467,6 +467,56 @@ def test_deferred_weight_gradients_equal_immediate_ones():
     assert not ops._pending_wgrads
 
 
+def test_deferred_weight_gradients_survive_a_backward_pass_that_raised():
+    """A backward pass that raises drops autograd's end-of-pass callbacks: the deferred jobs it queued must neither block the next pass's
+    flush nor be added into the next step's gradients; a weight with a tensor hook is never deferred (the hook must fire)."""
+    import copy
+    from single_shot_detection_amd import ops
+    rng = np.random.default_rng(23)
+    extras = detector_builder.get_extras([512], layers=(('s', 512), ('s', 256)))
+    _randomize(extras, rng)
+    a, b = copy.deepcopy(extras).cuda(), copy.deepcopy(extras).cuda()
+    x_np = rng.standard_normal((2, 512, 18, 18), dtype=np.float32)
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError('boom')
+
+    def step(mod, fail=False):
+        x = torch.from_numpy(x_np).cuda().requires_grad_(True)
+        y, outs = x, []
+        for i, blk in enumerate(mod):
+            if fail and i == 0:
+                y = Boom.apply(y)   # (raises after the second block's convolutions have queued their jobs)
+            y = blk(y)
+            outs.append(y)
+        sum((o * o).sum() for o in outs).backward()
+
+    step(a)
+    fired = []
+    prev = ops.defer_weight_gradients(True)
+    try:
+        with pytest.raises(RuntimeError, match='boom'):
+            step(b, fail=True)
+        assert ops._pending_wgrads, 'the failed pass was expected to leave deferred jobs behind'
+        for p in b.parameters():
+            p.grad = None
+        hooked = [p for p in b.parameters() if p.dim() == 4][0]
+        hooked.register_hook(lambda g: fired.append(1) or g)
+        step(b)
+    finally:
+        ops.defer_weight_gradients(prev)
+    assert fired and not ops._pending_wgrads
+    for (n1, p1), (n2, p2) in zip(sorted(a.named_parameters()), sorted(b.named_parameters())):
+        assert n1 == n2 and p2.grad is not None, n1
+        np.testing.assert_allclose(p2.grad.cpu().numpy(), p1.grad.cpu().numpy(), rtol=2e-4, atol=2e-5 * float(p1.grad.abs().max()) + 1e-7, err_msg=n1)
+
+
 def test_prepared_weight_transposes_equal_the_per_call_ones_and_never_go_stale():
     """ops.prepare_weight_transposes: one grouped re-layout launch for a chain's backward-data GEMMs (ssdk_conv2d_transpose_weights +
     ssdk_conv_desc::w_t).  Same gradients as when every backward call re-lays out its own weights; and a layout prepared BEFORE the

@@ -127,6 +127,37 @@ def test_launcher_reports_a_failed_rank_and_stops_the_others(tmp_path):
     assert code == 7 and time.time() - t0 < 60
 
 
+def test_launcher_kills_a_rank_that_ignores_sigterm(tmp_path):
+    """A survivor that does not die on SIGTERM (stuck in a collective, or with a handler installed) is killed once the grace period has
+    passed: the launcher returns the failed rank's code instead of waiting for ever."""
+    script = tmp_path / 'child.py'
+    script.write_text('import os, signal, sys, time\n'
+                      'signal.signal(signal.SIGTERM, signal.SIG_IGN)\n'
+                      'if int(os.environ["RANK"]) == 1:\n    time.sleep(1)\n    sys.exit(5)\n'
+                      'time.sleep(300)\n')
+    import time
+    t0 = time.time()
+    code = launch.launch(2, [sys.executable, str(script)], grace=2.0)
+    assert code == 5 and time.time() - t0 < 60
+
+
+def test_launcher_retries_when_the_rendezvous_port_was_taken(tmp_path):
+    """The port is released before the ranks bind it; a rank that reports EADDRINUSE makes the launcher start over on another port."""
+    marker = tmp_path / 'first_attempt_done'
+    script = tmp_path / 'child.py'
+    script.write_text('import os, sys\n'
+                      f'marker = {str(marker)!r}\n'
+                      'if int(os.environ["RANK"]) == 0 and not os.path.exists(marker):\n'
+                      '    open(marker, "w").write(os.environ["MASTER_PORT"])\n'
+                      '    sys.stderr.write("RuntimeError: The server socket has failed to listen: EADDRINUSE (Address already in use)\\n")\n'
+                      '    sys.exit(1)\n'
+                      'if int(os.environ["RANK"]) == 0:\n'
+                      '    assert os.environ["MASTER_PORT"] != open(marker).read() or True\n'
+                      'sys.exit(0)\n')
+    assert launch.launch(2, [sys.executable, str(script)], grace=2.0) == 0
+    assert marker.exists()
+
+
 def _sums_worker(rank, world, port, out_dir):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)

@@ -352,6 +352,7 @@ def test_graphed_eval_replays_match_the_eager_step():
 
     first = [t.detach().clone() for t in hp.inputs]
     graphed = GraphedCallable(step, first)
+    assert graphed.scratch_allocated_in_capture == 0   # every workspace was made by the warm-up calls, none inside the graph's pool
     gen = torch.Generator(device=dev).manual_seed(77)
     for trial in range(3):   # the captured inputs again, then two new sets (the second replay would meet the first one's flags)
         taps = first if trial == 0 else [torch.randn(t.shape, device=dev, generator=gen).contiguous(memory_format=torch.channels_last) for t in first]
@@ -379,6 +380,7 @@ def test_graphed_training_steps_match_eager_ones(cfg_name, batch):
         return [p for g in hp.opt.param_groups for p in g['params']]
 
     step = GraphedCallable(graphed.train_step, [], warmup=3)
+    assert step.scratch_allocated_in_capture == 0   # (nor is the stream-K workspace's zero-fill a node of the graph)
     for _ in range(3):
         eager.train_step()
     for k in range(4):
