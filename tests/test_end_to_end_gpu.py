@@ -339,7 +339,7 @@ def test_graphed_eval_replays_match_the_eager_step():
     whose flags must survive being replayed with the same launch arguments (they are reset by their consumer)."""
     import bench
     from single_shot_detection_amd.graphs import GraphedCallable
-    from test_postprocess_gpu import compare
+    from test_postprocess_gpu import Boundaries, compare
     dev = torch.device('cuda:0')
     hp = bench.HotPath('ssd_300_vgg16_voc', 2, dev)
     hp.heads.eval()
@@ -361,10 +361,14 @@ def test_graphed_eval_replays_match_the_eager_step():
         ref_rows, ref_counts = step(*taps)
         n, m = counts.cpu().numpy(), ref_counts.cpu().numpy()
         assert np.abs(n - m).max() <= 1
-        compare([rows[i, :n[i]] for i in range(len(n))], [ref_rows[i, :m[i]].cpu().numpy() for i in range(len(m))])
+        with torch.no_grad():   # (the logits behind both results, up to the head GEMM's summation order: they name the selection boundaries)
+            hp.inputs = list(taps)
+            logits = hp.forward_heads()[0].cpu().numpy()
+        compare([rows[i, :n[i]] for i in range(len(n))], [ref_rows[i, :m[i]].cpu().numpy() for i in range(len(m))],
+                boundaries=Boundaries(logits, hp.C, True))
 
 
-@pytest.mark.parametrize('cfg_name,batch', [('ssd_mb2_voc', 2), ('ssd_300_vgg16_voc', 2)])
+@pytest.mark.parametrize('cfg_name,batch', [('ssd_mb2_voc', 2), ('ssd_300_vgg16_voc', 2), ('retina_rn50_500_coco', 2), ('m2det_512_vgg16_coco', 2)])
 def test_graphed_training_steps_match_eager_ones(cfg_name, batch):
     """The whole training step (pyramid tail + heads forward, match, sampler, loss, backward, fused SGD) captured in a HIP graph with the
     ground truth in a PackedGroundTruth: every replay moves the parameters like the eagerly enqueued step does.  (Found with this
@@ -387,7 +391,7 @@ def test_graphed_training_steps_match_eager_ones(cfg_name, batch):
         loss_e = eager.train_step()
         loss_g = step()
         torch.cuda.synchronize()
-        assert abs(float(loss_e.detach()) - float(loss_g.detach())) <= 2e-4 * abs(float(loss_e.detach())), (k, float(loss_e.detach()), float(loss_g.detach()))
+        assert abs(float(loss_e.detach()) - float(loss_g.detach())) <= 2e-4 * abs(float(loss_e.detach())) + 1e-6, (k, float(loss_e.detach()), float(loss_g.detach()))
         for p, q in zip(params(graphed), params(eager)):
             scale = float(q.detach().abs().max()) + 1e-12
             assert float((p.detach() - q.detach()).abs().max()) <= 2e-3 * scale, k

@@ -20,15 +20,45 @@ def make_post(cfg, max_total=200, max_per_class=100, thr=0.01, soft=False):
     return Postprocessor(BoxCoder(10.0, 5.0), score_threshold=thr, nms=nms, score_converter=cfg['score_converter'], max_total=max_total)
 
 
-def compare(out, ref, tol=1e-4):
+class Boundaries(object):
+    """Where a selection of detection/postprocessor.py:24-78 is decided by the last ulp of an exp() (device expf vs host expf): the score
+    threshold (:45-47), a class's max_per_class-th best score (box_utils.py:186-188) and the image's max_total-th best kept score (:72-74).
+    ``compare`` lets ONE detection per image differ only if its score sits on one of them (1e-5 relative)."""
+
+    def __init__(self, logits, num_classes, softmax, thr=0.01, max_per_class=100, max_total=200):
+        self.logits, self.num_classes, self.softmax = np.asarray(logits), int(num_classes), bool(softmax)
+        self.thr, self.max_per_class, self.max_total = thr, max_per_class, max_total
+
+    def near(self, a, b):
+        return abs(a - b) <= 1e-5 * max(abs(a), abs(b)) + 1e-9
+
+    def explains(self, image, cls, score, num_classes, last_scores):
+        x = self.logits[image].astype(np.float64).reshape(-1, num_classes)
+        if self.softmax:
+            e = np.exp(x - x.max(1, keepdims=True))
+            p = (e / e.sum(1, keepdims=True))[:, int(cls)]
+        else:
+            p = 1.0 / (1.0 + np.exp(-x[:, int(cls) - 1]))
+        if self.near(score, self.thr):
+            return 'threshold'
+        k = self.max_per_class
+        if k is not None and k > 0 and (p > self.thr).sum() > k and self.near(score, np.sort(p)[-k]):
+            return 'max_per_class'
+        if self.max_total and any(self.near(score, s) for s in last_scores):
+            return 'max_total'
+        return None
+
+
+def compare(out, ref, tol=1e-4, boundaries=None, num_classes=None):
     """Same detections: class ids exact, scores rtol 1e-5, boxes rtol 1e-5 + atol 1e-4 (north_star).  Order is the
-    reference's (score descending) except that rows whose scores agree to 1e-5 relative may be permuted, and at most
-    one detection per image may differ at a selection boundary (top-k / threshold cut decided by the last ulp of an
-    exp(): device expf vs host expf) -- its score must then sit at the boundary."""
+    reference's (score descending) except that rows whose scores agree to 1e-5 relative may be permuted.  With ``boundaries``
+    (a Boundaries of the inputs) at most one detection per image may differ, and only at a selection boundary: its score must sit
+    within 1e-5 relative of the score threshold, of its class's max_per_class-th best score or of the image's max_total-th kept score --
+    a cut decided by the last ulp of an exp() (device expf vs host expf).  Without ``boundaries`` every row must match."""
     assert len(out) == len(ref)
     for i, (o, r) in enumerate(zip(out, ref)):
         o = o.cpu().numpy() if isinstance(o, torch.Tensor) else o
-        assert abs(o.shape[0] - r.shape[0]) <= 1, (i, o.shape, r.shape)
+        assert abs(o.shape[0] - r.shape[0]) <= (1 if boundaries is not None else 0), (i, o.shape, r.shape)
         used = np.zeros(len(o), bool)
         unmatched = []
         for k in range(len(r)):
@@ -40,7 +70,15 @@ def compare(out, ref, tol=1e-4):
                 assert abs(j - k) <= 3 or abs(o[j, 5] - o[min(k, len(o) - 1), 5]) <= 1e-5 * abs(r[k, 5]), (i, k, j)
             else:
                 unmatched.append(k)
+        odd = [('ref', r[k]) for k in unmatched] + [('out', o[j]) for j in np.where(~used)[0]]
         assert len(unmatched) <= 1 and (~used).sum() <= 1, (i, unmatched, np.where(~used)[0])
+        if odd:
+            assert boundaries is not None, (i, 'rows differ and no selection boundary was given', odd)
+            full = boundaries.max_total and (len(r) == boundaries.max_total or len(o) == boundaries.max_total)
+            last = ([float(r[-1, 5])] if len(r) else []) + ([float(o[-1, 5])] if len(o) else []) if full else []
+            for side, row in odd:
+                why = boundaries.explains(i, row[4], float(row[5]), num_classes if num_classes is not None else boundaries.num_classes, last)
+                assert why is not None, (i, side, row.tolist(), 'differs away from every selection boundary')
 
 
 def inputs(name, variant, batch=2, seeds=(5, 6)):
@@ -70,7 +108,7 @@ def test_postprocess_vs_golden(name, variant):
     cfg, g, logits, locs, softmax = inputs(name, variant)
     post = make_post(cfg)
     out = post.postprocess((torch.from_numpy(logits).cuda(), torch.from_numpy(locs).cuda()), torch.from_numpy(g['anchors']).cuda())
-    compare(out, split(g[f'post_{variant}_nms_contract_rows'], g[f'post_{variant}_nms_contract_counts']))
+    compare(out, split(g[f'post_{variant}_nms_contract_rows'], g[f'post_{variant}_nms_contract_counts']), boundaries=Boundaries(logits, cfg['num_classes'], softmax))
 
 
 @pytest.mark.parametrize('name,batch,variant', [('ssd_300_vgg16_voc', 32, 'rand'), ('ssd_300_vgg16_voc', 64, 'trained'),
@@ -82,7 +120,7 @@ def test_postprocess_full_size_vs_oracle(name, batch, variant):
     post = make_post(cfg)
     out = post.postprocess((torch.from_numpy(logits).cuda(), torch.from_numpy(locs).cuda()), torch.from_numpy(g['anchors']).cuda())
     ref, cand = oracle.postprocess(logits, locs, g['anchors'], softmax=softmax, nms_thr=cfg['nms_thr'], return_cand=True)
-    compare(out, ref)
+    compare(out, ref, boundaries=Boundaries(logits, cfg['num_classes'], softmax))
     assert np.array_equal(post.last_nms_candidates.cpu().numpy(), cand)
 
 
@@ -92,14 +130,14 @@ def test_soft_nms_vs_reference_golden(name):
     cfg, g, logits, locs, softmax = inputs(name, 'trained')
     post = make_post(cfg, soft=True)
     out = post.postprocess((torch.from_numpy(logits).cuda(), torch.from_numpy(locs).cuda()), torch.from_numpy(g['anchors']).cuda())
-    compare(out, split(g['post_trained_softnms_rows'], g['post_trained_softnms_counts']))
+    compare(out, split(g['post_trained_softnms_rows'], g['post_trained_softnms_counts']), boundaries=Boundaries(logits, cfg['num_classes'], softmax))
 
 
 def test_soft_nms_worst_case_vs_oracle():
     cfg, g, logits, locs, softmax = inputs('ssd_mb2_voc', 'rand', batch=2, seeds=(51, 52))
     out = make_post(cfg, soft=True).postprocess((torch.from_numpy(logits).cuda(), torch.from_numpy(locs).cuda()), torch.from_numpy(g['anchors']).cuda())
     ref = oracle.postprocess(logits, locs, g['anchors'], softmax=softmax, nms_thr=cfg['nms_thr'], soft=True, sigma=0.5)
-    compare(out, ref)
+    compare(out, ref, boundaries=Boundaries(logits, cfg['num_classes'], softmax))
 
 
 def test_postprocess_variants_vs_oracle():
@@ -112,7 +150,7 @@ def test_postprocess_variants_vs_oracle():
         out = make_post(cfg, **kw).postprocess(pred, anchors)
         ref = oracle.postprocess(logits, locs, g['anchors'], softmax=softmax, score_thr=kw['thr'], max_per_class=kw['max_per_class'],
                                  nms_thr=cfg['nms_thr'], max_total=kw['max_total'])
-        compare(out, ref)
+        compare(out, ref, boundaries=Boundaries(logits, cfg['num_classes'], softmax, kw['thr'], kw['max_per_class'], kw['max_total']))
 
 
 def test_postprocess_ties_and_identical_boxes():
@@ -124,7 +162,7 @@ def test_postprocess_ties_and_identical_boxes():
     cfg = dict(nms_thr=0.45, score_converter='SOFTMAX')
     out = make_post(cfg).postprocess((torch.from_numpy(logits).cuda(), torch.from_numpy(locs).cuda()), torch.from_numpy(anchors).cuda())
     ref = oracle.postprocess(logits, locs, anchors, softmax=True, nms_thr=0.45)
-    compare(out, ref)
+    compare(out, ref)   # (strict: nothing here sits on a boundary)
     assert out[0].shape[0] == C - 1
 
 
@@ -152,7 +190,7 @@ def test_postprocess_without_per_class_cap_vs_oracle(variant):
         post = Postprocessor(BoxCoder(10.0, 5.0), score_threshold=0.01, nms=nms, score_converter=cfg['score_converter'], max_total=mt)
         out = post.postprocess(pred, anchors)
         ref, cand = oracle.postprocess(logits, locs, g['anchors'], softmax=softmax, max_per_class=mpc, nms_thr=cfg['nms_thr'], max_total=mt, return_cand=True)
-        compare(out, ref)
+        compare(out, ref, boundaries=Boundaries(logits, cfg['num_classes'], softmax, 0.01, mpc, mt))
         assert np.array_equal(post.last_nms_candidates.cpu().numpy(), cand)
     # neither cap: everything that survives NMS, in class order (postprocessor.py:68-70)
     A, Cn = 400, 5
@@ -163,7 +201,7 @@ def test_postprocess_without_per_class_cap_vs_oracle(variant):
     post = Postprocessor(BoxCoder(10.0, 5.0), score_threshold=0.05, nms={'overlap_threshold': 0.45}, score_converter='SOFTMAX', max_total=None)
     out = post.postprocess((torch.from_numpy(lg).cuda(), torch.from_numpy(lc).cuda()), torch.from_numpy(pri).cuda())
     ref = oracle.postprocess(lg, lc, pri, softmax=True, score_thr=0.05, max_per_class=None, nms_thr=0.45, max_total=None)
-    compare(out, ref)
+    compare(out, ref, boundaries=Boundaries(lg, Cn, True, 0.05, None, None))
 
 
 @pytest.mark.parametrize('name', ['ssd_300_vgg16_voc', 'ssd_mb2_voc'])
@@ -187,7 +225,7 @@ def test_two_pass_nms_with_skewed_classes_vs_oracle(name):
     post = make_post(cfg)
     out = post.postprocess((torch.from_numpy(lg).cuda(), torch.from_numpy(lc).cuda()), torch.from_numpy(g['anchors']).cuda())
     ref, cand = oracle.postprocess(lg, lc, g['anchors'], softmax=True, nms_thr=cfg['nms_thr'], return_cand=True)
-    compare(out, ref)
+    compare(out, ref, boundaries=Boundaries(lg, Cn, True))
     assert np.array_equal(post.last_nms_candidates.cpu().numpy(), cand)
     per_class = [np.bincount(r[:, 4].astype(int), minlength=Cn) for r in ref]
     assert per_class[0].max() > 64   # image 0: one class holds more of the final rows than any head
@@ -206,4 +244,4 @@ def test_fewer_anchors_than_max_per_class_without_max_total():
                          max_total=None)
     out = post.postprocess((torch.from_numpy(lg).cuda(), torch.from_numpy(lc).cuda()), torch.from_numpy(pri).cuda())
     ref = oracle.postprocess(lg, lc, pri, softmax=False, score_thr=0.01, max_per_class=64, nms_thr=0.5, max_total=None)
-    compare(out, ref)
+    compare(out, ref, boundaries=Boundaries(lg, C, False, 0.01, 64, None))

@@ -53,7 +53,8 @@ def main():
           % (cfg, batch, eager * 1e3, replay * 1e3, l0, l1))
     # the same number of steps taken eagerly from the same initial state must arrive at the same loss (up to atomics' rounding)
     hp2 = bench.HotPath(cfg, batch, dev)
-    steps = 3 + 30 + 3 + 3 + 1 + 1 + 33   # everything hp ran before l1 was read: warm-up, timing, side-stream warm-up, capture, replays
+    steps = 3 + 30 + 3 + 1 + 30   # every step hp EXECUTED before l1 was read: warm-up, timing, side-stream warm-up, one replay, 30 timed replays
+    # (the capture itself executes nothing; round 2 counted 74 here and compared the 67th graph step with the 74th eager one)
     for _ in range(steps - 1):
         hp2.train_step()
     print('eager loss after the same %d steps: %.5f' % (steps, float(hp2.train_step().detach())))
