@@ -513,6 +513,27 @@ def gen_anchor_options(out_dir):
     print(f'anchor_options -> {path} ({os.path.getsize(path) / 1e3:.1f} KB)')
 
 
+def gen_blocks(out_dir):
+    """H2 / H3 / f1 compositions through the REFERENCE's own modules (bf/modules/conv.py, detection/detector_builder.get_extras,
+    detection/modules/predictors.SharedConvPredictor, bf/modules/features.FeaturePyramid / ThinnedUshapeModule /
+    ScalewiseFeatureAggregationModule) on the cases of tests/blocks_cases.py: eval() and one train() step, forward, input and
+    parameter gradients, BatchNorm buffers afterwards."""
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import blocks_cases
+    from bf.modules import conv as ref_conv, features as ref_features
+    from detection.modules import predictors as ref_predictors
+    mods = types.SimpleNamespace(Conv2dBn=ref_conv.Conv2dBn, DepthwiseConv2dBn=ref_conv.DepthwiseConv2dBn,
+                                 get_extras=detector_builder.get_extras, SharedConvPredictor=ref_predictors.SharedConvPredictor,
+                                 FeaturePyramid=ref_features.FeaturePyramid, ThinnedUshapeModule=ref_features.ThinnedUshapeModule,
+                                 ScalewiseFeatureAggregationModule=ref_features.ScalewiseFeatureAggregationModule)
+    res = {}
+    for name in blocks_cases.CASES:
+        res.update(blocks_cases.run_case(name, mods, torch.device('cpu')))
+    path = os.path.join(out_dir, 'blocks_small.npz')
+    np.savez_compressed(path, **res)
+    print(f'blocks -> {path} ({os.path.getsize(path) / 1e3:.1f} KB, {len(res)} arrays)')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(REPO, 'tests', 'golden'))
@@ -533,6 +554,8 @@ def main():
         gen_mixup(args.out)
     if args.only in (None, 'anchor_options'):
         gen_anchor_options(args.out)
+    if args.only in (None, 'blocks'):
+        gen_blocks(args.out)
     for name, b in batches.items():
         if args.only in (None, name):
             gen_config(name, args.out, b)
