@@ -80,16 +80,17 @@ class GradBucket(object):
             p._ssdk_grad_view = v
         return self
 
-    def allreduce_(self, group=None, average=True):
+    def allreduce_(self, group=None, average=True, force=False):
         """In-place all-reduce of ``p.grad`` for every parameter of the bucket."""
-        self.start_(group, average)
+        self.start_(group, average, force)
         self.finish_(group)
 
-    def start_(self, group=None, average=True):
+    def start_(self, group=None, average=True, force=False):
         """STARTS the all-reduce (async): whatever the caller launches next -- the backward of the layers in front of these
-        parameters -- overlaps with the ring.  ``finish_`` waits for it."""
+        parameters -- overlaps with the ring.  ``finish_`` waits for it.  ``force``: run the collective with one rank too (a group of
+        one leaves the values unchanged; tests use it to put the bucket through RCCL on a one-GPU box)."""
         self._work = None
-        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
             return
         grads = [p.grad for p in self.params]
         if any(g is None for g in grads):
@@ -112,7 +113,8 @@ class GradBucket(object):
                 self._post_div = world
         self._work = dist.all_reduce(self.flat, op=op, group=group, async_op=True)
 
-    def finish_(self, group=None, average=True):
+    def finish_(self, group=None):
+        """Waits for the collective ``start_`` began (the average was chosen there: ReduceOp.AVG, or a division here on gloo)."""
         if self._work is None:
             return
         self._work.wait()

@@ -333,6 +333,25 @@ def test_detection_init_distributed_two_ranks(tmp_path):
     assert all(os.path.exists(os.path.join(str(tmp_path), f'ok{r}.npy')) for r in range(2))
 
 
+def test_rccl_world_of_one(tmp_path):
+    """One REAL RCCL execution (backend 'nccl'), at world size 1, in a fresh child process: init_process_group('nccl', device_id=...),
+    the ReduceOp.AVG probe, the 36 MB head-gradient bucket forced through dist.all_reduce with its zero-copy views, a packed fp64
+    SyncBatchNorm buffer, destroy_process_group -- everything of the N > 1 exchange short of a second GPU (tests/rccl_worker.py)."""
+    import json
+    import os
+    import sys
+    from single_shot_detection_amd import launch
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'rccl_worker.py')
+    out = os.path.join(str(tmp_path), 'rccl.json')
+    rc = launch.launch(1, [sys.executable, worker, out])
+    assert rc == 0
+    res = json.load(open(out))
+    assert res['backend'] == 'nccl' and res['world'] == 1 and res['ipc_legacy_env'] == '0'
+    assert res['avg_supported'] is True              # RCCL has ReduceOp.AVG: the average costs no extra pass
+    assert res['bucket_bytes'] == 36046848 and res['views_alias_bucket'] and res['views_alias_after'] and res['copied_last'] == 0
+    assert res['max_abs_change'] == 0.0 and res['finite'] and res['sums_ok'] and res['streamk_timeouts'] == 0
+
+
 def test_graphed_eval_replays_match_the_eager_step():
     """single_shot_detection_amd.graphs: the evaluation step (pyramid tail + heads forward + postprocess) captured in a HIP graph and
     replayed on new inputs gives what the eagerly enqueued step gives.  Batch 2 of SSD-300: the head GEMM runs in its stream-K form,
