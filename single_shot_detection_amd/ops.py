@@ -258,6 +258,7 @@ def conv2d(xs, weight, bias=None, stride=1, padding=0, relu=False):
 
 
 _NO_FUSED_STATS = bool(__import__('os').environ.get('SSDK_NO_FUSED_STATS'))   # (measurement knob)
+_NO_BN_CHAIN = bool(__import__('os').environ.get('SSDK_NO_BN_CHAIN'))         # (measurement knob: every norm call zero-fills a scratch workspace)
 _NO_RELU_BY_NORM = bool(__import__('os').environ.get('SSDK_NO_RELU_BY_NORM'))   # (measurement knob)
 fused_stats_calls = 0   # (norm layers whose forward statistics were handed to a convolution's epilogue; tests read it)
 
@@ -320,7 +321,7 @@ class _SumsChain(object):
         self.stream = torch.cuda.current_stream(device).cuda_stream
 
     def usable(self, which, device):
-        return self.clean[which] and self.buf.device == device and self.stream == torch.cuda.current_stream(device).cuda_stream
+        return not _NO_BN_CHAIN and self.clean[which] and self.buf.device == device and self.stream == torch.cuda.current_stream(device).cuda_stream
 
 
 class _BatchNormFn(torch.autograd.Function):

@@ -4,9 +4,11 @@ bf/modules/conv.py:4-85, detection/detector_builder.py:57-109, detection/modules
 cases of tests/blocks_cases.py).  Both sides run the same harness (blocks_cases.run_case): eval() forward + backward, then one train()
 step; compared are the outputs, the input gradients, every parameter gradient and every BatchNorm buffer after the step.
 
-Tolerance (north_star: fp32 within 1e-4): rtol 1e-4 with an absolute floor of 1e-4 x the tensor's largest magnitude -- fp32 GEMM sums in
-another order than torch's CPU kernels, so an element that is a near-cancellation of K products cannot be held to 1e-4 of ITSELF.  The
-documented exceptions are BatchNorm statistics over very few samples (see LOOSE)."""
+Tolerance: north_star asks for 1e-4 in fp32; these compositions are held to 2e-5 -- |diff| <= 2e-5 * (|ref| + max|ref|) for every
+element of every output, gradient and buffer, no exceptions (measured on MI355X, tools/blocks_report.py: the worst element of any case is
+at 3.8e-6 on that scale, train()-mode statistics over 4 rows included).  The absolute floor is relative to the tensor's largest magnitude
+because fp32 GEMMs sum in another order than torch's CPU kernels: an element that is a near-cancellation of K products cannot be held to
+a fraction of ITSELF."""
 import os
 import types
 
@@ -27,19 +29,7 @@ MODS = types.SimpleNamespace(Conv2dBn=conv.Conv2dBn, DepthwiseConv2dBn=conv.Dept
                              ThinnedUshapeModule=features.ThinnedUshapeModule,
                              ScalewiseFeatureAggregationModule=features.ScalewiseFeatureAggregationModule)
 
-# (case, substring of the key) -> factor on the 1e-4 bar.  train()-mode BatchNorm over 4 rows (the tower's 1 x 1 level at batch 4) or 8
-# rows (the last extras map, 2 x 2 at batch 2) divides by a variance of a handful of samples: the normalised activations and everything
-# behind them amplify the convolution's last-bit differences by 1 / sigma of a near-degenerate channel.
-LOOSE = {('tower', '/train/'): 20.0, ('extras_ssd300', '/train/'): 10.0, ('extras_depthwise', '/train/'): 10.0, ('tum', '/train/'): 10.0,
-         ('fpn', '/train/'): 10.0, ('sfam', ''): 1.0}
-
-
-def _factor(case, key):
-    f = 1.0
-    for (c, sub), v in LOOSE.items():
-        if c == case and sub in key:
-            f = max(f, v)
-    return f
+BAR = 2e-5
 
 
 @pytest.fixture(scope='module')
@@ -55,7 +45,7 @@ def test_block_vs_reference_golden(case, golden_blocks):
     worst = {}
     for key in want_keys:
         ref, val = golden_blocks[key], got[key]
-        bar = 1e-4 * _factor(case, key)
+        bar = BAR
         if key.endswith('__shape'):
             assert np.array_equal(ref, val), key
         elif '/buffers/' in key and key.endswith('num_batches_tracked'):

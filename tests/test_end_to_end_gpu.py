@@ -387,7 +387,7 @@ def test_graphed_eval_replays_match_the_eager_step():
                 boundaries=Boundaries(logits, hp.C, True))
 
 
-@pytest.mark.parametrize('cfg_name,batch', [('ssd_mb2_voc', 2), ('ssd_300_vgg16_voc', 2), ('retina_rn50_500_coco', 2), ('m2det_512_vgg16_coco', 2)])
+@pytest.mark.parametrize('cfg_name,batch', [('ssd_mb2_voc', 2), ('ssd_300_vgg16_voc', 2), ('retina_rn50_500_coco', 2)])
 def test_graphed_training_steps_match_eager_ones(cfg_name, batch):
     """The whole training step (pyramid tail + heads forward, match, sampler, loss, backward, fused SGD) captured in a HIP graph with the
     ground truth in a PackedGroundTruth: every replay moves the parameters like the eagerly enqueued step does.  (Found with this
@@ -414,6 +414,62 @@ def test_graphed_training_steps_match_eager_ones(cfg_name, batch):
         for p, q in zip(params(graphed), params(eager)):
             scale = float(q.detach().abs().max()) + 1e-12
             assert float((p.detach() - q.detach()).abs().max()) <= 2e-3 * scale, k
+
+
+def _hot_path_state(hp):
+    """Every tensor a training step reads and writes besides its inputs: parameters, BatchNorm buffers, SGD momentum."""
+    mods = [m for m in (hp.heads, hp.extras, hp.tower, hp.neck) if m is not None]
+    out = [p for p in hp.params]
+    out += [b for m in mods for n, b in m.named_buffers() if not n.startswith('base.')]
+    out += [hp.opt.state[p]['momentum_buffer'] for p in hp.params]
+    return out
+
+
+def _copy_state(src, dst):
+    with torch.no_grad():
+        for a, b in zip(_hot_path_state(src), _hot_path_state(dst)):
+            b.copy_(a)   # (in place: the captured graph reads these very buffers)
+
+
+@pytest.mark.parametrize('cfg_name,batch', [('m2det_512_vgg16_coco', 2), ('retina_rn50_500_coco', 2)])
+def test_graphed_training_step_is_within_the_eager_steps_own_spread(cfg_name, batch):
+    """m2det_512_vgg16_coco's step is not a reproducible function of its state in fp32: the MLFPN neck is ~130 conv -> BatchNorm layers
+    deep with statistics over as few as 8 rows, the order of the split-K / scatter atomics differs from run to run, and that rounding
+    noise grows ~4x per TUM (tools/determinism_fwd.py: 1e-7 after the first TUM, 1e-4 after the eighth; gradients of the first layers
+    differ by several % between two EAGER runs from the same state -- round 2's "graph replay disagrees with eager on m2det" was this,
+    plus a miscounted step).  So a replay is held to the eager step's own run-to-run spread: from ONE state (copied in place into the
+    captured step's buffers) an eager step A, a second eager step B and a replay G; G - A must not be larger than a few times B - A,
+    in aggregate and per tensor -- a dead or stale graph node moves a tensor by its whole update, not by a few % of it.  Two rounds, so
+    that the second replay also meets what the first one left behind."""
+    import bench
+    from single_shot_detection_amd.detection.target_assigner import PackedGroundTruth
+    from single_shot_detection_amd.graphs import GraphedCallable
+    dev = torch.device('cuda:0')
+    a, b, g = (bench.HotPath(cfg_name, batch, dev) for _ in range(3))
+    g.gt = PackedGroundTruth.from_list(g.gt, dev, capacity=sum(len(t) for t in g.gt) + 7)
+    for _ in range(2):
+        a.train_step()
+    b.train_step()
+    step = GraphedCallable(g.train_step, [], warmup=3)
+    assert step.scratch_allocated_in_capture == 0
+    for rnd in range(2):
+        _copy_state(a, b)
+        _copy_state(a, g)
+        before = [t.detach().clone() for t in _hot_path_state(a)]
+        loss_a, loss_b, loss_g = a.train_step(), b.train_step(), step()
+        torch.cuda.synchronize()
+        la, lb, lg = float(loss_a.detach()), float(loss_b.detach()), float(loss_g.detach())
+        assert abs(lg - la) <= 3 * abs(lb - la) + 1e-5 * abs(la), (rnd, la, lb, lg)
+        num = den = 0.0
+        worst = (0.0, None)
+        for i, (ta, tb, tg, t0) in enumerate(zip(_hot_path_state(a), _hot_path_state(b), _hot_path_state(g), before)):
+            upd = float((ta.double() - t0.double()).norm())
+            dg, db = float((tg.double() - ta.double()).norm()), float((tb.double() - ta.double()).norm())
+            num, den = num + dg * dg, den + db * db
+            if upd > 0:
+                assert dg <= 8 * db + 0.02 * upd, (rnd, i, tuple(ta.shape), dg, db, upd)   # per tensor: within the spread (+ 2 % of its update)
+                worst = max(worst, (dg / upd, i))
+        assert num <= 6.0 * den + 1e-12, (rnd, num, den, worst)   # in aggregate: the replay is one more sample of the same spread
 
 
 def test_bench_n2_path_on_one_gpu_over_gloo():
