@@ -14,13 +14,17 @@ from single_shot_detection_amd.detection.modules import predictors
 pytestmark = pytest.mark.gpu
 
 
-def _close(got, want, bar=1e-4, err_msg=''):
+def _close(got, want, bar=1e-4, err_msg='', scale=None):
     """north_star's fp32 bar: |got - want| <= 1e-4 * (|want| + max|want|) for every element -- relative to the tensor's own scale, because the
     GPU's GEMMs and reductions sum in another order than torch's CPU kernels and an element that is a near-cancellation of K products
-    cannot be held to a fraction of itself.  (The same compositions against REFERENCE-generated fixtures: test_blocks_golden_gpu.py, 2e-5.)"""
+    cannot be held to a fraction of itself.  (The same compositions against REFERENCE-generated fixtures: test_blocks_golden_gpu.py, 2e-5.)
+    ``scale``: the magnitude to use instead of max|want| -- for a gradient that is analytically ZERO (a bias in front of a BatchNorm: the
+    norm subtracts the mean) both sides hold nothing but rounding noise of the sums they came from, and the scale is that of the sibling
+    weight gradient."""
     got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
     assert got.shape == want.shape, (err_msg, got.shape, want.shape)
-    scale = float(np.abs(want).max()) if want.size else 0.0
+    if scale is None:
+        scale = float(np.abs(want).max()) if want.size else 0.0
     err = np.abs(got - want)
     tol = bar * (np.abs(want) + scale) + 1e-12
     bad = err > tol
@@ -263,10 +267,12 @@ def test_m2det_neck_vs_torch():
     sum((a * g).sum() for a, g in zip(outs_r, gws)).backward()
     sum((a * g.cuda()).sum() for a, g in zip(outs_g, gws)).backward()
     _close(xg.grad.cpu().numpy(), xr.grad.numpy())
+    gw_max = max(float(p.grad.abs().max()) for p in ref.parameters())
     for (n1, p1), (n2, p2) in zip(sorted(neck.named_parameters()), sorted(ref.named_parameters())):
-        scale = float(p2.grad.abs().max()) + 1e-6
-        # biases feeding a BatchNorm have an analytically zero gradient: what is left is rounding noise, hence the absolute floor
-        _close(p1.grad.cpu().numpy(), p2.grad.numpy(), err_msg=n1)
+        # biases feeding a BatchNorm (the stub taps' convolutions sit in front of the reducers' norms only through a ReLU-free path when
+        # their gradient is analytically zero): what is left is rounding noise of sums of the weight gradient's magnitude
+        zero_grad_bias = n1.endswith('.bias') and float(p2.grad.abs().max()) < 1e-3 * gw_max
+        _close(p1.grad.cpu().numpy(), p2.grad.numpy(), err_msg=n1, scale=gw_max if zero_grad_bias else None)
 
 
 def test_ssd_mb2_depthwise_extras_chain_vs_torch():
@@ -606,4 +612,4 @@ def test_batchnorm_statistics_from_the_conv_epilogue_equal_the_separate_pass(cin
     assert int(a.bn.num_batches_tracked) == int(b.bn.num_batches_tracked) == 1
     gmax = max(float(p.grad.abs().max()) for p in b.parameters())   # (the conv bias' gradient through a BatchNorm is zero up to rounding: one scale for all)
     for (n1, p1), (n2, p2) in zip(sorted(a.named_parameters()), sorted(b.named_parameters())):
-        _close(p1.grad.cpu().numpy(), p2.grad.cpu().numpy(), err_msg=n1)
+        _close(p1.grad.cpu().numpy(), p2.grad.cpu().numpy(), err_msg=n1, scale=gmax if n1 == 'conv.bias' else None)

@@ -461,8 +461,9 @@ def test_graphed_training_step_is_within_the_eager_steps_own_spread(cfg_name, ba
         la, lb, lg = float(loss_a.detach()), float(loss_b.detach()), float(loss_g.detach())
         assert abs(lg - la) <= 3 * abs(lb - la) + 1e-5 * abs(la), (rnd, la, lb, lg)
         num = den = 0.0
-        worst = (0.0, None)
+        worst = (-1.0, -1)
         for i, (ta, tb, tg, t0) in enumerate(zip(_hot_path_state(a), _hot_path_state(b), _hot_path_state(g), before)):
+            ta, tb, tg = ta.detach(), tb.detach(), tg.detach()
             upd = float((ta.double() - t0.double()).norm())
             dg, db = float((tg.double() - ta.double()).norm()), float((tb.double() - ta.double()).norm())
             num, den = num + dg * dg, den + db * db
