@@ -544,6 +544,7 @@ __global__ void __launch_bounds__(kPostThreads) post_merge_kernel(int ncls, int 
 //   post_merge2_kernel    1 024 threads per image, the <= 8 192 keys of an image in registers, radix select + rank-by-counting.
 
 constexpr int kSelMaxC = 96;
+constexpr int kSelQueue = 256;       // post_select2_kernel: survivors of one wave's 16 rows that the compaction queue holds
 constexpr int kSampleStride = 8;
 constexpr int kWaveK = 128;          // post_nms_wave_kernel: sorted slots (max_per_class <= this)
 constexpr int kMergeSlots = 8192;    // post_merge2_kernel: ncls * max_per_class <= this (8 keys per thread)
@@ -731,8 +732,10 @@ struct SelArgs {
     int nseg;          // segment counters per (image, class)
     int seg0;          // index of this pass's segment 0 among them
     const unsigned* tau;   // [B * ncls] score-bit lower bounds (0 = none) or NULL
+    const unsigned* hotb;  // [B * ncls] score bits at or above which a key is HOT (NULL: every key is)
     u64* cand;         // [B * ncls][list_cap]
-    int* segcnt;       // [B * ncls][nseg]
+    int* segcnt;       // [B * ncls][nseg]  keys in the segment
+    int* seghot;       // [B * ncls][nseg]  of which hot (filled from the segment's front; the cold ones from its back)
     int stop;          // debug (SSDK_POST_STOP): 1 = staging only, 2 = no threshold test
 };
 
@@ -744,7 +747,14 @@ __global__ void __launch_bounds__(kPostThreads) post_select2_kernel(SelArgs a) {
     float* s_tile = reinterpret_cast<float*>(s_raw);
     float* s_pre = s_tile + align_up((size_t)kPostTileRows * Cp, 4);
     unsigned* s_taub = reinterpret_cast<unsigned*>(s_pre + ncls);
-    int* s_ccnt = reinterpret_cast<int*>(s_taub + ncls);
+    int* s_ccnt = reinterpret_cast<int*>(s_taub + ncls);            // hot keys of the class so far (slots from the front of the segment)
+    int* s_cold = s_ccnt + ncls;                                      // cold keys (slots from its back)
+    unsigned* s_hotb = reinterpret_cast<unsigned*>(s_cold + ncls);
+    float* s_rowmax = reinterpret_cast<float*>(s_hotb + ncls);   // [64] per row of the tile: max logit,
+    float* s_rowsum = s_rowmax + kPostTileRows;                    //      sum of the softmax terms,
+    float* s_rowinv = s_rowsum + kPostTileRows;                    //      its refined reciprocal
+    int* s_qn = reinterpret_cast<int*>(s_rowinv + kPostTileRows);   // [4] entries in each wave's survivor queue
+    unsigned short* s_queue = reinterpret_cast<unsigned short*>(s_qn + kPostThreads / kWave);   // [4][kSelQueue]: row << 8 | column
     const int i = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
     const float thr = a.thr;
     for (int c = tid; c < ncls; c += kPostThreads) {
@@ -752,27 +762,68 @@ __global__ void __launch_bounds__(kPostThreads) post_select2_kernel(SelArgs a) {
         const float teff = fmaxf(thr, __uint_as_float(tb));
         // conservative pre-test levels: softmax e > pre * sum, sigmoid x > pre (logit of the level, minus a margin far above logf's error)
         float pre;
-        if (SOFTMAX) pre = teff > 0.0f ? teff * (1.0f - 4.76837158203125e-07f) : teff * (1.0f + 4.76837158203125e-07f);
+        if (SOFTMAX) pre = teff > 0.0f ? teff * (1.0f - 1.9073486328125e-06f) : teff * (1.0f + 1.9073486328125e-06f);   // (2^-19: above the row pass' one-instruction exponential's error for every term that can pass: |t| <= log2(1 / thr))
         else pre = teff <= 0.0f ? -INFINITY : (teff >= 1.0f ? INFINITY : logf(teff / (1.0f - teff)) - 1e-3f);
         s_pre[c] = pre;
         s_taub[c] = tb;
         s_ccnt[c] = 0;
+        s_cold[c] = 0;
+        s_hotb[c] = a.hotb ? a.hotb[(size_t)i * ncls + c] : 0u;
     }
     __syncthreads();
     float lvl_min = INFINITY;   // (every thread the same loop: ncls broadcast reads once per workgroup)
     for (int c = 0; c < ncls; ++c) lvl_min = fminf(lvl_min, s_pre[c]);
     u64* seg = a.cand + (size_t)i * ncls * a.list_cap + a.seg_off + (size_t)g * a.tiles_per_wg * kPostTileRows;
     const unsigned cap32 = (unsigned)a.list_cap;   // (ncls * list_cap < 2^31: checked by the host)
+    const int seg_last = a.tiles_per_wg * kPostTileRows - 1;   // last slot of this workgroup's segment of a class list
     const int u_end = min(a.sel_tiles, (g + 1) * a.tiles_per_wg);
+    auto tile_of = [&](int u) { return a.mode == 0 ? u : (a.mode == 1 ? u * kSampleStride : u + u / (kSampleStride - 1) + 1); };
+    // The NEXT tile's 20 KB are fetched into registers (<= 6 float4 per thread) while this one is processed: a workgroup that loads,
+    // waits, computes and only then loads again keeps the memory system busy a third of the time (168 MB in 42 us with five workgroups
+    // per CU taking turns; the row pass and the survivors are another 40).  Only for 16-byte aligned, unpadded tiles; the other layouts
+    // stage as before.
+    constexpr int kPre = 6;   // 64 rows x 96 classes / 4 floats / 256 threads
+    float4 pre0, pre1, pre2, pre3, pre4, pre5;   // (named registers: an array here ended up in scratch memory)
+    pre0 = pre1 = pre2 = pre3 = pre4 = pre5 = make_float4(0.f, 0.f, 0.f, 0.f);
+    static_assert(kPre == 6, "six prefetch registers");
+    bool pre_valid = false;
+#define SSDK_SEL_PREFETCH(U)                                                                                                   \
+    do {                                                                                                                       \
+        const int a0n_ = tile_of(U) * kPostTileRows;                                                                           \
+        const int rowsn_ = min(kPostTileRows, a.A - a0n_);                                                                     \
+        const float* srcn_ = a.scores + ((size_t)i * a.A + a0n_) * C;                                                          \
+        pre_valid = !PAD && (reinterpret_cast<uintptr_t>(srcn_) & 15) == 0 && rowsn_ * C >= 4;                                 \
+        if (pre_valid) {                                                                                                       \
+            const int n4_ = (rowsn_ * C) >> 2;                                                                                 \
+            const float4* s4_ = reinterpret_cast<const float4*>(srcn_);                                                        \
+            pre0 = s4_[min(tid, n4_ - 1)];                                                                                     \
+            pre1 = s4_[min(tid + kPostThreads, n4_ - 1)];                                                                      \
+            pre2 = s4_[min(tid + 2 * kPostThreads, n4_ - 1)];                                                                  \
+            pre3 = s4_[min(tid + 3 * kPostThreads, n4_ - 1)];                                                                  \
+            pre4 = s4_[min(tid + 4 * kPostThreads, n4_ - 1)];                                                                  \
+            pre5 = s4_[min(tid + 5 * kPostThreads, n4_ - 1)];                                                                  \
+        }                                                                                                                      \
+    } while (0)
+    if (g * a.tiles_per_wg < u_end) SSDK_SEL_PREFETCH(g * a.tiles_per_wg);
     for (int u = g * a.tiles_per_wg; u < u_end; ++u) {
-        const int tile = a.mode == 0 ? u : (a.mode == 1 ? u * kSampleStride : u + u / (kSampleStride - 1) + 1);
+        const int tile = tile_of(u);
         const int a0 = tile * kPostTileRows;
         const int rows = min(kPostTileRows, a.A - a0);
         const int nfloat = rows * C;
         const float* src = a.scores + ((size_t)i * a.A + a0) * C;
         __syncthreads();
         const bool vec = (reinterpret_cast<uintptr_t>(src) & 15) == 0;
-        if (!PAD) {
+        if (!PAD && pre_valid) {   // (uniform: the same for every thread of the workgroup)
+            const int n4 = nfloat >> 2;
+            float4* t4 = reinterpret_cast<float4*>(s_tile);
+            t4[min(tid, n4 - 1)] = pre0;
+            t4[min(tid + kPostThreads, n4 - 1)] = pre1;
+            t4[min(tid + 2 * kPostThreads, n4 - 1)] = pre2;
+            t4[min(tid + 3 * kPostThreads, n4 - 1)] = pre3;
+            t4[min(tid + 4 * kPostThreads, n4 - 1)] = pre4;
+            t4[min(tid + 5 * kPostThreads, n4 - 1)] = pre5;
+            for (int t = (nfloat & ~3) + tid; t < nfloat; t += kPostThreads) s_tile[t] = src[t];
+        } else if (!PAD) {
             if (vec) {
                 if (nfloat >> 2) stage_tile_f4(reinterpret_cast<float4*>(s_tile), reinterpret_cast<const float4*>(src), nfloat >> 2);
                 for (int t = (nfloat & ~3) + tid; t < nfloat; t += kPostThreads) s_tile[t] = src[t];
@@ -808,6 +859,8 @@ __global__ void __launch_bounds__(kPostThreads) post_select2_kernel(SelArgs a) {
             }
         }
         __syncthreads();
+        pre_valid = false;
+        if (u + 1 < u_end) SSDK_SEL_PREFETCH(u + 1);   // in flight during the row pass and the survivors below
         if (a.stop == 1) continue;
         // --- row pass, 4 threads per row, the row's values in registers: softmax terms (written back to the tile), and a bit per
         // element that passes the conservative test.  Then every thread walks ITS set bits: the exact probability, the exact tests,
@@ -816,7 +869,7 @@ __global__ void __launch_bounds__(kPostThreads) post_select2_kernel(SelArgs a) {
         const int row = tid >> 2, q = tid & 3;
         const bool live = row < rows;
         float* x = s_tile + row * Cp;
-        float sum = 0.0f;
+        float sum = 0.0f, row_max = 0.0f;
         unsigned bits = 0;
         {
             float e[JMAX];
@@ -829,9 +882,14 @@ __global__ void __launch_bounds__(kPostThreads) post_select2_kernel(SelArgs a) {
             }
             if (SOFTMAX) {   // postprocessor.py:43 F.softmax(dim=-1)
                 m = quad_max(m);
+                // exp2((x - max) * log2 e) alone: the product's rounding error makes a term wrong by |t| * 2^-24 relative (t <= 0 its
+                // exponent), i.e. a few ulp for the terms that matter and ever less in absolute terms for the small ones -- the same size
+                // as what the order of the row's additions (here: four strided partial sums, in the reference torch's vector lanes)
+                // already puts into the sum.  The numerator of a SURVIVOR is computed with the two-term product form below.  The row
+                // pass was 14 of the kernel's ~35 vector instructions per logit, 8 of them this exponential's correction terms.
 #pragma unroll
                 for (int j = 0; j < JMAX; ++j) {
-                    e[j] = exp_nonpos(e[j] - m);
+                    e[j] = __builtin_amdgcn_exp2f((e[j] - m) * 1.44269502162933349609375f);
                     sum += e[j];
                 }
                 sum = quad_sum(sum);
@@ -839,30 +897,90 @@ __global__ void __launch_bounds__(kPostThreads) post_select2_kernel(SelArgs a) {
             if (a.stop == 2) continue;
             const float lvl = SOFTMAX ? lvl_min * sum : lvl_min;   // one level for the whole image: the lowest of its classes' bounds
 #pragma unroll
-            for (int j = 0; j < JMAX; ++j) {
-                const int c = q + 4 * j;
-                if (SOFTMAX && live && c < C) x[c] = e[j];
-                bits |= (e[j] > lvl) ? (1u << j) : 0u;
-            }
+            for (int j = 0; j < JMAX; ++j) bits |= (e[j] > lvl) ? (1u << j) : 0u;
+            if (SOFTMAX) row_max = m;
         }
         if (q == 0 && a.c_off) bits &= ~1u;   // postprocessor.py:46-48 drops the background column (c = 0 lives in q = 0, j = 0)
         if (!live) bits = 0;
-        const u64 akey = (u64)(0xFFFFFFFFu - (unsigned)(a0 + row));
-        while (bits) {
-            const int j = __ffs(bits) - 1;
-            bits &= bits - 1;
-            const int c = q + 4 * j, cls = c - a.c_off;
-            if (c >= C) continue;   // (only when the level is negative: -inf padding never passes otherwise)
-            const float v = x[c];
-            const float p = SOFTMAX ? v / sum : 1.0f / (1.0f + expf(-v));   // the reference's value (:43), exactly
-            if (p > thr && __float_as_uint(p) >= s_taub[cls]) {               // :63
-                const int slot = atomicAdd(&s_ccnt[cls], 1);
-                if (a.stop != 3) seg[(unsigned)cls * cap32 + (unsigned)slot] = ((u64)__float_as_uint(p) << 32) | akey;
+        // Survivors of the conservative test (a few % of the elements on trained-like scores): the exact probability, the exact tests, the
+        // key.  exp(x - max) is RECOMPUTED from the logit still in the tile (7 instructions) -- writing all 21 terms of every thread back
+        // to LDS for the few that are read again cost a ds_write per element, ~10 us of LDS time per call at batch 64 -- and e / sum is the
+        // compiler's IEEE division sequence (rcp, one Newton step on the reciprocal, two residual corrections of the quotient) with the
+        // per-ROW part hoisted: sum is in [1, C] and e in (0, 1], so the scaling / fix-up instructions of the general sequence
+        // (v_div_scale, v_div_fixup) have nothing to do.  5 instructions per survivor instead of ~12, same bits.
+        float rinv = 0.0f;
+        if (SOFTMAX) {
+            const float r0 = __builtin_amdgcn_rcpf(sum);
+            rinv = fmaf(fmaf(-sum, r0, 1.0f), r0, r0);
+        }
+        auto exact_p = [&](float xv, float mx, float sm, float ri) -> float {
+            if (!SOFTMAX) return 1.0f / (1.0f + expf(-xv));   // the reference's value (:43), exactly
+            const float v = exp_nonpos(xv - mx);
+            const float q0 = v * ri;
+            const float q1 = fmaf(fmaf(-sm, q0, v), ri, q0);
+            return fmaf(fmaf(-sm, q1, v), ri, q1);
+        };
+        // About one survivor per thread on trained-like scores, but four or five in SOME lane of every wave: a per-thread loop runs as
+        // long as its busiest lane.  So a wave first compacts its survivors into a queue in LDS (one returning LDS atomic per lane for
+        // the base, then 2-byte entries), and then all 64 lanes take one entry each.  A wave with more survivors than the queue holds
+        // (every pair passes: the worst case, where the lanes are evenly loaded anyway) keeps the per-thread loop.
+        const int lane = tid & 63, wave = tid >> 6;
+        if (SOFTMAX && q == 0 && live) { s_rowmax[row] = row_max; s_rowsum[row] = sum; s_rowinv[row] = rinv; }
+        if (lane == 0) s_qn[wave] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const int mycnt = __popc(bits);
+        int qbase = 0;
+        if (mycnt) qbase = atomicAdd(&s_qn[wave], mycnt);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const int total = s_qn[wave];   // (this wave's own DS operations complete in order)
+        if (total <= kSelQueue) {
+            unsigned short* qw = s_queue + wave * kSelQueue;
+            while (bits) {
+                const int j = __ffs(bits) - 1;
+                bits &= bits - 1;
+                qw[qbase++] = (unsigned short)((row << 8) | (q + 4 * j));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            for (int sidx = lane; sidx < total; sidx += kWave) {
+                const unsigned ent = qw[sidx];
+                const int r = (int)(ent >> 8), c = (int)(ent & 255u), cls = c - a.c_off;
+                if (c >= C) continue;   // (only when the level is negative: -inf padding never passes otherwise)
+                const float p = exact_p(s_tile[r * Cp + c], SOFTMAX ? s_rowmax[r] : 0.0f, SOFTMAX ? s_rowsum[r] : 0.0f, SOFTMAX ? s_rowinv[r] : 0.0f);
+                if (p > thr && __float_as_uint(p) >= s_taub[cls]) {               // :63
+                    // hot keys (at or above the class's bound: the few the NMS head will want) from the front of the segment, the others from its back
+                    const bool hot = __float_as_uint(p) >= s_hotb[cls];
+                    const int k = atomicAdd(hot ? &s_ccnt[cls] : &s_cold[cls], 1);
+                    const int slot = hot ? k : seg_last - k;
+                    if (a.stop != 3) seg[(unsigned)cls * cap32 + (unsigned)slot] = ((u64)__float_as_uint(p) << 32) | (u64)(0xFFFFFFFFu - (unsigned)(a0 + r));
+                }
+            }
+        } else {
+            const u64 akey = (u64)(0xFFFFFFFFu - (unsigned)(a0 + row));
+            while (bits) {
+                const int j = __ffs(bits) - 1;
+                bits &= bits - 1;
+                const int c = q + 4 * j, cls = c - a.c_off;
+                if (c >= C) continue;
+                const float p = exact_p(x[c], row_max, sum, rinv);
+                if (p > thr && __float_as_uint(p) >= s_taub[cls]) {               // :63
+                    const bool hot = __float_as_uint(p) >= s_hotb[cls];
+                    const int k = atomicAdd(hot ? &s_ccnt[cls] : &s_cold[cls], 1);
+                    const int slot = hot ? k : seg_last - k;
+                    if (a.stop != 3) seg[(unsigned)cls * cap32 + (unsigned)slot] = ((u64)__float_as_uint(p) << 32) | akey;
+                }
             }
         }
     }
+#undef SSDK_SEL_PREFETCH
     __syncthreads();
-    for (int c = tid; c < ncls; c += kPostThreads) a.segcnt[((size_t)i * ncls + c) * a.nseg + a.seg0 + g] = s_ccnt[c];
+    for (int c = tid; c < ncls; c += kPostThreads) {
+        const size_t at = ((size_t)i * ncls + c) * a.nseg + a.seg0 + g;
+        a.segcnt[at] = s_ccnt[c] + s_cold[c];
+        a.seghot[at] = s_ccnt[c];
+    }
 }
 
 // The keys of one (image, class) as one index space 0 .. n-1: first the `ntop` keys of a contiguous list, then the segments the select
@@ -875,6 +993,8 @@ struct KeySpace {
     const u64* segs;
     int seg_cap, nseg, n;
     const int* s_pref;
+    const int* s_hot;   // NULL: a segment's keys are its first (count) slots (the hot keys of a two-ended segment, or a front-filled one);
+                        // else [nseg] hot counts: key `off` of a segment is slot off when off < hot, else slot seg_cap - 1 - (off - hot)
     __device__ __forceinline__ u64 load(int p) const {
         if (p < ntop) return top[p];
         const int q = p - ntop;
@@ -883,7 +1003,12 @@ struct KeySpace {
             const int mid = (lo + hi) >> 1;
             if (s_pref[mid] <= q) lo = mid; else hi = mid;
         }
-        return segs[(size_t)lo * seg_cap + (q - s_pref[lo])];
+        int off = q - s_pref[lo];
+        if (s_hot) {
+            const int h = s_hot[lo];
+            off = off < h ? off : seg_cap - 1 - (off - h);
+        }
+        return segs[(size_t)lo * seg_cap + off];
     }
 };
 
@@ -967,14 +1092,16 @@ __device__ __forceinline__ int wave_collect(const KeySpace& ks, const u64* s_all
 // at most K, else the K largest -- and then tau = the K-th largest key's score, a rigorous lower bound of the final K-th score.
 __global__ void __launch_bounds__(kWave) post_tau_kernel(const u64* __restrict__ cand, long long list_cap, int seg_off, int seg_cap,
                                                          const int* __restrict__ segcnt, int nseg_all, int seg0, int nseg, int K,
-                                                         u64* __restrict__ top, int* __restrict__ topcnt, unsigned* __restrict__ tau) {
+                                                         u64* __restrict__ top, int* __restrict__ topcnt, unsigned* __restrict__ tau,
+                                                         int hot_rank, unsigned* __restrict__ hotb, int* __restrict__ tophot) {
     __shared__ unsigned s_hist[256];
     __shared__ int s_pref[kWave + 1];
     __shared__ u64 s_cache[kTauCache];
+    __shared__ u64 s_out[kWaveK];
     const int pc = blockIdx.x, lane = threadIdx.x;
     const int mycnt = lane < nseg ? segcnt[(size_t)pc * nseg_all + seg0 + lane] : 0;
     KeySpace ks;
-    ks.top = nullptr; ks.ntop = 0; ks.segs = cand + (size_t)pc * list_cap + seg_off; ks.seg_cap = seg_cap; ks.nseg = nseg; ks.s_pref = s_pref;
+    ks.top = nullptr; ks.ntop = 0; ks.segs = cand + (size_t)pc * list_cap + seg_off; ks.seg_cap = seg_cap; ks.nseg = nseg; ks.s_pref = s_pref; ks.s_hot = nullptr;
     ks.n = wave_prefix_to_lds(mycnt, nseg, s_pref);
     u64* out = top + (size_t)pc * K;
     u64 prefix = 0;
@@ -984,9 +1111,41 @@ __global__ void __launch_bounds__(kWave) post_tau_kernel(const u64* __restrict__
         s_all = s_cache;
     }
     if (ks.n > K) prefix = wave_radix_prefix(s_hist, K, K, ks, s_all);   // exactly K keys are >= prefix
-    const int outn = ks.n ? wave_collect(ks, s_all, prefix, K, [&](int pos, u64 key) { out[pos] = key; }) : 0;
+    const int outn = ks.n ? wave_collect(ks, s_all, prefix, K, [&](int pos, u64 key) { s_out[pos] = key; }) : 0;
+    __syncthreads();
+    // The hot bound: the score of the hot_rank-th largest sample key.  The sample is every 8th tile, so about 8 * hot_rank keys of the
+    // whole list lie at or above it -- enough for the NMS head's handful with a few % of exceptions (which then read the whole list),
+    // and a tenth of what the list holds.  Fewer than hot_rank sample keys: no bound, every key is hot.
+    unsigned hb = 0u;
+    const unsigned scA = lane < outn ? (unsigned)(s_out[lane] >> 32) : 0u, scB = lane + kWave < outn ? (unsigned)(s_out[lane + kWave] >> 32) : 0u;
+    if (hot_rank > 0 && outn >= hot_rank) {
+        // the largest value v with at least hot_rank scores >= v, bit by bit (two ballots and a count per bit: no LDS, no cross-lane
+        // reduction chains -- five rounds of a 64-bit wave maximum were 60 dependent ds_bpermute round trips, +5 us on this kernel)
+        for (int bit = 30; bit >= 0; --bit) {
+            const unsigned cand_v = hb | (1u << bit);
+            const int cnt = __popcll(__ballot(scA >= cand_v)) + __popcll(__ballot(scB >= cand_v));
+            if (cnt >= hot_rank) hb = cand_v;
+        }
+    }
+    // top[pc] = the sample's keys with the hot ones first
+    int nh = 0;
+    for (int e0 = 0; e0 < outn; e0 += kWave) nh += __popcll(__ballot(e0 + lane < outn && (unsigned)(s_out[min(e0 + lane, outn - 1)] >> 32) >= hb));
+    int ph = 0, pcold = nh;
+    for (int e0 = 0; e0 < outn; e0 += kWave) {
+        const int e = e0 + lane;
+        const u64 k = s_out[min(e, outn - 1)];
+        const bool live = e < outn, hot = live && (unsigned)(k >> 32) >= hb;
+        const unsigned long long mh = __ballot(hot), mc = __ballot(live && !hot);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (hot) out[ph + __popcll(mh & below)] = k;
+        else if (live) out[pcold + __popcll(mc & below)] = k;
+        ph += __popcll(mh);
+        pcold += __popcll(mc);
+    }
     if (lane == 0) {
         topcnt[pc] = outn;
+        tophot[pc] = nh;
+        hotb[pc] = hb;
         tau[pc] = ks.n > K ? (unsigned)(prefix >> 32) : 0u;
     }
 }
@@ -1003,9 +1162,11 @@ struct NmsSrc {
     long long list_cap;
     int seg_off, seg_cap; // the main pass's segments
     const int* segcnt;    // [npc][nseg_all]
+    const int* seghot;    // [npc][nseg_all] hot keys of a segment (its first slots; the cold ones fill it from the back)
     int nseg_all, seg0, nseg;
-    const u64* top;       // [npc][K] the sample pass's survivors (NULL: none)
+    const u64* top;       // [npc][K] the sample pass's survivors (NULL: none), hot ones first
     const int* topcnt;
+    const int* tophot;
 };
 
 // single-instruction min / max (fminf / fmaxf canonicalise every operand that may be a signalling NaN: four extra v_max per IoU here)
@@ -1043,14 +1204,33 @@ __global__ void __launch_bounds__(kWave) post_nms_wave_kernel(const float4* __re
         floor_bits = img_tau[i];
         if (hl == 0u || hl <= floor_bits) return;   // (hl - 1 < floor: every further candidate of this class is below the bound)
     }
+    __shared__ int s_hot[kWave];
     const int mycnt = lane < src.nseg ? src.segcnt[(size_t)pc * src.nseg_all + src.seg0 + lane] : 0;
+    const int myhot = lane < src.nseg ? src.seghot[(size_t)pc * src.nseg_all + src.seg0 + lane] : 0;
+    const int ntop_all = src.top ? src.topcnt[pc] : 0, ntop_hot = src.top ? src.tophot[pc] : 0;
+    s_hot[lane] = myhot;
     KeySpace ks;
-    ks.ntop = src.top ? src.topcnt[pc] : 0;
     ks.top = src.top ? src.top + (size_t)pc * K : nullptr;
     ks.segs = src.cand + (size_t)pc * src.list_cap + src.seg_off; ks.seg_cap = src.seg_cap; ks.nseg = src.nseg; ks.s_pref = s_pref;
-    ks.n = ks.ntop + wave_prefix_to_lds(mycnt, src.nseg, s_pref);
+    int n_all = ntop_all, n_hot = ntop_hot;
+    {
+        int ta = mycnt, th = myhot;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { ta += __shfl_xor(ta, d, kWave); th += __shfl_xor(th, d, kWave); }
+        n_all += ta; n_hot += th;
+    }
+    // The head wants the Khead best keys of the list: they are all among the hot keys when there are at least Khead of those (every
+    // cold key is below every hot one), and then it reads tens of keys instead of hundreds.  Anything else takes the whole list.
+    const bool hot_view = MODE == 1 && n_hot >= Khead && n_hot < n_all;
+    if (hot_view) {
+        ks.ntop = ntop_hot; ks.s_hot = nullptr;
+        ks.n = ntop_hot + wave_prefix_to_lds(myhot, src.nseg, s_pref);
+    } else {
+        ks.ntop = ntop_all; ks.s_hot = s_hot;
+        ks.n = ntop_all + wave_prefix_to_lds(mycnt, src.nseg, s_pref);
+    }
     const int n = ks.n;
-    if (n == 0) {
+    if (n_all == 0) {
         if (lane == 0) {
             pc_count[pc] = 0;
             pc_m[pc] = 0;
@@ -1090,8 +1270,8 @@ __global__ void __launch_bounds__(kWave) post_nms_wave_kernel(const float4* __re
     __syncthreads();
     int m = min(cnt, Kuse);   // box_utils.py:186-188
     if (MODE == 1 && lane == 0) {
-        pc_m[pc] = min(n, K);   // boxes that enter NMS in the reference, whatever part of the work the bound spares
-        head_last[pc] = n > Khead ? (unsigned)(s_sorted[Khead - 1] >> 32) + 1u : 0u;
+        pc_m[pc] = min(n_all, K);   // boxes that enter NMS in the reference, whatever part of the work the bound spares
+        head_last[pc] = n_all > Khead ? (unsigned)(s_sorted[Khead - 1] >> 32) + 1u : 0u;
     }
     if (MODE == 2 && floor_bits) {   // the sorted entries at or above the image's bound are a prefix
         const bool geA = lane < m && (unsigned)(s_sorted[lane] >> 32) >= floor_bits;
@@ -1366,7 +1546,7 @@ static PostPlan make_plan(int batch, int A, int C, int softmax, int K, int max_t
     const int ns = cdiv(p.tiles, kSampleStride);
     // sample pass + per-class bound only where the sample can hold well over max_per_class candidates
     p.ns = ((long long)ns * kPostTileRows >= 4LL * K && p.tiles - ns > 0 && !getenv("SSDK_POST_NO_SAMPLE")) ? ns : 0;
-    const int target_wgs = getenv("SSDK_POST_WGS") ? atoi(getenv("SSDK_POST_WGS")) : 1280;
+    const int target_wgs = getenv("SSDK_POST_WGS") ? atoi(getenv("SSDK_POST_WGS")) : 768;   // (three resident workgroups per CU: measured best of 384 .. 2048 at batch 64, tools/r03_post_wgs.sh)
     int per_image = cdiv(target_wgs, batch);   // about five resident workgroups per CU over the whole grid ...
     per_image = per_image < 1 ? 1 : (per_image > kWave ? kWave : per_image);   // ... and at most one segment counter per lane of the consumer
     const int tm = p.tiles - p.ns;
@@ -1387,9 +1567,12 @@ static PostPlan make_plan(int batch, int A, int C, int softmax, int K, int max_t
 struct PostWs2 {
     u64* cand;        // [npc][list_cap]
     int* segcnt;      // [npc][nseg]
+    int* seghot;      // [npc][nseg]
     u64* top;         // [npc][K]
     int* topcnt;      // [npc]
+    int* tophot;      // [npc]   hot keys at the front of top[pc]
     unsigned* tau;    // [npc]
+    unsigned* hotb;   // [npc]   score bits of the hot bound (0: every key is hot)
     float* pc_rows;   // [npc][K][6]
     float* pc_score;  // [npc][K]
     int* pc_count;    // [npc]
@@ -1414,9 +1597,12 @@ static PostWs2 carve_post_ws2(void* ws, size_t npc, size_t K, const PostPlan& p,
     PostWs2 w;
     w.cand = c.take<u64>(npc * (size_t)p.list_cap);
     w.segcnt = c.take<int>(npc * (size_t)p.nseg);
+    w.seghot = c.take<int>(npc * (size_t)p.nseg);
     w.top = c.take<u64>(npc * K);
     w.topcnt = c.take<int>(npc);
+    w.tophot = c.take<int>(npc);
     w.tau = c.take<unsigned>(npc);
+    w.hotb = c.take<unsigned>(npc);
     w.pc_rows = c.take<float>(npc * K * 6);
     w.pc_score = c.take<float>(npc * K);
     w.pc_count = c.take<int>(npc);
@@ -1480,14 +1666,15 @@ static int postprocess_v2(const PostPlan& p, const float* scores, const float* l
     const PostWs2 w = carve_post_ws2(workspace, (size_t)npc, (size_t)max_per_class, p, nullptr);
     const bool pad = (num_classes & 1) == 0;
     const int Cp = pad ? num_classes + 1 : num_classes;
-    const size_t lds = (align_up((size_t)kPostTileRows * Cp, 4) + 3 * (size_t)ncls) * 4;
+    const size_t lds = (align_up((size_t)kPostTileRows * Cp, 4) + 5 * (size_t)ncls + 3 * kPostTileRows + kPostThreads / kWave) * 4 + (size_t)(kPostThreads / kWave) * kSelQueue * 2;
     SelArgs a;
     a.scores = scores; a.A = num_anchors; a.C = num_classes; a.ncls = ncls; a.c_off = softmax ? 1 : 0; a.thr = score_threshold;
-    a.list_cap = p.list_cap; a.nseg = p.nseg; a.cand = w.cand; a.segcnt = w.segcnt;
+    a.list_cap = p.list_cap; a.nseg = p.nseg; a.cand = w.cand; a.segcnt = w.segcnt; a.seghot = w.seghot; a.hotb = nullptr;
     a.stop = getenv("SSDK_POST_STOP") ? atoi(getenv("SSDK_POST_STOP")) : 0;
     const int jneed = cdiv(num_classes, 4);
-    auto launch = [&](int mode, int sel_tiles, int G, int T, int seg_off, int seg0, const unsigned* tau) -> int {
-        a.mode = mode; a.sel_tiles = sel_tiles; a.tiles_per_wg = T; a.seg_off = seg_off; a.seg0 = seg0; a.tau = tau;
+    const int khead_plan = (getenv("SSDK_NMS_STOP") && atoi(getenv("SSDK_NMS_STOP"))) ? 0 : nms_head_size(ncls, max_per_class, max_total);
+    auto launch = [&](int mode, int sel_tiles, int G, int T, int seg_off, int seg0, const unsigned* tau, const unsigned* hotb) -> int {
+        a.mode = mode; a.sel_tiles = sel_tiles; a.tiles_per_wg = T; a.seg_off = seg_off; a.seg0 = seg0; a.tau = tau; a.hotb = hotb;
         const dim3 grid(G, batch), block(kPostThreads);
 #define SSDK_SEL(SM, PD, J) hipLaunchKernelGGL((post_select2_kernel<SM, PD, J>), grid, block, lds, s, a)
 #define SSDK_SEL_J(SM, PD)                          \
@@ -1508,15 +1695,18 @@ static int postprocess_v2(const PostPlan& p, const float* scores, const float* l
     };
     const int seg_off_main = p.Gs * p.Ts * kPostTileRows;
     if (p.ns) {
-        int rc = launch(1, p.ns, p.Gs, p.Ts, 0, 0, nullptr);
+        int rc = launch(1, p.ns, p.Gs, p.Ts, 0, 0, nullptr, nullptr);
         if (rc) return rc;
+        // hot bound = the hot_rank-th largest sample key: about kSampleStride * hot_rank keys of the whole list at or above it, against the
+        // Khead the head wants (5 / 16 of Khead: 3 % of the lists come out short and take the whole list, 8 % exceed the head's 64 slots)
+        const int hot_rank = (khead_plan && !getenv("SSDK_POST_NO_HOT")) ? (5 * khead_plan + 15) / 16 : 0;
         hipLaunchKernelGGL(post_tau_kernel, dim3(npc), dim3(kWave), 0, s, w.cand, p.list_cap, 0, p.Ts * kPostTileRows, w.segcnt, p.nseg, 0, p.Gs,
-                           max_per_class, w.top, w.topcnt, w.tau);
+                           max_per_class, w.top, w.topcnt, w.tau, hot_rank, w.hotb, w.tophot);
         SSDK_CHECK_LAUNCH("post_tau_kernel");
-        rc = launch(2, p.tiles - p.ns, p.Gm, p.Tm, seg_off_main, p.Gs, w.tau);
+        rc = launch(2, p.tiles - p.ns, p.Gm, p.Tm, seg_off_main, p.Gs, w.tau, hot_rank ? w.hotb : nullptr);
         if (rc) return rc;
     } else {
-        const int rc = launch(0, p.tiles, p.Gm, p.Tm, 0, 0, nullptr);
+        const int rc = launch(0, p.tiles, p.Gm, p.Tm, 0, 0, nullptr, nullptr);
         if (rc) return rc;
     }
     if (a.stop > 0) return SSDK_OK;   // debug: timing of the select stages alone (outputs are not written)
@@ -1528,8 +1718,8 @@ static int postprocess_v2(const PostPlan& p, const float* scores, const float* l
     const int tie_up = (int)(thr_bits & 1u);   // a tie rounds to the even mantissa: up to thr_next when thr's is odd
     NmsSrc src;
     src.cand = w.cand; src.list_cap = p.list_cap; src.seg_off = p.ns ? seg_off_main : 0; src.seg_cap = p.Tm * kPostTileRows;
-    src.segcnt = w.segcnt; src.nseg_all = p.nseg; src.seg0 = p.Gs; src.nseg = p.Gm;
-    src.top = p.ns ? w.top : nullptr; src.topcnt = w.topcnt;
+    src.segcnt = w.segcnt; src.seghot = w.seghot; src.nseg_all = p.nseg; src.seg0 = p.Gs; src.nseg = p.Gm;
+    src.top = p.ns ? w.top : nullptr; src.topcnt = w.topcnt; src.tophot = w.tophot;
     const int nms_stop = getenv("SSDK_NMS_STOP") ? atoi(getenv("SSDK_NMS_STOP")) : 0;
     const int khead = nms_stop ? 0 : nms_head_size(ncls, max_per_class, max_total);
 #define SSDK_NMS(TIE, MODE)                                                                                                                     \

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import oracle  # noqa: E402
 from single_shot_detection_amd.detection.box_coder import BoxCoder  # noqa: E402
 from single_shot_detection_amd.detection.postprocessor import Postprocessor  # noqa: E402
-from test_postprocess_gpu import compare  # noqa: E402
+from test_postprocess_gpu import Boundaries, compare  # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -55,7 +55,7 @@ for case in range(cases):
         out = post.postprocess((torch.from_numpy(lg.reshape(B, -1)).cuda(), torch.from_numpy(lc.reshape(B, -1)).cuda()), torch.from_numpy(pri).cuda())
         ref, cand = oracle.postprocess(lg.reshape(B, -1), lc.reshape(B, -1), pri, softmax=softmax, score_thr=thr, max_per_class=mpc, nms_thr=nms_thr,
                                        max_total=mt, return_cand=True, **(dict(soft=True, sigma=0.5) if soft else {}))
-        compare(out, ref)
+        compare(out, ref, boundaries=Boundaries(lg.reshape(B, -1), C, softmax, thr, mpc, mt))
         assert np.array_equal(post.last_nms_candidates.cpu().numpy(), cand), (post.last_nms_candidates.cpu().numpy(), cand)
     except Exception as e:   # noqa: BLE001
         bad += 1
