@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SSDK_VERSION 107
+#define SSDK_VERSION 108
 
 #define SSDK_OK 0
 #define SSDK_E_INVALID (-1)   /* bad argument / shape */
@@ -294,6 +294,11 @@ typedef struct ssdk_conv_desc {
 
 /* n <= 8 convolutions (e.g. the five pyramid levels of one shared tower layer) in one grouped launch. */
 int ssdk_conv2d_fwd(const ssdk_conv_desc* descs, int n, int batch, void* stream);
+/* The same with the stream-K workspace of ssdk_heads_fwd (ssdk_heads_fwd_workspace_bytes() bytes, zero-filled once by the caller, shared with
+ * ssdk_heads_fwd on the same stream; NULL = none): a launch of one or two rounds of whole tiles -- the large layers of a pyramid tail
+ * (detection/detector_builder.py:73-82 at 18 x 18 / 9 x 9) -- then runs in stream-K form instead of splitting K with atomics into a
+ * zero-filled output.  Same results up to fp32 summation order; a fix-up wait that runs out is loud (ssdk_heads_fwd_timeouts). */
+int ssdk_conv2d_fwd_ws(const ssdk_conv_desc* descs, int n, int batch, void* workspace, size_t workspace_bytes, void* stream);
 size_t ssdk_conv2d_bwd_workspace_bytes(const ssdk_conv_desc* descs, int n, int batch);
 /* accumulate != 0: dw / db are added to what the buffers hold; else they are overwritten (descriptors that name the
  * same dw / db -- weights shared across levels -- are summed into it). */

@@ -99,6 +99,7 @@ struct ConvProblem {
     // the LDS-DMA kernel, which rounds it up to 8 so that every 8-row DMA piece reads ONE weight tensor (one descriptor)
     int n0_pad;
     unsigned w0_bytes, w1_bytes;   // LDS-DMA kernel: sizes of the two weight tensors (buffer descriptors)
+    int forced;   // n_blocks / k_splits were set by the caller: launch_group keeps them
     // BatchNorm statistics of the output, fused into the epilogue (forward, one output, not split over K): per-column sums of the
     // stored values and of their squares are ADDED into stats[0 .. n0) / stats[n0 .. 2 n0) (fp64), stats[2 n0] = rows.  NULL: none.
     double* stats;
@@ -682,7 +683,7 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
             if (tid == 0 && poison == poison) __hip_atomic_store(sk_flag + part, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    conv_epilogue<SCATTER>(g, acc, m_base, wave, r32, h, tn, n_begin, M, N, hw, ksp, (!MIRROR && !SCATTER && !sk_mode) ? s_a0 : nullptr, WAVES);
+    conv_epilogue<SCATTER>(g, acc, m_base, wave, r32, h, tn, n_begin, M, N, hw, ksp, (!MIRROR && !SCATTER) ? s_a0 : nullptr, WAVES);   // (a stream-K owner too: the fix-up ends behind a barrier)
     PHASE(3)
 }
 
@@ -1805,6 +1806,14 @@ static bool maybe_split_k(ConvProblem& g) {
     const int blocks = cdiv(g.m_tiles, 8) * 8 * g.n_blocks;
     const int slices = g.ksize * g.ksize * cdiv(g.Cc, kBK);
     if (g.relu || blocks >= 256 || slices < 8) return false;
+    // Many row tiles, few column blocks (the SSD-300 tail's 1 x 1 512 -> 256 at 18 x 18, batch 32: 81 x 2 tiles of 128 x 128): 64-column
+    // workgroups fill the chip WITHOUT splitting K -- no atomic epilogue (3 x the output through 1.3 TB/s of atomics), no zero-fill
+    // launch: 57 -> 44 us (tools/conv_decomp_sweep.py; the other tail layers stay within 15 % of their best split)
+    if (g.tiles_n >= 4 && g.tiles_n % 2 == 0 && (long long)g.m_tiles * (g.tiles_n / 2) >= 256 && slices <= 32) {
+        g.n_blocks = g.tiles_n / 2;
+        g.forced = 1;
+        return false;
+    }
     int ks = cdiv(512, blocks);
     if (ks > slices / 4) ks = slices / 4;
     if (ks < 2) return false;
@@ -1828,6 +1837,32 @@ struct StreamKWs {
 };
 constexpr long long kStreamKMinRange = 24 * kMaxTN;
 constexpr int kStreamKMinWgs = 256;
+// generic convolutions (pyramid tail, tower, necks): the launches stream-K helps are ONE to two rounds of tiles on 256 CUs (the SSD-300
+// tail's 1 x 1 512 -> 256 at 18 x 18: 162 tiles of 128 x 128, split over K three ways with an atomic epilogue before), so their ranges are
+// shorter than the heads': 6 K slices of a 128-column block (SSDK_SK_MINRANGE: measurement knob)
+static long long streamk_generic_min_range() {
+    const char* e = getenv("SSDK_SK_MINRANGE");
+    const long long v = e ? atoll(e) : 0;
+    return v > 0 ? v : 6 * kMaxTN;
+}
+// would launch_group run these forward problems in stream-K form? (decided before the caller splits K: a split launch never does)
+static bool streamk_would_take(const ConvProblem* probs, int count, bool generic) {
+    // generic convolutions: OFF unless asked for (SSDK_CONV_STREAMK_GENERIC=1).  Measured on the SSD-300 tail at batch 32
+    // (tools/r03_sk_sweep.sh): the 1 x 1 512 -> 256 layer 56 -> 92-115 us and the 3 x 3 / 2 256 -> 512 layer 85 -> 140 us with ranges of
+    // 8 .. 32 units -- a launch of ONE round has no tail to even out, and every workgroup then parks and fixes up a 64 KB partial tile
+    if (getenv("SSDK_CONV_NO_STREAMK") || (generic && !getenv("SSDK_CONV_STREAMK_GENERIC"))) return false;
+    long long units = 0, blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        const ConvProblem& g = probs[i];
+        if (g.Cc % kBK || g.mode) return false;
+        const int tiles_n = cdiv((g.n1 > 0 ? cdiv(g.n0, 8) * 8 : g.n0) + g.n1, 32);
+        units += (long long)g.m_tiles * g.ksize * g.ksize * (g.Cc / kBK) * tiles_n;
+        blocks += (long long)cdiv(g.m_tiles, 8) * 8 * cdiv(tiles_n, kMaxTN);
+    }
+    const long long min_range = generic ? streamk_generic_min_range() : kStreamKMinRange;
+    const long long nwg = std::min<long long>(512, units / min_range / 8 * 8);
+    return nwg >= kStreamKMinWgs && blocks <= 16 * nwg;
+}
 static unsigned g_streamk_epoch = 0;   // (a launch counter: tells this launch's flags from an earlier launch's in the same workspace)
 // A stream-K owner that gave up on a parked partner says so in a word of pinned, device-visible HOST memory (one per process, allocated
 // on first use outside stream capture, never freed): reading it costs the host nothing, so every ssdk_heads_fwd checks it first and fails
@@ -1881,8 +1916,10 @@ static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t 
         ConvProblem& g = probs[i];
         g.n0_pad = (dma && g.n1 > 0) ? cdiv(g.n0, bk16 ? 16 : 8) * (bk16 ? 16 : 8) : g.n0;
         g.tiles_n = cdiv(g.n0_pad + g.n1, 32);
-        g.n_blocks = cdiv(g.tiles_n, tn6 ? 6 : kMaxTN);
-        if (!vtab && (scatter || g.k_splits > 1)) narrow_for_atomics(g);
+        if (!g.forced) {
+            g.n_blocks = cdiv(g.tiles_n, tn6 ? 6 : kMaxTN);
+            if (!vtab && (scatter || g.k_splits > 1)) narrow_for_atomics(g);
+        }
     }
     // 8-wave / 256-pixel tiling: measured 3 % (B=128) to 14 % (B=32) MORE cycles than two 4-wave workgroups per CU on the
     // SSD-300 heads (one barrier stalls all eight waves of the CU at once) -- kept as an opt-in experiment only
@@ -1930,7 +1967,7 @@ static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t 
         SSDK_CHECK_LAUNCH("build_vtab_kernel");
         grp.vtab = vtab;
         hipLaunchKernelGGL((igemm_dma_kernel<false, false, true, 4>), dim3(2048), dim3(kConvThreads), 0, s, grp);
-    } else if (dma && skws && !mirror && !generic && !scatter && !bk16 && !tn6 && !getenv("SSDK_CONV_NO_STREAMK")) {
+    } else if (dma && skws && !mirror && !scatter && !bk16 && !tn6 && !getenv("SSDK_CONV_NO_STREAMK")) {
         // stream-K only where it pays: a launch of a few rounds of whole tiles (its last round is then a large share of the time), and
         // every range at least as long as the longest tile (a tile is cut at most once)
         StreamK sk{};
@@ -1949,7 +1986,8 @@ static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t 
         // leave each a range of at least kStreamKMinRange units (24 K slices of a 128-column block): a tile longer than a range is cut
         // several times and its owner adds all the parked parts.  Below 256 workgroups the split-K path of the caller does as well (measured on ssd_mb2_voc).
         if (sk.nwg > 0 && begin > 16 * sk.nwg) sk.nwg = 0;
-        if (sk.nwg > 0) sk.nwg = (int)std::min<long long>(sk.nwg, sk.total_units / kStreamKMinRange / 8 * 8);
+        const long long min_range = generic ? streamk_generic_min_range() : kStreamKMinRange;
+        if (sk.nwg > 0) sk.nwg = (int)std::min<long long>(sk.nwg, sk.total_units / min_range / 8 * 8);
         (void)max_tile;
         const bool worth = sk.nwg >= kStreamKMinWgs;
         if (worth) {
@@ -1960,6 +1998,8 @@ static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t 
             sk.epoch = __atomic_add_fetch(&g_streamk_epoch, 1u, __ATOMIC_RELAXED);
             if (sk.epoch == 0) sk.epoch = __atomic_add_fetch(&g_streamk_epoch, 1u, __ATOMIC_RELAXED);   // (0 is what a fresh workspace holds)
             hipLaunchKernelGGL(igemm_streamk_kernel, dim3(sk.nwg), dim3(kConvThreads), 0, s, grp, sk);
+        } else if (generic) {
+            hipLaunchKernelGGL((igemm_dma_kernel<false, true, false, 4>), dim3(begin), dim3(kConvThreads), 0, s, grp);
         } else {
             hipLaunchKernelGGL((igemm_dma_kernel<false, false, false, 4>), dim3(begin), dim3(kConvThreads), 0, s, grp);
         }
@@ -2395,8 +2435,10 @@ static int check_conv(const char* fn, int batch, const ssdk_conv_desc& d) {
 }
 static inline int out_dim(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; }
 
-extern "C" int ssdk_conv2d_fwd(const ssdk_conv_desc* descs, int n, int batch, void* stream) {
+extern "C" int ssdk_conv2d_fwd_ws(const ssdk_conv_desc* descs, int n, int batch, void* workspace, size_t workspace_bytes, void* stream) {
     SSDK_REQUIRE(descs && n > 0 && n <= kMaxProblems, SSDK_E_INVALID, "ssdk_conv2d_fwd: n=%d (1..%d)", n, kMaxProblems);
+    SSDK_REQUIRE(!g_sk_host_err || *static_cast<volatile unsigned*>(g_sk_host_err) == 0u, SSDK_E_STREAMK_TIMEOUT,
+                 "ssdk_conv2d_fwd: an earlier stream-K launch of this process gave up waiting for a parked partial tile -- see ssdk_heads_fwd_timeouts");
     ConvProblem probs[kMaxProblems];
     ZeroList zl;
     for (int i = 0; i < n; ++i) {
@@ -2412,17 +2454,42 @@ extern "C" int ssdk_conv2d_fwd(const ssdk_conv_desc* descs, int n, int batch, vo
         g.o0 = d.y; g.ob0 = (long long)ho * wo * d.cout; g.os0 = d.cout; g.o1 = nullptr; g.ob1 = 0; g.os1 = 0;
         g.relu = d.relu;
         finish_problem(g);
-        const bool split = maybe_split_k(g);
+        probs[i] = g;
+    }
+    // One or two rounds of whole tiles on 256 CUs (the big layers of a pyramid tail): stream-K over all the launch's K slices instead of
+    // splitting K with an atomic epilogue into a zeroed output -- no zero-fill launch, no atomics, BatchNorm statistics still in the epilogue
+    const bool have_ws = workspace && workspace_bytes >= ssdk_heads_fwd_workspace_bytes();
+    const bool streamk = have_ws && streamk_would_take(probs, n, true);
+    for (int i = 0; i < n; ++i) {
+        const ssdk_conv_desc& d = descs[i];
+        ConvProblem& g = probs[i];
+        const int ho = g.Hout, wo = g.Wout;
+        bool split = !streamk && maybe_split_k(g);
+        if (const char* f = getenv("SSDK_CONV_FORCE")) {   // measurement knob (tools/conv_decomp_sweep.py): "<column blocks>,<K splits>"
+            int nb = 0, ks = 0;
+            if (!streamk && sscanf(f, "%d,%d", &nb, &ks) == 2 && nb > 0 && ks > 0) {
+                g.n_blocks = std::min(nb, g.tiles_n);
+                g.k_splits = (g.relu || ks < 2) ? 1 : ks;
+                g.forced = 1;
+                split = g.k_splits > 1;
+            }
+        }
         if (split) zl.add(d.y, (size_t)batch * ho * wo * d.cout);
         if (d.stats) {
             SSDK_REQUIRE(d.cout % 4 == 0 && ((uintptr_t)d.y & 15) == 0, SSDK_E_UNSUPPORTED, "ssdk_conv2d_fwd: stats need cout %% 4 == 0 and a 16-byte aligned output");
             if (!split) g.stats = d.stats;   // in the epilogue; a split-K output is only complete after the launch: a pass of its own below
         }
-        probs[i] = g;
     }
     int rc = zl.launch((hipStream_t)stream);
     if (rc) return rc;
-    rc = launch_group(probs, n, false, (hipStream_t)stream, true);
+    StreamKWs sk{};
+    if (streamk) {
+        Carver c(workspace);
+        sk.partial = c.take<float>((size_t)(kStreamKWgs + 1) * (4 * kMaxTN * 4 * 64 * 4));
+        sk.flags = c.take<unsigned>((size_t)kStreamKWgs + 2);
+        sk.nwg = kStreamKWgs;
+    }
+    rc = launch_group(probs, n, false, (hipStream_t)stream, true, false, nullptr, streamk ? &sk : nullptr);
     if (rc) return rc;
     for (int i = 0; i < n; ++i) {
         const ssdk_conv_desc& d = descs[i];
@@ -2432,6 +2499,10 @@ extern "C" int ssdk_conv2d_fwd(const ssdk_conv_desc* descs, int n, int batch, vo
         if (rc) return rc;
     }
     return SSDK_OK;
+}
+
+extern "C" int ssdk_conv2d_fwd(const ssdk_conv_desc* descs, int n, int batch, void* stream) {
+    return ssdk_conv2d_fwd_ws(descs, n, batch, nullptr, 0, stream);
 }
 
 // The weights of n convolutions in the layout their backward-data GEMM reads (stride 1: [cin][tap][cout], mirrored-tap dgrad; strided:
