@@ -434,6 +434,59 @@ def train_graph_legs(device, cases=(('ssd_300_vgg16_voc', 32), ('ssd_mb2_voc', 2
     return out
 
 
+PEAK_BF16_MATRIX_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA (the 5 PF headline figure includes 2:1 sparsity)
+
+
+def fast_mode_legs(device, cfg_name='ssd_300_vgg16_voc', batch=32, steps=10):
+    """The opt-in split-bf16 mode of the forward head GEMM (heads.set_fast_mode('bf16x3'); reference analogue: apex AMP O1,
+    bf/training/env.py:87-95), reported on its own: never part of `value` or `roofline`.  Its time against the fp32 launch on the same
+    inputs, its error against the fp32 outputs and loss, the train step with it switched on, and its fraction of the BF16 peak --
+    algorithmic FLOPs (what the fp32 kernel is priced with) and issued FLOPs (three bf16 products per fp32 product)."""
+    from single_shot_detection_amd.detection.modules import heads as heads_mod
+    from single_shot_detection_amd.detection.modules.heads import multi_level_heads
+    hp = HotPath(cfg_name, batch, device)
+    for _ in range(2):
+        hp.train_step()
+    with torch.no_grad():
+        srcs = [t.detach() for t in hp.pyramid()]
+        us32 = gpu_time_us(lambda: multi_level_heads(srcs, srcs, hp.heads), inner=5)
+        s32, l32 = multi_level_heads(srcs, srcs, hp.heads)
+        prev = heads_mod.set_fast_mode('bf16x3')
+        try:
+            usf = gpu_time_us(lambda: multi_level_heads(srcs, srcs, hp.heads), inner=5)
+            sf, lf = multi_level_heads(srcs, srcs, hp.heads)
+        finally:
+            heads_mod.set_fast_mode(prev)
+    err_s = float((sf - s32).abs().max()) / float(s32.abs().max())
+    err_l = float((lf - l32).abs().max()) / float(l32.abs().max())
+    losses = []
+    for sc, lo in ((s32, l32), (sf, lf)):
+        target = hp.assigner.encode_ground_truth(hp.gt, hp.anchors)
+        losses.append(float(hp.criterion((sc, lo), hp.anchors, target)[0]))
+    prev = heads_mod.set_fast_mode('bf16x3')
+    try:
+        for _ in range(2):
+            hp.train_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            hp.train_step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+    finally:
+        heads_mod.set_fast_mode(prev)
+    flops = head_flops_per_image(hp.levels, hp.C) * batch
+    tf = flops / (usf * 1e-6) / 1e12
+    return {'mode': 'bf16x3', 'what': 'forward head GEMM with operands split into bf16 pieces, a_hi b_hi + a_hi b_mid + a_mid b_hi on '
+                                      'v_mfma_f32_32x32x16_bf16, fp32 accumulate; weights split per call (included in the time); backward unchanged (fp32)',
+            'workload': f'{cfg_name} batch {batch}', 'heads_fwd_us': usf, 'heads_fwd_fp32_us': us32, 'speedup_vs_fp32_launch': us32 / usf,
+            'max_abs_err_over_scale': {'scores': err_s, 'locs': err_l}, 'loss_fp32': losses[0], 'loss_fast': losses[1],
+            'loss_abs_diff': abs(losses[0] - losses[1]),
+            'train_step_ms': ms, 'train_images_per_sec': batch / (ms * 1e-3),
+            'roofline': {'bound': 'mfma', 'dtype': 'bf16', 'peak': PEAK_BF16_MATRIX_TFLOPS, 'unit': 'TFLOP/s', 'achieved_algorithmic': tf,
+                         'frac_algorithmic': tf / PEAK_BF16_MATRIX_TFLOPS, 'achieved_issued': 3.0 * tf, 'frac_issued': 3.0 * tf / PEAK_BF16_MATRIX_TFLOPS}}
+
+
 def per_config_legs(device, steps=4, warmup=2):
     """The other BASELINE.json configs (parity-test cases, not the headline): a few train steps each."""
     out = []
@@ -473,6 +526,7 @@ def main():
     ap.add_argument('--sync-bn', action='store_true',
                     help='N > 1: synchronise the pyramid tail\'s BatchNorm statistics over the ranks (detection/init.py:85 convert_syncbn_model); '
                          'default is local statistics, the documented local-BN mode of SURVEY.md 8e')
+    ap.add_argument('--fast-mode-only', action='store_true', help='print only the fast_mode block (opt-in split-bf16 head GEMM), N = 1')
     ap.add_argument('--rendezvous-only', action='store_true',
                     help='ranks form the process group, all-reduce their rank numbers, rank 0 prints a JSON line; no GPU work (launcher test)')
     args = ap.parse_args()
@@ -517,6 +571,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.fast_mode_only:
+        print(json.dumps({'fast_mode': fast_mode_legs(device, args.config, args.batch)}), flush=True)
+        return
     hp = HotPath(args.config, args.batch, device)
     bn_modules = [m for m in (hp.extras, hp.tower, hp.neck) if m is not None]
     sync_bn = bool(args.sync_bn and world > 1 and bn_modules)
@@ -622,6 +679,7 @@ def main():
             out['per_config'] = per_config_legs(device)
             out['serving'] = serving_legs(device)
             out['train_graph'] = train_graph_legs(device)
+            out['fast_mode'] = fast_mode_legs(device)
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(hp)
         print(json.dumps(out), flush=True)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SSDK_VERSION 108
+#define SSDK_VERSION 109
 
 #define SSDK_OK 0
 #define SSDK_E_INVALID (-1)   /* bad argument / shape */
@@ -255,6 +255,18 @@ size_t ssdk_heads_fwd_workspace_bytes(void);
 int ssdk_heads_fwd_timeouts(const void* workspace, size_t workspace_bytes, void* stream, unsigned* timeouts_host);
 int ssdk_heads_fwd(const ssdk_head_level* levels, int n_levels, int batch, float* scores, long long scores_batch_stride,
                    float* locs, long long locs_batch_stride, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * FAST MODE of ssdk_heads_fwd (opt-in, never the default): the role of apex AMP O1 in the reference (bf/training/env.py:87-95 runs these
+ * convolutions in half precision; detection/postprocessor.py:39-40 casts back to fp32).  Every fp32 operand is split into bf16 pieces and
+ * the product is the sum of its `terms` = 3 largest cross terms (a_hi b_hi + a_hi b_mid + a_mid b_hi) on v_mfma_f32_32x32x16_bf16 with
+ * fp32 accumulation: a product is wrong by ~2^-16 relative instead of exact, logits by ~1e-5 of their scale.  Same arguments, layouts
+ * and outputs as ssdk_heads_fwd; Cin % 32 == 0 on every level; workspace = ssdk_heads_fwd_fast_workspace_bytes() bytes (the split
+ * weights of this call; nothing is kept between calls).  The backward pass stays ssdk_heads_bwd (fp32).
+ */
+size_t ssdk_heads_fwd_fast_workspace_bytes(const ssdk_head_level* levels, int n_levels);
+int ssdk_heads_fwd_fast(const ssdk_head_level* levels, int n_levels, int batch, float* scores, long long scores_batch_stride, float* locs,
+                        long long locs_batch_stride, int terms, void* workspace, size_t workspace_bytes, void* stream);
 
 size_t ssdk_heads_bwd_workspace_bytes(const ssdk_head_level* levels, int n_levels, int batch);
 

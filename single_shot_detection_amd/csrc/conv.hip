@@ -1754,6 +1754,246 @@ __global__ void __launch_bounds__(256) zero_many_kernel(ZeroArgs a) {
     }
 }
 
+
+// =====================================================================================================================
+// Split-bf16 FAST MODE of the forward head GEMM (opt-in; the fp32 kernel above stays the default and the parity path).
+// Reference analogue: apex AMP O1 (bf/training/env.py:87-95) runs these convolutions in half precision.  Here every fp32 operand is
+// split into bf16 pieces a = a_hi + a_mid (+ a_lo, dropped) and the product is the sum of the three largest cross terms
+//     a b ~= a_hi b_hi + a_hi b_mid + a_mid b_hi        (relative error of a product ~ 2^-16, accumulated in fp32 on the matrix cores)
+// on v_mfma_f32_32x32x16_bf16: 3 x 32 cycles per 32 x 32 x 16 block against 8 x 64 cycles of v_mfma_f32_32x32x2_f32 for the same
+// block, i.e. 5.3x fewer matrix-pipe cycles.  The weights are split once per call by split_weights_kernel into two bf16 matrices laid out
+// in the launch's column index space ([n][9 * Cin], score rows then loc rows); the activations stay fp32 in HBM and LDS (same LDS-DMA
+// staging, same XOR swizzle as dma_tile) and are split in registers after the fragment read.  Tiling, epilogue and the concatenated
+// output layout are those of the fp32 kernel (the C / D register map of the 32 x 32 MFMAs does not depend on the input type).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct FastProblem {
+    const __bf16* w_hi;   // [n_rows][K] bf16, K = 9 * Cin
+    const __bf16* w_mid;
+    unsigned w_bytes;     // n_rows * K * 2
+};
+struct FastGroup {
+    FastProblem p[kMaxProblems];
+};
+
+struct SplitJob {
+    const float* w0;
+    const float* w1;
+    int n0, n1, n_rows, K;   // rows [0, n0) = w0, [n0, n0 + n1) = w1, the rest zeros
+    __bf16* hi;
+    __bf16* mid;
+    int block_begin;
+};
+struct SplitGroup {
+    int count;
+    SplitJob j[kMaxProblems];
+};
+
+__global__ void __launch_bounds__(256) split_weights_kernel(SplitGroup sg) {
+    int ji = 0;
+#pragma unroll 1
+    for (int i = 1; i < sg.count; ++i)
+        if ((int)blockIdx.x >= sg.j[i].block_begin) ji = i;
+    const SplitJob& J = sg.j[ji];
+    const long long q4 = (long long)J.n_rows * J.K / 4;
+    const long long q = (long long)(blockIdx.x - J.block_begin) * 256 + threadIdx.x;
+    if (q >= q4) return;
+    const long long e = q * 4;
+    const int n = (int)(e / J.K);
+    const long long k = e - (long long)n * J.K;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (n < J.n0) v = *reinterpret_cast<const f32x4*>(J.w0 + (long long)n * J.K + k);
+    else if (n < J.n0 + J.n1) v = *reinterpret_cast<const f32x4*>(J.w1 + (long long)(n - J.n0) * J.K + k);
+    __bf16 h[4], m[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        h[t] = (__bf16)v[t];
+        m[t] = (__bf16)(v[t] - (float)h[t]);
+    }
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<bf16x4*>(J.hi + e) = bf16x4{h[0], h[1], h[2], h[3]};
+    *reinterpret_cast<bf16x4*>(J.mid + e) = bf16x4{m[0], m[1], m[2], m[3]};
+}
+
+__device__ __forceinline__ void split8(const f32x4& lo4, const f32x4& hi4, bf16x8& a_hi, bf16x8& a_mid) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const __bf16 h0 = (__bf16)lo4[t], h1 = (__bf16)hi4[t];
+        a_hi[t] = h0;
+        a_hi[4 + t] = h1;
+        a_mid[t] = (__bf16)(lo4[t] - (float)h0);
+        a_mid[4 + t] = (__bf16)(hi4[t] - (float)h1);
+    }
+}
+
+__device__ __forceinline__ void fast_tile(const ConvProblem& g, const FastProblem& fp, int m_tile, int n_block) {
+    constexpr int BM = 128;
+    __shared__ __attribute__((aligned(1024))) float s_a0[BM * kBK];
+    __shared__ __attribute__((aligned(1024))) float s_a1[BM * kBK];
+    __shared__ __attribute__((aligned(1024))) __bf16 s_w0[2 * kMaxTN * 32 * kBK];   // [plane][128 columns][32 k]
+    __shared__ __attribute__((aligned(1024))) __bf16 s_w1[2 * kMaxTN * 32 * kBK];
+
+    const int Cc = g.Cc, ks = g.ksize, taps = ks * ks, chunks = Cc / kBK, n_slices = taps * chunks;
+    const int K = taps * Cc;
+    const int N = g.n0_pad + g.n1;
+    const int hw = g.Hout * g.Wout;
+    const int M = g.B * hw;
+    const int m_base = m_tile * BM;
+    const int base_t = g.tiles_n / g.n_blocks, rem_t = g.tiles_n % g.n_blocks;
+    const int tn = base_t + (n_block < rem_t ? 1 : 0);
+    const int n_begin = (n_block * base_t + min(n_block, rem_t)) * 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32 = lane & 31, h = lane >> 5;
+
+    // ---- A: as dma_tile (forward): per-lane source offsets of the wave's four pieces, padding taps / rows past M read out of range
+    const int a_ps = g.a_pstride, win_ps = g.Win * a_ps;
+    const int shift = -g.pad * (win_ps + a_ps);
+    unsigned a_vo[4], a_nmask[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 8 * i + lane / 8;
+        const int src_chunk = (lane % 8) ^ ((row >> 1) & 7);
+        const int m = m_base + wave * 32 + row;
+        a_vo[i] = kOobBit;
+        a_nmask[i] = 0;
+        if (m < M) {
+            const int b = m / hw, r = m % hw;
+            const int y = r / g.Wout, x = r % g.Wout;
+            unsigned mask = 0;
+            int by = y * g.stride - g.pad, bx = x * g.stride - g.pad;
+            for (int t = 0; t < taps; ++t) {
+                const int iy = by + t / ks, ix = bx + t % ks;
+                if (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) mask |= 1u << t;
+            }
+            by += g.pad;
+            bx += g.pad;
+            a_vo[i] = (unsigned)(b * (int)g.a_bstride + by * win_ps + bx * a_ps + src_chunk * 4) * 4u;
+            a_nmask[i] = ~mask;
+        }
+    }
+    // ---- W: 16 pieces per slice (2 planes x 8 pieces of 16 columns x 64 B); wave w issues pieces 4w .. 4w + 3
+    unsigned w_vo[4];
+    bool w_mid[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pid = wave * 4 + i;
+        const int col = (pid & 7) * 16 + lane / 4;                   // column of the 128-column block
+        const int src_chunk = (lane % 4) ^ ((col >> 2) & 3);          // 64-byte rows: chunk position q of column c holds chunk q ^ ((c >> 2) & 3)
+        const int n = n_begin + col;
+        w_vo[i] = (col < tn * 32 && n < N) ? (unsigned)n * (unsigned)K * 2u + (unsigned)src_chunk * 16u : kOobBit;
+        w_mid[i] = pid >= 8;                                          // (uniform)
+    }
+    const long long a_records = ((long long)g.B * g.a_bstride - shift) * 4;
+    const __amdgpu_buffer_rsrc_t rsrc_a =
+        __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(g.a + shift), 0, (int)(a_records > 0x7FFFFFFFLL ? 0x7FFFFFFFLL : a_records), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_wh = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(reinterpret_cast<const float*>(fp.w_hi)), 0, (int)fp.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_wm = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(reinterpret_cast<const float*>(fp.w_mid)), 0, (int)fp.w_bytes, 0x00020000);
+
+    int ld_tap = 0, ld_chunk = 0, ld_ky = 0, ld_kx = 0;
+    unsigned so_a = 0, so_w = 0, tap_bit = 0;
+    auto slice_offsets = [&](bool advance) {
+        so_a = (unsigned)(ld_ky * win_ps + ld_kx * a_ps + ld_chunk * kBK) * 4u;
+        so_w = (unsigned)(ld_tap * Cc + ld_chunk * kBK) * 2u;
+        tap_bit = (unsigned)ld_tap;
+        const int inc = advance ? 1 : 0;
+        ld_tap += inc;
+        ld_kx += inc;
+        const bool wrap_x = ld_kx == ks, wrap_t = ld_tap == taps;
+        ld_kx = (wrap_x || wrap_t) ? 0 : ld_kx;
+        ld_ky = wrap_t ? 0 : ld_ky + (wrap_x ? 1 : 0);
+        ld_tap = wrap_t ? 0 : ld_tap;
+        ld_chunk += wrap_t ? 1 : 0;
+    };
+    auto stage_a = [&](int DST, int i) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)((DST ? s_a1 : s_a0) + (wave * 32 + 8 * i) * kBK), 16,
+                                                 a_vo[i] | ((a_nmask[i] >> tap_bit) << 31), so_a, 0, 0);
+    };
+    auto stage_w = [&](int DST, int i) {
+        const int pid = wave * 4 + i;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_mid[i] ? rsrc_wm : rsrc_wh, (lds_ptr_t)((DST ? s_w1 : s_w0) + pid * 16 * kBK), 16, w_vo[i], so_w, 0, 0);
+    };
+
+    f32x16 acc[kMaxTN];
+#pragma unroll
+    for (int j = 0; j < kMaxTN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
+
+    const int fa = (r32 >> 1) & 7;                 // swizzle of this lane's A row
+    const int a_row = (wave * 32 + r32) * kBK;     // floats
+    slice_offsets(true);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { stage_a(0, i); stage_w(0, i); }
+    __syncthreads();
+
+    auto k_loop = [&](auto tn_c) {
+        constexpr int TN = decltype(tn_c)::value;
+        auto body = [&](auto st_c, int slice) {
+            constexpr int ST = decltype(st_c)::value;
+            slice_offsets(slice + 2 < n_slices);
+            const float* sa = ST ? s_a1 : s_a0;
+            const __bf16* sw = ST ? s_w1 : s_w0;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                // lane (r, h): A[row r][k = 16 s2 + 8 h .. + 7] = chunks 4 s2 + 2 h and + 1 of its 128-byte row
+                const int c0 = 4 * s2 + 2 * h;
+                const f32x4 alo = *reinterpret_cast<const f32x4*>(&sa[a_row + ((c0 ^ fa) * 4)]);
+                const f32x4 ahi = *reinterpret_cast<const f32x4*>(&sa[a_row + (((c0 + 1) ^ fa) * 4)]);
+                bf16x8 wh[TN], wm[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = j * 32 + r32;
+                    const int pos = ((2 * s2 + h) ^ ((col >> 2) & 3)) * 8;   // bf16 elements
+                    wh[j] = *reinterpret_cast<const bf16x8*>(&sw[col * kBK + pos]);
+                    wm[j] = *reinterpret_cast<const bf16x8*>(&sw[(kMaxTN * 32 + col) * kBK + pos]);
+                }
+                // the next slice's pieces between the two halves of this one's MFMAs (two A + two W per half)
+                stage_a(ST ^ 1, 2 * s2);
+                stage_w(ST ^ 1, 2 * s2);
+                stage_a(ST ^ 1, 2 * s2 + 1);
+                stage_w(ST ^ 1, 2 * s2 + 1);
+                bf16x8 a_hi, a_mid;
+                split8(alo, ahi, a_hi, a_mid);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, wh[j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, wm[j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, wh[j], acc[j], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        };
+        for (int slice = 0; slice < n_slices; slice += 2) {
+            body(std::integral_constant<int, 0>{}, slice);
+            if (slice + 1 < n_slices) body(std::integral_constant<int, 1>{}, slice + 1);
+        }
+    };
+    switch (tn) {
+        case 4: k_loop(std::integral_constant<int, 4>{}); break;
+        case 3: k_loop(std::integral_constant<int, 3>{}); break;
+        case 2: k_loop(std::integral_constant<int, 2>{}); break;
+        default: k_loop(std::integral_constant<int, 1>{}); break;
+    }
+    conv_epilogue<false>(g, acc, m_base, wave, r32, h, tn, n_begin, M, N, hw, 0, nullptr, 4);
+}
+
+__global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_bf16x3_kernel(ConvGroup grp, FastGroup fg) {
+    int pi = 0;
+#pragma unroll 1
+    for (int i = 1; i < grp.count; ++i)
+        if ((int)blockIdx.x >= grp.p[i].block_begin) pi = i;
+    const ConvProblem& g = grp.p[pi];
+    const int id = blockIdx.x - g.block_begin;
+    const int per_chunk = 8 * g.n_blocks;
+    const int chunk = id / per_chunk, within = id % per_chunk;
+    const int m_tile = chunk * 8 + (within & 7);
+    const int n_block = within >> 3;
+    if (m_tile >= g.m_tiles) return;
+    fast_tile(g, fg.p[pi], m_tile, n_block);
+}
+
 }  // namespace ssdk
 
 using namespace ssdk;
@@ -2142,6 +2382,86 @@ extern "C" int ssdk_heads_fwd_timeouts(const void* workspace, size_t workspace_b
     SSDK_CHECK_HIP(hipMemcpyAsync(timeouts_host, flags + kStreamKWgs, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream));
     SSDK_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
     if (g_sk_host_err && *static_cast<volatile unsigned*>(g_sk_host_err) && *timeouts_host == 0u) *timeouts_host = 1u;   // (another workspace's)
+    return SSDK_OK;
+}
+
+
+// ---- fast mode of the forward heads (opt-in): bf16 x 3 split operands on v_mfma_f32_32x32x16_bf16, fp32 accumulate ----------------
+static inline int fast_rows_of(const ssdk_head_level& lv) { return cdiv(lv.n_score + lv.n_loc, 32) * 32; }
+
+extern "C" size_t ssdk_heads_fwd_fast_workspace_bytes(const ssdk_head_level* levels, int n_levels) {
+    if (!levels || n_levels <= 0 || n_levels > kMaxProblems) return 0;
+    Carver c(nullptr);
+    for (int i = 0; i < n_levels; ++i) {
+        const size_t elems = (size_t)fast_rows_of(levels[i]) * 9 * (size_t)levels[i].cin;
+        c.take<__bf16>(elems);
+        c.take<__bf16>(elems);
+    }
+    return c.off;
+}
+
+extern "C" int ssdk_heads_fwd_fast(const ssdk_head_level* levels, int n_levels, int batch, float* scores, long long scores_batch_stride,
+                                   float* locs, long long locs_batch_stride, int terms, void* workspace, size_t workspace_bytes, void* stream) {
+    SSDK_REQUIRE(levels && n_levels > 0 && n_levels <= kMaxProblems, SSDK_E_INVALID, "ssdk_heads_fwd_fast: n_levels=%d (1..%d)", n_levels, kMaxProblems);
+    SSDK_REQUIRE(terms == 3, SSDK_E_UNSUPPORTED, "ssdk_heads_fwd_fast: terms=%d (3 = a_hi b_hi + a_hi b_mid + a_mid b_hi is the one form built)", terms);
+    SSDK_REQUIRE(scores, SSDK_E_INVALID, "ssdk_heads_fwd_fast: null scores");
+    SSDK_REQUIRE(workspace && workspace_bytes >= ssdk_heads_fwd_fast_workspace_bytes(levels, n_levels), SSDK_E_WORKSPACE, "ssdk_heads_fwd_fast: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    Carver c(workspace);
+    ConvProblem probs[kMaxProblems];
+    FastProblem fps[kMaxProblems];
+    SplitGroup sg{};
+    int split_blocks = 0;
+    for (int i = 0; i < n_levels; ++i) {
+        const ssdk_head_level& lv = levels[i];
+        int rc = check_level("ssdk_heads_fwd_fast", batch, lv);
+        if (rc) return rc;
+        SSDK_REQUIRE(lv.n_loc == 0 || locs, SSDK_E_INVALID, "ssdk_heads_fwd_fast: null locs");
+        SSDK_REQUIRE(lv.cin % kBK == 0 && ((uintptr_t)lv.x & 15) == 0 && ((uintptr_t)lv.w_score & 15) == 0 && (!lv.n_loc || ((uintptr_t)lv.w_loc & 15) == 0),
+                     SSDK_E_UNSUPPORTED, "ssdk_heads_fwd_fast: level %d needs Cin %% 32 == 0 and 16-byte aligned operands (Cin=%d)", i, lv.cin);
+        const int K = 9 * lv.cin, rows = fast_rows_of(lv);
+        const long long span_a = ((long long)batch * lv.h * lv.w * lv.cin + (long long)(3 + 1) * ((long long)lv.w + 1) * lv.cin) * 4;
+        SSDK_REQUIRE(span_a < (1LL << 31) - 4096 && (long long)rows * K * 2 < (1LL << 31) - 4096, SSDK_E_UNSUPPORTED, "ssdk_heads_fwd_fast: level %d too large for 32-bit buffer offsets", i);
+        ConvProblem g{};
+        g.a = lv.x; g.a_bstride = (long long)lv.h * lv.w * lv.cin; g.a_pstride = lv.cin; g.Cc = lv.cin;
+        g.B = batch; g.Hout = lv.h; g.Wout = lv.w; g.Hin = lv.h; g.Win = lv.w; g.ksize = 3; g.stride = 1; g.pad = 1;
+        g.w0 = lv.w_score; g.w1 = lv.n_loc ? lv.w_loc : nullptr; g.bias0 = lv.b_score; g.bias1 = lv.b_loc; g.n0 = lv.n_score; g.n1 = lv.n_loc;
+        g.o0 = scores + lv.scores_offset; g.ob0 = scores_batch_stride; g.os0 = lv.n_score;
+        g.o1 = lv.n_loc ? locs + lv.locs_offset : nullptr; g.ob1 = locs_batch_stride; g.os1 = lv.n_loc;
+        g.relu = 0;
+        finish_problem(g);   // n0_pad = n0: the split weights are ONE matrix in the column index space, no padding between the two heads
+        probs[i] = g;
+        __bf16* hi = c.take<__bf16>((size_t)rows * K);
+        __bf16* mid = c.take<__bf16>((size_t)rows * K);
+        fps[i].w_hi = hi; fps[i].w_mid = mid; fps[i].w_bytes = (unsigned)((size_t)rows * K * 2);
+        SplitJob& J = sg.j[sg.count++];
+        J.w0 = lv.w_score; J.w1 = lv.n_loc ? lv.w_loc : nullptr; J.n0 = lv.n_score; J.n1 = lv.n_loc; J.n_rows = rows; J.K = K; J.hi = hi; J.mid = mid;
+        J.block_begin = split_blocks;
+        split_blocks += (int)(((long long)rows * K / 4 + 255) / 256);
+    }
+    hipLaunchKernelGGL(split_weights_kernel, dim3(split_blocks), dim3(256), 0, s, sg);
+    SSDK_CHECK_LAUNCH("split_weights_kernel");
+    // grouped launch, problems ordered by decreasing work per workgroup (as launch_group)
+    int order[kMaxProblems];
+    for (int i = 0; i < n_levels; ++i) order[i] = i;
+    for (int i = 0; i < n_levels; ++i)
+        for (int j = i + 1; j < n_levels; ++j)
+            if (problem_block_work(probs[order[j]]) > problem_block_work(probs[order[i]])) { int t = order[i]; order[i] = order[j]; order[j] = t; }
+    ConvGroup grp;
+    FastGroup fg;
+    int begin = 0;
+    for (int i = 0; i < n_levels; ++i) {
+        ConvProblem& g = probs[order[i]];
+        g.block_begin = begin;
+        begin += cdiv(g.m_tiles, 8) * 8 * g.n_blocks;
+        grp.p[i] = g;
+        fg.p[i] = fps[order[i]];
+    }
+    grp.count = n_levels;
+    grp.total_blocks = begin;
+    grp.vtab = nullptr;
+    hipLaunchKernelGGL(igemm_bf16x3_kernel, dim3(begin), dim3(kConvThreads), 0, s, grp, fg);
+    SSDK_CHECK_LAUNCH("igemm_bf16x3_kernel");
     return SSDK_OK;
 }
 

@@ -10,6 +10,21 @@ from ... import _lib
 from ...distributed import grad_sink
 
 
+_fast_mode = (__import__('os').environ.get('SSDK_FAST_MODE') or None)
+
+
+def set_fast_mode(mode):
+    """Opt-in reduced-precision mode of the forward head GEMMs (the reference's analogue: apex AMP O1, bf/training/env.py:87-95).
+    ``None`` (default): exact fp32 on v_mfma_f32_32x32x2_f32.  ``'bf16x3'``: operands split into bf16 pieces, three cross terms per product
+    on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (ssdk_heads_fwd_fast) -- logits within ~1e-5 of their scale; the backward pass
+    is unchanged.  Every level needs Cin % 32 == 0 (the call raises otherwise: no silent fallback).  Returns the previous setting."""
+    global _fast_mode
+    if mode not in (None, 'bf16x3'):
+        raise ValueError(f'fast mode {mode!r}: None or "bf16x3"')
+    prev, _fast_mode = _fast_mode, mode
+    return prev
+
+
 def to_nhwc(x):
     """[B,C,H,W] tensor whose memory is NHWC (zero-copy when the producer already runs channels_last)."""
     x = x.float()
@@ -71,8 +86,14 @@ class _HeadsFn(torch.autograd.Function):
         scores = torch.empty((B, s_off), dtype=torch.float32, device=dev)
         locs = torch.empty((B, l_off), dtype=torch.float32, device=dev)
         arr = _HeadsFn._level_array(levels)
-        sk = _lib.scratch(lib.ssdk_heads_fwd_workspace_bytes(), dev, _lib.STREAMK_TAG, zeroed=True)   # (state kept by the library between calls)
-        _lib.check(lib.ssdk_heads_fwd(arr, L, B, _dp(scores), s_off, _dp(locs), l_off, _dp(sk), sk.numel(), _lib.current_stream()), 'ssdk_heads_fwd')
+        if _fast_mode == 'bf16x3':
+            need = lib.ssdk_heads_fwd_fast_workspace_bytes(arr, L)
+            ws = _lib.scratch(need, dev, 'heads_fwd_fast')
+            _lib.check(lib.ssdk_heads_fwd_fast(arr, L, B, _dp(scores), s_off, _dp(locs), l_off, 3, _dp(ws), ws.numel(), _lib.current_stream()),
+                       'ssdk_heads_fwd_fast')
+        else:
+            sk = _lib.scratch(lib.ssdk_heads_fwd_workspace_bytes(), dev, _lib.STREAMK_TAG, zeroed=True)   # (state kept by the library between calls)
+            _lib.check(lib.ssdk_heads_fwd(arr, L, B, _dp(scores), s_off, _dp(locs), l_off, _dp(sk), sk.numel(), _lib.current_stream()), 'ssdk_heads_fwd')
         # tensors go through save_for_backward (autograd's version counters then catch an in-place edit of a tapped source map
         # between forward and backward, as they do for torch's own conv); ctx keeps only shapes and offsets
         for lv in levels:

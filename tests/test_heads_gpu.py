@@ -206,3 +206,76 @@ def test_heads_adjoint_identity_at_baseline_size(cfg_name, batch, density):
     tol = 2e-6 * scale   # fp32 products summed in fp32 inside the GEMMs: relative to the sum of magnitudes
     assert abs(float(lhs - bias_part - via_x)) <= tol, (float(lhs), float(bias_part), float(via_x), tol)
     assert abs(float(lhs - bias_part - via_w)) <= tol, (float(lhs), float(bias_part), float(via_w), tol)
+
+
+@pytest.mark.parametrize('cfg_name,batch', [('ssd_300_vgg16_voc', 4), ('ssd_512_vgg16_coco', 2), ('retina_rn50_500_coco', 2), ('m2det_512_vgg16_coco', 2)])
+def test_fast_mode_bf16x3_forward_vs_fp32(cfg_name, batch):
+    """Opt-in fast mode (heads.set_fast_mode('bf16x3'): split-bf16 operands, three cross terms, fp32 accumulate on v_mfma_f32_32x32x16_bf16;
+    the reference's analogue is apex AMP O1, bf/training/env.py:87-95) against the exact fp32 path AND torch's fp32 CPU convolution on the
+    first level: every logit / loc within 1e-4 of the tensor's scale (a product is wrong by ~2^-16 relative, random in sign over K = 9 Cin
+    terms), and the multibox loss of the same batch within north_star's 1e-4."""
+    import functools
+    from single_shot_detection_amd import synthetic as syn
+    from single_shot_detection_amd.detection import anchor_generators, sampler
+    from single_shot_detection_amd.detection.box_coder import BoxCoder
+    from single_shot_detection_amd.detection.losses.multibox_loss import MultiboxLoss
+    from single_shot_detection_amd.detection.modules import heads as heads_mod
+    from single_shot_detection_amd.detection.target_assigner import TargetAssigner
+    cfg = syn.CONFIGS[cfg_name]
+    levels, C = cfg['levels'], cfg['num_classes']
+    torch.manual_seed(3)
+    heads = detector_builder.get_heads([l[0] for l in levels], [l[2] for l in levels], C,
+                                       score_head_bias_init=(-4.6 if cfg['loss'] != 'ce_hnm' else 0.0)).cuda()
+    with torch.no_grad():
+        for p in heads.parameters():
+            if p.dim() > 1:
+                p.copy_(torch.randn_like(p) * 0.03)
+    xs = [torch.randn((batch, cin, h, h), device='cuda').contiguous(memory_format=torch.channels_last) for cin, h, _ in levels]
+    with torch.no_grad():
+        s32, l32 = multi_level_heads(xs, xs, heads)
+        prev = heads_mod.set_fast_mode('bf16x3')
+        try:
+            sf, lf = multi_level_heads(xs, xs, heads)
+        finally:
+            heads_mod.set_fast_mode(prev)
+    for a, b in ((sf, s32), (lf, l32)):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 1e-4 * scale, (float((a - b).abs().max()), scale)
+    assert float((sf - s32).abs().max()) > 0.0   # (it IS another arithmetic)
+    # first level against torch's CPU convolution
+    h0 = heads[0]
+    ref = F.conv2d(xs[0].cpu(), h0['score'].weight.detach().cpu().contiguous(), h0['score'].bias.detach().cpu(), padding=1).permute(0, 2, 3, 1).reshape(batch, -1)
+    n0 = ref.shape[1]
+    assert float((sf[:, :n0].cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    # the loss the two sets of predictions give on the same targets
+    p = dict(cfg['anchor'])
+    gens = getattr(anchor_generators, p.pop('type')).build_anchor_generators(**p)
+    img = torch.empty((1, 3, cfg['size'], cfg['size']), device='cuda')
+    anchors = torch.cat([g.generate(img, (h, h)).reshape(-1) for g, (_, h, _) in zip(gens, levels)]).view(-1, 4)
+    gt = [torch.from_numpy(g).cuda() for g in syn.make_ground_truth(batch, cfg['size'], C, seed=1, background=cfg['score_converter'] == 'SOFTMAX')]
+    if cfg['loss'] == 'ce_hnm':
+        smp = functools.partial(sampler.hard_negative_mining, negative_per_positive_ratio=3, min_negative_per_image=5)
+        cl = {'name': 'CrossEntropyLoss'}
+    else:
+        smp, cl = sampler.naive_sampler, {'name': 'SigmoidFocalLoss', 'gamma': 2.0, 'alpha': 0.25}
+    crit = MultiboxLoss(sampler=smp, box_coder=BoxCoder(10.0, 5.0), classification_loss=cl, localization_loss={'name': 'SmoothL1Loss'})
+    assigner = TargetAssigner(cfg['matched'], cfg['unmatched'])
+    losses = []
+    for sc, lo in ((s32, l32), (sf, lf)):
+        target = assigner.encode_ground_truth(gt, anchors)
+        losses.append(float(crit((sc, lo), anchors, target)[0]))
+    assert abs(losses[0] - losses[1]) <= 1e-4 * max(1.0, abs(losses[0])), losses
+
+
+def test_fast_mode_refuses_channel_counts_it_cannot_take():
+    from single_shot_detection_amd.detection.modules import heads as heads_mod
+    heads = detector_builder.get_heads([24], [3], 7).cuda()
+    x = torch.randn((1, 24, 5, 5), device='cuda')
+    prev = heads_mod.set_fast_mode('bf16x3')
+    try:
+        with pytest.raises(ValueError):
+            multi_level_heads([x], [x], heads)
+    finally:
+        heads_mod.set_fast_mode(prev)
+    with pytest.raises(ValueError):
+        heads_mod.set_fast_mode('fp8')
