@@ -2054,6 +2054,20 @@ static bool maybe_split_k(ConvProblem& g) {
         g.forced = 1;
         return false;
     }
+    // Few row tiles and a deep K (the 3 x 3 / 2 layers on 16 x 16 .. 4 x 4 maps: M <= 1 024 rows, 36 .. 72 slices): 32-column workgroups
+    // first, then only as many K splits as bring the launch to ~256 workgroups with at least 8 slices each -- the rule below split the
+    // M2Det TUM's 256 -> 256 layer at 16 x 16 eighteen ways (49 us; 26 us with 8 column blocks x 4 splits), tools/conv_decomp_sweep.py
+    if (g.m_tiles >= 3 && g.m_tiles <= 8 && slices >= 32) {   // (one or two row tiles: the rule below measured as good or better)
+        g.n_blocks = g.tiles_n;
+        int ks = std::max(2, 256 / std::max(1, g.m_tiles * g.n_blocks));
+        ks = std::min(ks, slices / 8);
+        if (ks >= 2) {
+            g.k_splits = ks;
+            g.forced = 1;
+            return true;
+        }
+        g.n_blocks = cdiv(g.tiles_n, kMaxTN);
+    }
     int ks = cdiv(512, blocks);
     if (ks > slices / 4) ks = slices / 4;
     if (ks < 2) return false;

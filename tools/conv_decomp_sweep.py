@@ -15,7 +15,13 @@ cfg = sys.argv[2] if len(sys.argv) > 2 else 'ssd300'
 LAYERS = {'ssd300': [(512, 256, 1, 1, 0, 18), (256, 512, 3, 2, 1, 18), (512, 128, 1, 1, 0, 9), (128, 256, 3, 2, 1, 9), (256, 128, 1, 1, 0, 5),
                      (128, 256, 3, 2, 1, 5), (256, 128, 1, 1, 0, 3), (128, 256, 3, 2, 1, 3)],
           'ssd512': [(512, 256, 1, 1, 0, 32), (256, 512, 3, 2, 1, 32), (512, 128, 1, 1, 0, 16), (128, 256, 3, 2, 1, 16), (256, 128, 1, 1, 0, 8),
-                     (128, 256, 3, 2, 1, 8)]}[cfg]
+                     (128, 256, 3, 2, 1, 8)],
+          # MLFPN neck of m2det_512_vgg16_coco (bf/modules/features.py:215-393): reducers, TUM down / up / smooth layers at their map sizes
+          'm2det': [(512, 512, 1, 1, 0, 64), (1024, 256, 1, 1, 0, 32), (768, 128, 1, 1, 0, 64), (768, 256, 3, 2, 1, 64), (256, 256, 3, 2, 1, 64),
+                    (256, 256, 3, 2, 1, 32), (256, 256, 3, 2, 1, 16), (256, 256, 3, 2, 1, 8), (256, 256, 3, 2, 1, 4), (256, 768, 1, 1, 0, 32),
+                    (256, 256, 1, 1, 0, 32), (256, 256, 1, 1, 0, 16), (256, 256, 1, 1, 0, 8), (256, 256, 1, 1, 0, 4), (256, 256, 1, 1, 0, 2),
+                    (256, 128, 1, 1, 0, 64), (256, 128, 1, 1, 0, 32), (256, 128, 1, 1, 0, 16), (256, 128, 1, 1, 0, 8), (256, 128, 1, 1, 0, 4),
+                    (256, 128, 1, 1, 0, 2)]}[cfg]
 dev = torch.device('cuda')
 
 
