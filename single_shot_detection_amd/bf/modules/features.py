@@ -159,7 +159,10 @@ class ThinnedUshapeModule(nn.Module):
         for down_x, layer in zip(reversed(down_path[:-1]), reversed(self.up_layers)):
             x = _upsample_add(down_x, layer(x), self.interpolation_mode)   # features.py:263-265: interpolate to the skip's size, add the skip
             up_path.append(x)
-        return [layer(x) for layer, x in zip(reversed(self.smooth_layers), up_path)]
+        smooth = list(reversed(self.smooth_layers))
+        if len(smooth) <= 8 and all(isinstance(l, conv.Conv2dBn) and l._hip_ok() and x.is_cuda for l, x in zip(smooth, up_path)):
+            return ops.conv2d_bn_group(up_path, smooth)   # features.py:267: the scale branches are independent -> ONE grouped launch
+        return [layer(x) for layer, x in zip(smooth, up_path)]
 
 
 class ScalewiseFeatureAggregationModule(nn.Module):
@@ -176,6 +179,12 @@ class ScalewiseFeatureAggregationModule(nn.Module):
     def forward(self, features):
         assert len(features) == len(self.fc1)
         result = []
+        if len(features) <= 8 and all(f.is_cuda for f in features):
+            # the per-scale gates are independent (features.py:290-296): fc1 of every scale in one grouped launch, fc2 likewise
+            pooled = [ops.global_avg_pool(f) for f in features]
+            hidden = ops.conv2d_group(pooled, list(self.fc1), relu=True)    # fc1 + F.relu
+            z = ops.conv2d_group(hidden, list(self.fc2))
+            return [ops.sigmoid_gate(f, zz) for f, zz in zip(features, z)]   # feature * sigmoid(x)
         for feature, fc1, fc2 in zip(features, self.fc1, self.fc2):
             x = ops.global_avg_pool(feature)
             x = ops.conv2d(x, fc1.weight, fc1.bias, relu=True)     # fc1 + F.relu

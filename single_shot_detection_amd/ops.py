@@ -101,23 +101,166 @@ class _ConvFn(torch.autograd.Function):
             d.w_t = _dp(ctx.w_t)
         if defer:
             # jobs belong to ONE autograd graph task: a backward pass that raised leaves its callbacks unrun and its jobs behind -- they are
-            # dropped here (never added into a later step's gradients), and the flush is queued once per task, not "when the list was empty"
-            task = torch._C._current_graph_task_id()
-            stale = [j for j in _pending_wgrads if j['task'] != task]
-            if stale:
-                _pending_wgrads[:] = [j for j in _pending_wgrads if j['task'] == task]
-            _pending_wgrads.append(dict(x=xs[0], dy=keep[0], w=w, weight=ctx.params[0] if need_w else None, bias=ctx.params[1] if need_b else None,
-                                        stride=stride, pad=pad, task=task))
-            global _flush_queued_for
-            if _flush_queued_for != task:
-                _flush_queued_for = task
-                torch.autograd.Variable._execution_engine.queue_callback(_flush_weight_gradients)
+            # dropped (never added into a later step's gradients), and the flush is queued once per task, not "when the list was empty"
+            _queue_deferred_wgrad(dict(x=xs[0], dy=keep[0], w=w, weight=ctx.params[0] if need_w else None, bias=ctx.params[1] if need_b else None,
+                                       stride=stride, pad=pad))
             if all(dx is None for dx in dxs):
                 return (None, None, None, None, None, None) + tuple(dxs)
         need = lib.ssdk_conv2d_bwd_workspace_bytes(arr, n, B)
         ws = _lib.scratch(need, w.device, 'conv2d_bwd')
         _lib.check(lib.ssdk_conv2d_bwd(arr, n, B, 0, _dp(ws), ws.numel(), stream), 'ssdk_conv2d_bwd')
         return (dw, db, None, None, None, None) + tuple(dxs)
+
+
+class _GroupConvFn(torch.autograd.Function):
+    """apply(meta, x_0, w_0, b_0, x_1, w_1, b_1, ...) -> outputs: n <= 8 INDEPENDENT convolutions -- own input, weights, kernel size, stride --
+    in one grouped launch forward and one grouped call backward (the six scale branches of an M2Det TUM's smoothing layers, SFAM's per-scale
+    gates: bf/modules/features.py:267, 290-296).  meta[i] = (stride, pad, relu, stats): relu / stats as in _ConvFn."""
+
+    @staticmethod
+    def forward(ctx, meta, *flat):
+        lib = _lib.lib()
+        n = len(meta)
+        xs = [_nhwc(flat[3 * i]) for i in range(n)]
+        weights = [flat[3 * i + 1] for i in range(n)]
+        biases = [flat[3 * i + 2] for i in range(n)]
+        _lib.require_cuda(*xs, *weights)
+        ws = [w.float().contiguous(memory_format=torch.channels_last) for w in weights]
+        bs = [None if b is None else b.float().contiguous() for b in biases]
+        B = xs[0].shape[0]
+        arr = (_lib.ConvDesc * n)()
+        ys = []
+        for i in range(n):
+            stride, pad, relu, stats = meta[i]
+            x, w = xs[i], ws[i]
+            cout, cin, k, k2 = w.shape
+            assert k == k2 and x.shape[0] == B and x.shape[1] == cin, (tuple(x.shape), tuple(w.shape))
+            ho, wo = _out_dim(x.shape[2], k, stride, pad), _out_dim(x.shape[3], k, stride, pad)
+            y = torch.empty((B, cout, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+            ys.append(y)
+            d = arr[i]
+            d.x, d.hin, d.win, d.cin = _dp(x), x.shape[2], x.shape[3], cin
+            d.w, d.bias, d.cout, d.ksize, d.stride, d.pad, d.relu = _dp(w), _dp(bs[i]), cout, k, stride, pad, int(bool(relu))
+            d.y = _dp(y)
+            d.stats = stats
+        sk = _lib.scratch(lib.ssdk_heads_fwd_workspace_bytes(), xs[0].device, _lib.STREAMK_TAG, zeroed=True)
+        _lib.check(lib.ssdk_conv2d_fwd_ws(arr, n, B, _dp(sk), sk.numel(), _lib.current_stream()), 'ssdk_conv2d_fwd')
+        ctx.w_ts = [_transposed_weights_of(weights[i], meta[i][0]) for i in range(n)]
+        ctx.save_for_backward(*ws, *xs, *[ys[i] if meta[i][2] == 1 else xs[i].new_empty(0) for i in range(n)])
+        ctx.meta = tuple((m[0], m[1], m[2] == 1) for m in meta)
+        ctx.params = [(weights[i], biases[i]) for i in range(n)]
+        ctx.yshapes = [tuple(y.shape) for y in ys]
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        lib = _lib.lib()
+        n = len(ctx.meta)
+        saved = ctx.saved_tensors
+        ws, xs, ysv = saved[:n], saved[n:2 * n], saved[2 * n:3 * n]
+        B = xs[0].shape[0]
+        stream = _lib.current_stream()
+        arr = (_lib.ConvDesc * n)()
+        out = [None]
+        keep = []
+        any_launch = False
+        for i in range(n):
+            stride, pad, relu = ctx.meta[i]
+            w, x = ws[i], xs[i]
+            weight, bias = ctx.params[i]
+            cout, cin, k, _ = w.shape
+            need_x, need_w, need_b = ctx.needs_input_grad[1 + 3 * i], ctx.needs_input_grad[2 + 3 * i], ctx.needs_input_grad[3 + 3 * i] and bias is not None
+            dy = dys[i]
+            dy = torch.zeros(ctx.yshapes[i], dtype=torch.float32, device=w.device).contiguous(memory_format=torch.channels_last) if dy is None else _nhwc(dy)
+            if relu:
+                g = torch.empty_like(dy, memory_format=torch.channels_last)
+                _lib.check(lib.ssdk_relu_bwd(_dp(ysv[i]), _dp(dy), dy.numel(), _dp(g), stream), 'ssdk_relu_bwd')
+                dy = g
+            keep.append(dy)
+            defer = (_defer_wgrad and (need_w or need_b) and weight.is_leaf and (bias is None or bias.is_leaf) and not _has_hooks(weight) and not _has_hooks(bias))
+            dw = db = None
+            if need_w and not defer:
+                dw = grad_sink(weight)
+                if dw is None or dw.stride() != w.stride():
+                    dw = torch.empty_like(w, memory_format=torch.channels_last)
+            if need_b and not defer:
+                db = grad_sink(bias)
+                if db is None:
+                    db = torch.empty((cout,), dtype=torch.float32, device=w.device)
+            dx = torch.empty_like(x, memory_format=torch.channels_last) if need_x else None
+            d = arr[i]
+            d.x, d.hin, d.win, d.cin = _dp(x), x.shape[2], x.shape[3], cin
+            d.w, d.bias, d.cout, d.ksize, d.stride, d.pad, d.relu = _dp(w), None, cout, k, stride, pad, 0
+            d.dy, d.dx, d.dw, d.db = _dp(dy), _dp(dx), _dp(dw), _dp(db)
+            d.w_t = _dp(ctx.w_ts[i])
+            any_launch = any_launch or dx is not None or dw is not None or db is not None
+            if defer:
+                _queue_deferred_wgrad(dict(x=x, dy=dy, w=w, weight=weight if need_w else None, bias=bias if need_b else None, stride=stride, pad=pad))
+            out += [dx, dw, db]
+        if any_launch:
+            need = lib.ssdk_conv2d_bwd_workspace_bytes(arr, n, B)
+            wsb = _lib.scratch(need, ws[0].device, 'conv2d_bwd')
+            _lib.check(lib.ssdk_conv2d_bwd(arr, n, B, 0, _dp(wsb), wsb.numel(), stream), 'ssdk_conv2d_bwd')
+        return tuple(out)
+
+
+def _queue_deferred_wgrad(job):
+    """One deferred weight-gradient job of the current autograd graph task (see _ConvFn.backward)."""
+    global _flush_queued_for
+    task = torch._C._current_graph_task_id()
+    if any(j['task'] != task for j in _pending_wgrads):
+        _pending_wgrads[:] = [j for j in _pending_wgrads if j['task'] == task]
+    job['task'] = task
+    _pending_wgrads.append(job)
+    if _flush_queued_for != task:
+        _flush_queued_for = task
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_weight_gradients)
+
+
+def conv2d_bn_group(xs, blocks):
+    """[block(x) for block, x in zip(blocks, xs)] for INDEPENDENT Conv2dBn blocks (bf/modules/conv.py:30-36: conv -> BatchNorm -> ReLU) with
+    the n <= 8 convolutions in ONE grouped launch (and one grouped backward call); the norms' statistics come from the convolutions'
+    epilogues where they can.  Blocks the kernels do not take (see Conv2dBn._why_not_hip) must not be passed."""
+    n = len(blocks)
+    assert n == len(xs) and 0 < n <= 8
+    chains = []
+    for x, blk in zip(xs, blocks):
+        bn = blk._modules.get('bn')
+        ok = bn is not None and type(bn) is torch.nn.BatchNorm2d and x.is_cuda and torch.is_grad_enabled() and blk.conv.out_channels % 4 == 0
+        chains.append(_local_training_chain(bn, x.device) if ok else None)
+    global fused_stats_calls
+    for c in chains:
+        if c is not None:
+            c.clean[0] = False
+    fused_stats_calls += sum(c is not None for c in chains)
+    meta, flat = [], []
+    for x, blk, c in zip(xs, blocks, chains):
+        cv = blk.conv
+        has_bn, has_act = 'bn' in blk._modules, 'activation' in blk._modules
+        meta.append((cv.stride[0], cv.padding[0], 1 if (has_act and not has_bn) else 0, None if c is None else c.buf[0].data_ptr()))
+        flat += [x, cv.weight, cv.bias]
+    ys = _GroupConvFn.apply(tuple(meta), *flat)
+    out = []
+    for y, blk, c in zip(ys, blocks, chains):
+        bn = blk._modules.get('bn')
+        has_act = 'activation' in blk._modules
+        if bn is None:
+            out.append(y)
+        elif c is None:
+            out.append(batch_norm(y, bn, relu=has_act) if type(bn) is torch.nn.BatchNorm2d else (torch.relu(bn(y)) if has_act else bn(y)))
+        else:
+            out.append(_BatchNormFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum, bn.eps,
+                                          True, int(has_act), c, True))
+    return out
+
+
+def conv2d_group(xs, convs, relu=False):
+    """[conv(x) (-> ReLU)] for independent nn.Conv2d layers, one grouped launch (SFAM's per-scale fc1 / fc2, features.py:290-296)."""
+    meta, flat = [], []
+    for x, cv in zip(xs, convs):
+        meta.append((cv.stride[0], cv.padding[0], 1 if relu else 0, None))
+        flat += [x, cv.weight, cv.bias]
+    return list(_GroupConvFn.apply(tuple(meta), *flat))
 
 
 _defer_wgrad = False
