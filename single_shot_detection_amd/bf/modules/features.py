@@ -244,13 +244,48 @@ class MultilevelFeaturePyramid(Features):
         upscaled = [base_reduced[0]] + [ops.upsample_nearest(f, size) for f in base_reduced[1:]]   # features.py:369-371
         base_features = torch.cat(upscaled, dim=1)
         features = [[f] for f in self.tums[0](base_features)]
-        for tum, reducer in zip(self.tums[1:], self.reducers):
-            x = torch.cat([features[-1][-1], reducer(base_features)], dim=1)                     # :378-380
+        reduced_all = self._reducers_merged(base_features)
+        for k, (tum, reducer) in enumerate(zip(self.tums[1:], self.reducers)):
+            reduced = reduced_all[k] if reduced_all is not None else reducer(base_features)
+            x = torch.cat([features[-1][-1], reduced], dim=1)                                      # :378-380
             for i, feature in enumerate(tum(x)):
                 features[i].append(feature)
         features = [torch.cat(f, dim=1) for f in reversed(features)]                              # :385
         features = self.sfam(features)
         return features, features[-1]
+
+    def _reducers_merged(self, base_features):
+        """[reducer(base_features) for reducer in self.reducers] (features.py:379) as ONE convolution: the num_tums - 1 reducers are 1 x 1
+        Conv2dBn blocks on the SAME input, so their weights stack along the output channels, and BatchNorm being per channel, one norm
+        over the stacked channels is the seven norms.  The 200 MB base map (batch 16) is then read once instead of seven times, and the
+        backward pass has one data-gradient GEMM instead of seven plus six full-size gradient additions.  The modules keep their own
+        parameters and buffers (state_dict unchanged): gradients reach them through torch.cat, the running statistics are copied back.
+        None when the blocks are not plain libssdk Conv2dBn blocks with identical settings (then they run one by one)."""
+        rs = list(self.reducers)
+        if len(rs) < 2 or not base_features.is_cuda:
+            return None
+        ok = all(isinstance(r, conv.Conv2dBn) and r._hip_ok() and type(r._modules.get('bn')) is nn.BatchNorm2d and r.conv.bias is None
+                 and r.conv.kernel_size == (1, 1) and r.conv.stride == (1, 1) and r.conv.padding == (0, 0) and ops.sync_group_of(r.bn) is None
+                 and r.bn.affine and r.bn.track_running_stats and r.bn.momentum == rs[0].bn.momentum and r.bn.eps == rs[0].bn.eps
+                 and r.bn.training == rs[0].bn.training and r.conv.out_channels == rs[0].conv.out_channels for r in rs)
+        if not ok:
+            return None
+        has_act = 'activation' in rs[0]._modules
+        w = torch.cat([r.conv.weight for r in rs], dim=0).contiguous(memory_format=torch.channels_last)
+        y = ops.conv2d(base_features, w, None, 1, 0)
+        bn0 = rs[0].bn
+        gamma, beta = torch.cat([r.bn.weight for r in rs]), torch.cat([r.bn.bias for r in rs])
+        with torch.no_grad():
+            rm, rv = torch.cat([r.bn.running_mean for r in rs]), torch.cat([r.bn.running_var for r in rs])
+        out = ops._BatchNormFn.apply(y, gamma, beta, rm, rv, bn0.num_batches_tracked if bn0.training else None, bn0.momentum, bn0.eps, bn0.training,
+                                     int(has_act), None, False)
+        if bn0.training:
+            with torch.no_grad():
+                c = rs[0].conv.out_channels
+                torch._foreach_copy_([r.bn.running_mean for r in rs], list(rm.split(c)))
+                torch._foreach_copy_([r.bn.running_var for r in rs], list(rv.split(c)))
+                torch._foreach_add_([r.bn.num_batches_tracked for r in rs[1:]], 1)
+        return list(out.split(rs[0].conv.out_channels, dim=1))
 
     def get_out_channels(self):
         return [self.tum_out_channels * self.num_tums] * self.num_outputs

@@ -217,8 +217,8 @@ def test_m2det_neck_vs_torch():
 
     rng = np.random.default_rng(9)
     torch.manual_seed(0)
-    neck = MultilevelFeaturePyramid(_Base(), out_layers=(0, 1), num_scales=3, num_tums=2, base_reduced_channels=[16, 8], reduced_channels=8,
-                                    tum={'inner_channels': 16, 'out_channels': 8}, sfam={'reduction_ratio': 4})
+    neck = MultilevelFeaturePyramid(_Base(), out_layers=(0, 1), num_scales=3, num_tums=3, base_reduced_channels=[16, 8], reduced_channels=8,   # (three TUMs: two reducers, merged into one convolution)
+                                    tum={'inner_channels': 16, 'out_channels': 8}, sfam={'reduction_ratio': 2})
     for grp in (neck.base_reducers, neck.tums, neck.reducers, neck.sfam):
         _randomize(grp, rng)
     ref = copy.deepcopy(neck)
