@@ -1391,6 +1391,7 @@ struct PackLevel {
     // columns; every anchor with a non-zero gradient becomes one row [Jpad] of segment k: C scores, 4 locs, zero padding
     int nb, C, Jpad, cap;
     float* ga; int* apix; int* acount;
+    const int* mode;   // pack_store_kernel: the level's backward form as decide_sparse_kernel chose it (2 = anchor rows: `out` is not needed)
 };
 struct PackGroup {
     int count, B;
@@ -1402,7 +1403,7 @@ struct PackGroup {
 // type are fixed for the block, so a row costs one select + one add per load and no branches; two rows are in flight.
 // (The first version re-derived source and bounds per element behind divergent branches: ~25 instructions per load, 2 TB/s.)
 // Returns the mask of this wave's rows that are not entirely zero; leaves the wave's column sums in `sum`.
-template <int ITERS>
+template <int ITERS, bool STORE, bool COUNT>
 __device__ __forceinline__ unsigned long long pack_rows(const PackLevel& L, const float* __restrict__ ds, const float* __restrict__ dl, long long sb,
                                               long long lb, int B, int m0, int M, float* __restrict__ sum, unsigned* __restrict__ s_amask) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: row bases stay in SGPRs)
@@ -1448,10 +1449,13 @@ __device__ __forceinline__ unsigned long long pack_rows(const PackLevel& L, cons
 #pragma unroll
             for (int k = 0; k < ITERS; ++k) {
                 const float x = v[u][k];
-                if (k * 64 + lane < Npad) orow[k * 64 + lane] = x;
-                acc[k] += x;
-                amask |= x != 0.0f ? ((1u << ((unsigned)(anchor_of >> (4 * k)) & 15u)) | 0x80000000u) : 0u;
+                if (STORE && k * 64 + lane < Npad) orow[k * 64 + lane] = x;
+                if (COUNT) {
+                    acc[k] += x;
+                    amask |= x != 0.0f ? ((1u << ((unsigned)(anchor_of >> (4 * k)) & 15u)) | 0x80000000u) : 0u;
+                }
             }
+            if (!COUNT) continue;
             if (__ballot(amask != 0u)) mine |= 1ull << r;
             if (L.ga) {   // which anchor types of this row carry a gradient (wave-wide OR of the lanes' masks)
                 unsigned row_mask = 0u;
@@ -1461,12 +1465,17 @@ __device__ __forceinline__ unsigned long long pack_rows(const PackLevel& L, cons
             }
         }
     }
+    if (COUNT) {
 #pragma unroll
-    for (int k = 0; k < ITERS; ++k) sum[k * 64 + lane] = acc[k];
+        for (int k = 0; k < ITERS; ++k) sum[k * 64 + lane] = acc[k];
+    }
     return mine;
 }
 
-template <int ITERS>
+// STORE = false: the counting half alone (bias gradients, row lists, anchor rows) -- the dense [pixel][Npad] rows, which only the dense and
+// the pixel-sparse backward read, are then written by pack_store_kernel AFTER decide_sparse_kernel, and only for levels that did not take
+// the anchor form: with hard-negative mining (4 % of the anchors) that is no level, and 92 MB of writes per SSD-300 step are not made.
+template <int ITERS, bool STORE>
 __global__ void __launch_bounds__(256) pack_dy_kernel(PackGroup grp) {
     int pi = 0;
 #pragma unroll 1
@@ -1498,7 +1507,7 @@ __global__ void __launch_bounds__(256) pack_dy_kernel(PackGroup grp) {
     if (threadIdx.x < kPackRows) s_amask[threadIdx.x] = 0u;
     __syncthreads();
     unsigned long long mine = 0ull;
-    mine = pack_rows<ITERS>(L, ds, dl, sb, lb, B, m0, M, s_sum[wave], s_amask);
+    mine = pack_rows<ITERS, STORE, true>(L, ds, dl, sb, lb, B, m0, M, s_sum[wave], s_amask);
     if (lane == 0 && mine) atomicOr(&s_flag, mine);
     __syncthreads();
     for (int n = threadIdx.x; n < N; n += 256) {
@@ -1547,6 +1556,26 @@ __global__ void __launch_bounds__(256) pack_dy_kernel(PackGroup grp) {
                 grow[j] = j < L.C ? srow[a * L.C + j] : (j < L.C + 4 ? lrow[a * 4 + j - L.C] : 0.0f);
             if (lane == 0) L.apix[(long long)a * L.cap + idx] = m;
         }
+    }
+}
+
+// second half of the pack: the dense rows of the levels whose chosen form reads them (mode 0 / 1); a fixed grid walks the row blocks
+template <int ITERS>
+__global__ void __launch_bounds__(256) pack_store_kernel(PackGroup grp, int total_blocks) {
+    __shared__ float s_dummy[kPackColIters * 64];
+    __shared__ unsigned s_amask[kPackRows];
+    bool any = false;
+    for (int i = 0; i < grp.count; ++i) any = any || *grp.lv[i].mode != 2;
+    if (!any) return;
+    for (int blk = blockIdx.x; blk < total_blocks; blk += gridDim.x) {
+        int pi = 0;
+#pragma unroll 1
+        for (int i = 1; i < grp.count; ++i)
+            if (blk >= grp.lv[i].block_begin) pi = i;
+        const PackLevel& L = grp.lv[pi];
+        if (*L.mode == 2) continue;
+        const int M = grp.B * L.HW, m0 = (blk - L.block_begin) * kPackRows;
+        pack_rows<ITERS, true, false>(L, L.ds, L.dl, grp.sb, grp.lb, grp.B, m0, M, s_dummy, s_amask);
     }
 }
 
@@ -2637,13 +2666,30 @@ extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int b
         // one instantiation per launch: column trips of the widest level (6 / 8 / 12: Npad <= 384 / 512 / 768)
         int max_npad = 0;
         for (int i = 0; i < n_levels; ++i) max_npad = std::max(max_npad, pg.lv[i].Npad);
-        if (max_npad <= 384) hipLaunchKernelGGL(pack_dy_kernel<6>, dim3(begin), dim3(256), 0, s, pg);
-        else if (max_npad <= 512) hipLaunchKernelGGL(pack_dy_kernel<8>, dim3(begin), dim3(256), 0, s, pg);
-        else hipLaunchKernelGGL(pack_dy_kernel<12>, dim3(begin), dim3(256), 0, s, pg);
+        // two-stage when every level can take the anchor form (then the dense rows are usually not needed at all); else the one-pass form
+        bool two_stage = !getenv("SSDK_PACK_ONE_PASS");
+        for (int i = 0; i < n_levels; ++i) two_stage = two_stage && h_totals.nb[i] > 0;
+        if (two_stage) {
+            if (max_npad <= 384) hipLaunchKernelGGL((pack_dy_kernel<6, false>), dim3(begin), dim3(256), 0, s, pg);
+            else if (max_npad <= 512) hipLaunchKernelGGL((pack_dy_kernel<8, false>), dim3(begin), dim3(256), 0, s, pg);
+            else hipLaunchKernelGGL((pack_dy_kernel<12, false>), dim3(begin), dim3(256), 0, s, pg);
+        } else {
+            if (max_npad <= 384) hipLaunchKernelGGL((pack_dy_kernel<6, true>), dim3(begin), dim3(256), 0, s, pg);
+            else if (max_npad <= 512) hipLaunchKernelGGL((pack_dy_kernel<8, true>), dim3(begin), dim3(256), 0, s, pg);
+            else hipLaunchKernelGGL((pack_dy_kernel<12, true>), dim3(begin), dim3(256), 0, s, pg);
+        }
         SSDK_CHECK_LAUNCH("pack_dy_kernel");
+        hipLaunchKernelGGL(decide_sparse_kernel, dim3(1), dim3(64), 0, s, w.counts, w.acounts, h_totals, n_levels, w.mode);
+        SSDK_CHECK_LAUNCH("decide_sparse_kernel");
+        if (two_stage) {
+            for (int i = 0; i < n_levels; ++i) pg.lv[i].mode = w.mode + i;
+            const int grid = std::min(begin, 4096);
+            if (max_npad <= 384) hipLaunchKernelGGL(pack_store_kernel<6>, dim3(grid), dim3(256), 0, s, pg, begin);
+            else if (max_npad <= 512) hipLaunchKernelGGL(pack_store_kernel<8>, dim3(grid), dim3(256), 0, s, pg, begin);
+            else hipLaunchKernelGGL(pack_store_kernel<12>, dim3(grid), dim3(256), 0, s, pg, begin);
+            SSDK_CHECK_LAUNCH("pack_store_kernel");
+        }
     }
-    hipLaunchKernelGGL(decide_sparse_kernel, dim3(1), dim3(64), 0, s, w.counts, w.acounts, h_totals, n_levels, w.mode);
-    SSDK_CHECK_LAUNCH("decide_sparse_kernel");
 
     // 2. backward-data.  dense: dX[m][c] = sum_(tap,n) dY[m + pad - tap][n] * W[n][tap][c] (output stationary);
     //    sparse: T[row][tap*Cin + c] = dY[row][:] . W[:, tap, c] for the non-zero rows only, scatter-added into dX.
