@@ -487,6 +487,32 @@ def fast_mode_legs(device, cfg_name='ssd_300_vgg16_voc', batch=32, steps=10):
                          'frac_algorithmic': tf / PEAK_BF16_MATRIX_TFLOPS, 'achieved_issued': 3.0 * tf, 'frac_issued': 3.0 * tf / PEAK_BF16_MATRIX_TFLOPS}}
 
 
+def graph_replay_leg(hp, device, n):
+    """The same training step (same kernels, same arguments) captured once in a HIP graph and replayed (single_shot_detection_amd/graphs.py):
+    `ms_per_step` above is the step as the reference's loop would drive it, launch by launch from Python -- for the configs with hundreds of
+    small launches per step (M2Det's neck, RetinaNet's towers, MobileNet's tail at batch 2) that is the host's enqueue rate, not the GPU.
+    Reported beside it, never instead of it."""
+    from single_shot_detection_amd.detection.target_assigner import PackedGroundTruth
+    from single_shot_detection_amd.graphs import GraphedCallable
+    try:
+        hp.fwd_events = []
+        hp.gt = PackedGroundTruth.from_list(hp.gt, device, capacity=sum(len(g) for g in hp.gt) + 7)
+        step = GraphedCallable(hp.train_step, [], warmup=2)
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        loss = float(step.static_out.detach())
+        if not np.isfinite(loss):
+            raise RuntimeError('loss after the replays is %r' % loss)
+        return {'graph_replay_ms_per_step': dt * 1e3, 'graph_replay_images_per_sec': hp.batch / dt}
+    except Exception as e:   # (reported, not fatal: the eager number above is the leg's result)
+        return {'graph_replay_ms_per_step': None, 'graph_replay_error': '%s: %s' % (type(e).__name__, e)}
+
+
 def per_config_legs(device, steps=4, warmup=2):
     """The other BASELINE.json configs (parity-test cases, not the headline): a few train steps each."""
     out = []
@@ -518,10 +544,24 @@ def per_config_legs(device, steps=4, warmup=2):
         sc, lo = hp.forward_heads()
         sc, lo = sc.detach(), lo.detach()
         us = gpu_time_us(lambda: hp.post.postprocess_padded((sc, lo), hp.anchors), inner=3, reps=3)
-        out.append({'config': name, 'per_gpu_batch': batch, 'ms_per_step': dt * 1e3, 'images_per_sec': batch / dt, 'head_gemm_ms': fwd_ms,
-                    'head_gemm_tflops': tf, 'head_gemm_frac': tf / PEAK_FP32_MATRIX_TFLOPS,
-                    'postprocess_worst_case_images_per_sec': batch / (us * 1e-6)})
-        del hp, sc, lo
+        # the head GEMM launch alone, back to back with the host ahead of the GPU: `head_gemm_ms` above is the interval between two events
+        # INSIDE the training step, which for a step the host can barely keep ahead of (the 21-class SSD-300 at 2.4 ms, MobileNet at
+        # batch 2) also holds the host's time to prepare the call
+        from single_shot_detection_amd.detection.modules.heads import multi_level_heads
+        with torch.no_grad():
+            srcs = hp.pyramid()
+            ssrc, lsrc = (srcs, srcs) if hp.tower is None else hp.tower(srcs)
+            alone_ms = gpu_time_us(lambda: multi_level_heads(ssrc, lsrc, hp.heads), inner=5, reps=5) * 1e-3
+        tf_alone = head_flops_per_image(hp.levels, hp.C) * batch / (alone_ms * 1e-3) / 1e12
+        row = {'config': name, 'per_gpu_batch': batch, 'ms_per_step': dt * 1e3, 'images_per_sec': batch / dt, 'head_gemm_ms': fwd_ms,
+               'head_gemm_tflops': tf, 'head_gemm_frac': tf / PEAK_FP32_MATRIX_TFLOPS,
+               'head_gemm_alone_ms': alone_ms, 'head_gemm_alone_frac': tf_alone / PEAK_FP32_MATRIX_TFLOPS,
+               'postprocess_worst_case_images_per_sec': batch / (us * 1e-6)}
+        del srcs, ssrc, lsrc
+        del sc, lo
+        row.update(graph_replay_leg(hp, device, n))
+        out.append(row)
+        del hp
         torch.cuda.empty_cache()
     return out
 

@@ -100,6 +100,9 @@ struct ConvProblem {
     int n0_pad;
     unsigned w0_bytes, w1_bytes;   // LDS-DMA kernel: sizes of the two weight tensors (buffer descriptors)
     int forced;   // n_blocks / k_splits were set by the caller: launch_group keeps them
+    // The last 32-column tile holds at most 16 columns (N = 104 of the 21-class heads: 3 tiles + 8 columns): it is computed as a 16-column
+    // tile by v_mfma_f32_16x16x1_4b_f32 at half the cycles of a 32 x 32 x 2 (dma_tile, forward LDS-DMA form only; set by launch_group)
+    int half_last;
     // BatchNorm statistics of the output, fused into the epilogue (forward, one output, not split over K): per-column sums of the
     // stored values and of their squares are ADDED into stats[0 .. n0) / stats[n0 .. 2 n0) (fp64), stats[2 n0] = rows.  NULL: none.
     double* stats;
@@ -121,7 +124,7 @@ struct ConvGroup {
 struct StreamK {
     int nwg;
     long long total_units;
-    long long unit_begin[kMaxProblems + 1];   // prefix over the problems in launch order; unit = one K slice of one 32-column tile
+    long long unit_begin[kMaxProblems + 1];   // prefix over the problems in launch order; unit = one K slice of HALF a 32-column tile (a tile = 2, a 16-column remainder tile = 1)
     float* partial;                           // [nwg][4 waves][kMaxTN][4][64 lanes][4]: a workgroup's accumulators as they lie in registers
     unsigned* flags;                          // [nwg]: flags[s] == epoch <=> workgroup s parked its partial tile
     unsigned* timeouts;                       // DEV counter of partners given up on (stays 0; ssdk_heads_fwd_timeouts reads it)
@@ -164,7 +167,7 @@ struct GVecT<1> { typedef const float __attribute__((address_space(1))) * type; 
 // Epilogue shared by the GEMM kernels: bias, optional ReLU, store (or atomic add for split-K / scatter).
 template <bool SCATTER, int NT>
 __device__ __forceinline__ void conv_epilogue(const ConvProblem& g, const f32x16 (&acc)[NT], int m_base, int wave, int r32, int h, int tn,
-                                              int n_begin, int M, int N, int hw, int ksp, float* s_red = nullptr, int waves = 4) {
+                                              int n_begin, int M, int N, int hw, int ksp, float* s_red = nullptr, int waves = 4, int half_j = -1) {
     // epilogue: C/D map of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
     if (SCATTER) {
         // row = a pixel (or one anchor of a pixel) with a non-zero output gradient; column n = tap * Cin + c: add the product into
@@ -275,7 +278,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvProblem& g, const f32x16
     for (int j = 0; j < NT; ++j) {
         const int n = n_begin + j * 32 + r32;
         const bool second = n >= n0;
-        const bool ok = j < tn && n < N && !(second && n < n0_pad);   // (n0 .. n0_pad: padding columns between the two heads)
+        const bool ok = j < tn && j != half_j && n < N && !(second && n < n0_pad);   // (n0 .. n0_pad: padding columns between the two heads)
         colj[j] = second ? n - n0_pad : n;
         const float* bias = second ? g.bias1 : g.bias0;
         biasj[j] = (ok && bias && ksp == 0) ? bias[colj[j]] : 0.0f;
@@ -310,6 +313,36 @@ __device__ __forceinline__ void conv_epilogue(const ConvProblem& g, const f32x16
                 cs2[j] += out * out;
             }
         }
+    }
+    if (half_j >= 0) {
+        // the 16-column remainder tile: C/D map of the four 16 x 16 blocks of v_mfma_f32_16x16x1_4b_f32 (tools/mfma_16x16x1_layout.hip):
+        // register 4 * b + r of lane l = block b, row 4 * (l >> 4) + r, column l & 15; blocks b and b + 2 are the two K halves of the
+        // wave's rows 16 * b .. 16 * b + 15
+        const int lane = h * 32 + r32;
+        const int n = n_begin + half_j * 32 + (lane & 15);
+        const bool second = n >= n0;
+        const bool ok = n < N && !(second && n < n0_pad);
+        const int col = second ? n - n0_pad : n;
+        const float* bias = second ? g.bias1 : g.bias0;
+        const float bv = (ok && bias && ksp == 0) ? bias[col] : 0.0f;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int src = 16 * b + 4 * (lane >> 4) + r;   // row of the wave = the lane that worked out its offsets
+                const long long r0 = (long long)((unsigned long long)(unsigned)__shfl((int)lo0, src, kWave) | ((unsigned long long)(unsigned)__shfl((int)hi0, src, kWave) << 32));
+                long long r1 = 0;
+                if (o1) r1 = (long long)((unsigned long long)(unsigned)__shfl((int)lo1, src, kWave) | ((unsigned long long)(unsigned)__shfl((int)hi1, src, kWave) << 32));
+                if (r0 < 0 || !ok) continue;
+                float* const dst = (second ? o1 + r1 : o0 + r0) + col;
+                float v = 0.0f;
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    if (j == half_j) v = acc[j][4 * b + r] + acc[j][4 * (b + 2) + r];
+                v += bv;
+                if (split) atomicAdd(dst, v);
+                else *dst = relu ? fmaxf(v, 0.0f) : v;
+            }
     }
     if (stats) {
         // BatchNorm statistics of what was just stored: a lane holds the sums of its column over 16 rows of the wave's 32; the two lane
@@ -445,6 +478,8 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
     const int base_t = g.tiles_n / g.n_blocks, rem_t = g.tiles_n % g.n_blocks;
     const int tn = base_t + (n_block < rem_t ? 1 : 0);
     const int n_begin = (n_block * base_t + min(n_block, rem_t)) * 32;
+    // the launch's last tile as a 16-column tile (ConvProblem::half_last): tile tn - 1 of the last column block
+    const bool half = !MIRROR && !SCATTER && WAVES == 4 && BK == 32 && MAXTN == 4 && g.half_last && n_block == g.n_blocks - 1;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -557,6 +592,10 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
     // fragment reads: lane (r, h) reads source chunk 2*gk + h of its row, stored at position (2*gk + h) ^ ((r >> 1) & 7)
     const int pos0 = h ^ (BK == 32 ? (r32 >> 1) & 7 : (r32 >> 2) & 3);
     const int a_row = (wave * 32 + r32) * kBK, b_row = r32 * kBK;
+    // 16-column remainder tile: lane l reads W row (l & 15) of that tile, the same K chunk 2 * gk + h as its A fragment -- block l >> 4 of
+    // the four-block MFMA then multiplies rows 16 * ((l >> 4) & 1) + (l & 15) of the wave (what the lane's A fragment holds) with K half h
+    const int pos0h = h ^ (((lane & 15) >> 1) & 7);
+    const int bh_row = (lane & 15) * kBK;
 
     slice_offsets(true);
 #pragma unroll
@@ -565,8 +604,10 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
     for (int i = 0; i < kWPieces; ++i) stage_w_piece(0, i);
     __syncthreads();   // (waits for the DMA: it is a pending LDS write of this wave)
 
-    auto k_loop = [&](auto tn_c) {
-        constexpr int TN = decltype(tn_c)::value;
+    auto k_loop = [&](auto tn_c, auto half_c) {
+        constexpr int TN = decltype(tn_c)::value;     // whole 32-column tiles
+        constexpr bool HALF = decltype(half_c)::value && TN < MAXTN;   // + the 16-column tile in acc[TN]
+        constexpr int TH = HALF ? TN : 0;
 #ifdef SSDK_CONV_TRACE
         const bool trace_on = pi == 0 && (blockIdx.x % 31) == 0 && blockIdx.x / 31 < 32;
         const int trace_blk = blockIdx.x / 31;
@@ -581,12 +622,13 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
             slice_offsets(slice + 2 < n_slices);   // the slice staged now is slice + 1
             // fragments of group gk + 1 are read, and DMA piece gk is issued, BEFORE the 16 MFMAs of group gk (pinned with a
             // scheduling barrier: left alone the scheduler sinks the DMAs to the end of the slice, right in front of the wait)
-            f32x4 av[2], bv[2][TN];
+            f32x4 av[2], bv[2][TN > 0 ? TN : 1], bh[2];
             auto read_frags = [&](int buf, int gk) {
                 const int pos = (pos0 ^ (2 * gk)) * 4;
                 av[buf] = *reinterpret_cast<const f32x4*>(&(ST ? s_a1 : s_a0)[a_row + pos]);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bv[buf][j] = *reinterpret_cast<const f32x4*>(&(ST ? s_b1 : s_b0)[b_row + j * 32 * kBK + pos]);
+                if (HALF) bh[buf] = *reinterpret_cast<const f32x4*>(&(ST ? s_b1 : s_b0)[bh_row + TH * 32 * kBK + (pos0h ^ (2 * gk)) * 4]);
             };
             read_frags(0, 0);
 #pragma unroll
@@ -597,9 +639,11 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
                 if (gk + kBK / 8 < kWPieces) stage_w_piece(ST ^ 1, gk + kBK / 8);   // (192-column workgroups: 6 W pieces per wave)
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
+                for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[gk & 1][kk], bv[gk & 1][j][kk], acc[j], 0, 0, 0);
+                    if (HALF) acc[TH] = __builtin_amdgcn_mfma_f32_16x16x1f32(av[gk & 1][kk], bh[gk & 1][kk], acc[TH], 0, 0, 0);
+                }
 #ifdef SSDK_CONV_TRACE
                 if (gk == 0) { TRACE(1) }
                 if (gk == 1) { TRACE(2) }
@@ -616,13 +660,24 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
         }
     };
     PHASE(1)
-    switch (tn) {
-        case 6: if constexpr (MAXTN >= 6) { k_loop(std::integral_constant<int, 6>{}); } break;
-        case 5: if constexpr (MAXTN >= 6) { k_loop(std::integral_constant<int, 5>{}); } break;
-        case 4: k_loop(std::integral_constant<int, 4>{}); break;
-        case 3: k_loop(std::integral_constant<int, 3>{}); break;
-        case 2: k_loop(std::integral_constant<int, 2>{}); break;
-        default: k_loop(std::integral_constant<int, 1>{}); break;
+    if (half) {
+        if constexpr (!MIRROR && !SCATTER && WAVES == 4 && BK == 32 && MAXTN == 4) {
+            switch (tn - 1) {
+                case 3: k_loop(std::integral_constant<int, 3>{}, std::true_type{}); break;
+                case 2: k_loop(std::integral_constant<int, 2>{}, std::true_type{}); break;
+                case 1: k_loop(std::integral_constant<int, 1>{}, std::true_type{}); break;
+                default: k_loop(std::integral_constant<int, 0>{}, std::true_type{}); break;
+            }
+        }
+    } else {
+        switch (tn) {
+            case 6: if constexpr (MAXTN >= 6) { k_loop(std::integral_constant<int, 6>{}, std::false_type{}); } break;
+            case 5: if constexpr (MAXTN >= 6) { k_loop(std::integral_constant<int, 5>{}, std::false_type{}); } break;
+            case 4: k_loop(std::integral_constant<int, 4>{}, std::false_type{}); break;
+            case 3: k_loop(std::integral_constant<int, 3>{}, std::false_type{}); break;
+            case 2: k_loop(std::integral_constant<int, 2>{}, std::false_type{}); break;
+            default: k_loop(std::integral_constant<int, 1>{}, std::false_type{}); break;
+        }
     }
     PHASE(2)
     if (!MIRROR && !GENERIC && !SCATTER && WAVES == 4 && sk_mode) {
@@ -683,7 +738,8 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
             if (tid == 0 && poison == poison) __hip_atomic_store(sk_flag + part, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    conv_epilogue<SCATTER>(g, acc, m_base, wave, r32, h, tn, n_begin, M, N, hw, ksp, (!MIRROR && !SCATTER) ? s_a0 : nullptr, WAVES);   // (a stream-K owner too: the fix-up ends behind a barrier)
+    conv_epilogue<SCATTER>(g, acc, m_base, wave, r32, h, tn, n_begin, M, N, hw, ksp, (!MIRROR && !SCATTER) ? s_a0 : nullptr, WAVES,
+                           half ? tn - 1 : -1);   // (a stream-K owner too: the fix-up ends behind a barrier)
     PHASE(3)
 }
 
@@ -757,11 +813,13 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_streamk_k
         const int base_t = g.tiles_n / g.n_blocks, rem_t = g.tiles_n % g.n_blocks;
         int nb = 0;
         long long acc_u = 0;
-        tn = base_t + (0 < rem_t ? 1 : 0);
+        // `tn` here = the weight of a K slice of the column block in units of half a tile (see StreamK::unit_begin)
+        auto weight = [&](int b) { return 2 * (base_t + (b < rem_t ? 1 : 0)) - ((g.half_last && b == g.n_blocks - 1) ? 1 : 0); };
+        tn = weight(0);
         while (nb + 1 < g.n_blocks && local >= acc_u + (long long)g.m_tiles * slices * tn) {
             acc_u += (long long)g.m_tiles * slices * tn;
             ++nb;
-            tn = base_t + (nb < rem_t ? 1 : 0);
+            tn = weight(nb);
         }
         n_block = nb;
         local -= acc_u;
@@ -2118,6 +2176,8 @@ struct StreamKWs {
     unsigned* flags;
     int nwg;
 };
+// does a column space of N end in a tile of at most 16 columns?
+static inline bool half_tile_of(int N) { return N % 32 != 0 && N % 32 <= 16; }
 constexpr long long kStreamKMinRange = 24 * kMaxTN;
 constexpr int kStreamKMinWgs = 256;
 // generic convolutions (pyramid tail, tower, necks): the launches stream-K helps are ONE to two rounds of tiles on 256 CUs (the SSD-300
@@ -2138,12 +2198,13 @@ static bool streamk_would_take(const ConvProblem* probs, int count, bool generic
     for (int i = 0; i < count; ++i) {
         const ConvProblem& g = probs[i];
         if (g.Cc % kBK || g.mode) return false;
-        const int tiles_n = cdiv((g.n1 > 0 ? cdiv(g.n0, 8) * 8 : g.n0) + g.n1, 32);
-        units += (long long)g.m_tiles * g.ksize * g.ksize * (g.Cc / kBK) * tiles_n;
+        const int N = (g.n1 > 0 ? cdiv(g.n0, 8) * 8 : g.n0) + g.n1, tiles_n = cdiv(N, 32);
+        const int half = (!g.stats && half_tile_of(N) && !getenv("SSDK_CONV_NO_HALF_TILE")) ? 1 : 0;   // (as launch_group will set half_last)
+        units += (long long)g.m_tiles * g.ksize * g.ksize * (g.Cc / kBK) * (2 * tiles_n - half);           // half-tile units, as StreamK counts
         blocks += (long long)cdiv(g.m_tiles, 8) * 8 * cdiv(tiles_n, kMaxTN);
     }
     const long long min_range = generic ? streamk_generic_min_range() : kStreamKMinRange;
-    const long long nwg = std::min<long long>(512, units / min_range / 8 * 8);
+    const long long nwg = std::min<long long>(512, units / (2 * min_range) / 8 * 8);
     return nwg >= kStreamKMinWgs && blocks <= 16 * nwg;
 }
 static unsigned g_streamk_epoch = 0;   // (a launch counter: tells this launch's flags from an earlier launch's in the same workspace)
@@ -2199,6 +2260,8 @@ static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t 
         ConvProblem& g = probs[i];
         g.n0_pad = (dma && g.n1 > 0) ? cdiv(g.n0, bk16 ? 16 : 8) * (bk16 ? 16 : 8) : g.n0;
         g.tiles_n = cdiv(g.n0_pad + g.n1, 32);
+        g.half_last = (dma && !mirror && !scatter && !bk16 && !tn6 && !g.stats && half_tile_of(g.n0_pad + g.n1) && !getenv("SSDK_CONV_W8") &&
+                       !getenv("SSDK_CONV_NO_HALF_TILE")) ? 1 : 0;
         if (!g.forced) {
             g.n_blocks = cdiv(g.tiles_n, tn6 ? 6 : kMaxTN);
             if (!vtab && (scatter || g.k_splits > 1)) narrow_for_atomics(g);
@@ -2260,7 +2323,7 @@ static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t 
             const ConvProblem& g = grp.p[i];
             const long long slices = (long long)g.ksize * g.ksize * (g.Cc / kBK);
             sk.unit_begin[i] = sk.total_units;
-            sk.total_units += (long long)g.m_tiles * slices * g.tiles_n;
+            sk.total_units += (long long)g.m_tiles * slices * (2 * g.tiles_n - g.half_last);
             max_tile = std::max(max_tile, slices * cdiv(g.tiles_n, g.n_blocks));
             if (g.k_splits != 1 || g.mode) sk.nwg = 0;
         }
@@ -2270,7 +2333,7 @@ static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t 
         // several times and its owner adds all the parked parts.  Below 256 workgroups the split-K path of the caller does as well (measured on ssd_mb2_voc).
         if (sk.nwg > 0 && begin > 16 * sk.nwg) sk.nwg = 0;
         const long long min_range = generic ? streamk_generic_min_range() : kStreamKMinRange;
-        if (sk.nwg > 0) sk.nwg = (int)std::min<long long>(sk.nwg, sk.total_units / min_range / 8 * 8);
+        if (sk.nwg > 0) sk.nwg = (int)std::min<long long>(sk.nwg, sk.total_units / (2 * min_range) / 8 * 8);   // (min_range counts whole tiles)
         (void)max_tile;
         const bool worth = sk.nwg >= kStreamKMinWgs;
         if (worth) {
@@ -2364,14 +2427,10 @@ extern "C" int ssdk_heads_fwd(const ssdk_head_level* levels, int n_levels, int b
     // a level are divided over several workgroups that add into the zeroed outputs, like the pyramid tail's convolutions.
     long long blocks = 0;
     for (int i = 0; i < n_levels; ++i) blocks += (long long)cdiv(probs[i].m_tiles, 8) * 8 * probs[i].n_blocks;
-    long long units = 0;
     bool dma_ok = true;   // (what launch_group asks of its LDS-DMA kernel; stream-K is a form of it)
-    for (int i = 0; i < n_levels; ++i) {
-        units += (long long)probs[i].m_tiles * 9 * cdiv(probs[i].Cc, kBK) * probs[i].tiles_n;
-        dma_ok = dma_ok && probs[i].Cc % kBK == 0;
-    }
+    for (int i = 0; i < n_levels; ++i) dma_ok = dma_ok && probs[i].Cc % kBK == 0;
     const bool have_ws = workspace && workspace_bytes >= ssdk_heads_fwd_workspace_bytes();
-    const bool streamk_takes_it = have_ws && dma_ok && units / kStreamKMinRange >= kStreamKMinWgs && !getenv("SSDK_CONV_NO_STREAMK");
+    const bool streamk_takes_it = have_ws && dma_ok && streamk_would_take(probs, n_levels, false);
     if (blocks <= kStreamKWgs && !streamk_takes_it && !getenv("SSDK_HEADS_NO_SPLITK")) {
         bool any = false;
         for (int i = 0; i < n_levels; ++i) any = maybe_split_k(probs[i]) || any;

@@ -138,6 +138,39 @@ def _heads_vs_torch_cpu_conv(levels, C, B, pixel_density, mode, monkeypatch):
             np.testing.assert_allclose(heads[i][k].bias.grad.cpu().numpy(), bref.grad.numpy(), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('levels,C,B', [
+    (SSD300_LEVELS, 21, 32),                      # N = 104 (3 tiles + 8 columns) and 152: the grouped stream-K launch
+    (SSD300_LEVELS, 21, 8),                       # ... cut several times per tile
+    (SSD300_LEVELS, 21, 1),                       # ... split over K, added into zeroed outputs
+    ([(64, 19, 1), (128, 10, 6)], 2, 16),         # N = 12 (the 16-column tile alone) and 40 (1 tile + 8 columns)
+    ([(256, 8, 9)], 80, 32),                      # retina score + loc: 720 + 36 = 756 = 23 tiles + 20 columns (no remainder tile: unchanged)
+])
+def test_heads_forward_16_column_remainder_tile(levels, C, B, monkeypatch):
+    """A column space that ends in a tile of at most 16 columns (N = 104 of the 21-class heads) computes that tile with
+    v_mfma_f32_16x16x1_4b_f32 (conv.hip dma_tile, ConvProblem::half_last) in every forward form: the result must be the one of the
+    32-column tiling (SSDK_CONV_NO_HALF_TILE=1, the form every other test pins) up to the order of the fp32 sums over K."""
+    rng = np.random.default_rng(3)
+    weights, xs_np = {}, []
+    for i, (cin, h, nb) in enumerate(levels):
+        xs_np.append(rng.standard_normal((B, cin, h, h), dtype=np.float32))
+        for k, nout in (('score', nb * C), ('loc', nb * 4)):
+            weights[(k, i)] = (rng.standard_normal((nout, cin, 3, 3), dtype=np.float32) * np.float32(0.02),
+                               rng.standard_normal((nout,), dtype=np.float32) * np.float32(0.1))
+    heads = build_heads(levels, C, weights)
+    xs = [torch.from_numpy(x).cuda() for x in xs_np]
+    with torch.no_grad():
+        monkeypatch.delenv('SSDK_CONV_NO_HALF_TILE', raising=False)
+        s1, l1 = multi_level_heads(xs, xs, heads)
+        s1b, l1b = multi_level_heads(xs, xs, heads)
+        monkeypatch.setenv('SSDK_CONV_NO_HALF_TILE', '1')
+        s0, l0 = multi_level_heads(xs, xs, heads)
+    tol = 2e-6 * np.sqrt(9 * max(l[0] for l in levels))
+    np.testing.assert_allclose(s1.cpu().numpy(), s0.cpu().numpy(), rtol=1e-5, atol=tol)
+    np.testing.assert_allclose(l1.cpu().numpy(), l0.cpu().numpy(), rtol=1e-5, atol=tol)
+    if B >= 8 and len(levels) == len(SSD300_LEVELS):   # (stream-K launches do not add atomically: the same call twice is the same bits)
+        assert torch.equal(s1, s1b) and torch.equal(l1, l1b)
+
+
 @pytest.mark.parametrize('flag', ['SSDK_CONV_BK16', 'SSDK_CONV_TN6'])
 def test_heads_forward_experimental_variants(monkeypatch, flag):
     """Opt-in instantiations of the LDS-DMA kernel that were measured and not adopted -- 16-float K slices (3 workgroups per CU: +5 %
