@@ -462,10 +462,10 @@ class _SumsChain(object):
     def __init__(self, channels, device):
         self.buf = torch.zeros((2, 2 * channels + 2), dtype=torch.float64, device=device)
         self.clean = [True, True]   # forward buffer, backward buffer
-        self.stream = torch.cuda.current_stream(device).cuda_stream
+        self.stream = _lib.raw_stream(device)
 
     def usable(self, which, device):
-        return not _NO_BN_CHAIN and self.clean[which] and self.buf.device == device and self.stream == torch.cuda.current_stream(device).cuda_stream
+        return not _NO_BN_CHAIN and self.clean[which] and self.buf.device == device and self.stream == _lib.raw_stream(device)
 
 
 class _BatchNormFn(torch.autograd.Function):
