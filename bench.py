@@ -477,7 +477,10 @@ def fast_mode_legs(device, cfg_name='ssd_300_vgg16_voc', batch=32, steps=10):
         heads_mod.set_fast_mode(prev)
     flops = head_flops_per_image(hp.levels, hp.C) * batch
     tf = flops / (usf * 1e-6) / 1e12
-    return {'mode': 'bf16x3', 'what': 'forward head GEMM with operands split into bf16 pieces, a_hi b_hi + a_hi b_mid + a_mid b_hi on '
+    del hp
+    torch.cuda.empty_cache()
+    tower = fast_mode_tower_leg(device)
+    return {'mode': 'bf16x3', 'tower': tower, 'what': 'forward head GEMM with operands split into bf16 pieces, a_hi b_hi + a_hi b_mid + a_mid b_hi on '
                                       'v_mfma_f32_32x32x16_bf16, fp32 accumulate; weights split per call (included in the time); backward unchanged (fp32)',
             'workload': f'{cfg_name} batch {batch}', 'heads_fwd_us': usf, 'heads_fwd_fp32_us': us32, 'speedup_vs_fp32_launch': us32 / usf,
             'max_abs_err_over_scale': {'scores': err_s, 'locs': err_l}, 'loss_fp32': losses[0], 'loss_fast': losses[1],
@@ -485,6 +488,33 @@ def fast_mode_legs(device, cfg_name='ssd_300_vgg16_voc', batch=32, steps=10):
             'train_step_ms': ms, 'train_images_per_sec': batch / (ms * 1e-3),
             'roofline': {'bound': 'mfma', 'dtype': 'bf16', 'peak': PEAK_BF16_MATRIX_TFLOPS, 'unit': 'TFLOP/s', 'achieved_algorithmic': tf,
                          'frac_algorithmic': tf / PEAK_BF16_MATRIX_TFLOPS, 'achieved_issued': 3.0 * tf, 'frac_issued': 3.0 * tf / PEAK_BF16_MATRIX_TFLOPS}}
+
+
+def fast_mode_tower_leg(device, cfg_name='retina_rn50_500_coco', batch=32):
+    """The same mode on the generic convolutions (ssdk_conv2d_fwd_fast): RetinaNet's two 4-layer towers + heads, forward (evaluation mode:
+    what a serving step runs), fp32 against split-bf16 on the same inputs."""
+    from single_shot_detection_amd.detection.modules import heads as heads_mod
+    from single_shot_detection_amd.detection.modules.heads import multi_level_heads
+    hp = HotPath(cfg_name, batch, device)
+    hp.set_training(False)
+
+    def fwd():
+        with torch.no_grad():
+            srcs = hp.pyramid()
+            ssrc, lsrc = (srcs, srcs) if hp.tower is None else hp.tower(srcs)
+            return multi_level_heads(ssrc, lsrc, hp.heads)
+    us32 = gpu_time_us(fwd, inner=3, reps=3)
+    s32, l32 = fwd()
+    prev = heads_mod.set_fast_mode('bf16x3')
+    try:
+        usf = gpu_time_us(fwd, inner=3, reps=3)
+        sf, lf = fwd()
+    finally:
+        heads_mod.set_fast_mode(prev)
+    return {'workload': f'{cfg_name} batch {batch}: towers + heads forward, evaluation mode', 'fwd_us': usf, 'fwd_fp32_us': us32,
+            'speedup_vs_fp32': us32 / usf,
+            'max_abs_err_over_scale': {'scores': float((sf - s32).abs().max()) / float(s32.abs().max()),
+                                       'locs': float((lf - l32).abs().max()) / float(l32.abs().max())}}
 
 
 def graph_replay_leg(hp, device, n):

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SSDK_VERSION 109
+#define SSDK_VERSION 110
 
 #define SSDK_OK 0
 #define SSDK_E_INVALID (-1)   /* bad argument / shape */
@@ -311,6 +311,12 @@ int ssdk_conv2d_fwd(const ssdk_conv_desc* descs, int n, int batch, void* stream)
  * (detection/detector_builder.py:73-82 at 18 x 18 / 9 x 9) -- then runs in stream-K form instead of splitting K with atomics into a
  * zero-filled output.  Same results up to fp32 summation order; a fix-up wait that runs out is loud (ssdk_heads_fwd_timeouts). */
 int ssdk_conv2d_fwd_ws(const ssdk_conv_desc* descs, int n, int batch, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same split-bf16 GEMM for a group of convolutions (ssdk_conv2d_fwd's descriptors: RetinaNet's towers, detection/modules/predictors.py:60-76,
+ * and any tail / neck convolution with Cin % 32 == 0).  Bias, ReLU and outputs as ssdk_conv2d_fwd; descriptors that share a weight tensor
+ * (a tower layer over five pyramid levels) share its split planes; ssdk_conv_desc::stats is honoured by a statistics pass after the launch. */
+size_t ssdk_conv2d_fwd_fast_workspace_bytes(const ssdk_conv_desc* descs, int n);
+int ssdk_conv2d_fwd_fast(const ssdk_conv_desc* descs, int n, int batch, int terms, void* workspace, size_t workspace_bytes, void* stream);
 size_t ssdk_conv2d_bwd_workspace_bytes(const ssdk_conv_desc* descs, int n, int batch);
 /* accumulate != 0: dw / db are added to what the buffers hold; else they are overwritten (descriptors that name the
  * same dw / db -- weights shared across levels -- are summed into it). */

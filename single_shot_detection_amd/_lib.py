@@ -61,6 +61,8 @@ _SIGNATURES = {
     'ssdk_heads_fwd_fast_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int]),
     'ssdk_heads_fwd_fast': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_size_t,
                                       C.c_void_p]),
+    'ssdk_conv2d_fwd_fast_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int]),
+    'ssdk_conv2d_fwd_fast': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     'ssdk_heads_fwd_timeouts': (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     'ssdk_heads_bwd_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     'ssdk_heads_bwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong,
@@ -194,6 +196,11 @@ def check(status, what):
         if status < 0:
             raise ValueError(f'{what}: {msg} (status {status})')
         raise SsdkError(f'{what}: {msg} (hipError {status})')
+
+
+# Opt-in reduced-precision mode of the forward GEMMs (detection.modules.heads.set_fast_mode; SSDK_FAST_MODE): None = exact fp32,
+# 'bf16x3' = split-bf16 operands on the bf16 matrix cores.  Read by the head GEMM (heads.py) and by ops.conv2d.
+fast_mode = os.environ.get('SSDK_FAST_MODE') or None
 
 
 def raw_stream(device=None):

@@ -2567,6 +2567,97 @@ extern "C" int ssdk_heads_fwd_fast(const ssdk_head_level* levels, int n_levels, 
     return SSDK_OK;
 }
 
+// ---- the same split-bf16 GEMM for the generic convolutions (RetinaNet's towers, neck and tail convolutions with Cin % 32 == 0) ----------
+// out_dim / check_conv are defined further down with ssdk_conv2d_fwd
+static int check_conv(const char* fn, int batch, const ssdk_conv_desc& d);
+static inline int out_dim(int in, int k, int s, int p);
+
+extern "C" size_t ssdk_conv2d_fwd_fast_workspace_bytes(const ssdk_conv_desc* descs, int n) {
+    if (!descs || n <= 0 || n > kMaxProblems) return 0;
+    Carver c(nullptr);
+    for (int i = 0; i < n; ++i) {   // (an upper bound: descriptors that share a weight tensor share its two planes)
+        const size_t elems = (size_t)cdiv(descs[i].cout, 32) * 32 * descs[i].ksize * descs[i].ksize * (size_t)descs[i].cin;
+        c.take<__bf16>(elems);
+        c.take<__bf16>(elems);
+    }
+    return c.off;
+}
+
+extern "C" int ssdk_conv2d_fwd_fast(const ssdk_conv_desc* descs, int n, int batch, int terms, void* workspace, size_t workspace_bytes, void* stream) {
+    SSDK_REQUIRE(descs && n > 0 && n <= kMaxProblems, SSDK_E_INVALID, "ssdk_conv2d_fwd_fast: n=%d (1..%d)", n, kMaxProblems);
+    SSDK_REQUIRE(terms == 3, SSDK_E_UNSUPPORTED, "ssdk_conv2d_fwd_fast: terms=%d (3 is the one form built)", terms);
+    SSDK_REQUIRE(workspace && workspace_bytes >= ssdk_conv2d_fwd_fast_workspace_bytes(descs, n), SSDK_E_WORKSPACE, "ssdk_conv2d_fwd_fast: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    Carver c(workspace);
+    ConvProblem probs[kMaxProblems];
+    FastProblem fps[kMaxProblems];
+    SplitGroup sg{};
+    int split_blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const ssdk_conv_desc& d = descs[i];
+        int rc = check_conv("ssdk_conv2d_fwd_fast", batch, d);
+        if (rc) return rc;
+        SSDK_REQUIRE(d.y, SSDK_E_INVALID, "ssdk_conv2d_fwd_fast: null output");
+        SSDK_REQUIRE(d.cin % kBK == 0 && ((uintptr_t)d.x & 15) == 0 && ((uintptr_t)d.w & 15) == 0, SSDK_E_UNSUPPORTED,
+                     "ssdk_conv2d_fwd_fast: descriptor %d needs Cin %% 32 == 0 and 16-byte aligned operands (Cin=%d)", i, d.cin);
+        const int ho = out_dim(d.hin, d.ksize, d.stride, d.pad), wo = out_dim(d.win, d.ksize, d.stride, d.pad);
+        const int K = d.ksize * d.ksize * d.cin, rows = cdiv(d.cout, 32) * 32;
+        const long long span_a = ((long long)batch * d.hin * d.win * d.cin + (long long)(d.ksize + d.pad) * ((long long)d.win + 1) * d.cin) * 4;
+        SSDK_REQUIRE(span_a < (1LL << 31) - 4096 && (long long)rows * K * 2 < (1LL << 31) - 4096, SSDK_E_UNSUPPORTED,
+                     "ssdk_conv2d_fwd_fast: descriptor %d too large for 32-bit buffer offsets", i);
+        ConvProblem g{};
+        g.a = d.x; g.a_bstride = (long long)d.hin * d.win * d.cin; g.a_pstride = d.cin; g.Cc = d.cin;
+        g.B = batch; g.Hout = ho; g.Wout = wo; g.Hin = d.hin; g.Win = d.win; g.ksize = d.ksize; g.stride = d.stride; g.pad = d.pad;
+        g.w0 = d.w; g.w1 = nullptr; g.bias0 = d.bias; g.bias1 = nullptr; g.n0 = d.cout; g.n1 = 0;
+        g.o0 = d.y; g.ob0 = (long long)ho * wo * d.cout; g.os0 = d.cout; g.o1 = nullptr; g.ob1 = 0; g.os1 = 0;
+        g.relu = d.relu;
+        finish_problem(g);
+        probs[i] = g;
+        int same = -1;   // a tower layer's weights are shared by all pyramid levels: split them once
+        for (int j = 0; j < i && same < 0; ++j)
+            if (descs[j].w == d.w && descs[j].cout == d.cout && descs[j].cin == d.cin && descs[j].ksize == d.ksize) same = j;
+        if (same >= 0) { fps[i] = fps[same]; continue; }
+        __bf16* hi = c.take<__bf16>((size_t)rows * K);
+        __bf16* mid = c.take<__bf16>((size_t)rows * K);
+        fps[i].w_hi = hi; fps[i].w_mid = mid; fps[i].w_bytes = (unsigned)((size_t)rows * K * 2);
+        SplitJob& J = sg.j[sg.count++];
+        J.w0 = d.w; J.w1 = nullptr; J.n0 = d.cout; J.n1 = 0; J.n_rows = rows; J.K = K; J.hi = hi; J.mid = mid;
+        J.block_begin = split_blocks;
+        split_blocks += (int)(((long long)rows * K / 4 + 255) / 256);
+    }
+    hipLaunchKernelGGL(split_weights_kernel, dim3(split_blocks), dim3(256), 0, s, sg);
+    SSDK_CHECK_LAUNCH("split_weights_kernel");
+    int order[kMaxProblems];
+    for (int i = 0; i < n; ++i) order[i] = i;
+    for (int i = 0; i < n; ++i)
+        for (int j = i + 1; j < n; ++j)
+            if (problem_block_work(probs[order[j]]) > problem_block_work(probs[order[i]])) { int t = order[i]; order[i] = order[j]; order[j] = t; }
+    ConvGroup grp;
+    FastGroup fg;
+    int begin = 0;
+    for (int i = 0; i < n; ++i) {
+        ConvProblem& g = probs[order[i]];
+        g.block_begin = begin;
+        begin += cdiv(g.m_tiles, 8) * 8 * g.n_blocks;
+        grp.p[i] = g;
+        fg.p[i] = fps[order[i]];
+    }
+    grp.count = n;
+    grp.total_blocks = begin;
+    grp.vtab = nullptr;
+    hipLaunchKernelGGL(igemm_bf16x3_kernel, dim3(begin), dim3(kConvThreads), 0, s, grp, fg);
+    SSDK_CHECK_LAUNCH("igemm_bf16x3_kernel");
+    for (int i = 0; i < n; ++i) {   // BatchNorm statistics of the outputs (ssdk_conv_desc::stats): a pass of their own, as after a split-K launch
+        const ssdk_conv_desc& d = descs[i];
+        if (!d.stats) continue;
+        SSDK_REQUIRE(d.cout % 4 == 0 && ((uintptr_t)d.y & 15) == 0, SSDK_E_UNSUPPORTED, "ssdk_conv2d_fwd_fast: stats need cout %% 4 == 0 and a 16-byte aligned output");
+        const long long rows = (long long)batch * out_dim(d.hin, d.ksize, d.stride, d.pad) * out_dim(d.win, d.ksize, d.stride, d.pad);
+        const int rc = ssdk_batchnorm_stats_accumulate(d.y, rows, d.cout, d.stats, stream);
+        if (rc) return rc;
+    }
+    return SSDK_OK;
+}
+
 struct HeadsBwdWs {
     float* dyp[kMaxProblems];
     float* wd[kMaxProblems];

@@ -10,18 +10,16 @@ from ... import _lib
 from ...distributed import grad_sink
 
 
-_fast_mode = (__import__('os').environ.get('SSDK_FAST_MODE') or None)
-
-
 def set_fast_mode(mode):
-    """Opt-in reduced-precision mode of the forward head GEMMs (the reference's analogue: apex AMP O1, bf/training/env.py:87-95).
+    """Opt-in reduced-precision mode of the forward GEMMs (the reference's analogue: apex AMP O1, bf/training/env.py:87-95).
     ``None`` (default): exact fp32 on v_mfma_f32_32x32x2_f32.  ``'bf16x3'``: operands split into bf16 pieces, three cross terms per product
-    on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (ssdk_heads_fwd_fast) -- logits within ~1e-5 of their scale; the backward pass
-    is unchanged.  Every level needs Cin % 32 == 0 (the call raises otherwise: no silent fallback).  Returns the previous setting."""
-    global _fast_mode
+    on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- the head GEMM (ssdk_heads_fwd_fast) and every ``ops.conv2d`` whose input has
+    Cin % 32 == 0 (ssdk_conv2d_fwd_fast: RetinaNet's towers, the pyramid tail); outputs within ~1e-5 of their scale; the backward pass is
+    unchanged.  The heads need Cin % 32 == 0 on every level (the call raises otherwise); other convolutions stay fp32 where it does not
+    hold.  Returns the previous setting."""
     if mode not in (None, 'bf16x3'):
         raise ValueError(f'fast mode {mode!r}: None or "bf16x3"')
-    prev, _fast_mode = _fast_mode, mode
+    prev, _lib.fast_mode = _lib.fast_mode, mode
     return prev
 
 
@@ -86,7 +84,7 @@ class _HeadsFn(torch.autograd.Function):
         scores = torch.empty((B, s_off), dtype=torch.float32, device=dev)
         locs = torch.empty((B, l_off), dtype=torch.float32, device=dev)
         arr = _HeadsFn._level_array(levels)
-        if _fast_mode == 'bf16x3':
+        if _lib.fast_mode == 'bf16x3':
             need = lib.ssdk_heads_fwd_fast_workspace_bytes(arr, L)
             ws = _lib.scratch(need, dev, 'heads_fwd_fast')
             _lib.check(lib.ssdk_heads_fwd_fast(arr, L, B, _dp(scores), s_off, _dp(locs), l_off, 3, _dp(ws), ws.numel(), _lib.current_stream()),

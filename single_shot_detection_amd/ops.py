@@ -47,8 +47,12 @@ class _ConvFn(torch.autograd.Function):
             d.w, d.bias, d.cout, d.ksize, d.stride, d.pad, d.relu = _dp(w), _dp(b), cout, k, stride, pad, int(bool(relu))
             d.y = _dp(y)
             d.stats = None if stats is None else stats[i]
-        sk = _lib.scratch(lib.ssdk_heads_fwd_workspace_bytes(), xs[0].device, _lib.STREAMK_TAG, zeroed=True)   # (the stream-K state the heads use too)
-        _lib.check(lib.ssdk_conv2d_fwd_ws(arr, len(xs), B, _dp(sk), sk.numel(), _lib.current_stream()), 'ssdk_conv2d_fwd')
+        if _lib.fast_mode == 'bf16x3' and cin % 32 == 0:   # opt-in split-bf16 forward (heads.set_fast_mode); the backward below is unchanged
+            fw = _lib.scratch(lib.ssdk_conv2d_fwd_fast_workspace_bytes(arr, len(xs)), xs[0].device, 'conv_fwd_fast')
+            _lib.check(lib.ssdk_conv2d_fwd_fast(arr, len(xs), B, 3, _dp(fw), fw.numel(), _lib.current_stream()), 'ssdk_conv2d_fwd_fast')
+        else:
+            sk = _lib.scratch(lib.ssdk_heads_fwd_workspace_bytes(), xs[0].device, _lib.STREAMK_TAG, zeroed=True)   # (the stream-K state the heads use too)
+            _lib.check(lib.ssdk_conv2d_fwd_ws(arr, len(xs), B, _dp(sk), sk.numel(), _lib.current_stream()), 'ssdk_conv2d_fwd')
         ctx.w_t = _transposed_weights_of(weight, stride)   # (prepare_weight_transposes ran for this step: the backward skips its re-layout)
         ctx.save_for_backward(w, *xs, *(ys if relu == 1 else []))
         # relu == 2: ReLU in the forward epilogue as usual, but its gradient is taken by the consumer (a BatchNorm that masks its dx where

@@ -312,3 +312,67 @@ def test_fast_mode_refuses_channel_counts_it_cannot_take():
         heads_mod.set_fast_mode(prev)
     with pytest.raises(ValueError):
         heads_mod.set_fast_mode('fp8')
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,pad,relu,sizes', [
+    (256, 256, 3, 1, 1, True, (32, 16, 8)),     # a RetinaNet tower layer: one weight tensor over several pyramid levels
+    (1024, 256, 1, 1, 0, True, (19,)),          # the SSD tail's 1 x 1
+    (256, 512, 3, 2, 1, False, (19,)),          # ... and its strided 3 x 3
+    (64, 40, 3, 1, 1, False, (7,)),             # Cout not a multiple of 32
+])
+def test_fast_mode_bf16x3_generic_convolutions_vs_fp32(cin, cout, k, stride, pad, relu, sizes):
+    """ops.conv2d in the opt-in split-bf16 mode (ssdk_conv2d_fwd_fast) against the fp32 kernel and torch's CPU convolution: within 1e-4
+    of the output's scale; the backward pass (fp32, unchanged) gives the same gradients for the same upstream gradient."""
+    from single_shot_detection_amd import ops
+    from single_shot_detection_amd.detection.modules import heads as heads_mod
+    torch.manual_seed(5)
+    w = (torch.randn((cout, cin, k, k), device='cuda') * 0.03).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    b = (torch.randn((cout,), device='cuda') * 0.1).requires_grad_(True)
+    xs = [torch.randn((2, cin, h, h), device='cuda').contiguous(memory_format=torch.channels_last).requires_grad_(True) for h in sizes]
+    y32 = ops.conv2d(xs, w, b, stride, pad, relu=relu)
+    prev = heads_mod.set_fast_mode('bf16x3')
+    try:
+        yf = ops.conv2d(xs, w, b, stride, pad, relu=relu)
+    finally:
+        heads_mod.set_fast_mode(prev)
+    differs = False
+    for a, r, x in zip(yf, y32, xs):
+        a, r = a.detach(), r.detach()
+        scale = float(r.abs().max())
+        assert float((a - r).abs().max()) <= 1e-4 * scale, (float((a - r).abs().max()), scale)
+        differs = differs or float((a - r).abs().max()) > 0.0
+        ref = F.conv2d(x.detach().cpu(), w.detach().cpu().contiguous(), b.detach().cpu(), stride=stride, padding=pad)
+        ref = F.relu(ref) if relu else ref
+        assert float((a.cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    assert differs   # (it IS another arithmetic)
+    if relu:   # (an output within rounding of zero may be masked in one arithmetic and not in the other: one such element is |g x| of a
+        return  # weight gradient -- seen: 6.3 on a scale of 180 -- so the fp32 backward is compared where there is no mask)
+    gs = [torch.randn_like(r) for r in y32]
+    g32 = torch.autograd.grad([r for r in y32], [w, b] + xs, gs)
+    gf = torch.autograd.grad([a for a in yf], [w, b] + xs, gs)
+    for a, r in zip(gf, g32):
+        assert float((a - r).abs().max()) <= 1e-4 * float(r.abs().max()) + 1e-6, (float((a - r).abs().max()), float(r.abs().max()))
+
+
+def test_fast_mode_conv_batch_norm_block_trains_like_fp32():
+    """Conv2dBn (conv -> BatchNorm statistics -> apply -> ReLU) with the convolution in the split-bf16 mode: output, running statistics
+    and num_batches_tracked of a train() step next to the fp32 block's."""
+    import copy
+    from single_shot_detection_amd.bf.modules.conv import Conv2dBn
+    from single_shot_detection_amd.detection.modules import heads as heads_mod
+    torch.manual_seed(7)
+    blk = Conv2dBn(128, 64, kernel_size=3, padding=1, bias=False).cuda().to(memory_format=torch.channels_last).train()
+    blk_f = copy.deepcopy(blk)
+    x = torch.randn((4, 128, 10, 10), device='cuda').contiguous(memory_format=torch.channels_last)
+    y32 = blk(x)
+    prev = heads_mod.set_fast_mode('bf16x3')
+    try:
+        yf = blk_f(x)
+    finally:
+        heads_mod.set_fast_mode(prev)
+    assert float((yf.detach() - y32.detach()).abs().max()) <= 1e-4 * float(y32.detach().abs().max())
+    bn32 = [m for m in blk.modules() if isinstance(m, torch.nn.BatchNorm2d)][0]
+    bnf = [m for m in blk_f.modules() if isinstance(m, torch.nn.BatchNorm2d)][0]
+    assert int(bnf.num_batches_tracked) == int(bn32.num_batches_tracked) == 1
+    assert float((bnf.running_mean - bn32.running_mean).abs().max()) <= 1e-5
+    assert float((bnf.running_var - bn32.running_var).abs().max()) <= 1e-5 * float(bn32.running_var.abs().max())
