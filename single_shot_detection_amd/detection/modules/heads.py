@@ -23,6 +23,12 @@ def set_fast_mode(mode):
     return prev
 
 
+# Measurement hook (bench.py): a list that receives one (start, end) pair of torch.cuda.Event per head GEMM launch, recorded on the launch
+# stream immediately around the library call -- an interval taken around multi_level_heads() also holds this module's host-side
+# preparation whenever the GPU is waiting for the host at that point.  None: nothing is recorded.
+launch_events = None
+
+
 def to_nhwc(x):
     """[B,C,H,W] tensor whose memory is NHWC (zero-copy when the producer already runs channels_last)."""
     x = x.float()
@@ -84,6 +90,10 @@ class _HeadsFn(torch.autograd.Function):
         scores = torch.empty((B, s_off), dtype=torch.float32, device=dev)
         locs = torch.empty((B, l_off), dtype=torch.float32, device=dev)
         arr = _HeadsFn._level_array(levels)
+        events = launch_events
+        if events is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         if _lib.fast_mode == 'bf16x3':
             need = lib.ssdk_heads_fwd_fast_workspace_bytes(arr, L)
             ws = _lib.scratch(need, dev, 'heads_fwd_fast')
@@ -92,6 +102,10 @@ class _HeadsFn(torch.autograd.Function):
         else:
             sk = _lib.scratch(lib.ssdk_heads_fwd_workspace_bytes(), dev, _lib.STREAMK_TAG, zeroed=True)   # (state kept by the library between calls)
             _lib.check(lib.ssdk_heads_fwd(arr, L, B, _dp(scores), s_off, _dp(locs), l_off, _dp(sk), sk.numel(), _lib.current_stream()), 'ssdk_heads_fwd')
+        if events is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            events.append((e0, e1))
         # tensors go through save_for_backward (autograd's version counters then catch an in-place edit of a tapped source map
         # between forward and backward, as they do for torch's own conv); ctx keeps only shapes and offsets
         for lv in levels:
