@@ -61,3 +61,15 @@ def _streamk_waits_never_ran_out(request):
         return
     from single_shot_detection_amd import _lib
     assert _lib.streamk_timeouts() == 0, 'a stream-K fix-up wait timed out during this test'
+
+
+@pytest.fixture(autouse=True)
+def _process_wide_switches_do_not_leak():
+    """bench.HotPath switches ops.defer_weight_gradients on for its step (process-wide, as documented) and tests construct HotPaths: every
+    test starts from the library's defaults -- deferral off, fast mode off -- whatever ran before it."""
+    from single_shot_detection_amd import _lib, ops
+    ops.defer_weight_gradients(False)
+    _lib.fast_mode = None
+    yield
+    ops.defer_weight_gradients(False)
+    _lib.fast_mode = None
