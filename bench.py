@@ -74,6 +74,22 @@ def head_flops_per_image(levels, C):
     return sum(2.0 * h * h * 9 * cin * nb * (C + 4) for cin, h, nb in levels)
 
 
+def head_gemm_time(hp):
+    """(ms per step, algorithmic FLOPs per image) of the head GEMM launches the heads module timed inside the steps (heads.launch_events).
+    One grouped launch per step, or -- with the dependency split (HotPath.overlap) -- the DOMINANT one: the levels taken from the
+    backbone, on the main stream; the tail levels' small launch runs beside it on the second stream and is not added."""
+    per_launch = {}
+    for a, b, lv in hp.fwd_events:
+        per_launch.setdefault(lv, []).append(a.elapsed_time(b))
+    if not per_launch:
+        return float('nan'), 0.0
+    flops = {lv: sum(2.0 * h * w * 9 * cin * n for h, w, cin, n in lv) for lv in per_launch}
+    if hp.overlap:
+        lv = max(flops, key=flops.get)
+        return float(np.sum(per_launch[lv])) / max(hp.fwd_steps, 1), flops[lv]
+    return float(np.sum([t for ts in per_launch.values() for t in ts])) / max(hp.fwd_steps, 1), sum(flops.values())
+
+
 class HotPath(object):
     def __init__(self, cfg_name, batch, device, seed=23):
         from single_shot_detection_amd.detection import detector_builder, anchor_generators, sampler
@@ -150,6 +166,16 @@ class HotPath(object):
         self.bucket_rest = GradBucket(self.rest_params).attach_(device) if self.rest_params else None
         self.fwd_events = []
         self.fwd_steps = 0
+        # dependency split (SSD configs): the heads of the backbone taps on the current stream, the pyramid tail and its levels' heads on a
+        # second one -- forward and, through autograd's per-node streams, backward (detection/modules/heads.py multi_level_heads_split)
+        # OFF by default: measured on MI355X (tools/overlap_probe.py, profiles/r04_overlap_*): replayed from a HIP graph the split step is
+        # 1.5 % faster (3.20 -> 3.15 ms), enqueued eagerly it is 2 % slower (more autograd nodes, events and a second queue on the host)
+        self.overlap = self.extras is not None and self.tower is None and self.neck is None and bool(os.environ.get('SSDK_OVERLAP'))
+        self.side = None
+        self.main_workgroups = int(os.environ.get('SSDK_MAIN_WGS', '0'))
+        self.side_workgroups = int(os.environ.get('SSDK_SIDE_WGS', '0'))
+        self.one_launch = not os.environ.get('SSDK_SPLIT_FORWARD')        # forward GEMM: all levels in one grouped launch (only the backward is split)
+        self.ordered_backward = bool(os.environ.get('SSDK_ORDERED_BACKWARD'))
 
     def pyramid(self):
         sources = list(self.inputs)
@@ -168,6 +194,8 @@ class HotPath(object):
 
     def forward_heads(self, timed=False):
         from single_shot_detection_amd.detection.modules.heads import multi_level_heads
+        if self.overlap and not getattr(self, 'two_phase', False):
+            return self.forward_heads_split(timed)
         sources = self.pyramid()
         score_sources = loc_sources = sources
         if self.tower is not None:
@@ -191,6 +219,33 @@ class HotPath(object):
             heads_mod.launch_events = None
         self.fwd_steps += 1 if timed else 0
         return out
+
+    def forward_heads_split(self, timed=False):
+        from single_shot_detection_amd import ops
+        from single_shot_detection_amd.detection.modules import heads as heads_mod
+        if self.side is None and not os.environ.get('SSDK_OVERLAP_ONE_STREAM'):
+            # (default priority: a HIGH-priority queue is served strictly first on this hardware -- the main GEMM's dispatch packet was not
+            # looked at until the whole tail chain had drained, tools/graph_branch_probe.py)
+            self.side = torch.cuda.Stream(priority=int(os.environ.get('SSDK_SIDE_PRIORITY', '0')))
+
+        def run_tail():
+            x, outs = self.inputs[-1], []
+            if self.extras.training:
+                ops.prepare_weight_transposes(self.extras)
+            for layer in self.extras:
+                x = layer(x)
+                outs.append(x)
+            return outs
+        heads_mod.launch_events = self.fwd_events if timed else None
+        try:
+            scores, locs, sources = heads_mod.multi_level_heads_split(self.inputs, self.heads, len(self.inputs), run_tail, side_stream=self.side,
+                                                                       main_workgroups=self.main_workgroups, side_workgroups=self.side_workgroups,
+                                                                       one_launch=self.one_launch, ordered_backward=self.ordered_backward)
+        finally:
+            heads_mod.launch_events = None
+        self.fwd_steps += 1 if timed else 0
+        assert [tuple(s.shape[1:3]) for s in sources] == [(c, h) for c, h, _ in self.levels], [tuple(s.shape) for s in sources]
+        return scores, locs
 
     def train_step(self, world=1, timed=False):
         self.two_phase = world > 1 or getattr(self, 'force_two_phase', False)
@@ -573,8 +628,8 @@ def per_config_legs(device, steps=4, warmup=2):
             dt = (time.perf_counter() - t0) / n
         finally:
             gc.enable()
-        fwd_ms = float(np.sum([a.elapsed_time(b) for a, b in hp.fwd_events])) / max(hp.fwd_steps, 1)
-        tf = head_flops_per_image(hp.levels, hp.C) * batch / (fwd_ms * 1e-3) / 1e12
+        fwd_ms, fl_img = head_gemm_time(hp)
+        tf = fl_img * batch / (fwd_ms * 1e-3) / 1e12
         sc, lo = hp.forward_heads()
         sc, lo = sc.detach(), lo.detach()
         us = gpu_time_us(lambda: hp.post.postprocess_padded((sc, lo), hp.anchors), inner=3, reps=3)
@@ -692,8 +747,8 @@ def main():
     value = world * args.batch * args.steps / dt
 
     # forward head GEMMs (igemm_streamk_kernel, ONE grouped launch per step) timed with events inside the timed region
-    fwd_ms = float(np.sum([a.elapsed_time(b) for a, b in hp.fwd_events])) / max(hp.fwd_steps, 1)
-    flops_step = head_flops_per_image(hp.levels, hp.C) * args.batch
+    fwd_ms, fl_img = head_gemm_time(hp)
+    flops_step = fl_img * args.batch
     achieved = flops_step / (fwd_ms * 1e-3) / 1e12
 
     # eval leg: heads forward + postprocess (NMS boxes/s = candidates entering NMS per second)

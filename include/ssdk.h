@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SSDK_VERSION 110
+#define SSDK_VERSION 111
 
 #define SSDK_OK 0
 #define SSDK_E_INVALID (-1)   /* bad argument / shape */
@@ -255,6 +255,13 @@ size_t ssdk_heads_fwd_workspace_bytes(void);
 int ssdk_heads_fwd_timeouts(const void* workspace, size_t workspace_bytes, void* stream, unsigned* timeouts_host);
 int ssdk_heads_fwd(const ssdk_head_level* levels, int n_levels, int batch, float* scores, long long scores_batch_stride,
                    float* locs, long long locs_batch_stride, void* workspace, size_t workspace_bytes, void* stream);
+/* The same with a cap on the persistent workgroups of the stream-K form (0 = the library's choice: 512 = every 64 KB LDS slot of the
+ * chip; otherwise rounded down to a multiple of 8, at least 256): a caller that runs the levels taken from the backbone
+ * (detection/detector.py:36-38) on one stream and the pyramid tail (detector.py:39-43) with its levels' heads on another leaves the
+ * tail's kernels room beside this launch.  Several calls may fill disjoint level slices of the same scores / locs rows concurrently
+ * on different streams, each with its own workspace. */
+int ssdk_heads_fwd_ex(const ssdk_head_level* levels, int n_levels, int batch, float* scores, long long scores_batch_stride,
+                      float* locs, long long locs_batch_stride, int max_workgroups, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * FAST MODE of ssdk_heads_fwd (opt-in, never the default): the role of apex AMP O1 in the reference (bf/training/env.py:87-95 runs these

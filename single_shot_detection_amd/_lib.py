@@ -58,6 +58,8 @@ _SIGNATURES = {
                                   C.c_void_p]),
     'ssdk_heads_fwd_workspace_bytes': (C.c_size_t, []),
     'ssdk_heads_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'ssdk_heads_fwd_ex': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_size_t,
+                                    C.c_void_p]),
     'ssdk_heads_fwd_fast_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int]),
     'ssdk_heads_fwd_fast': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_size_t,
                                       C.c_void_p]),

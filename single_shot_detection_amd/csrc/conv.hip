@@ -2401,6 +2401,13 @@ extern "C" size_t ssdk_heads_fwd_workspace_bytes(void) {
 extern "C" int ssdk_heads_fwd(const ssdk_head_level* levels, int n_levels, int batch, float* scores,
                               long long scores_batch_stride, float* locs, long long locs_batch_stride, void* workspace,
                               size_t workspace_bytes, void* stream) {
+    return ssdk_heads_fwd_ex(levels, n_levels, batch, scores, scores_batch_stride, locs, locs_batch_stride, 0, workspace, workspace_bytes, stream);
+}
+
+extern "C" int ssdk_heads_fwd_ex(const ssdk_head_level* levels, int n_levels, int batch, float* scores,
+                                 long long scores_batch_stride, float* locs, long long locs_batch_stride, int max_workgroups,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    SSDK_REQUIRE(max_workgroups >= 0, SSDK_E_INVALID, "ssdk_heads_fwd_ex: max_workgroups=%d", max_workgroups);
     SSDK_REQUIRE(levels && n_levels > 0 && n_levels <= kMaxProblems, SSDK_E_INVALID, "ssdk_heads_fwd: n_levels=%d (1..%d)", n_levels, kMaxProblems);
     SSDK_REQUIRE(scores, SSDK_E_INVALID, "ssdk_heads_fwd: null scores");
     SSDK_REQUIRE(!g_sk_host_err || *static_cast<volatile unsigned*>(g_sk_host_err) == 0u, SSDK_E_STREAMK_TIMEOUT,
@@ -2471,6 +2478,9 @@ extern "C" int ssdk_heads_fwd(const ssdk_head_level* levels, int n_levels, int b
         sk.partial = c.take<float>((size_t)(kStreamKWgs + 1) * (4 * kMaxTN * 4 * 64 * 4));
         sk.flags = c.take<unsigned>((size_t)kStreamKWgs + 2);
         sk.nwg = kStreamKWgs;
+        // a caller that runs other kernels BESIDE this launch (the pyramid tail on a second stream) leaves them LDS slots: the persistent
+        // workgroups of the stream-K form otherwise hold every slot of the chip until the launch ends
+        if (max_workgroups > 0) sk.nwg = std::max(kStreamKMinWgs, std::min(kStreamKWgs, max_workgroups / 8 * 8));
     }
     return launch_group(probs, n_levels, false, (hipStream_t)stream, false, false, nullptr, sk.nwg ? &sk : nullptr);
 }

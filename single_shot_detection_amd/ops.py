@@ -215,6 +215,7 @@ def _queue_deferred_wgrad(job):
     if any(j['task'] != task for j in _pending_wgrads):
         _pending_wgrads[:] = [j for j in _pending_wgrads if j['task'] == task]
     job['task'] = task
+    job['stream'] = torch.cuda.current_stream()   # (the node's stream: x and dy are complete there, the flush enqueues behind them)
     _pending_wgrads.append(job)
     if _flush_queued_for != task:
         _flush_queued_for = task
@@ -356,6 +357,25 @@ def _flush_weight_gradients():
     _flush_queued_for = None
     if not jobs:
         return
+    # jobs queued by nodes of another stream (a pyramid tail differentiated beside the heads: detection/modules/heads.py
+    # multi_level_heads_split) are flushed on THAT stream, behind the launches that made their operands, and the caller's stream --
+    # on which the optimizer runs next -- waits for it
+    caller = torch.cuda.current_stream()
+    streams = []
+    for j in jobs:
+        if all(j['stream'] != s_ for s_ in streams):
+            streams.append(j['stream'])
+    for s_ in streams:
+        mine = [j for j in jobs if j['stream'] == s_]
+        if s_ == caller:
+            _flush_jobs(mine)
+        else:
+            with torch.cuda.stream(s_):
+                _flush_jobs(mine)
+            caller.wait_stream(s_)
+
+
+def _flush_jobs(jobs):
     lib = _lib.lib()
     stream = _lib.current_stream()
     for first in range(0, len(jobs), 8):

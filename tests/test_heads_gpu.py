@@ -376,3 +376,115 @@ def test_fast_mode_conv_batch_norm_block_trains_like_fp32():
     assert int(bnf.num_batches_tracked) == int(bn32.num_batches_tracked) == 1
     assert float((bnf.running_mean - bn32.running_mean).abs().max()) <= 1e-5
     assert float((bnf.running_var - bn32.running_var).abs().max()) <= 1e-5 * float(bn32.running_var.abs().max())
+
+
+def _cpu_heads(xs_cpu, heads_cpu):
+    """detection/detector.py:50-66 on torch's fp32 CPU convolution for a (sub-)batch: (scores, locs) rows."""
+    B = xs_cpu[0].shape[0]
+    sc, lo = [], []
+    for x, (ws, bs, wl, bl) in zip(xs_cpu, heads_cpu):
+        sc.append(F.conv2d(x, ws, bs, padding=1).permute(0, 2, 3, 1).reshape(B, -1))
+        lo.append(F.conv2d(x, wl, bl, padding=1).permute(0, 2, 3, 1).reshape(B, -1))
+    return torch.cat(sc, 1), torch.cat(lo, 1)
+
+
+@pytest.mark.parametrize('cfg_name,batch', [('ssd_300_vgg16_voc', 32), ('ssd_300_vgg16_voc', 64), ('ssd_512_vgg16_coco', 16),
+                                            ('m2det_512_vgg16_coco', 16)])
+def test_headline_launch_elementwise_vs_torch_cpu(cfg_name, batch):
+    """The EXACT launches bench.py times (BASELINE.json's batch sizes: the stream-K range cuts, `parts` and the XCD remapping of
+    igemm_streamk_kernel depend on the batch), checked element by element: images are independent, so torch's fp32 CPU convolution of
+    images {0, B/2, B-1} pins those rows of scores / locs (2e-6 * sqrt(K), K = 9 Cin), and -- for a hard-negative-mining-like sampled
+    gradient over the WHOLE batch (the anchor-granular backward the step runs) -- their rows of dx.  dw / db add over images (the
+    heads are bilinear): a second backward with the gradient confined to the three images is compared with the CPU's sum over them."""
+    from single_shot_detection_amd import synthetic as syn
+    from single_shot_detection_amd import _lib
+    cfg = syn.CONFIGS[cfg_name]
+    levels, C = cfg['levels'], cfg['num_classes']
+    torch.manual_seed(29)
+    heads = detector_builder.get_heads([l[0] for l in levels], [l[2] for l in levels], C).cuda()
+    with torch.no_grad():
+        for p in heads.parameters():
+            p.copy_(torch.randn_like(p) * (0.02 if p.dim() > 1 else 0.1))
+    xs = [torch.randn((batch, cin, h, h), device='cuda').contiguous(memory_format=torch.channels_last).requires_grad_(True) for cin, h, _ in levels]
+    picks = [0, batch // 2, batch - 1]
+    scores, locs = multi_level_heads(xs, xs, heads)
+    A = scores.shape[1] // C
+    # the reference on the three images
+    xs_cpu = [x.detach()[picks].cpu().contiguous().requires_grad_(True) for x in xs]
+    heads_cpu = [tuple(t.detach().cpu().contiguous().requires_grad_(True) for t in (h['score'].weight, h['score'].bias, h['loc'].weight, h['loc'].bias))
+                 for h in heads]
+    sc_ref, lo_ref = _cpu_heads(xs_cpu, heads_cpu)
+    tol = 2e-6 * np.sqrt(9 * max(l[0] for l in levels))
+    np.testing.assert_allclose(scores.detach()[picks].cpu().numpy(), sc_ref.detach().numpy(), rtol=1e-5, atol=tol)
+    np.testing.assert_allclose(locs.detach()[picks].cpu().numpy(), lo_ref.detach().numpy(), rtol=1e-5, atol=tol)
+    # sampled gradient, every image: ~4 % of the anchors carry one (all their classes + their box)
+    keep = (torch.rand((batch, A, 1), device='cuda') < 0.04).float()
+    gs = (torch.randn_like(scores).view(batch, A, C) * keep).view(batch, -1)
+    gl = (torch.randn_like(locs).view(batch, A, 4) * keep).view(batch, -1)
+    torch.autograd.backward([scores, locs], [gs, gl], retain_graph=True)
+    torch.autograd.backward([sc_ref, lo_ref], [gs[picks].cpu(), gl[picks].cpu()])
+    for i in range(len(levels)):
+        ref = xs_cpu[i].grad.numpy()
+        scale = float(np.abs(ref).max())
+        np.testing.assert_allclose(xs[i].grad[picks].cpu().numpy(), ref, rtol=1e-4, atol=2e-5 * scale + 1e-6, err_msg=f'dx level {i}')
+    # dw / db: the same gradient confined to the three images
+    for p in heads.parameters():
+        p.grad = None
+    only = torch.zeros((batch, 1), device='cuda')
+    only[picks] = 1.0
+    torch.autograd.backward([scores, locs], [gs * only, gl * only])
+    for i, (h, hc) in enumerate(zip(heads, heads_cpu)):
+        for name, t, r in (('score.weight', h['score'].weight, hc[0]), ('score.bias', h['score'].bias, hc[1]),
+                           ('loc.weight', h['loc'].weight, hc[2]), ('loc.bias', h['loc'].bias, hc[3])):
+            ref = r.grad.numpy()
+            scale = float(np.abs(ref).max()) + 1e-12
+            np.testing.assert_allclose(t.grad.cpu().numpy(), ref, rtol=1e-4, atol=2e-5 * scale + 1e-6, err_msg=f'level {i} {name}')
+    assert _lib.streamk_timeouts() == 0
+
+
+@pytest.mark.parametrize('cfg_name,batch,side,main_wgs,one_launch,ordered', [
+    ('ssd_300_vgg16_voc', 32, True, 448, False, False), ('ssd_300_vgg16_voc', 32, False, 0, False, False),
+    ('ssd_300_vgg16_voc', 4, True, 0, False, True), ('ssd_512_vgg16_coco', 16, True, 480, False, False),
+    ('ssd_300_vgg16_voc', 32, True, 0, True, False), ('ssd_300_vgg16_voc', 32, True, 0, True, True), ('ssd_512_vgg16_coco', 16, False, 0, True, False)])
+def test_split_heads_match_the_single_launch(cfg_name, batch, side, main_wgs, one_launch, ordered):
+    """multi_level_heads_split (two autograd nodes: the backbone-tap levels on the current stream, the tail's levels on a second one, a
+    join that hands the loss' gradient rows to both) against multi_level_heads on the same inputs: same scores / locs rows and the
+    same gradients up to the order of the fp32 sums (the stream-K ranges of the two part launches are cut elsewhere)."""
+    from single_shot_detection_amd import synthetic as syn
+    from single_shot_detection_amd import _lib
+    from single_shot_detection_amd.detection.modules.heads import multi_level_heads_split
+    cfg = syn.CONFIGS[cfg_name]
+    levels, C = cfg['levels'], cfg['num_classes']
+    torch.manual_seed(31)
+    heads = detector_builder.get_heads([l[0] for l in levels], [l[2] for l in levels], C).cuda()
+    with torch.no_grad():
+        for p in heads.parameters():
+            p.copy_(torch.randn_like(p) * (0.02 if p.dim() > 1 else 0.1))
+    xs = [torch.randn((batch, cin, h, h), device='cuda').contiguous(memory_format=torch.channels_last).requires_grad_(True) for cin, h, _ in levels]
+    s0, l0 = multi_level_heads(xs, xs, heads)
+    A = s0.shape[1] // C
+    keep = (torch.rand((batch, A, 1), device='cuda') < 0.04).float()
+    gs = (torch.randn_like(s0).view(batch, A, C) * keep).view(batch, -1)
+    gl = (torch.randn_like(l0).view(batch, A, 4) * keep).view(batch, -1)
+    params = list(heads.parameters())
+    g0 = torch.autograd.grad([s0, l0], xs + params, [gs, gl])
+    stream = torch.cuda.Stream(priority=-1) if side else None
+    # the "tail" of this test: a scaled copy made on the side stream, so that the levels behind the split are produced there
+    xs2 = [x.detach().clone().requires_grad_(True) for x in xs]
+
+    def run_tail():
+        return [x * 1.0 for x in xs2[2:]]
+    s1, l1, srcs = multi_level_heads_split(xs2[:2], heads, 2, run_tail, side_stream=stream, main_workgroups=main_wgs, one_launch=one_launch,
+                                           ordered_backward=ordered)
+    if one_launch:   # (the same grouped launch as multi_level_heads: the same bits)
+        assert torch.equal(s1.detach(), s0.detach()) and torch.equal(l1.detach(), l0.detach())
+    assert len(srcs) == len(levels)
+    tol = 2e-6 * np.sqrt(9 * max(l[0] for l in levels))
+    np.testing.assert_allclose(s1.detach().cpu().numpy(), s0.detach().cpu().numpy(), rtol=1e-5, atol=tol)
+    np.testing.assert_allclose(l1.detach().cpu().numpy(), l0.detach().cpu().numpy(), rtol=1e-5, atol=tol)
+    g1 = torch.autograd.grad([s1, l1], xs2 + params, [gs, gl])
+    torch.cuda.synchronize()
+    for a, b in zip(g1, g0):
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-6, (tuple(b.shape), float((a - b).abs().max()), scale)
+    assert _lib.streamk_timeouts() == 0
