@@ -98,8 +98,9 @@ class HotPath(object):
         from single_shot_detection_amd.detection.postprocessor import Postprocessor
         from single_shot_detection_amd.detection.target_assigner import TargetAssigner
         import functools
-        from single_shot_detection_amd import ops
-        ops.defer_weight_gradients(True)   # the pyramid tail's weight gradients: one grouped launch at the end of the backward pass
+        # the pyramid tail's weight gradients in one grouped launch at the end of the backward pass: scoped to train_step (the switch is
+        # process-wide and changes what torch.autograd.grad returns for a convolution weight)
+        self.defer_weight_gradients = True
         self.cfg = cfg = syn.CONFIGS[cfg_name]
         self.batch, self.device = batch, device
         self.levels, self.C = cfg['levels'], cfg['num_classes']
@@ -248,6 +249,11 @@ class HotPath(object):
         return scores, locs
 
     def train_step(self, world=1, timed=False):
+        from single_shot_detection_amd import ops
+        with ops.deferred_weight_gradients(self.defer_weight_gradients):
+            return self._train_step(world, timed)
+
+    def _train_step(self, world=1, timed=False):
         self.two_phase = world > 1 or getattr(self, 'force_two_phase', False)
         self.opt.zero_grad(set_to_none=True)   # (shared parameters: also clears the gradients the split optimizers see)
         for s in self.inputs:
@@ -509,20 +515,16 @@ def fast_mode_legs(device, cfg_name='ssd_300_vgg16_voc', batch=32, steps=10):
         srcs = [t.detach() for t in hp.pyramid()]
         us32 = gpu_time_us(lambda: multi_level_heads(srcs, srcs, hp.heads), inner=5)
         s32, l32 = multi_level_heads(srcs, srcs, hp.heads)
-        prev = heads_mod.set_fast_mode('bf16x3')
-        try:
+        with heads_mod.fast_mode('bf16x3'):
             usf = gpu_time_us(lambda: multi_level_heads(srcs, srcs, hp.heads), inner=5)
             sf, lf = multi_level_heads(srcs, srcs, hp.heads)
-        finally:
-            heads_mod.set_fast_mode(prev)
     err_s = float((sf - s32).abs().max()) / float(s32.abs().max())
     err_l = float((lf - l32).abs().max()) / float(l32.abs().max())
     losses = []
     for sc, lo in ((s32, l32), (sf, lf)):
         target = hp.assigner.encode_ground_truth(hp.gt, hp.anchors)
         losses.append(float(hp.criterion((sc, lo), hp.anchors, target)[0]))
-    prev = heads_mod.set_fast_mode('bf16x3')
-    try:
+    with heads_mod.fast_mode('bf16x3'):
         for _ in range(2):
             hp.train_step()
         torch.cuda.synchronize()
@@ -531,8 +533,6 @@ def fast_mode_legs(device, cfg_name='ssd_300_vgg16_voc', batch=32, steps=10):
             hp.train_step()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
-    finally:
-        heads_mod.set_fast_mode(prev)
     flops = head_flops_per_image(hp.levels, hp.C) * batch
     tf = flops / (usf * 1e-6) / 1e12
     del hp
@@ -563,12 +563,9 @@ def fast_mode_tower_leg(device, cfg_name='retina_rn50_500_coco', batch=32):
             return multi_level_heads(ssrc, lsrc, hp.heads)
     us32 = gpu_time_us(fwd, inner=3, reps=3)
     s32, l32 = fwd()
-    prev = heads_mod.set_fast_mode('bf16x3')
-    try:
+    with heads_mod.fast_mode('bf16x3'):
         usf = gpu_time_us(fwd, inner=3, reps=3)
         sf, lf = fwd()
-    finally:
-        heads_mod.set_fast_mode(prev)
     return {'workload': f'{cfg_name} batch {batch}: towers + heads forward, evaluation mode', 'fwd_us': usf, 'fwd_fp32_us': us32,
             'speedup_vs_fp32': us32 / usf,
             'max_abs_err_over_scale': {'scores': float((sf - s32).abs().max()) / float(s32.abs().max()),

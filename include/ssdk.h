@@ -253,6 +253,15 @@ typedef struct ssdk_head_level {
  * healthy value.  (Reference: none -- torch.nn.Conv2d has no such failure mode; detection/detector.py:50-63.) */
 size_t ssdk_heads_fwd_workspace_bytes(void);
 int ssdk_heads_fwd_timeouts(const void* workspace, size_t workspace_bytes, void* stream, unsigned* timeouts_host);
+/* The sticky host word alone, without synchronising anything: 1 once any stream-K launch of this process has given up on a parked
+ * partial tile.  For callers that replay captured HIP graphs (a replay does not pass through ssdk_heads_fwd's own check): test it before
+ * every replay.  The kernel is loud on its own as well: from the first loss on, every launch on that workspace -- replayed or not --
+ * stores NaN in every tile. */
+int ssdk_streamk_poisoned(void);
+/* TEST HOOK (fault injection, process-wide, synchronises the device): the stream-K workgroup with range index `drop_workgroup` never
+ * raises its flag (-1: none), and an owner gives up after `spin_limit` polls (0: the default 2^22).  Used by
+ * tests/streamk_fault_worker.py in a child process; never by the product path. */
+int ssdk_debug_streamk_fault(int drop_workgroup, unsigned spin_limit);
 int ssdk_heads_fwd(const ssdk_head_level* levels, int n_levels, int batch, float* scores, long long scores_batch_stride,
                    float* locs, long long locs_batch_stride, void* workspace, size_t workspace_bytes, void* stream);
 /* The same with a cap on the persistent workgroups of the stream-K form (0 = the library's choice: 512 = every 64 KB LDS slot of the

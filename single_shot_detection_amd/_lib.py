@@ -66,6 +66,8 @@ _SIGNATURES = {
     'ssdk_conv2d_fwd_fast_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int]),
     'ssdk_conv2d_fwd_fast': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     'ssdk_heads_fwd_timeouts': (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    'ssdk_streamk_poisoned': (C.c_int, []),
+    'ssdk_debug_streamk_fault': (C.c_int, [C.c_int, C.c_uint]),
     'ssdk_heads_bwd_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     'ssdk_heads_bwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong,
                                  C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -258,6 +260,12 @@ def scratch(nbytes, device, tag, zeroed=False):
 
 
 STREAMK_TAG = 'heads_fwd_streamk'
+
+
+def streamk_poisoned():
+    """True once a stream-K launch of this process has given up on a parked partial tile (the sticky pinned-host word; no
+    synchronisation): every later head GEMM on that workspace, eager or replayed from a HIP graph, stores NaN."""
+    return bool(lib().ssdk_streamk_poisoned())
 
 
 def streamk_timeouts():

@@ -427,10 +427,15 @@ extern "C" int ssdk_debug_read_phase(unsigned long long* host) { return (int)hip
 // sk_mode (stream-K): 0 = a whole tile (or a split-K part `ksp`); 1 = K slices [sk_s0, sk_s1) of the tile, the accumulators are parked
 // in sk_buf and *sk_flag set to sk_epoch; 2 = K slices [sk_s0, sk_s1), then the accumulators parked by another workgroup are added
 // (once *sk_flag == sk_epoch) and the epilogue runs.
+// Test hook (ssdk_debug_streamk_fault): the stream-K workgroup whose range index equals g_sk_drop_wg never raises its "parked" flag (a
+// workgroup that never ran), and an owner gives up after g_sk_spin_limit polls instead of 2^22.  -1 / 0: off (the defaults).
+__device__ int g_sk_drop_wg = -1;
+__device__ unsigned g_sk_spin_limit = 0;
+
 template <bool MIRROR, bool GENERIC, bool SCATTER, int WAVES, int BK, int MAXTN>
 __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_tile, int n_block, int ksp, int sk_mode = 0, int sk_s0 = 0, int sk_s1 = 0,
                                          float* sk_buf = nullptr, unsigned* sk_flag = nullptr, unsigned sk_epoch = 0, unsigned* sk_timeouts = nullptr,
-                                         int sk_parts = 1, unsigned* sk_host_err = nullptr) {
+                                         int sk_parts = 1, unsigned* sk_host_err = nullptr, bool sk_poisoned = false, bool sk_drop = false) {
     PHASE(0)
     // BK = K slice: 32 floats (128-byte rows, 8 rows per DMA piece, 64 KB of LDS: 2 workgroups per CU) or 16 floats (64-byte rows,
     // 16 rows per piece, 32 KB: 3 workgroups per CU at <= 170 VGPRs, a barrier every 32 MFMAs instead of 64)
@@ -691,7 +696,7 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
                     for (int q = 0; q < 4; ++q) img[(j * 4 + q) * 64] = f32x4{acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // every wave: its stores have reached memory the other XCDs see ...
             __syncthreads();
-            if (tid == 0) __hip_atomic_store(sk_flag, sk_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // ... before the flag does
+            if (tid == 0 && !sk_drop) __hip_atomic_store(sk_flag, sk_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // ... before the flag does
             return;
         }
         // the rest of the tile was parked by the next sk_parts workgroups (one when a range is longer than a tile, several when a
@@ -701,9 +706,10 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
             if (tid == 0) {
                 unsigned spins = 0;
                 bool lost = false;
+                const unsigned limit = g_sk_spin_limit ? g_sk_spin_limit : (1u << 22);
                 while (__hip_atomic_load(sk_flag + part, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != sk_epoch) {
                     __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1u << 22)) { lost = true; break; }   // (never hangs: a lost partner costs the tile, not the GPU)
+                    if (++spins > limit) { lost = true; break; }   // (never hangs: a lost partner costs the tile, not the GPU)
                 }
                 if (lost) {
                     // LOUD: the device counter (ssdk_heads_fwd_timeouts), a sticky word in pinned host memory that makes every later
@@ -737,6 +743,16 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
             // A flag that was NOT consumed (timeout) is left alone: the late partner may still be writing it.
             if (tid == 0 && poison == poison) __hip_atomic_store(sk_flag + part, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+    if (!MIRROR && !GENERIC && !SCATTER && WAVES == 4 && sk_poisoned) {
+        // an EARLIER launch on this workspace lost a partner (igemm_streamk_kernel read the counter at entry): its flag may still be up,
+        // and a launch replayed from a HIP graph carries the same epoch -- it would add that launch's stale partial tile without
+        // noticing.  From the first loss on, every tile of every launch on the workspace is NaN.
+        const float nanv = __builtin_nanf("");
+#pragma unroll
+        for (int j = 0; j < MAXTN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = nanv;
     }
     conv_epilogue<SCATTER>(g, acc, m_base, wave, r32, h, tn, n_begin, M, N, hw, ksp, (!MIRROR && !SCATTER) ? s_a0 : nullptr, WAVES,
                            half ? tn - 1 : -1);   // (a stream-K owner too: the fix-up ends behind a barrier)
@@ -833,6 +849,10 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_streamk_k
     const long long u_end = s + 1 == sk.nwg ? sk.total_units : locate(sk.total_units * (s + 1) / sk.nwg, pj, mj, nj, sj, tj);
     float* const my_buf = sk.partial + (size_t)s * (4 * kMaxTN * 4 * 64 * 4);
     float* const next_buf = my_buf + (size_t)(4 * kMaxTN * 4 * 64 * 4);
+    // sticky: a fix-up wait of an earlier launch on this workspace ran out (see dma_tile) -- HIP-graph replays never pass through
+    // ssdk_heads_fwd's host-side check, so the kernel itself refuses to produce numbers from then on
+    const bool poisoned = __hip_atomic_load(sk.timeouts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    const bool drop = g_sk_drop_wg == s;
     while (u < u_end) {
         locate(u, pi, m_tile, n_block, slice, tn);
         const ConvProblem& g = grp.p[pi];
@@ -841,15 +861,16 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_streamk_k
         const int s1 = (int)min((long long)slices, (long long)slice + left);
         if (s1 <= slice) break;   // (cannot happen: boundaries are whole slices; a guard against walking on the spot)
         if (slice == 0 && s1 == slices) {
-            dma_tile<false, false, false, 4, kBK, kMaxTN>(g, pi, m_tile, n_block, 0);
+            dma_tile<false, false, false, 4, kBK, kMaxTN>(g, pi, m_tile, n_block, 0, 0, 0, 0, nullptr, nullptr, 0u, nullptr, 1, nullptr, poisoned);
         } else if (slice > 0) {   // second K part of a tile whose first part closes the previous workgroup's range: park the partial sums
-            dma_tile<false, false, false, 4, kBK, kMaxTN>(g, pi, m_tile, n_block, 0, 1, slice, s1, my_buf, sk.flags + s, sk.epoch, sk.timeouts);
+            dma_tile<false, false, false, 4, kBK, kMaxTN>(g, pi, m_tile, n_block, 0, 1, slice, s1, my_buf, sk.flags + s, sk.epoch, sk.timeouts, 1, nullptr,
+                                                          false, drop);
         } else {                  // first K part: the rest was computed by the following workgroup(s) right after launch
             const long long tile_end = u + (long long)slices * tn;
             int parts = 1;
             while (s + 1 + parts < sk.nwg && sk.total_units * (s + 1 + parts) / sk.nwg < tile_end) ++parts;
             dma_tile<false, false, false, 4, kBK, kMaxTN>(g, pi, m_tile, n_block, 0, 2, 0, s1, next_buf, sk.flags + s + 1, sk.epoch, sk.timeouts,
-                                                          parts, sk.host_err);
+                                                          parts, sk.host_err, poisoned);
         }
         u += (long long)(s1 - slice) * tn;
         __syncthreads();   // the next tile's first DMA overwrites LDS stage 0
@@ -2485,6 +2506,17 @@ extern "C" int ssdk_heads_fwd_ex(const ssdk_head_level* levels, int n_levels, in
     return launch_group(probs, n_levels, false, (hipStream_t)stream, false, false, nullptr, sk.nwg ? &sk : nullptr);
 }
 
+extern "C" int ssdk_streamk_poisoned(void) {
+    return (g_sk_host_err && *static_cast<volatile unsigned*>(g_sk_host_err) != 0u) ? 1 : 0;
+}
+
+extern "C" int ssdk_debug_streamk_fault(int drop_workgroup, unsigned spin_limit) {
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_sk_drop_wg), &drop_workgroup, sizeof(int));
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_sk_spin_limit), &spin_limit, sizeof(unsigned));
+    SSDK_REQUIRE(e == hipSuccess, (int)e, "ssdk_debug_streamk_fault: %s", hipGetErrorString(e));
+    return SSDK_OK;
+}
+
 extern "C" int ssdk_heads_fwd_timeouts(const void* workspace, size_t workspace_bytes, void* stream, unsigned* timeouts_host) {
     SSDK_REQUIRE(workspace && timeouts_host && workspace_bytes >= ssdk_heads_fwd_workspace_bytes(), SSDK_E_WORKSPACE,
                  "ssdk_heads_fwd_timeouts: workspace of ssdk_heads_fwd_workspace_bytes() bytes and a host word are required");
@@ -2993,6 +3025,9 @@ extern "C" int ssdk_conv2d_fwd_ws(const ssdk_conv_desc* descs, int n, int batch,
         g.w0 = d.w; g.w1 = nullptr; g.bias0 = d.bias; g.bias1 = nullptr; g.n0 = d.cout; g.n1 = 0;
         g.o0 = d.y; g.ob0 = (long long)ho * wo * d.cout; g.os0 = d.cout; g.o1 = nullptr; g.ob1 = 0; g.os1 = 0;
         g.relu = d.relu;
+        if (d.stats)
+            SSDK_REQUIRE(d.cout % 4 == 0 && ((uintptr_t)d.y & 15) == 0, SSDK_E_UNSUPPORTED, "ssdk_conv2d_fwd: stats need cout %% 4 == 0 and a 16-byte aligned output");
+        g.stats = d.stats;   // (known before the stream-K decision counts its units: a statistics epilogue rules the half-width last tile out; dropped again below for a split-K launch)
         finish_problem(g);
         probs[i] = g;
     }
@@ -3015,10 +3050,7 @@ extern "C" int ssdk_conv2d_fwd_ws(const ssdk_conv_desc* descs, int n, int batch,
             }
         }
         if (split) zl.add(d.y, (size_t)batch * ho * wo * d.cout);
-        if (d.stats) {
-            SSDK_REQUIRE(d.cout % 4 == 0 && ((uintptr_t)d.y & 15) == 0, SSDK_E_UNSUPPORTED, "ssdk_conv2d_fwd: stats need cout %% 4 == 0 and a 16-byte aligned output");
-            if (!split) g.stats = d.stats;   // in the epilogue; a split-K output is only complete after the launch: a pass of its own below
-        }
+        if (split) g.stats = nullptr;   // (in the epilogue otherwise; a split-K output is only complete after the launch: a pass of its own below)
     }
     int rc = zl.launch((hipStream_t)stream);
     if (rc) return rc;

@@ -23,6 +23,23 @@ def set_fast_mode(mode):
     return prev
 
 
+class fast_mode(object):
+    """``with heads.fast_mode('bf16x3'):`` -- ``set_fast_mode`` for the calls inside the block; the previous mode comes back on exit."""
+
+    def __init__(self, mode):
+        if mode not in (None, 'bf16x3'):
+            raise ValueError(f'fast mode {mode!r}: None or "bf16x3"')
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = set_fast_mode(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        set_fast_mode(self.prev)
+        return False
+
+
 # Measurement hook (bench.py): a list that receives one (start event, end event, ((H, W, Cin, N), ...) of the launch's levels) per head GEMM
 # launch, recorded on the launch stream immediately around the library call -- an interval taken around multi_level_heads() also holds this module's host-side
 # preparation whenever the GPU is waiting for the host at that point.  None: nothing is recorded.

@@ -46,6 +46,10 @@ class GraphedCallable(object):
 
     def __call__(self, *args):
         assert len(args) == len(self.static_in)
+        from . import _lib
+        if _lib.streamk_poisoned():   # (a replay never passes through ssdk_heads_fwd's own check; the kernels store NaN from then on)
+            raise _lib.SsdkError('GraphedCallable: an earlier stream-K head GEMM of this process gave up waiting for a parked partial tile; '
+                                 'its outputs (and every replay since) are NaN -- see _lib.streamk_timeouts()')
         for dst, src in zip(self.static_in, args):
             if dst.shape != src.shape or dst.dtype != src.dtype:
                 raise ValueError('GraphedCallable: captured for %s %s, called with %s %s' % (tuple(dst.shape), dst.dtype, tuple(src.shape), src.dtype))

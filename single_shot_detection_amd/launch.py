@@ -27,8 +27,18 @@ def free_port():
 EADDRINUSE_HINTS = ('EADDRINUSE', 'Address already in use', 'address already in use')
 
 
-def _run_once(nproc, argv, base, poll, grace):
-    """One attempt: returns (exit code, True when a rank died with the rendezvous port taken)."""
+def _is_listen_error(line, port):
+    """A c10d / TCPStore complaint that the RENDEZVOUS port could not be bound -- not any line that mentions EADDRINUSE (another socket of
+    the job, late in a long run, is not a lost port race)."""
+    return any(h in line for h in EADDRINUSE_HINTS) and ('server socket' in line or 'listen' in line or 'bind' in line or str(port) in line)
+
+
+def _run_once(nproc, argv, base, poll, grace, race_window=180.0):
+    """One attempt: returns (exit code, True when a rank died with the rendezvous port taken).  A lost race shows within the ranks'
+    start-up (interpreter start + imports + init_process_group): a failure later than ``race_window`` seconds after the launch is never
+    taken for one, whatever its stderr says -- re-running a job that has already done work would duplicate its side effects."""
+    t_launch = time.monotonic()
+    t_first_failure = None
     procs = []
     for rank in range(nproc):
         e = dict(base, RANK=str(rank), LOCAL_RANK=str(rank))
@@ -56,6 +66,7 @@ def _run_once(nproc, argv, base, poll, grace):
             alive.remove(p)
             if rc != 0 and code == 0:
                 code = rc
+                t_first_failure = time.monotonic()
                 deadline = time.monotonic() + grace
                 for q in alive:   # a dead rank would leave the others waiting in a collective for ever (helpers.py:142-143 just joins)
                     q.terminate()
@@ -65,7 +76,9 @@ def _run_once(nproc, argv, base, poll, grace):
             deadline = float('inf')
     for t in threads:
         t.join(timeout=5)
-    port_race = code != 0 and any(h in line for tail in tails for line in tail for h in EADDRINUSE_HINTS)
+    port = base.get('MASTER_PORT', '')
+    port_race = (code != 0 and t_first_failure is not None and t_first_failure - t_launch <= race_window and
+                 any(_is_listen_error(line, port) for tail in tails for line in tail))
     return code, port_race
 
 

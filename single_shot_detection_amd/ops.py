@@ -51,8 +51,7 @@ class _ConvFn(torch.autograd.Function):
             fw = _lib.scratch(lib.ssdk_conv2d_fwd_fast_workspace_bytes(arr, len(xs)), xs[0].device, 'conv_fwd_fast')
             _lib.check(lib.ssdk_conv2d_fwd_fast(arr, len(xs), B, 3, _dp(fw), fw.numel(), _lib.current_stream()), 'ssdk_conv2d_fwd_fast')
         else:
-            sk = _lib.scratch(lib.ssdk_heads_fwd_workspace_bytes(), xs[0].device, _lib.STREAMK_TAG, zeroed=True)   # (the stream-K state the heads use too)
-            _lib.check(lib.ssdk_conv2d_fwd_ws(arr, len(xs), B, _dp(sk), sk.numel(), _lib.current_stream()), 'ssdk_conv2d_fwd')
+            _conv2d_fwd(lib, arr, len(xs), B, xs[0].device)
         ctx.w_t = _transposed_weights_of(weight, stride)   # (prepare_weight_transposes ran for this step: the backward skips its re-layout)
         ctx.save_for_backward(w, *xs, *(ys if relu == 1 else []))
         # relu == 2: ReLU in the forward epilogue as usual, but its gradient is taken by the consumer (a BatchNorm that masks its dx where
@@ -116,6 +115,19 @@ class _ConvFn(torch.autograd.Function):
         return (dw, db, None, None, None, None) + tuple(dxs)
 
 
+# stream-K for the generic convolutions is an opt-in of the library (SSDK_CONV_STREAMK_GENERIC, conv.hip streamk_would_take: measured
+# slower on the one-round launches of a pyramid tail); read once: only then do these calls carry the heads' 33 MB stream-K workspace
+_GENERIC_STREAMK = bool(__import__('os').environ.get('SSDK_CONV_STREAMK_GENERIC'))
+
+
+def _conv2d_fwd(lib, arr, n, batch, device):
+    if _GENERIC_STREAMK:
+        sk = _lib.scratch(lib.ssdk_heads_fwd_workspace_bytes(), device, _lib.STREAMK_TAG, zeroed=True)   # (the stream-K state the heads use too)
+        _lib.check(lib.ssdk_conv2d_fwd_ws(arr, n, batch, _dp(sk), sk.numel(), _lib.current_stream()), 'ssdk_conv2d_fwd')
+    else:   # (the library's sticky stream-K error word is checked either way)
+        _lib.check(lib.ssdk_conv2d_fwd_ws(arr, n, batch, None, 0, _lib.current_stream()), 'ssdk_conv2d_fwd')
+
+
 class _GroupConvFn(torch.autograd.Function):
     """apply(meta, x_0, w_0, b_0, x_1, w_1, b_1, ...) -> outputs: n <= 8 INDEPENDENT convolutions -- own input, weights, kernel size, stride --
     in one grouped launch forward and one grouped call backward (the six scale branches of an M2Det TUM's smoothing layers, SFAM's per-scale
@@ -147,8 +159,7 @@ class _GroupConvFn(torch.autograd.Function):
             d.w, d.bias, d.cout, d.ksize, d.stride, d.pad, d.relu = _dp(w), _dp(bs[i]), cout, k, stride, pad, int(bool(relu))
             d.y = _dp(y)
             d.stats = stats
-        sk = _lib.scratch(lib.ssdk_heads_fwd_workspace_bytes(), xs[0].device, _lib.STREAMK_TAG, zeroed=True)
-        _lib.check(lib.ssdk_conv2d_fwd_ws(arr, n, B, _dp(sk), sk.numel(), _lib.current_stream()), 'ssdk_conv2d_fwd')
+        _conv2d_fwd(lib, arr, n, B, xs[0].device)
         ctx.w_ts = [_transposed_weights_of(weights[i], meta[i][0]) for i in range(n)]
         ctx.save_for_backward(*ws, *xs, *[ys[i] if meta[i][2] == 1 else xs[i].new_empty(0) for i in range(n)])
         ctx.meta = tuple((m[0], m[1], m[2] == 1) for m in meta)
@@ -347,6 +358,23 @@ def defer_weight_gradients(enabled=True):
     prev = _defer_wgrad
     _defer_wgrad = bool(enabled)
     return prev
+
+
+class deferred_weight_gradients(object):
+    """``with ops.deferred_weight_gradients():`` -- the opt-in of ``defer_weight_gradients`` for the backward passes run inside the block
+    only (the previous setting comes back on exit, also when the block raises): a training step that owns its parameters' gradients
+    (bench.HotPath.train_step) scopes it to itself instead of changing what ``torch.autograd.grad`` returns for the rest of the process."""
+
+    def __init__(self, enabled=True):
+        self.enabled = enabled
+
+    def __enter__(self):
+        self.prev = defer_weight_gradients(self.enabled)
+        return self
+
+    def __exit__(self, *exc):
+        defer_weight_gradients(self.prev)
+        return False
 
 
 def _flush_weight_gradients():

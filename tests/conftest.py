@@ -65,11 +65,13 @@ def _streamk_waits_never_ran_out(request):
 
 @pytest.fixture(autouse=True)
 def _process_wide_switches_do_not_leak():
-    """bench.HotPath switches ops.defer_weight_gradients on for its step (process-wide, as documented) and tests construct HotPaths: every
-    test starts from the library's defaults -- deferral off, fast mode off -- whatever ran before it."""
+    """The two process-wide switches (ops.defer_weight_gradients, the heads' fast mode) are only ever set through scoped forms
+    (ops.deferred_weight_gradients / heads.fast_mode context managers; bench.HotPath scopes deferral to its train_step): every test starts
+    from the library's defaults, and a test that LEAVES one switched on fails here instead of changing what the next test measures."""
     from single_shot_detection_amd import _lib, ops
     ops.defer_weight_gradients(False)
     _lib.fast_mode = None
     yield
-    ops.defer_weight_gradients(False)
+    leaked = (ops.defer_weight_gradients(False), _lib.fast_mode)
     _lib.fast_mode = None
+    assert leaked == (False, None), f'a process-wide switch leaked out of this test: (defer_weight_gradients, fast_mode) = {leaked}'

@@ -152,10 +152,25 @@ def test_launcher_retries_when_the_rendezvous_port_was_taken(tmp_path):
                       '    sys.stderr.write("RuntimeError: The server socket has failed to listen: EADDRINUSE (Address already in use)\\n")\n'
                       '    sys.exit(1)\n'
                       'if int(os.environ["RANK"]) == 0:\n'
-                      '    assert os.environ["MASTER_PORT"] != open(marker).read() or True\n'
+                      '    open(marker + ".second", "w").write(os.environ["MASTER_PORT"])\n'
                       'sys.exit(0)\n')
     assert launch.launch(2, [sys.executable, str(script)], grace=2.0) == 0
-    assert marker.exists()
+    assert marker.exists() and (tmp_path / 'first_attempt_done.second').exists()   # (two attempts ran; the second may reuse the freed port)
+
+
+def test_launcher_does_not_retry_an_unrelated_address_in_use(tmp_path):
+    """'Address already in use' from some OTHER socket of the job (not the rendezvous listen / bind) is an ordinary failure: one attempt."""
+    count = tmp_path / 'attempts'
+    script = tmp_path / 'child.py'
+    script.write_text('import os, sys\n'
+                      f'count = {str(count)!r}\n'
+                      'if int(os.environ["RANK"]) == 0:\n'
+                      '    open(count, "a").write("x")\n'
+                      '    sys.stderr.write("OSError: [Errno 98] Address already in use (metrics exporter)\\n")\n'
+                      '    sys.exit(3)\n'
+                      'sys.exit(0)\n')
+    assert launch.launch(2, [sys.executable, str(script)], grace=2.0) == 3
+    assert count.read_text() == 'x'
 
 
 def _sums_worker(rank, world, port, out_dir):

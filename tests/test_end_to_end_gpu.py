@@ -495,3 +495,31 @@ def test_bench_n2_path_on_one_gpu_over_gloo():
     assert line['config']['parallelism'] == 'dp2' and line['config']['sync_bn'] is True and line['config']['global_batch'] == 64
     assert line['scaling'] == 'weak' and line['value'] > 0 and line['grad_bucket_bytes']['heads'] == 36046848
     assert line['streamk_timeouts'] == 0   # two ranks time-slicing one card: every stream-K partner still arrived
+
+
+def test_hot_path_scopes_its_process_wide_switches():
+    """bench.HotPath defers the pyramid tail's weight gradients inside train_step only (ops.deferred_weight_gradients): constructing one
+    and stepping it leaves torch.autograd.grad with respect to a Conv2dBn weight working for everything else in the process, and the
+    heads' fast mode where it was."""
+    import bench
+    from single_shot_detection_amd import _lib, ops
+    from single_shot_detection_amd.bf.modules.conv import Conv2dBn
+    dev = torch.device('cuda:0')
+    hp = bench.HotPath('ssd_300_vgg16_voc', 2, dev)
+    assert ops.defer_weight_gradients(False) is False      # (constructing it switched nothing on)
+    hp.train_step()
+    assert ops.defer_weight_gradients(False) is False and _lib.fast_mode is None
+    assert all(p.grad is not None for p in hp.extras.parameters())   # (the deferred flush ran inside the step)
+    blk = Conv2dBn(32, 32, kernel_size=3, padding=1, bias=False).to(dev).to(memory_format=torch.channels_last).train()
+    x = torch.randn((2, 32, 6, 6), device=dev).contiguous(memory_format=torch.channels_last)
+    (gw,) = torch.autograd.grad(blk(x).square().sum(), [blk.conv.weight])
+    assert gw is not None and float(gw.abs().sum()) > 0.0
+    with ops.deferred_weight_gradients():
+        assert ops._defer_wgrad is True
+        try:
+            with ops.deferred_weight_gradients(False):
+                raise RuntimeError('x')
+        except RuntimeError:
+            pass
+        assert ops._defer_wgrad is True                     # (restored although the inner block raised)
+    assert ops._defer_wgrad is False

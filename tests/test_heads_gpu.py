@@ -148,7 +148,8 @@ def _heads_vs_torch_cpu_conv(levels, C, B, pixel_density, mode, monkeypatch):
 def test_heads_forward_16_column_remainder_tile(levels, C, B, monkeypatch):
     """A column space that ends in a tile of at most 16 columns (N = 104 of the 21-class heads) computes that tile with
     v_mfma_f32_16x16x1_4b_f32 (conv.hip dma_tile, ConvProblem::half_last) in every forward form: the result must be the one of the
-    32-column tiling (SSDK_CONV_NO_HALF_TILE=1, the form every other test pins) up to the order of the fp32 sums over K."""
+    32-column tiling (SSDK_CONV_NO_HALF_TILE=1; the default form is also held to torch's CPU convolution by the C = 21 cases of
+    test_heads_vs_torch_cpu_conv) up to the order of the fp32 sums over K."""
     rng = np.random.default_rng(3)
     weights, xs_np = {}, []
     for i, (cin, h, nb) in enumerate(levels):
@@ -488,3 +489,22 @@ def test_split_heads_match_the_single_launch(cfg_name, batch, side, main_wgs, on
         scale = float(b.abs().max()) + 1e-12
         assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-6, (tuple(b.shape), float((a - b).abs().max()), scale)
     assert _lib.streamk_timeouts() == 0
+
+
+def test_streamk_timeout_is_loud_in_graph_replays(tmp_path):
+    """A stream-K partner that never arrives (fault injection, tests/streamk_fault_worker.py in a child process: the poison is sticky per
+    process) -- in a HIP-graph REPLAY, which never passes through ssdk_heads_fwd's host-side check: the losing replay has NaN in the
+    owner's tile and only there, the sticky word is set, GraphedCallable refuses the next call, a raw replay afterwards stores NaN in
+    every tile (not the previous replay's stale partial sums), and the eager entry point fails."""
+    import json
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'streamk_fault_worker.py')
+    out = os.path.join(str(tmp_path), 'fault.json')
+    r = subprocess.run([sys.executable, worker, out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.load(open(out))
+    assert res['healthy_finite'] and not res['healthy_poisoned']
+    assert res['nan_in_faulted_replay'] > 0 and res['untouched_rows_equal'], res
+    assert res['poisoned_after_fault'] and res['timeouts'] >= 1, res
+    assert res['graphed_callable_raises'] and res['all_nan_in_later_replay'] and res['eager_raises'], res
