@@ -599,6 +599,25 @@ def graph_replay_leg(hp, device, n):
         return {'graph_replay_ms_per_step': None, 'graph_replay_error': '%s: %s' % (type(e).__name__, e)}
 
 
+def deterministic_leg(hp, n):
+    """The same training step under ops.set_deterministic (the reference's cudnn.deterministic = True, bf/training/env.py:74-76): no fp32
+    atomics -- dense data / weight gradients for the heads, no K splits, ordered reductions.  ms per step, reported beside the default."""
+    from single_shot_detection_amd import ops
+    try:
+        with ops.deterministic():
+            for _ in range(2):
+                hp.train_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                hp.train_step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+        return {'deterministic_ms_per_step': dt * 1e3, 'deterministic_images_per_sec': hp.batch / dt}
+    except Exception as e:   # (reported, not fatal)
+        return {'deterministic_ms_per_step': None, 'deterministic_error': '%s: %s' % (type(e).__name__, e)}
+
+
 def per_config_legs(device, steps=4, warmup=2):
     """The other BASELINE.json configs (parity-test cases, not the headline): a few train steps each."""
     out = []
@@ -645,6 +664,7 @@ def per_config_legs(device, steps=4, warmup=2):
                'postprocess_worst_case_images_per_sec': batch / (us * 1e-6)}
         del srcs, ssrc, lsrc
         del sc, lo
+        row.update(deterministic_leg(hp, n))
         row.update(graph_replay_leg(hp, device, n))
         out.append(row)
         del hp
@@ -822,6 +842,9 @@ def main():
         if world == 1 and not args.no_extra_legs:
             del scores, locs, tl
             torch.cuda.empty_cache()
+            hp.set_training(True)
+            out['deterministic'] = deterministic_leg(hp, max(4, args.steps // 2))
+            hp.set_training(False)
             out['roofline_hbm'] = hbm_legs(device)
             out['per_config'] = per_config_legs(device)
             out['serving'] = serving_legs(device)

@@ -47,6 +47,22 @@ extern "C" {
 #define SSDK_LOC_GIOU 1      /* GeneralizedIoULoss, losses.py:109-114, on decoded corners (multibox_loss.py:77-79) */
 
 int ssdk_version(void);
+
+/*
+ * DETERMINISTIC MODE (process-wide; default off, or SSDK_DETERMINISTIC=1 in the environment).  The reference runs every GPU job with
+ * torch.backends.cudnn.deterministic = True / benchmark = False (bf/training/env.py:74-76).  Off, several kernels add fp32 partial
+ * results with atomics in the order the hardware happens to retire them: split-K convolutions (forward too), the scatter form of the
+ * data gradients, the K-split weight gradients, the bias-gradient column sums.  On, every fp32 sum is taken in an order fixed by the
+ * launch: convolutions are not split over K with atomics (stream-K's parked partial tiles are already added in range order), data
+ * gradients take the output-stationary (gather) form -- the heads' too: their sparse scatter forms are not used --, weight gradients
+ * write one partial tile per K split and a second kernel adds the partials in split order, bias gradients likewise.  Same inputs ->
+ * the same bits, run to run and eager vs HIP-graph replay; the cost is reported by bench.py (per_config[*].deterministic_ms_per_step).
+ * (The BatchNorm sums stay fp64 atomics over per-workgroup fp32 partials: such sums are exact -- hence order-independent -- unless the
+ * partials span more than ~2^18 in magnitude.)  The workspace sizes of ssdk_heads_bwd / ssdk_conv2d_bwd depend on the mode: size and
+ * call under the same setting.  Returns the previous setting.
+ */
+int ssdk_set_deterministic(int enabled);
+int ssdk_get_deterministic(void);
 const char* ssdk_last_error_string(void);
 
 /* ---- anchors ------------------------------------------------------------------------------------------------ */

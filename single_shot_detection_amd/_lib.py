@@ -32,6 +32,8 @@ _SIGNATURES = {
     # name: (restype, argtypes)
     'ssdk_version': (C.c_int, []),
     'ssdk_last_error_string': (C.c_char_p, []),
+    'ssdk_set_deterministic': (C.c_int, [C.c_int]),
+    'ssdk_get_deterministic': (C.c_int, []),
     'ssdk_anchor_sizes_ssd': (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     'ssdk_anchor_sizes_retina': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_int]),
     'ssdk_linspace_f32': (C.c_int, [C.c_float, C.c_float, C.c_int, C.c_void_p]),

@@ -12,6 +12,9 @@ namespace ssdk {
 constexpr int kWave = 64;
 
 void set_error(const char* fmt, ...);
+// Deterministic mode (ssdk_set_deterministic): every reduction of the training kernels runs in an order fixed by the launch, not by the
+// hardware -- no fp32 atomics; see include/ssdk.h.
+bool deterministic();
 
 #define SSDK_REQUIRE(cond, code, ...)     \
     do {                                  \

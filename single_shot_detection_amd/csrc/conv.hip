@@ -1143,6 +1143,10 @@ struct WgradProblem {
     int segs, seg_cap;
     long long dw0_seg, dw1_seg;
     unsigned dy_bytes, x_bytes;   // LDS-DMA kernel: buffer descriptor sizes (dy: one segment when segmented)
+    // deterministic mode: != 0 -> K split `ksp` STORES its partial tile into copy ksp of a [N][taps*Cc] image (dw0 = the first copy,
+    // dw1 = dw0 + n0 * taps * Cc, consecutive copies det_stride floats apart) instead of adding into dw with atomics;
+    // reduce_partials_kernel then adds the copies in split order
+    long long det_stride;
 };
 struct WgradGroup {
     int count;
@@ -1271,12 +1275,15 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_wgrad_ker
     for (int e = 0; e < 16; ++e) {
         const int n = n_begin + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (n >= N) continue;
-        float* row = n < g.n0 ? dw0_p + (long long)n * K : dw1_p + (long long)(n - g.n0) * K;
+        float* row = (n < g.n0 ? dw0_p + (long long)n * K : dw1_p + (long long)(n - g.n0) * K) + (long long)ksp * g.det_stride;
 #pragma unroll
         for (int j = 0; j < kMaxTN; ++j) {
             if (j >= tn) continue;
             const int c = c_begin + j * 32 + r32;
-            if (c < Cc) atomicAdd(row + (long long)tap * Cc + c, acc[j][e]);
+            if (c < Cc) {
+                if (g.det_stride) row[(long long)tap * Cc + c] = acc[j][e];
+                else atomicAdd(row + (long long)tap * Cc + c, acc[j][e]);
+            }
         }
     }
 }
@@ -1437,8 +1444,9 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_wgrad_dma
     if (c >= Cc) return;
     // (everything but n * K hoisted out of the 64 elements: the two row bases already carry tap, channel and the -n0 shift)
     const int n0 = g.n0;
-    float* const base0 = dw0_p + (long long)tap * Cc + c;
-    float* const base1 = dw1_p ? dw1_p + (long long)tap * Cc + c - (long long)n0 * K : base0;
+    float* const base0 = dw0_p + (long long)tap * Cc + c + (long long)ksp * g.det_stride;
+    float* const base1 = dw1_p ? dw1_p + (long long)tap * Cc + c - (long long)n0 * K + (long long)ksp * g.det_stride : base0;
+    const bool ordered = g.det_stride != 0;   // deterministic mode: this split's own copy, plain stores
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int i = (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -1448,7 +1456,9 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_wgrad_dma
         for (int q = 0; q < 4; ++q) {
             const int n = nq + q;   // MFMA q, row i
             if (n >= N) continue;
-            atomicAdd((n < n0 ? base0 : base1) + nK + q * K, acc[q][e]);
+            float* const dst = (n < n0 ? base0 : base1) + nK + q * K;
+            if (ordered) *dst = acc[q][e];
+            else atomicAdd(dst, acc[q][e]);
         }
     }
 }
@@ -1706,6 +1716,63 @@ __global__ void build_vtab_kernel(VtabArgs a) {
     }
     vt[1 + a.count] = v;
     vt[0] = v;
+}
+
+// Deterministic mode: out[e] (+)= sum_k src[k * stride + e], k = 0 .. n_src - 1 IN THAT ORDER (the partial tiles of a K-split weight
+// gradient, the per-workgroup column sums of a bias gradient): the fixed-order second half of what the atomics do in any order.
+struct ReduceJob {
+    float* dst; const float* src;
+    long long elems, stride;
+    int n_src, accumulate, block_begin, pad_;
+};
+constexpr int kMaxReduceJobs = 40;
+struct ReduceGroup { int count; ReduceJob j[kMaxReduceJobs]; };
+__global__ void __launch_bounds__(256) reduce_partials_kernel(ReduceGroup grp) {
+    int ji = 0;
+#pragma unroll 1
+    for (int i = 1; i < grp.count; ++i)
+        if ((int)blockIdx.x >= grp.j[i].block_begin) ji = i;
+    const ReduceJob& J = grp.j[ji];
+    const long long e4 = ((long long)(blockIdx.x - J.block_begin) * 256 + threadIdx.x) * 4;
+    if (e4 >= J.elems) return;
+    if (e4 + 4 <= J.elems && ((J.stride | (long long)((uintptr_t)J.src >> 2) | (long long)((uintptr_t)J.dst >> 2)) & 3) == 0) {
+        f32x4 a = J.accumulate ? *reinterpret_cast<const f32x4*>(J.dst + e4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* p = J.src + e4;
+        int k = 0;
+        for (; k + 4 <= J.n_src; k += 4) {   // four copies in flight, added in order
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(p), v1 = *reinterpret_cast<const f32x4*>(p + J.stride);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + 2 * J.stride), v3 = *reinterpret_cast<const f32x4*>(p + 3 * J.stride);
+            a += v0; a += v1; a += v2; a += v3;
+            p += 4 * J.stride;
+        }
+        for (; k < J.n_src; ++k) { a += *reinterpret_cast<const f32x4*>(p); p += J.stride; }
+        *reinterpret_cast<f32x4*>(J.dst + e4) = a;
+    } else {
+        for (long long e = e4; e < min(J.elems, e4 + 4); ++e) {
+            float a = J.accumulate ? J.dst[e] : 0.0f;
+            for (int k = 0; k < J.n_src; ++k) a += J.src[(long long)k * J.stride + e];
+            J.dst[e] = a;
+        }
+    }
+}
+
+// part[blockIdx.x][n] = sum over this workgroup's rows of dy[row][n]  (deterministic mode's first half of colsum_kernel)
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __restrict__ dy, long long M, int N, int ld, float* __restrict__ part,
+                                                             int rows_per_block) {
+    const long long m0 = (long long)blockIdx.x * rows_per_block, m1 = min(M, m0 + rows_per_block);
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        float s = 0.0f;
+        long long m = m0;
+        for (; m + 8 <= m1; m += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = dy[(m + u) * ld + n];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; m < m1; ++m) s += dy[m * ld + n];
+        part[(long long)blockIdx.x * N + n] = s;
+    }
 }
 
 // db[n] += sum over rows of dy[row][n]   (dense [M][N] rows)
@@ -2150,7 +2217,17 @@ static long long problem_block_work(const ConvProblem& g) {
 }
 // small GEMMs (pyramid tail): too few output tiles to fill 256 CUs -> split K, add partial tiles atomically (the
 // caller zeroes the output first).  Not with a fused ReLU (needs the complete sum).
+static bool maybe_split_k_any(ConvProblem& g);
 static bool maybe_split_k(ConvProblem& g) {
+    if (!deterministic()) return maybe_split_k_any(g);
+    // deterministic mode: a K split adds its partial tiles with fp32 atomics in hardware order -- never taken (the column-block choices
+    // that come without a split are kept)
+    ConvProblem t = g;
+    maybe_split_k_any(t);
+    if (t.k_splits == 1) g = t;
+    return false;
+}
+static bool maybe_split_k_any(ConvProblem& g) {
     const int blocks = cdiv(g.m_tiles, 8) * 8 * g.n_blocks;
     const int slices = g.ksize * g.ksize * cdiv(g.Cc, kBK);
     if (g.relu || blocks >= 256 || slices < 8) return false;
@@ -2700,6 +2777,8 @@ extern "C" int ssdk_conv2d_fwd_fast(const ssdk_conv_desc* descs, int n, int batc
     return SSDK_OK;
 }
 
+constexpr int kColsumBlocks = 256;   // deterministic bias gradients: at most this many per-workgroup partial column sums per tensor
+
 struct HeadsBwdWs {
     float* dyp[kMaxProblems];
     float* wd[kMaxProblems];
@@ -2713,7 +2792,25 @@ struct HeadsBwdWs {
     int* counts;  // [kMaxProblems] non-zero gradient rows per level
     int* totals;  // [kMaxProblems] pixel rows per level
     int* mode;    // [kMaxProblems] 1 = sparse backward, 0 = dense
+    // deterministic mode only: per level the K-split copies of the weight gradient [k_splits][N][9*Cin] and the per-workgroup column sums
+    // of the bias gradient [kColsumBlocks][N]
+    float* dw_part[kMaxProblems];
+    int dw_splits[kMaxProblems];
+    float* db_part[kMaxProblems];
 };
+
+static void size_wgrad_splits(WgradGroup& wg, int n, int density_div);
+// the dense weight-gradient problem of one head level (dy / row lists / outputs are filled in by the caller)
+static WgradProblem heads_wgrad_problem(const ssdk_head_level& lv, int batch) {
+    WgradProblem g{};
+    g.x = lv.x; g.Npad = cdiv(lv.n_score + lv.n_loc, 32) * 32; g.Cc = lv.cin;
+    g.B = batch; g.Hout = lv.h; g.Wout = lv.w; g.Hin = lv.h; g.Win = lv.w; g.ksize = 3; g.stride = 1; g.pad = 1;
+    g.dw0 = lv.dw_score; g.dw1 = lv.dw_loc; g.n0 = lv.n_score; g.n1 = lv.n_loc;
+    g.n_tiles = cdiv(lv.n_score + lv.n_loc, 128);
+    g.c_tiles32 = cdiv(lv.cin, 32);
+    g.c_blocks = cdiv(g.c_tiles32, kMaxTN);
+    return g;
+}
 
 static HeadsBwdWs carve_heads_bwd(void* ws, const ssdk_head_level* levels, int n_levels, int batch, size_t* total) {
     Carver c(ws);
@@ -2738,6 +2835,14 @@ static HeadsBwdWs carve_heads_bwd(void* ws, const ssdk_head_level* levels, int n
         w.wd[i] = c.take<float>((size_t)lv.cin * 9 * npad);
         w.wt[i] = c.take<float>((size_t)lv.cin * 9 * npad);
         w.row_list[i] = c.take<int>(M);
+        if (deterministic()) {
+            WgradGroup one{};
+            one.p[0] = heads_wgrad_problem(lv, batch);
+            size_wgrad_splits(one, 1, 1);
+            w.dw_splits[i] = one.p[0].k_splits;
+            w.dw_part[i] = c.take<float>((size_t)one.p[0].k_splits * (lv.n_score + lv.n_loc) * 9 * lv.cin);
+            w.db_part[i] = c.take<float>((size_t)kColsumBlocks * (lv.n_score + lv.n_loc));
+        }
     }
     if (total) *total = c.off;
     return w;
@@ -2770,6 +2875,34 @@ static int launch_wgrad(WgradGroup& wg, hipStream_t s) {
     return SSDK_OK;
 }
 
+// Host side of the deterministic reductions: jobs for reduce_partials_kernel, launched in groups of kMaxReduceJobs.
+struct ReduceList {
+    ReduceGroup g;
+    int blocks;
+    ReduceList() : blocks(0) { g.count = 0; }
+    int add(float* dst, const float* src, long long elems, long long stride, int n_src, int accumulate, hipStream_t s) {
+        if (!dst || elems <= 0 || n_src <= 0) return SSDK_OK;
+        if (g.count == kMaxReduceJobs) { const int rc = launch(s); if (rc) return rc; }
+        ReduceJob& J = g.j[g.count++];
+        J.dst = dst; J.src = src; J.elems = elems; J.stride = stride; J.n_src = n_src; J.accumulate = accumulate; J.block_begin = blocks; J.pad_ = 0;
+        blocks += (int)((elems + 1023) / 1024);
+        return SSDK_OK;
+    }
+    int launch(hipStream_t s) {
+        if (!g.count) return SSDK_OK;
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, s, g);
+        SSDK_CHECK_LAUNCH("reduce_partials_kernel");
+        g.count = 0;
+        blocks = 0;
+        return SSDK_OK;
+    }
+};
+// K splits of a dense weight-gradient problem that actually get rows (the last of `k_splits` equal ranges can be empty)
+static int wgrad_used_splits(const WgradProblem& g) {
+    const int slices = cdiv(g.B * g.Hout * g.Wout, 32);
+    const int per = cdiv(slices, g.k_splits);
+    return cdiv(slices, per);
+}
 static void size_wgrad_splits(WgradGroup& wg, int n, int density_div) {
     int begin = 0;
     for (int i = 0; i < n; ++i) {
@@ -2819,6 +2952,14 @@ extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int b
         const char* f = getenv("SSDK_HEADS_BWD_MODE");
         h_totals.force = f ? atoi(f) : -1;
     }
+    // Deterministic mode: the sparse forms scatter-add into dX with fp32 atomics and list their rows in the order the pack's workgroups
+    // finish -- the dense (output-stationary) data gradient and a dense weight gradient whose K splits are added in split order take
+    // their place; the bias gradients are column sums of the packed rows in two fixed-order stages
+    const bool det = deterministic();
+    if (det) {
+        h_totals.force = 0;
+        for (int i = 0; i < n_levels; ++i) { h_totals.nb[i] = 0; h_totals.jpad[i] = 0; }
+    }
     // 0. zero everything the atomics of this call add into, in one launch (two when > 32 buffers); the row / anchor counters ride along
     {
         ZeroList zl;
@@ -2847,7 +2988,7 @@ extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int b
             PackLevel& L = pg.lv[i];
             L.ds = dscores + lv.scores_offset; L.dl = lv.n_loc ? dlocs + lv.locs_offset : nullptr;
             L.n0 = lv.n_score; L.n1 = lv.n_loc; L.Npad = npad_of(lv); L.HW = lv.h * lv.w;
-            L.out = w.dyp[i]; L.db0 = lv.db_score; L.db1 = lv.db_loc; L.row_list = w.row_list[i]; L.row_count = w.counts + i;
+            L.out = w.dyp[i]; L.db0 = det ? nullptr : lv.db_score; L.db1 = det ? nullptr : lv.db_loc; L.row_list = w.row_list[i]; L.row_count = w.counts + i;
             if (h_totals.nb[i]) {
                 L.nb = h_totals.nb[i]; L.C = lv.n_score / L.nb; L.Jpad = h_totals.jpad[i]; L.cap = batch * L.HW;
                 L.ga = w.ga[i]; L.apix = w.apix[i]; L.acount = w.acounts + i * kMaxAnchorTypes;
@@ -2894,7 +3035,7 @@ extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int b
         const ssdk_head_level& lv = levels[i];
         if (!lv.dx) continue;
         const int npad = npad_of(lv);
-        for (int kind = 0; kind < 2; ++kind) {
+        for (int kind = 0; kind < (det ? 1 : 2); ++kind) {
             TransposeJob& J = tg.j[tg.count++];
             J.w0 = lv.w_score; J.w1 = lv.w_loc; J.out = kind == 0 ? w.wd[i] : w.wt[i];
             J.kind = kind; J.n0 = lv.n_score; J.n1 = lv.n_loc; J.Npad = npad; J.taps = 9; J.Cc = lv.cin; J.mode = w.mode + i;
@@ -2945,7 +3086,7 @@ extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int b
     if (n_dgrad) {
         int rc = launch_group(dense, n_dgrad, true, s);
         if (rc) return rc;
-        rc = launch_group(sparse, n_dgrad, false, s, false, true, w.vtab[0]);
+        if (!det) rc = launch_group(sparse, n_dgrad, false, s, false, true, w.vtab[0]);
         if (rc) return rc;
     }
     if (n_anchor) {
@@ -2960,14 +3101,14 @@ extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int b
         const ssdk_head_level& lv = levels[i];
         if (!lv.dw_score) continue;
         SSDK_REQUIRE(lv.n_loc == 0 || lv.dw_loc, SSDK_E_INVALID, "ssdk_heads_bwd: dw_loc missing");
-        WgradProblem g{};
-        g.dy = w.dyp[i]; g.x = lv.x; g.Npad = npad_of(lv); g.Cc = lv.cin;
-        g.B = batch; g.Hout = lv.h; g.Wout = lv.w; g.Hin = lv.h; g.Win = lv.w; g.ksize = 3; g.stride = 1; g.pad = 1;
-        g.dw0 = lv.dw_score; g.dw1 = lv.dw_loc; g.n0 = lv.n_score; g.n1 = lv.n_loc;
-        g.n_tiles = cdiv(lv.n_score + lv.n_loc, 128);
-        g.c_tiles32 = cdiv(lv.cin, 32);
-        g.c_blocks = cdiv(g.c_tiles32, kMaxTN);
+        WgradProblem g = heads_wgrad_problem(lv, batch);
+        g.dy = w.dyp[i];
         g.mode = w.mode + i; g.want_mode = 0;
+        if (det) {   // every K split stores its own copy; reduce_partials_kernel adds them in split order (below)
+            g.dw0 = w.dw_part[i];
+            g.dw1 = lv.n_loc ? w.dw_part[i] + (size_t)lv.n_score * 9 * lv.cin : nullptr;
+            g.det_stride = (long long)(lv.n_score + lv.n_loc) * 9 * lv.cin;
+        }
         wd_.p[n_wgrad] = g;
         g.want_mode = 1; g.row_list = w.row_list[i]; g.row_count = w.counts + i;
         ws_.p[n_wgrad] = g;
@@ -2985,8 +3126,39 @@ extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int b
     if (n_wgrad) {
         size_wgrad_splits(wd_, n_wgrad, 1);
         { int rc = launch_wgrad(wd_, s); if (rc) return rc; }
-        size_wgrad_splits(ws_, n_wgrad, 4);  // sparse mode means < 1/4 of the rows
-        { int rc = launch_wgrad(ws_, s); if (rc) return rc; }
+        if (!det) {
+            size_wgrad_splits(ws_, n_wgrad, 4);  // sparse mode means < 1/4 of the rows
+            int rc = launch_wgrad(ws_, s); if (rc) return rc;
+        }
+    }
+    if (det) {
+        // fixed-order second halves: weight gradients = sum over the K-split copies, bias gradients = column sums of the packed rows
+        ReduceList rl;
+        int wi = 0;
+        for (int i = 0; i < n_levels; ++i) {
+            const ssdk_head_level& lv = levels[i];
+            const long long K9 = (long long)9 * lv.cin, N = lv.n_score + lv.n_loc;
+            if (lv.dw_score) {
+                const WgradProblem& g = wd_.p[wi++];
+                SSDK_REQUIRE(g.k_splits == w.dw_splits[i], SSDK_E_WORKSPACE, "ssdk_heads_bwd: the workspace was sized under another deterministic-mode setting");
+                const int used = wgrad_used_splits(g);
+                int rc = rl.add(lv.dw_score, w.dw_part[i], (long long)lv.n_score * K9, N * K9, used, 0, s);
+                if (!rc && lv.n_loc) rc = rl.add(lv.dw_loc, w.dw_part[i] + (size_t)lv.n_score * K9, (long long)lv.n_loc * K9, N * K9, used, 0, s);
+                if (rc) return rc;
+            }
+            if (lv.db_score || lv.db_loc) {
+                const long long M = (long long)batch * lv.h * lv.w;
+                const int rows_per_block = (int)std::max<long long>(64, (M + kColsumBlocks - 1) / kColsumBlocks);
+                const int blocks = (int)((M + rows_per_block - 1) / rows_per_block);
+                hipLaunchKernelGGL(colsum_partial_kernel, dim3(blocks), dim3(256), 0, s, w.dyp[i], M, (int)N, npad_of(lv), w.db_part[i], rows_per_block);
+                SSDK_CHECK_LAUNCH("colsum_partial_kernel");
+                int rc = rl.add(lv.db_score, w.db_part[i], lv.n_score, N, blocks, 0, s);
+                if (!rc && lv.n_loc) rc = rl.add(lv.db_loc, w.db_part[i] + lv.n_score, lv.n_loc, N, blocks, 0, s);
+                if (rc) return rc;
+            }
+        }
+        const int rc = rl.launch(s);
+        if (rc) return rc;
     }
     if (n_wanchor) {
         size_wgrad_splits(wa_, n_wanchor, 16);   // anchor mode: a few % of the anchors of one type
@@ -3040,7 +3212,8 @@ extern "C" int ssdk_conv2d_fwd_ws(const ssdk_conv_desc* descs, int n, int batch,
         ConvProblem& g = probs[i];
         const int ho = g.Hout, wo = g.Wout;
         bool split = !streamk && maybe_split_k(g);
-        if (const char* f = getenv("SSDK_CONV_FORCE")) {   // measurement knob (tools/conv_decomp_sweep.py): "<column blocks>,<K splits>"
+        const char* f = deterministic() ? nullptr : getenv("SSDK_CONV_FORCE");
+        if (f) {   // measurement knob (tools/conv_decomp_sweep.py): "<column blocks>,<K splits>"
             int nb = 0, ks = 0;
             if (!streamk && sscanf(f, "%d,%d", &nb, &ks) == 2 && nb > 0 && ks > 0) {
                 g.n_blocks = std::min(nb, g.tiles_n);
@@ -3101,12 +3274,35 @@ extern "C" int ssdk_conv2d_transpose_weights(const ssdk_conv_desc* descs, int n,
     return SSDK_OK;
 }
 
+// the dense weight-gradient problem of one generic convolution (dy / outputs are filled in by the caller)
+static WgradProblem conv_wgrad_problem(const ssdk_conv_desc& d, int batch) {
+    WgradProblem g{};
+    g.x = d.x; g.Npad = d.cout; g.Cc = d.cin;
+    g.B = batch; g.Hout = out_dim(d.hin, d.ksize, d.stride, d.pad); g.Wout = out_dim(d.win, d.ksize, d.stride, d.pad);
+    g.Hin = d.hin; g.Win = d.win; g.ksize = d.ksize; g.stride = d.stride; g.pad = d.pad;
+    g.n0 = d.cout; g.n1 = 0;
+    g.n_tiles = cdiv(d.cout, 128);
+    g.c_tiles32 = cdiv(d.cin, 32);
+    g.c_blocks = cdiv(g.c_tiles32, kMaxTN);
+    return g;
+}
+static int conv_wgrad_splits(const ssdk_conv_desc& d, int batch) {
+    WgradGroup one{};
+    one.p[0] = conv_wgrad_problem(d, batch);
+    size_wgrad_splits(one, 1, 1);
+    return one.p[0].k_splits;
+}
+
 extern "C" size_t ssdk_conv2d_bwd_workspace_bytes(const ssdk_conv_desc* descs, int n, int batch) {
-    (void)batch;
     size_t total = 0;
     for (int i = 0; i < n; ++i) {
         const ssdk_conv_desc& d = descs[i];
-        total += align_up((size_t)d.cin * d.ksize * d.ksize * (size_t)d.cout * sizeof(float), 256);
+        const size_t wsz = (size_t)d.cin * d.ksize * d.ksize * (size_t)d.cout;
+        total += align_up(wsz * sizeof(float), 256);
+        if (deterministic() && batch > 0 && d.ksize > 0 && d.stride > 0) {   // K-split copies of dw, per-workgroup column sums of db
+            if (d.dw) total += align_up((size_t)conv_wgrad_splits(d, batch) * wsz * sizeof(float), 256);
+            if (d.db) total += align_up((size_t)kColsumBlocks * d.cout * sizeof(float), 256);
+        }
     }
     return total;
 }
@@ -3119,10 +3315,16 @@ extern "C" int ssdk_conv2d_bwd(const ssdk_conv_desc* descs, int n, int batch, in
     SSDK_REQUIRE(workspace && workspace_bytes >= ssdk_conv2d_bwd_workspace_bytes(descs, n, batch), SSDK_E_WORKSPACE, "ssdk_conv2d_bwd: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     Carver carve(workspace);
-    ConvProblem dgrad[kMaxProblems], scat[kMaxProblems];
+    ConvProblem dgrad[kMaxProblems], scat[kMaxProblems], dgrad_strided[kMaxProblems];
     WgradGroup wg{};
     ZeroList zl{};
-    int n_dgrad = 0, n_scat = 0, n_wgrad = 0;
+    int n_dgrad = 0, n_scat = 0, n_wgrad = 0, n_dgrad_strided = 0;
+    // Deterministic mode: no K split with atomics, strided data gradients in the output-stationary (gather) form instead of the
+    // scatter form, weight gradients as K-split copies added in split order, bias gradients as two-stage column sums
+    const bool det = deterministic();
+    float* dw_part[kMaxProblems] = {};
+    float* db_part[kMaxProblems] = {};
+    int wg_of[kMaxProblems];
     for (int i = 0; i < n; ++i) {
         const ssdk_conv_desc& d = descs[i];
         int rc = check_conv("ssdk_conv2d_bwd", batch, d);
@@ -3132,13 +3334,28 @@ extern "C" int ssdk_conv2d_bwd(const ssdk_conv_desc* descs, int n, int batch, in
                      "ssdk_conv2d_bwd: channels must be multiples of 4 and buffers 16-byte aligned");
         const int ho = out_dim(d.hin, d.ksize, d.stride, d.pad), wo = out_dim(d.win, d.ksize, d.stride, d.pad);
         const int taps = d.ksize * d.ksize;
-        float* wd = carve.take<float>((size_t)d.cin * taps * d.cout);
+        float* const wd_own = carve.take<float>((size_t)d.cin * taps * d.cout);
+        float* wd = wd_own;
         const bool have_wt = d.w_t != nullptr;   // re-laid out beforehand by ssdk_conv2d_transpose_weights (one launch for many layers)
         if (have_wt) {
             SSDK_REQUIRE(((uintptr_t)d.w_t & 15) == 0, SSDK_E_INVALID, "ssdk_conv2d_bwd: w_t must be 16-byte aligned");
             wd = const_cast<float*>(d.w_t);
         }
-        if (d.dx && d.stride == 1) {
+        if (det && d.dx && d.stride != 1) {
+            // output stationary with a stride (igemm_fwd_kernel<.., MIRROR, STRIDED>): a dx pixel gathers the taps whose source
+            // (y + pad - ky) / stride exists; the weights in the stride-1 layout [cin][taps*cout] (a layout prepared for the scatter form is not used)
+            wd = wd_own;
+            hipLaunchKernelGGL(transpose_taps_kernel, dim3(cdiv(d.cout, 32), cdiv(d.cin, 32), taps), dim3(256), 0, s, d.w, (const float*)nullptr,
+                               d.cout, 0, d.cout, taps, d.cin, wd);
+            SSDK_CHECK_LAUNCH("transpose_taps_kernel");
+            ConvProblem g{};
+            g.a = d.dy; g.a_bstride = (long long)ho * wo * d.cout; g.a_pstride = d.cout; g.Cc = d.cout;
+            g.B = batch; g.Hout = d.hin; g.Wout = d.win; g.Hin = ho; g.Win = wo; g.ksize = d.ksize; g.stride = d.stride; g.pad = d.pad;
+            g.w0 = wd; g.n0 = d.cin; g.n1 = 0;
+            g.o0 = d.dx; g.ob0 = (long long)d.hin * d.win * d.cin; g.os0 = d.cin;
+            finish_problem(g);
+            dgrad_strided[n_dgrad_strided++] = g;
+        } else if (d.dx && d.stride == 1) {
             // output stationary: rows are INPUT pixels, A = dy [ho*wo][cout] with mirrored taps, W = wd [cin][taps*cout]
             if (!have_wt) {
                 hipLaunchKernelGGL(transpose_taps_kernel, dim3(cdiv(d.cout, 32), cdiv(d.cin, 32), taps), dim3(256), 0, s, d.w, (const float*)nullptr,
@@ -3170,20 +3387,24 @@ extern "C" int ssdk_conv2d_bwd(const ssdk_conv_desc* descs, int n, int batch, in
             finish_problem(g);
             scat[n_scat++] = g;
         }
+        wg_of[i] = -1;
         if (d.dw) {
             bool seen = false;  // descriptors that share weights share dw: zero it once
             for (int q = 0; q < i; ++q) seen = seen || descs[q].dw == d.dw;
-            if (!accumulate && !seen) zl.add(d.dw, (size_t)d.cout * taps * d.cin);
-            WgradProblem g{};
-            g.dy = d.dy; g.x = d.x; g.Npad = d.cout; g.Cc = d.cin;
-            g.B = batch; g.Hout = ho; g.Wout = wo; g.Hin = d.hin; g.Win = d.win; g.ksize = d.ksize; g.stride = d.stride; g.pad = d.pad;
-            g.dw0 = d.dw; g.dw1 = nullptr; g.n0 = d.cout; g.n1 = 0;
-            g.n_tiles = cdiv(d.cout, 128);
-            g.c_tiles32 = cdiv(d.cin, 32);
-            g.c_blocks = cdiv(g.c_tiles32, kMaxTN);
+            if (!accumulate && !seen && !det) zl.add(d.dw, (size_t)d.cout * taps * d.cin);
+            WgradProblem g = conv_wgrad_problem(d, batch);
+            g.dy = d.dy;
+            g.dw0 = d.dw; g.dw1 = nullptr;
+            if (det) {   // every K split stores its own copy (added in split order below)
+                dw_part[i] = carve.take<float>((size_t)conv_wgrad_splits(d, batch) * d.cout * taps * d.cin);
+                g.dw0 = dw_part[i];
+                g.det_stride = (long long)d.cout * taps * d.cin;
+            }
+            wg_of[i] = n_wgrad;
             wg.p[n_wgrad++] = g;
         }
-        if (d.db && !accumulate) {
+        if (d.db && det) db_part[i] = carve.take<float>((size_t)kColsumBlocks * d.cout);
+        if (d.db && !accumulate && !det) {
             bool seen = false;
             for (int q = 0; q < i; ++q) seen = seen || descs[q].db == d.db;
             if (!seen) zl.add(d.db, (size_t)d.cout);
@@ -3191,7 +3412,23 @@ extern "C" int ssdk_conv2d_bwd(const ssdk_conv_desc* descs, int n, int batch, in
     }
     int rc = zl.launch(s);
     if (rc) return rc;
-    for (int i = 0; i < n; ++i) {
+    ReduceList rl;
+    for (int i = 0; i < n && det; ++i) {   // bias gradients: per-workgroup column sums, then their sum in workgroup order
+        const ssdk_conv_desc& d = descs[i];
+        if (!d.db) continue;
+        const int ho = out_dim(d.hin, d.ksize, d.stride, d.pad), wo = out_dim(d.win, d.ksize, d.stride, d.pad);
+        const long long M = (long long)batch * ho * wo;
+        const int rows_per_block = (int)std::max<long long>(64, (M + kColsumBlocks - 1) / kColsumBlocks);
+        const int blocks = (int)((M + rows_per_block - 1) / rows_per_block);
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(blocks), dim3(256), 0, s, d.dy, M, d.cout, d.cout, db_part[i], rows_per_block);
+        SSDK_CHECK_LAUNCH("colsum_partial_kernel");
+        bool seen = false;   // (descriptors that share a bias: the later ones add to what the earlier ones left -- in separate launches)
+        for (int q = 0; q < i; ++q) seen = seen || descs[q].db == d.db;
+        if (seen) { rc = rl.launch(s); if (rc) return rc; }
+        rc = rl.add(d.db, db_part[i], d.cout, d.cout, blocks, (accumulate || seen) ? 1 : 0, s);
+        if (rc) return rc;
+    }
+    for (int i = 0; i < n && !det; ++i) {
         const ssdk_conv_desc& d = descs[i];
         if (!d.db) continue;
         const int ho = out_dim(d.hin, d.ksize, d.stride, d.pad), wo = out_dim(d.win, d.ksize, d.stride, d.pad);
@@ -3211,9 +3448,28 @@ extern "C" int ssdk_conv2d_bwd(const ssdk_conv_desc* descs, int n, int batch, in
         rc = launch_group(scat, n_scat, false, s, false, true);
         if (rc) return rc;
     }
+    if (n_dgrad_strided) {
+        rc = launch_group(dgrad_strided, n_dgrad_strided, true, s);
+        if (rc) return rc;
+    }
     if (n_wgrad) {
         size_wgrad_splits(wg, n_wgrad, 1);
         { int rc2 = launch_wgrad(wg, s); if (rc2) return rc2; }
+    }
+    if (det) {
+        for (int i = 0; i < n; ++i) {
+            const ssdk_conv_desc& d = descs[i];
+            if (!d.dw) continue;
+            const WgradProblem& g = wg.p[wg_of[i]];
+            bool seen = false;   // (shared weights: one reduction per descriptor, in descriptor order, in separate launches)
+            for (int q = 0; q < i; ++q) seen = seen || descs[q].dw == d.dw;
+            if (seen) { rc = rl.launch(s); if (rc) return rc; }
+            const long long elems = (long long)d.cout * d.ksize * d.ksize * d.cin;
+            rc = rl.add(d.dw, dw_part[i], elems, elems, wgrad_used_splits(g), (accumulate || seen) ? 1 : 0, s);
+            if (rc) return rc;
+        }
+        rc = rl.launch(s);
+        if (rc) return rc;
     }
     return SSDK_OK;
 }

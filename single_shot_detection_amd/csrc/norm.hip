@@ -791,6 +791,7 @@ extern "C" int ssdk_depthwise_conv2d_bwd(const float* x, const float* w, const f
         const long long M = (long long)batch * ho * wo;
         int chunks = (int)((M + 255) / 256);   // >= 256 pixels per block ...
         if (chunks > 512) chunks = 512;         // ... and at most 512 partials per (channel, tap)
+        if (ssdk::deterministic()) chunks = 1;  // (one workgroup per 64 channel quads walks all pixels: its single "atomic" per element adds to zero)
         const int ppb = (int)((M + chunks - 1) / chunks);
         hipLaunchKernelGGL(ssdk::dw_wgrad_kernel, dim3((unsigned)((c4 + 63) / 64), (unsigned)chunks), dim3(256), 0, s, reinterpret_cast<const float4*>(x),
                            reinterpret_cast<const float4*>(dy), batch, hin, win, c4, ksize, stride, pad, ho, wo, ppb, dw, db);

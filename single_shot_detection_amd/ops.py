@@ -112,6 +112,7 @@ class _ConvFn(torch.autograd.Function):
         need = lib.ssdk_conv2d_bwd_workspace_bytes(arr, n, B)
         ws = _lib.scratch(need, w.device, 'conv2d_bwd')
         _lib.check(lib.ssdk_conv2d_bwd(arr, n, B, 0, _dp(ws), ws.numel(), stream), 'ssdk_conv2d_bwd')
+        _forget_transposed_weights(ctx.params[0])
         return (dw, db, None, None, None, None) + tuple(dxs)
 
 
@@ -216,6 +217,8 @@ class _GroupConvFn(torch.autograd.Function):
             need = lib.ssdk_conv2d_bwd_workspace_bytes(arr, n, B)
             wsb = _lib.scratch(need, ws[0].device, 'conv2d_bwd')
             _lib.check(lib.ssdk_conv2d_bwd(arr, n, B, 0, _dp(wsb), wsb.numel(), stream), 'ssdk_conv2d_bwd')
+        for weight, _ in ctx.params:
+            _forget_transposed_weights(weight)
         return tuple(out)
 
 
@@ -300,13 +303,20 @@ def _transposed_weights_of(weight, stride):
     return ent[3]
 
 
+def _forget_transposed_weights(weight):
+    """A prepared layout serves ONE backward pass (the one of the forward pass prepare_weight_transposes preceded): an optimizer step comes
+    next, and a fused one leaves no trace in the parameter's version counter."""
+    _wt_cache.pop(id(weight), None)
+
+
 def prepare_weight_transposes(module):
     """Call at the start of a training step's forward pass over a chain of libssdk convolutions (the pyramid tail, the RetinaNet
     tower): the weights of every ``nn.Conv2d`` under ``module`` that the hot-path blocks run on libssdk are re-laid out for their
     backward-data GEMMs in ONE launch (``ssdk_conv2d_transpose_weights``) instead of one small launch in front of every backward call
     (8 per SSD-300 step, 40 per tower step: a shared tower weight was re-laid out once per level).  The layouts are keyed by parameter
     identity and version, so a stale one is never used: after an optimizer step (or for a convolution that was not prepared) the
-    backward simply re-lays out its own weights as before.  No-op when gradients are off."""
+    backward simply re-lays out its own weights as before.  No-op when gradients are off.  The entries only carry the layout from this
+    call to the backward pass of the forward pass it precedes: the next call makes new ones."""
     import weakref
     import ctypes
     if not torch.is_grad_enabled():
@@ -314,10 +324,14 @@ def prepare_weight_transposes(module):
     convs = [m for m in module.modules() if isinstance(m, torch.nn.Conv2d) and m.groups == 1 and m.weight.is_cuda and m.weight.requires_grad
              and m.weight.dtype == torch.float32 and m.weight.is_contiguous(memory_format=torch.channels_last)
              and m.kernel_size[0] == m.kernel_size[1] and m.stride[0] == m.stride[1] and m.in_channels % 4 == 0 and m.out_channels % 4 == 0]
+    # EVERY call re-lays out every weight: a layout made by an earlier step is never trusted.  (Round 3 skipped weights whose cache entry
+    # still matched the parameter's ``_version`` -- but a fused optimizer step (torch.optim.SGD(fused=True): torch._fused_sgd_) updates
+    # the parameter WITHOUT bumping its version counter, so from the second step on the backward-data GEMMs multiplied with the weights
+    # of the step in which the entry was made.  Found by the deterministic-mode test, tools/determinism_step_diag.py.)
     seen, todo = set(), []
     for m in convs:
         w = m.weight
-        if id(w) in seen or _transposed_weights_of(w, m.stride[0]) is not None:
+        if id(w) in seen:
             continue
         seen.add(id(w))
         todo.append((w, m.kernel_size[0], m.stride[0]))
@@ -358,6 +372,33 @@ def defer_weight_gradients(enabled=True):
     prev = _defer_wgrad
     _defer_wgrad = bool(enabled)
     return prev
+
+
+def set_deterministic(enabled=True):
+    """Process-wide deterministic mode of libssdk (``ssdk_set_deterministic``; also ``SSDK_DETERMINISTIC=1`` in the environment) -- the
+    counterpart of the reference's ``torch.backends.cudnn.deterministic = True`` (bf/training/env.py:74-76).  On: no fp32 atomics anywhere
+    in the training kernels -- convolutions are not split over K, data gradients take the output-stationary form (the heads' sparse
+    scatter forms are not used), weight and bias gradients are reduced in a fixed order -- so the same inputs give the same bits, run to
+    run and eager vs HIP-graph replay.  Slower (bench.py reports ``deterministic_ms_per_step`` per config).  Returns the previous
+    setting; ``with ops.deterministic():`` scopes it."""
+    return bool(_lib.lib().ssdk_set_deterministic(1 if enabled else 0))
+
+
+def is_deterministic():
+    return bool(_lib.lib().ssdk_get_deterministic())
+
+
+class deterministic(object):
+    def __init__(self, enabled=True):
+        self.enabled = enabled
+
+    def __enter__(self):
+        self.prev = set_deterministic(self.enabled)
+        return self
+
+    def __exit__(self, *exc):
+        set_deterministic(self.prev)
+        return False
 
 
 class deferred_weight_gradients(object):

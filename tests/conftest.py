@@ -71,7 +71,10 @@ def _process_wide_switches_do_not_leak():
     from single_shot_detection_amd import _lib, ops
     ops.defer_weight_gradients(False)
     _lib.fast_mode = None
+    built = __import__('os').path.exists(_lib.LIB_PATH)
+    if built:
+        ops.set_deterministic(False)
     yield
-    leaked = (ops.defer_weight_gradients(False), _lib.fast_mode)
+    leaked = (ops.defer_weight_gradients(False), _lib.fast_mode, ops.set_deterministic(False) if built else False)
     _lib.fast_mode = None
-    assert leaked == (False, None), f'a process-wide switch leaked out of this test: (defer_weight_gradients, fast_mode) = {leaked}'
+    assert leaked == (False, None, False), f'a process-wide switch leaked out of this test: (defer_weight_gradients, fast_mode, deterministic) = {leaked}'

@@ -552,7 +552,7 @@ def test_prepared_weight_transposes_equal_the_per_call_ones_and_never_go_stale()
         x = torch.from_numpy(x_np).cuda().requires_grad_(True)
         if prepare:
             assert ops.prepare_weight_transposes(mod) == 6        # the six convolutions of the three blocks, one launch
-            assert ops.prepare_weight_transposes(mod) == 0        # ... all current: nothing to do
+            assert ops.prepare_weight_transposes(mod) == 6        # ... every call: a layout of an earlier step is never trusted
         y, outs = x, []
         for blk in mod:
             y = blk(y)
@@ -571,7 +571,7 @@ def test_prepared_weight_transposes_equal_the_per_call_ones_and_never_go_stale()
     for m in (a, b):
         m.zero_grad(set_to_none=True)
     conv0 = b[0][0].conv
-    assert ops._transposed_weights_of(conv0.weight, conv0.stride[0]) is None
+    assert ops._transposed_weights_of(conv0.weight, conv0.stride[0]) is None   # (and the backward pass that used a layout forgot it)
     ga2, gb2 = run(a, False), run(b, False)   # b is NOT prepared again: its backward must re-lay out the new weights itself
     np.testing.assert_allclose(gb2.cpu().numpy(), ga2.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(ga2.abs().max()))
     assert not np.allclose(gb2.cpu().numpy(), gb.cpu().numpy(), rtol=1e-3, atol=1e-5 * float(ga.abs().max()))
@@ -613,3 +613,72 @@ def test_batchnorm_statistics_from_the_conv_epilogue_equal_the_separate_pass(cin
     gmax = max(float(p.grad.abs().max()) for p in b.parameters())   # (the conv bias' gradient through a BatchNorm is zero up to rounding: one scale for all)
     for (n1, p1), (n2, p2) in zip(sorted(a.named_parameters()), sorted(b.named_parameters())):
         _close(p1.grad.cpu().numpy(), p2.grad.cpu().numpy(), err_msg=n1, scale=gmax if n1 == 'conv.bias' else None)
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,pad,sizes,B', [
+    (256, 512, 3, 2, 1, (19,), 4),            # the SSD tail's strided 3 x 3: the gather form of its data gradient
+    (512, 128, 1, 1, 0, (9,), 4),             # 1 x 1
+    (128, 256, 3, 2, 1, (5,), 8),             # small map (a K split with atomics in the default mode)
+    (256, 256, 3, 1, 1, (16, 8, 4), 2),       # one weight tensor over three maps (shared dw / db: reduced descriptor by descriptor)
+    (64, 40, 3, 2, 0, (9,), 3),               # no padding, Cout not a multiple of 32
+])
+def test_deterministic_mode_convolution_vs_torch_cpu(cin, cout, k, stride, pad, sizes, B):
+    """ops.conv2d under ops.deterministic(): forward, data / weight / bias gradients against torch's fp32 CPU convolution, and the same
+    call twice gives the same bits (no fp32 atomics: the strided data gradient in its output-stationary form, K-split weight-gradient
+    copies and per-workgroup bias column sums added in a fixed order)."""
+    import torch.nn.functional as F
+    from single_shot_detection_amd import ops
+    torch.manual_seed(13)
+    w = (torch.randn((cout, cin, k, k), device='cuda') * 0.03).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    b = (torch.randn((cout,), device='cuda') * 0.1).requires_grad_(True)
+    xs = [torch.randn((B, cin, h, h), device='cuda').contiguous(memory_format=torch.channels_last).requires_grad_(True) for h in sizes]
+    runs = []
+    with ops.deterministic():
+        for _ in range(2):
+            ys = ops.conv2d(xs, w, b, stride, pad)
+            gs = [torch.randn(y.shape, device='cuda', generator=torch.Generator(device='cuda').manual_seed(5 + i)) for i, y in enumerate(ys)]
+            grads = torch.autograd.grad(ys, [w, b] + xs, gs)
+            runs.append(([y.detach() for y in ys], grads))
+    for t0, t1 in zip(runs[0][0] + list(runs[0][1]), runs[1][0] + list(runs[1][1])):
+        assert torch.equal(t0, t1)
+    wc, bc = w.detach().cpu().contiguous().requires_grad_(True), b.detach().cpu().requires_grad_(True)
+    xc = [x.detach().cpu().contiguous().requires_grad_(True) for x in xs]
+    yc = [F.conv2d(x, wc, bc, stride=stride, padding=pad) for x in xc]
+    gc = torch.autograd.grad(yc, [wc, bc] + xc, [g.cpu() for g in gs])
+    for y, r in zip(runs[1][0], yc):
+        assert float((y.cpu() - r.detach()).abs().max()) <= 2e-6 * (k * k * cin) ** 0.5 + 1e-5 * float(r.detach().abs().max())
+    for a, r in zip(runs[1][1], gc):
+        scale = float(r.abs().max()) + 1e-12
+        assert float((a.cpu() - r).abs().max()) <= 2e-5 * scale + 1e-6, (tuple(r.shape), float((a.cpu() - r).abs().max()), scale)
+
+
+def test_prepared_weight_transposes_follow_a_fused_optimizer_step():
+    """ops.prepare_weight_transposes caches the weights' backward-data layouts per parameter.  torch.optim.SGD(fused=True) updates a
+    parameter WITHOUT bumping its version counter, so a cache keyed on the version served the layout of an OLD step's weights to every
+    later backward pass (round 3; found by the deterministic-mode test).  Two steps with a large learning rate: the second step's input
+    gradient must be the one torch's CPU convolution gives for the UPDATED weights."""
+    import torch.nn.functional as F
+    from single_shot_detection_amd import ops
+    from single_shot_detection_amd.bf.modules.conv import Conv2dBn
+    torch.manual_seed(3)
+    tail = torch.nn.Sequential(Conv2dBn(64, 32, kernel_size=1, bias=False, use_bn=False, activation_params=None),
+                               Conv2dBn(32, 64, kernel_size=3, stride=2, padding=1, bias=False, use_bn=False, activation_params=None)).cuda()
+    tail = tail.to(memory_format=torch.channels_last).train()
+    try:
+        opt = torch.optim.SGD(tail.parameters(), lr=0.5, fused=True)
+    except (TypeError, RuntimeError, ValueError):
+        pytest.skip('no fused SGD in this torch build')
+    x = torch.randn((2, 64, 9, 9), device='cuda').contiguous(memory_format=torch.channels_last)
+    for step in range(3):
+        xi = x.clone().requires_grad_(True)
+        opt.zero_grad(set_to_none=True)
+        assert ops.prepare_weight_transposes(tail) == 2      # (every call re-lays out every weight)
+        y = tail(xi)
+        g = torch.randn(y.shape, device='cuda', generator=torch.Generator(device='cuda').manual_seed(step))
+        y.backward(g)
+        w0, w1 = (m.conv.weight.detach().cpu().contiguous() for m in tail)
+        xc = x.cpu().contiguous().requires_grad_(True)
+        F.conv2d(F.conv2d(xc, w0), w1, stride=2, padding=1).backward(g.cpu())
+        scale = float(xc.grad.abs().max())
+        assert float((xi.grad.cpu() - xc.grad).abs().max()) <= 2e-5 * scale, (step, float((xi.grad.cpu() - xc.grad).abs().max()), scale)
+        opt.step()   # (moves the weights by half their gradient: a stale layout is off by far more than the bound)

@@ -439,10 +439,14 @@ def test_graphed_training_step_is_within_the_eager_steps_own_spread(cfg_name, ba
     differ by several % between two EAGER runs from the same state -- round 2's "graph replay disagrees with eager on m2det" was this,
     plus a miscounted step).  So a replay is held to the eager step's own run-to-run spread: from ONE state (copied in place into the
     captured step's buffers) an eager step A, a second eager step B and a replay G; G - A must not be larger than a few times B - A
-    plus a small share of the step itself (per tensor 10 % of its update, in aggregate 5 %, the loss 0.5 %: one eager pair's spread can
-    be ~0 when the atomics happen to fall alike, and round 3 saw a replay 2.02 % of a smooth layer's update away from such a pair) --
-    a dead or stale graph node moves a tensor by its whole update.  Two rounds, so
-    that the second replay also meets what the first one left behind."""
+    plus a small share of the step itself (per tensor 5 % of its update, in aggregate 2.5 %, the loss 0.2 %): two eager steps enqueued
+    back to back by the same process tend to retire their atomics alike (round 4 saw a pair 0.005 % apart on a tensor where the replay,
+    whose kernels start at other times, was 1.4 % away), a dead or stale graph node moves a tensor by its whole update.  (Round 3
+    needed 10 % / 5 %: its eager steps also multiplied the data gradients with weight layouts of an OLD step --
+    ops.prepare_weight_transposes trusted the parameters' version counters, which a fused optimizer step does not bump -- while the
+    captured step re-laid them out every replay.)  The strict form of this check is test_deterministic_mode_steps_are_bit_identical:
+    under ops.deterministic() eager, eager and replay agree bit for bit on this network.  Two rounds, so that the
+    second replay also meets what the first one left behind."""
     import bench
     from single_shot_detection_amd.detection.target_assigner import PackedGroundTruth
     from single_shot_detection_amd.graphs import GraphedCallable
@@ -463,7 +467,7 @@ def test_graphed_training_step_is_within_the_eager_steps_own_spread(cfg_name, ba
         la, lb, lg = float(loss_a.detach()), float(loss_b.detach()), float(loss_g.detach())
         # (the spread of ONE eager pair can be anything from 0 -- the atomics happened to fall in the same order -- to several %: every
         # bound below also allows a fixed share of the step's own size, far below what a dead or stale node would cost)
-        assert abs(lg - la) <= 3 * abs(lb - la) + 5e-3 * abs(la), (rnd, la, lb, lg)
+        assert abs(lg - la) <= 3 * abs(lb - la) + 2e-3 * abs(la), (rnd, la, lb, lg)
         num = den = upd2 = 0.0
         worst = (-1.0, -1)
         for i, (ta, tb, tg, t0) in enumerate(zip(_hot_path_state(a), _hot_path_state(b), _hot_path_state(g), before)):
@@ -472,9 +476,9 @@ def test_graphed_training_step_is_within_the_eager_steps_own_spread(cfg_name, ba
             dg, db = float((tg.double() - ta.double()).norm()), float((tb.double() - ta.double()).norm())
             num, den, upd2 = num + dg * dg, den + db * db, upd2 + upd * upd
             if upd > 0:
-                assert dg <= 8 * db + 0.10 * upd, (rnd, i, tuple(ta.shape), dg, db, upd)   # per tensor: within the spread (+ 10 % of its update)
+                assert dg <= 8 * db + 0.05 * upd, (rnd, i, tuple(ta.shape), dg, db, upd)   # per tensor: within the spread (+ 5 % of its update)
                 worst = max(worst, (dg / upd, i))
-        assert num <= 6.0 * den + 0.05 ** 2 * upd2 + 1e-12, (rnd, num, den, upd2, worst)   # in aggregate: one more sample of the same spread
+        assert num <= 6.0 * den + 0.025 ** 2 * upd2 + 1e-12, (rnd, num, den, upd2, worst)   # in aggregate: one more sample of the same spread
 
 
 def test_bench_n2_path_on_one_gpu_over_gloo():
@@ -523,3 +527,58 @@ def test_hot_path_scopes_its_process_wide_switches():
             pass
         assert ops._defer_wgrad is True                     # (restored although the inner block raised)
     assert ops._defer_wgrad is False
+
+
+@pytest.mark.parametrize('cfg_name,batch', [('ssd_300_vgg16_voc', 4), ('ssd_mb2_voc', 2), ('retina_rn50_500_coco', 2), ('m2det_512_vgg16_coco', 2)])
+def test_deterministic_mode_steps_are_bit_identical(cfg_name, batch):
+    """ops.set_deterministic (the reference runs cudnn.deterministic = True, bf/training/env.py:74-76): from ONE state, two eager training
+    steps on two HotPaths and two replays of the captured step give the same bits -- loss, every parameter, BatchNorm buffer and momentum
+    buffer -- over three consecutive steps (the state is copied once, then the three runs evolve on their own).  Off, the same network
+    (m2det) differs by several % in its neck gradients between two eager runs (profiles/r03_determinism_grads.txt)."""
+    import bench
+    from single_shot_detection_amd import ops
+    from single_shot_detection_amd.detection.target_assigner import PackedGroundTruth
+    from single_shot_detection_amd.graphs import GraphedCallable
+    dev = torch.device('cuda:0')
+    with ops.deterministic():
+        a, b, g = (bench.HotPath(cfg_name, batch, dev) for _ in range(3))
+        g.gt = PackedGroundTruth.from_list(g.gt, dev, capacity=sum(len(t) for t in g.gt) + 7)
+        a.train_step()
+        b.train_step()
+        step = GraphedCallable(g.train_step, [], warmup=2)
+        assert step.scratch_allocated_in_capture == 0
+        _copy_state(a, b)
+        _copy_state(a, g)
+        for k in range(3):
+            loss_a, loss_b, loss_g = a.train_step(), b.train_step(), step()
+            torch.cuda.synchronize()
+            la, lb, lg = (float(t.detach()) for t in (loss_a, loss_b, loss_g))
+            assert np.isfinite(la) and la == lb == lg, (k, la, lb, lg)
+            for i, (ta, tb, tg) in enumerate(zip(_hot_path_state(a), _hot_path_state(b), _hot_path_state(g))):
+                assert torch.equal(ta.detach(), tb.detach()), (k, i, tuple(ta.shape), float((ta.detach() - tb.detach()).abs().max()))
+                assert torch.equal(ta.detach(), tg.detach()), (k, i, tuple(ta.shape), float((ta.detach() - tg.detach()).abs().max()))
+            # ... and the gradients themselves (a parameter update could hide a difference below its rounding)
+            for i, (p, q) in enumerate(zip(a.params, b.params)):
+                assert torch.equal(p.grad, q.grad), (k, i, tuple(p.shape))
+
+
+@pytest.mark.parametrize('cfg_name,batch', [('ssd_300_vgg16_voc', 4), ('m2det_512_vgg16_coco', 2)])
+def test_deterministic_mode_computes_the_same_step(cfg_name, batch):
+    """The deterministic forms are other decompositions of the same sums (dense instead of sparse data / weight gradients, no K split):
+    one step from the same state gives the default mode's loss and gradients up to fp32 summation order."""
+    import bench
+    from single_shot_detection_amd import ops
+    dev = torch.device('cuda:0')
+    a, b = bench.HotPath(cfg_name, batch, dev), bench.HotPath(cfg_name, batch, dev)
+    a.train_step()
+    b.train_step()   # (the momentum buffers exist from the first step on)
+    _copy_state(a, b)
+    loss_a = float(a.train_step().detach())
+    with ops.deterministic():
+        loss_b = float(b.train_step().detach())
+    assert abs(loss_a - loss_b) <= 1e-5 * abs(loss_a) + 1e-6, (loss_a, loss_b)
+    if cfg_name.startswith('m2det'):
+        return   # (its gradients are chaotic in the last bits of the forward pass: tools/determinism_fwd.py; the loss is what is compared)
+    for i, (p, q) in enumerate(zip(a.params, b.params)):
+        scale = float(p.grad.abs().max()) + 1e-12
+        assert float((p.grad - q.grad).abs().max()) <= 1e-4 * scale, (i, tuple(p.shape), float((p.grad - q.grad).abs().max()), scale)

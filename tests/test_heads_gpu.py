@@ -508,3 +508,13 @@ def test_streamk_timeout_is_loud_in_graph_replays(tmp_path):
     assert res['nan_in_faulted_replay'] > 0 and res['untouched_rows_equal'], res
     assert res['poisoned_after_fault'] and res['timeouts'] >= 1, res
     assert res['graphed_callable_raises'] and res['all_nan_in_later_replay'] and res['eager_raises'], res
+
+
+@pytest.mark.parametrize('levels,C,B,density', [(SSD300_LEVELS, 81, 2, 0.05), (SSD300_LEVELS, 21, 2, 1.0), ([(24, 7, 3), (40, 5, 5)], 7, 3, 0.4),
+                                                ([(256, 8, 9)], 80, 1, 0.05)])
+def test_deterministic_mode_heads_vs_torch_cpu_conv(levels, C, B, density, monkeypatch):
+    """The heads under ops.deterministic(): the dense data gradient, K-split weight-gradient copies added in split order and two-stage
+    bias column sums against torch's CPU convolution (same bounds as the default forms), for sampled and dense upstream gradients."""
+    from single_shot_detection_amd import ops
+    with ops.deterministic():
+        _heads_vs_torch_cpu_conv(levels, C, B, density, None, monkeypatch)
