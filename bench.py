@@ -157,7 +157,7 @@ class HotPath(object):
                       ([p for p in self.tower.parameters()] if self.tower is not None else []) + \
                       ([p for n, p in self.neck.named_parameters() if not n.startswith('base.')] if self.neck is not None else [])
         self.opt = _sgd(self.params, lr=1e-3, momentum=0.9, weight_decay=5e-4)
-        self.opt_split = None   # N > 1: one optimizer per gradient bucket (built on first use), so the head update overlaps the second ring
+        self.exchange = None    # N > 1: distributed.BucketedDataParallel around the path's modules (enable_exchange)
         # exchange step (N > 1): the head gradients are complete as soon as the heads' backward has run, so their ring starts
         # there and overlaps with the backward of the extras / tower; a second, small bucket carries the rest
         self.head_params = [p for p in self.heads.parameters()]
@@ -195,21 +195,12 @@ class HotPath(object):
 
     def forward_heads(self, timed=False):
         from single_shot_detection_amd.detection.modules.heads import multi_level_heads
-        if self.overlap and not getattr(self, 'two_phase', False):
+        if self.overlap:
             return self.forward_heads_split(timed)
         sources = self.pyramid()
         score_sources = loc_sources = sources
         if self.tower is not None:
             score_sources, loc_sources = self.tower(sources)
-        if getattr(self, 'two_phase', False):
-            # N > 1: cut the graph in front of the heads, so that the first autograd pass stops at the heads' inputs
-            # (a pyramid level also feeds the next extras layer; its gradient through that path belongs to the second pass)
-            same = loc_sources is score_sources
-            self.head_sources = list(score_sources) + ([] if same else list(loc_sources))
-            cut = [t.detach().requires_grad_(t.requires_grad) for t in self.head_sources]
-            score_sources = cut[:len(score_sources)]
-            loc_sources = score_sources if same else cut[len(score_sources):]
-            self.head_inputs = cut
         # timed: event pairs recorded by the heads module right around its library call(s) -- one grouped launch, or two when the score and
         # the loc tower feed separate maps (RetinaNet); self.fwd_steps counts the steps they belong to
         from single_shot_detection_amd.detection.modules import heads as heads_mod
@@ -253,49 +244,33 @@ class HotPath(object):
         with ops.deferred_weight_gradients(self.defer_weight_gradients):
             return self._train_step(world, timed)
 
+    def enable_exchange(self, process_group=None):
+        """N > 1: the path's modules inside distributed.BucketedDataParallel -- the SAME wrapper detection.init(distributed=True) puts
+        around the predictor (the role of apex DDP, detection/init.py:80-86): rank 0's parameters broadcast, two flat fp32 buckets
+        (heads / the rest), the heads' ring started by the hook of the last head parameter, i.e. under the backward pass of the
+        pyramid tail, both rings awaited at the end of backward()."""
+        from single_shot_detection_amd.distributed import BucketedDataParallel
+        if self.exchange is None:
+            mods = torch.nn.ModuleDict({k: m for k, m in (('heads', self.heads), ('extras', self.extras), ('tower', self.tower), ('neck', self.neck)) if m is not None})
+            for n, p in mods.named_parameters():   # (the backbone stand-in inside the M2Det neck is not part of the path)
+                if all(p is not q for q in self.params):
+                    p.requires_grad_(False)
+            groups = [g for g in (self.head_params, self.rest_params) if g]
+            self.exchange = BucketedDataParallel(mods, groups=groups, process_group=process_group)
+            self.bucket_heads = self.exchange.buckets[0]
+            self.bucket_rest = self.exchange.buckets[1] if len(self.exchange.buckets) > 1 else None
+        return self.exchange
+
     def _train_step(self, world=1, timed=False):
-        self.two_phase = world > 1 or getattr(self, 'force_two_phase', False)
-        self.opt.zero_grad(set_to_none=True)   # (shared parameters: also clears the gradients the split optimizers see)
+        if world > 1 and self.exchange is None:
+            self.enable_exchange()
+        self.opt.zero_grad(set_to_none=True)
         for s in self.inputs:
             s.grad = None
         scores, locs = self.forward_heads(timed)
         target = self.assigner.encode_ground_truth(self.gt, self.anchors)
         loss, class_loss, loc_loss = self.criterion((scores, locs), self.anchors, target)
-        if self.two_phase:
-            # same kernels as loss.backward(), in two autograd passes so that the ring over the head gradients (one flat fp32
-            # bucket, RCCL over xGMI) runs while the extras / tower are still being differentiated
-            need = [t for t in self.head_inputs if t.requires_grad]
-            grads = torch.autograd.grad(loss, self.head_params + need)
-            for p, g in zip(self.head_params, grads):
-                p.grad = g
-            self.bucket_heads.start_()
-            src, src_g = [], []
-            gi = iter(grads[len(self.head_params):])
-            for cut, orig in zip(self.head_inputs, self.head_sources):
-                if not cut.requires_grad:
-                    continue
-                g = next(gi)
-                if orig.is_leaf:
-                    orig.grad = g if orig.grad is None else orig.grad + g
-                else:
-                    src.append(orig)
-                    src_g.append(g)
-            if src:
-                torch.autograd.backward(src, grad_tensors=src_g)
-            if self.bucket_rest is not None:
-                self.bucket_rest.start_()
-            self.bucket_heads.finish_()
-            if self.bucket_rest is None:
-                self.opt.step()
-                return loss
-            if self.opt_split is None:   # same hyper-parameters, disjoint parameter sets: the update is the one self.opt would make
-                kw = dict(lr=1e-3, momentum=0.9, weight_decay=5e-4)
-                self.opt_split = (_sgd(self.head_params, **kw), _sgd(self.rest_params, **kw))
-            self.opt_split[0].step()        # head parameters: their averaged gradients are complete; the second ring is still running
-            self.bucket_rest.finish_()
-            self.opt_split[1].step()
-            return loss
-        loss.backward()
+        loss.backward()   # (N > 1: the exchange runs inside -- BucketedDataParallel's hooks and end-of-backward callback)
         self.opt.step()
         return loss
 
@@ -829,6 +804,12 @@ def main():
                        'global_batch': world * args.batch, 'per_gpu_batch': args.batch, 'parallelism': f'dp{world}', 'sync_bn': sync_bn},
             'rccl_ranks': rccl_ranks, 'collective_backend': (backend if world > 1 else None), 'streamk_timeouts': sk_timeouts,
             'grad_bucket_bytes': {'heads': hp.bucket_heads.nbytes, 'rest': hp.bucket_rest.nbytes if hp.bucket_rest is not None else 0},
+            'exchange': (None if hp.exchange is None else
+                         {'what': 'distributed.BucketedDataParallel (the wrapper detection.init(distributed=True) uses): bucket indices in the order their '
+                                  'all-reduces started in the last step, those started from a gradient hook (before the backward pass ended), and the '
+                                  'head gradients that had to be copied into their bucket slots (0 = the kernels wrote them there)',
+                          'start_order': hp.exchange.start_order, 'started_early': hp.exchange.started_early,
+                          'heads_copied': int(getattr(hp.bucket_heads, 'copied_last', -1))}),
             'nms_boxes_per_sec': world * cand / dtp, 'postprocess_images_per_sec': world * args.batch / dtp,
             'eval_images_per_sec': world * args.batch / dte, 'nms_candidates_per_image': cand / args.batch,
             'postprocess_trained_like': {'images_per_sec': world * args.batch / dtp_tl, 'nms_boxes_per_sec': world * cand_tl / dtp_tl,

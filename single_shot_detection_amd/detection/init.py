@@ -33,13 +33,13 @@ def init(device, model_args, box_coder_args, postprocess_args, loss_args, sample
             detector.load_state_dict(state.pop('model_dict'))
     detector = detector.to(device).to(memory_format=torch.channels_last)
     if distributed:
-        # one process per GPU; gradients of the predictor are averaged over RCCL/xGMI (init.py:80-86 used apex DDP + SyncBN).
-        # Hot-path BatchNorms stay on libssdk with their statistics all-reduced (distributed.convert_sync_batchnorm).
-        from ..distributed import convert_sync_batchnorm
+        # one process per GPU; gradients of the predictor are averaged over RCCL/xGMI (init.py:80-86 used apex DDP + SyncBN): the flat
+        # two-bucket exchange bench.py --gpus N measures (distributed.BucketedDataParallel: the heads' ring starts as soon as the heads'
+        # backward has run, under the backward pass of the pyramid tail and the backbone; zero-copy where the weight-gradient kernels
+        # write into the bucket).  Hot-path BatchNorms stay on libssdk with their statistics all-reduced (convert_sync_batchnorm).
+        from ..distributed import BucketedDataParallel, convert_sync_batchnorm
         detector = convert_sync_batchnorm(detector)
-        dev = torch.device(device)
-        index = dev.index if dev.index is not None else (torch.cuda.current_device() if dev.type == 'cuda' else None)
-        detector.predictor = torch.nn.parallel.DistributedDataParallel(detector.predictor, device_ids=None if index is None else [index])
+        detector.predictor = BucketedDataParallel(detector.predictor)
     # (the pyramid tail's weight gradients in one grouped launch per backward pass -- ops.defer_weight_gradients -- is an opt-in of the
     # caller: it bypasses autograd's AccumulateGrad, which hooks, autograd.grad and DistributedDataParallel rely on)
     logging.info(detector)

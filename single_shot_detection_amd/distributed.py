@@ -153,3 +153,112 @@ def convert_sync_batchnorm(module, process_group=None):
                 walk(child, h)
     walk(module, isinstance(module, hot))
     return module
+
+
+class BucketedDataParallel(torch.nn.Module):
+    """One process per GPU, gradients averaged over the ranks through flat fp32 ``GradBucket``s -- the role of apex
+    DistributedDataParallel in the reference (detection/init.py:80-86), and the exchange ``bench.py --gpus N`` measures.
+
+    ``groups``: lists of parameters in the order their gradients complete during the backward pass; default: the heads' parameters
+    (``module.heads``; complete as soon as the heads' backward node has run, i.e. first) and everything else.  A
+    post-accumulate-grad hook per parameter counts arrivals; when a bucket is complete its all-reduce STARTS (async), so the heads' ring
+    runs under the backward pass of the pyramid tail / towers / backbone; a callback at the end of the backward pass starts whatever has
+    not started (parameters that took no part in the step count as zero gradients) and waits for all rings, so ``backward()`` returns
+    with averaged gradients like DDP's does.  Producers that write a parameter's gradient into its bucket slot (``grad_sink``: the
+    heads' / convolutions' weight-gradient kernels) make the exchange zero-copy.  ``no_sync()`` skips the exchange (gradient
+    accumulation).  Parameters and buffers are broadcast from rank 0 at construction.  ``state_dict`` keys carry the ``module.`` prefix
+    like DDP's."""
+
+    def __init__(self, module, groups=None, process_group=None, broadcast=True):
+        super(BucketedDataParallel, self).__init__()
+        self.module = module
+        self.process_group = process_group
+        params = [p for p in module.parameters() if p.requires_grad]
+        if groups is None:
+            heads = getattr(module, 'heads', None)
+            first = [p for p in heads.parameters() if p.requires_grad] if heads is not None else []
+            ids = {id(p) for p in first}
+            groups = [g for g in (first, [p for p in params if id(p) not in ids]) if g]
+        seen = set()
+        for g in groups:
+            for p in g:
+                assert id(p) not in seen, 'BucketedDataParallel: a parameter appears in two groups'
+                seen.add(id(p))
+        assert seen == {id(p) for p in params}, 'BucketedDataParallel: the groups must cover every parameter that requires a gradient'
+        if broadcast and dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+            with torch.no_grad():
+                for t in list(module.parameters()) + list(module.buffers()):
+                    dist.broadcast(t.data, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0, group=process_group)
+        self.buckets = [GradBucket(g) for g in groups]
+        for b in self.buckets:
+            b.attach_(b.params[0].device)
+        self._bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b.params}
+        self._arrived = [0] * len(self.buckets)
+        self._started = [False] * len(self.buckets)
+        self._callback_queued = False
+        self.require_sync = True
+        self.start_order = []          # (diagnostics / tests: bucket indices in the order their rings started in the last backward pass)
+        self.started_early = []        # ... and which of them started from a hook, i.e. before the backward pass had ended
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for b in self.buckets for p in b.params]
+        for b in self.buckets:
+            for p in b.params:
+                p._ssdk_exchange_hook = True   # (ops.defer_weight_gradients may still defer this parameter: _finish_all flushes first)
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    class _NoSync(object):
+        def __init__(self, owner):
+            self.owner = owner
+
+        def __enter__(self):
+            self.prev, self.owner.require_sync = self.owner.require_sync, False
+
+        def __exit__(self, *exc):
+            self.owner.require_sync = self.prev
+            return False
+
+    def no_sync(self):
+        return BucketedDataParallel._NoSync(self)
+
+    def _active(self):
+        return self.require_sync and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1
+
+    def _on_grad(self, param):
+        if not self._active():
+            return
+        if not self._callback_queued:
+            self._callback_queued = True
+            self.start_order, self.started_early = [], []
+            torch.autograd.Variable._execution_engine.queue_callback(self._finish_all)
+        i = self._bucket_of[id(param)]
+        self._arrived[i] += 1
+        if self._arrived[i] == len(self.buckets[i].params) and not self._started[i]:
+            self._start(i, early=True)
+
+    def _start(self, i, early):
+        b = self.buckets[i]
+        for p, v in zip(b.params, b.views):
+            if p.grad is None:   # took no part in this step: a zero gradient on every rank that agrees, the others' share otherwise
+                p.grad = v.zero_().detach()
+        b.start_(self.process_group)
+        self._started[i] = True
+        self.start_order.append(i)
+        if early:
+            self.started_early.append(i)
+
+    def _finish_all(self):
+        try:
+            # weight gradients deferred to the end of the backward pass (ops.defer_weight_gradients) are written now, before the buckets
+            # they belong to start: this callback was queued by the FIRST gradient of the pass, the deferred flush's own callback later
+            from . import ops
+            ops._flush_weight_gradients()
+            for i in range(len(self.buckets)):
+                if not self._started[i]:
+                    self._start(i, early=False)
+            for b in self.buckets:
+                b.finish_(self.process_group)
+        finally:
+            self._arrived = [0] * len(self.buckets)
+            self._started = [False] * len(self.buckets)
+            self._callback_queued = False

@@ -289,8 +289,15 @@ _flush_queued_for = None   # the autograd graph task (torch._C._current_graph_ta
 
 def _has_hooks(p):
     """Tensor hooks / post-accumulate-grad hooks on a parameter: they only fire when autograd itself delivers the gradient, so such a
-    parameter's gradient is never deferred."""
-    return p is not None and bool(getattr(p, '_backward_hooks', None) or getattr(p, '_post_accumulate_grad_hooks', None))
+    parameter's gradient is never deferred.  (The one exception: a parameter whose only hook is libssdk's own exchange wrapper --
+    distributed.BucketedDataParallel marks it ``_ssdk_exchange_hook`` -- which flushes the deferred gradients itself before it starts
+    the bucket they belong to.)"""
+    if p is None:
+        return False
+    if getattr(p, '_backward_hooks', None):
+        return True
+    post = getattr(p, '_post_accumulate_grad_hooks', None)
+    return bool(post) and not (len(post) == 1 and getattr(p, '_ssdk_exchange_hook', False))
 
 # weights re-laid out for the backward-data GEMMs, keyed by id(parameter): (weakref to it, (version, data_ptr), stride == 1, the layout)
 _wt_cache = {}

@@ -32,7 +32,8 @@ def main():
         {'name': 'hard_negative_mining', 'negative_per_positive_ratio': 3, 'min_negative_per_image': 5},
         {'matched_threshold': 0.5, 'unmatched_threshold': 0.5}, distributed=True)
     detector = wrapper.model
-    assert isinstance(detector.predictor, torch.nn.parallel.DistributedDataParallel)
+    from single_shot_detection_amd.distributed import BucketedDataParallel
+    assert isinstance(detector.predictor, BucketedDataParallel)   # libssdk's exchange, not stock DistributedDataParallel
     hot = [bn for m in detector.modules() if isinstance(m, (Conv2dBn, DepthwiseConv2dBn))
            for bn in m.children() if type(bn) is torch.nn.BatchNorm2d]
     assert hot and all(ops.sync_group_of(bn) is not None for bn in hot)           # the pyramid tail's norms stay on libssdk, marked
@@ -46,6 +47,30 @@ def main():
     torch.cuda.synchronize()
     params = [p for p in detector.parameters() if p.requires_grad]
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in params)
+    # the bucket path ran: the heads' ring first, started from the last head parameter's hook (before the pyramid tail and the backbone had
+    # been differentiated), then the rest at the end of the backward pass; the heads' gradients were written into their bucket slots by the
+    # kernels (nothing copied), every gradient now IS a slot of a flat bucket
+    ex = detector.predictor
+    assert ex.start_order == [0, 1] and 0 in ex.started_early, (ex.start_order, ex.started_early)
+    assert ex.buckets[0].copied_last == 0, ex.buckets[0].copied_last
+    assert all(p.grad.data_ptr() == p._ssdk_grad_view.data_ptr() for p in params)
+    # ... and it averaged: the same step without the exchange gives this rank's own gradients; their mean over the ranks is what the
+    # exchange left (SyncBatchNorm statistics are exchanged in both runs)
+    synced = [p.grad.detach().clone() for p in params]
+    for p in params:
+        p.grad = None
+    with ex.no_sync():
+        loss2, _, _ = step_fn(1, 'train', (imgs, gt), init_state())
+        loss2.backward()
+    torch.cuda.synchronize()
+    worst = 0.0
+    for p, sg in zip(params, synced):
+        mean = p.grad.detach().clone()
+        dist.all_reduce(mean)
+        mean /= world
+        worst = max(worst, float((mean - sg).abs().max()) / (float(sg.abs().max()) + 1e-12))
+        p.grad = sg
+    assert worst <= 5e-4, worst   # (two forward passes: the running statistics moved in between, batch statistics did not)
     # DistributedDataParallel averaged the gradients: every rank holds the same ones, although the ranks saw different images
     mine = torch.stack([p.grad.double().sum() for p in params] + [loss.detach().double()]).cpu()
     both = [torch.zeros_like(mine) for _ in range(world)]

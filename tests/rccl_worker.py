@@ -26,7 +26,7 @@ def main():
     res = {'backend': dist.get_backend(), 'world': dist.get_world_size(), 'ipc_legacy_env': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}
     res['avg_supported'] = bool(distributed._avg_supported(None, dev))
     hp = bench.HotPath('ssd_300_vgg16_voc', 2, dev)
-    hp.force_two_phase = True            # the N > 1 step: heads' gradients first, their ring started, then the pyramid tail's
+    hp.enable_exchange()                 # the N > 1 wrapper (inactive at world size 1: its buckets are driven by hand below)
     hp.train_step()
     hp.train_step()
     torch.cuda.synchronize()

@@ -199,3 +199,67 @@ def test_sync_batchnorm_packed_sums_allreduce_gloo_world2(tmp_path):
     """The exchange step of synchronised BatchNorm: one all-reduce(sum) of the packed per-level (sum, sum^2, rows) buffers."""
     mp.spawn(_sums_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert all(os.path.exists(tmp_path / f'sums{r}.npy') for r in range(2))
+
+
+class _ToyPredictor(torch.nn.Module):
+    """features -> heads, like detection.detector.Predictor: the heads' gradients are complete before the features' are."""
+
+    def __init__(self):
+        super().__init__()
+        self.features = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 8, 3, padding=1))
+        self.heads = torch.nn.ModuleList([torch.nn.Conv2d(8, 6, 3, padding=1), torch.nn.Conv2d(8, 4, 3, padding=1)])
+        self.unused = torch.nn.Linear(4, 4)   # takes no part in forward(): its gradient is zero on every rank
+
+    def forward(self, x):
+        f = self.features(x)
+        return torch.cat([h(f).flatten(1) for h in self.heads], 1)
+
+
+def _bdp_worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from single_shot_detection_amd.distributed import BucketedDataParallel
+    torch.manual_seed(100 + rank)          # different initial weights per rank: the wrapper broadcasts rank 0's
+    net = BucketedDataParallel(_ToyPredictor())
+    w0 = [p.detach().clone() for p in net.parameters()]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, [w.numpy() for w in w0])
+    assert all(np.array_equal(a, b) for a, b in zip(gathered[0], gathered[rank]))
+    assert list(net.state_dict())[0].startswith('module.')
+    x = torch.randn((2, 3, 9, 9), generator=torch.Generator().manual_seed(7 + rank))   # this rank's own images
+    params = [p for p in net.parameters()]
+    # reference: every rank's local gradients, no exchange, averaged by hand
+    with net.no_sync():
+        net(x).square().sum().backward()
+    local = [None if p.grad is None else p.grad.clone() for p in params]
+    assert net.start_order == []
+    dist.all_gather_object(gathered, [None if g is None else g.numpy() for g in local])
+    for p in params:
+        p.grad = None
+    # the exchange: two rings, the heads' started from its last parameter's hook -- before the features' gradients existed
+    net(x).square().sum().backward()
+    assert net.start_order == [0, 1] and 0 in net.started_early, (net.start_order, net.started_early)
+    for i, p in enumerate(params):
+        if gathered[0][i] is None:
+            assert float(p.grad.abs().max()) == 0.0      # the unused layer: a zero gradient, not a hang and not None
+            continue
+        want = sum(torch.from_numpy(gathered[r][i]) for r in range(world)) / world
+        assert torch.allclose(p.grad, want, atol=1e-6, rtol=1e-5), (rank, i)
+        assert p.grad.data_ptr() == p._ssdk_grad_view.data_ptr()          # .grad IS the bucket slot
+    # a second step: counters were reset, gradients accumulate into the slots' values only after zero_grad
+    for p in params:
+        p.grad = None
+    net(x).square().sum().backward()
+    assert net.start_order == [0, 1]
+    np.save(os.path.join(out_dir, f'bdp{rank}.npy'), np.array([1]))
+    dist.destroy_process_group()
+
+
+def test_bucketed_data_parallel_gloo_world2(tmp_path):
+    """distributed.BucketedDataParallel (what detection.init(distributed=True) wraps the predictor in, and what bench.py --gpus N runs):
+    broadcast of rank 0's weights, hook-driven start of the heads' ring, averaged gradients equal to the hand-made average of the ranks'
+    local ones, zero gradients for parameters that took no part, no_sync()."""
+    world = 2
+    mp.spawn(_bdp_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f'bdp{r}.npy') for r in range(world))
