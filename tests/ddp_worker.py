@@ -63,14 +63,22 @@ def main():
         loss2, _, _ = step_fn(1, 'train', (imgs, gt), init_state())
         loss2.backward()
     torch.cuda.synchronize()
-    worst = 0.0
+    worst = (0.0, '')
+    names = {id(p): n for n, p in detector.named_parameters()}
     for p, sg in zip(params, synced):
         mean = p.grad.detach().clone()
         dist.all_reduce(mean)
         mean /= world
-        worst = max(worst, float((mean - sg).abs().max()) / (float(sg.abs().max()) + 1e-12))
+        # (on the scale of the ranks' own gradients: a bias in front of a synchronised BatchNorm has local gradients of 1e-2 whose mean
+        # over the ranks is analytically zero -- rounding noise of 1e-8 in both runs)
+        local_scale = p.grad.detach().abs().max().clone()
+        dist.all_reduce(local_scale, op=dist.ReduceOp.MAX)
+        rel = float((mean - sg).abs().max()) / (float(local_scale) + 1e-12)
+        if rel > worst[0]:
+            worst = (rel, '%s |synced| %.3e |mean of locals| %.3e |local| %.3e' % (names[id(p)], float(sg.abs().max()), float(mean.abs().max()), float(p.grad.abs().max())))
         p.grad = sg
-    assert worst <= 5e-4, worst   # (two forward passes: the running statistics moved in between, batch statistics did not)
+    # (two forward / backward passes of a 50-layer network with fp32 atomics: ~1e-3 of run-to-run noise; a missing or wrong average is O(1))
+    assert worst[0] <= 1e-2, worst
     # DistributedDataParallel averaged the gradients: every rank holds the same ones, although the ranks saw different images
     mine = torch.stack([p.grad.double().sum() for p in params] + [loss.detach().double()]).cpu()
     both = [torch.zeros_like(mine) for _ in range(world)]
