@@ -577,10 +577,28 @@ def fast_mode_tower_leg(device, cfg_name='retina_rn50_500_coco', batch=32):
     with heads_mod.fast_mode('bf16x3'):
         usf = gpu_time_us(fwd, inner=3, reps=3)
         sf, lf = fwd()
+    # the whole training step: fp32 against forward + data gradients in the split-bf16 mode (weight gradients stay fp32)
+    hp.set_training(True)
+
+    def step_ms(n=4):
+        for _ in range(2):
+            hp.train_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            hp.train_step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+    ms32 = step_ms()
+    with heads_mod.fast_mode('bf16x3'):
+        msf = step_ms()
     return {'workload': f'{cfg_name} batch {batch}: towers + heads forward, evaluation mode', 'fwd_us': usf, 'fwd_fp32_us': us32,
             'speedup_vs_fp32': us32 / usf,
             'max_abs_err_over_scale': {'scores': float((sf - s32).abs().max()) / float(s32.abs().max()),
-                                       'locs': float((lf - l32).abs().max()) / float(l32.abs().max())}}
+                                       'locs': float((lf - l32).abs().max()) / float(l32.abs().max())},
+            'train_step': {'what': 'full training step (towers + heads fwd / bwd, focal loss, SGD): fp32 against forward + data gradients in the '
+                                   'split-bf16 mode, weight gradients fp32', 'fp32_ms': ms32, 'fast_ms': msf, 'speedup': ms32 / msf,
+                           'images_per_sec_fast': batch / (msf * 1e-3)}}
 
 
 def graph_replay_leg(hp, device, n):

@@ -302,6 +302,18 @@ int ssdk_heads_fwd_fast(const ssdk_head_level* levels, int n_levels, int batch, 
 
 size_t ssdk_heads_bwd_workspace_bytes(const ssdk_head_level* levels, int n_levels, int batch);
 
+/* FAST MODE of the backward pass (opt-in, like ssdk_heads_fwd_fast / ssdk_conv2d_fwd_fast; the reference's AMP covers forward AND
+ * backward: bf/training/env.py:87-95, bf/training/callbacks.py:34-40): the DATA gradients that are dense stride-1 convolutions -- the
+ * heads' dense form (every level of a focal-loss step), the 3 x 3 / 1 x 1 stride-1 layers of towers, necks and tails -- run as the forward
+ * convolution of dy with the mirrored kernel on the split-bf16 GEMM (three cross terms on v_mfma_f32_32x32x16_bf16, fp32 accumulate);
+ * the weights' two bf16 planes are split per call from the re-laid-out fp32 weights.  Everything else of ssdk_heads_bwd /
+ * ssdk_conv2d_bwd (sparse forms, strided data gradients, weight and bias gradients) is unchanged fp32, as are the arguments; the
+ * workspaces are larger (the planes): size them with the _fast_ functions.  A level / layer the kernel cannot take (channels not a
+ * multiple of 32, operands beyond 2 GiB) silently stays on the fp32 kernel. */
+size_t ssdk_heads_bwd_fast_workspace_bytes(const ssdk_head_level* levels, int n_levels, int batch);
+int ssdk_heads_bwd_fast(const ssdk_head_level* levels, int n_levels, int batch, const float* dscores, long long scores_batch_stride,
+                        const float* dlocs, long long locs_batch_stride, int terms, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Backward of ssdk_heads_fwd (what autograd derives for detector.py:50-66): dscores / dlocs are the gradients of the
  * concatenated outputs, addressed like scores / locs. */
 int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int batch, const float* dscores,
@@ -354,6 +366,10 @@ size_t ssdk_conv2d_bwd_workspace_bytes(const ssdk_conv_desc* descs, int n, int b
  * same dw / db -- weights shared across levels -- are summed into it). */
 int ssdk_conv2d_bwd(const ssdk_conv_desc* descs, int n, int batch, int accumulate, void* workspace, size_t workspace_bytes,
                     void* stream);
+/* ... with the stride-1 data gradients in fast mode (see ssdk_heads_bwd_fast above). */
+size_t ssdk_conv2d_bwd_fast_workspace_bytes(const ssdk_conv_desc* descs, int n, int batch);
+int ssdk_conv2d_bwd_fast(const ssdk_conv_desc* descs, int n, int batch, int accumulate, int terms, void* workspace, size_t workspace_bytes,
+                         void* stream);
 /* The weights of n <= 24 convolutions in the layout ssdk_conv2d_bwd's backward-data GEMM reads (stride 1: [cin][tap][cout], else
  * [tap][cin][cout]), outs[i] = cin * ksize^2 * cout floats, 16-byte aligned, ONE launch: called once per training step for all the
  * layers of a chain, the results passed as ssdk_conv_desc::w_t (the reference has no counterpart: cuDNN re-lays weights out inside

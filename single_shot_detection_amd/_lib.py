@@ -73,6 +73,11 @@ _SIGNATURES = {
     'ssdk_heads_bwd_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     'ssdk_heads_bwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong,
                                  C.c_void_p, C.c_size_t, C.c_void_p]),
+    'ssdk_heads_bwd_fast_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    'ssdk_heads_bwd_fast': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_int,
+                                      C.c_void_p, C.c_size_t, C.c_void_p]),
+    'ssdk_conv2d_bwd_fast_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    'ssdk_conv2d_bwd_fast': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     'ssdk_conv2d_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'ssdk_conv2d_fwd_ws': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     'ssdk_conv2d_bwd_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),

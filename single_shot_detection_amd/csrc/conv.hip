@@ -1958,6 +1958,9 @@ struct SplitJob {
     __bf16* hi;
     __bf16* mid;
     int block_begin;
+    // backward-data: the source rows are [taps][tap_len] (the re-laid-out weights [cin][tap][cout]) and the planes get them with the
+    // taps in REVERSE order -- the data gradient of a stride-1 convolution is the forward convolution of dy with the mirrored kernel
+    int flip_taps, tap_len;
 };
 struct SplitGroup {
     int count;
@@ -1975,7 +1978,11 @@ __global__ void __launch_bounds__(256) split_weights_kernel(SplitGroup sg) {
     if (q >= q4) return;
     const long long e = q * 4;
     const int n = (int)(e / J.K);
-    const long long k = e - (long long)n * J.K;
+    long long k = e - (long long)n * J.K;
+    if (J.flip_taps) {   // (tap_len % 4 == 0: the four elements stay inside one tap)
+        const int t = (int)(k / J.tap_len);
+        k = (long long)(J.flip_taps - 1 - t) * J.tap_len + (k - (long long)t * J.tap_len);
+    }
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
     if (n < J.n0) v = *reinterpret_cast<const f32x4*>(J.w0 + (long long)n * J.K + k);
     else if (n < J.n0 + J.n1) v = *reinterpret_cast<const f32x4*>(J.w1 + (long long)(n - J.n0) * J.K + k);
@@ -2160,6 +2167,7 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_bf16x3_ke
     for (int i = 1; i < grp.count; ++i)
         if ((int)blockIdx.x >= grp.p[i].block_begin) pi = i;
     const ConvProblem& g = grp.p[pi];
+    if (g.mode && *g.mode != g.want_mode) return;
     const int id = blockIdx.x - g.block_begin;
     const int per_chunk = 8 * g.n_blocks;
     const int chunk = id / per_chunk, within = id % per_chunk;
@@ -2777,6 +2785,48 @@ extern "C" int ssdk_conv2d_fwd_fast(const ssdk_conv_desc* descs, int n, int batc
     return SSDK_OK;
 }
 
+// Fast-mode (split-bf16) launch of forward-form problems whose weight planes `fps` are produced by the split jobs of `sg` (both filled
+// by the caller): one split launch, one grouped GEMM launch ordered by work per workgroup.
+static int launch_fast_group(ConvProblem* probs, FastProblem* fps, int n, SplitGroup& sg, int split_blocks, hipStream_t s) {
+    if (sg.count) {
+        hipLaunchKernelGGL(split_weights_kernel, dim3(split_blocks), dim3(256), 0, s, sg);
+        SSDK_CHECK_LAUNCH("split_weights_kernel");
+    }
+    int order[kMaxProblems];
+    for (int i = 0; i < n; ++i) order[i] = i;
+    for (int i = 0; i < n; ++i)
+        for (int j = i + 1; j < n; ++j)
+            if (problem_block_work(probs[order[j]]) > problem_block_work(probs[order[i]])) { int t = order[i]; order[i] = order[j]; order[j] = t; }
+    ConvGroup grp;
+    FastGroup fg;
+    int begin = 0;
+    for (int i = 0; i < n; ++i) {
+        ConvProblem& g = probs[order[i]];
+        g.block_begin = begin;
+        begin += cdiv(g.m_tiles, 8) * 8 * g.n_blocks;
+        grp.p[i] = g;
+        fg.p[i] = fps[order[i]];
+    }
+    grp.count = n;
+    grp.total_blocks = begin;
+    grp.vtab = nullptr;
+    hipLaunchKernelGGL(igemm_bf16x3_kernel, dim3(begin), dim3(kConvThreads), 0, s, grp, fg);
+    SSDK_CHECK_LAUNCH("igemm_bf16x3_kernel");
+    return SSDK_OK;
+}
+// fast mode: launches below this many FLOPs stay fp32 (SSDK_FAST_MIN_FLOPS: tests set 0 to put small shapes through the bf16 kernel)
+static double fast_min_flops() {
+    const char* e = getenv("SSDK_FAST_MIN_FLOPS");
+    return e ? atof(e) : 1.0e9;
+}
+// can a stride-1 data gradient -- the forward-form convolution of `a` [batch][h][w][ch] with a ksize x ksize kernel, `wrows` weight
+// rows of K = ksize^2 * ch -- take the fast kernel? (whole 32-float K slices, 16-byte rows, 32-bit buffer offsets)
+static bool fast_conv_ok(const float* a, int batch, int h, int w, int ch, int ksize, int pad, int wrows) {
+    const long long span_a = ((long long)batch * h * w * ch + (long long)(ksize + pad) * ((long long)w + 1) * ch) * 4;
+    const long long K = (long long)ksize * ksize * ch;
+    return ch % kBK == 0 && ((uintptr_t)a & 15) == 0 && span_a < (1LL << 31) - 4096 && (long long)cdiv(wrows, 32) * 32 * K * 2 < (1LL << 31) - 4096;
+}
+
 constexpr int kColsumBlocks = 256;   // deterministic bias gradients: at most this many per-workgroup partial column sums per tensor
 
 struct HeadsBwdWs {
@@ -2797,6 +2847,9 @@ struct HeadsBwdWs {
     float* dw_part[kMaxProblems];
     int dw_splits[kMaxProblems];
     float* db_part[kMaxProblems];
+    // fast mode only (ssdk_heads_bwd_fast): the two bf16 planes of the mirrored kernel [cin][tap'][Npad] per level
+    __bf16* fast_hi[kMaxProblems];
+    __bf16* fast_mid[kMaxProblems];
 };
 
 static void size_wgrad_splits(WgradGroup& wg, int n, int density_div);
@@ -2812,7 +2865,7 @@ static WgradProblem heads_wgrad_problem(const ssdk_head_level& lv, int batch) {
     return g;
 }
 
-static HeadsBwdWs carve_heads_bwd(void* ws, const ssdk_head_level* levels, int n_levels, int batch, size_t* total) {
+static HeadsBwdWs carve_heads_bwd(void* ws, const ssdk_head_level* levels, int n_levels, int batch, size_t* total, bool fast = false) {
     Carver c(ws);
     HeadsBwdWs w{};
     w.counts = c.take<int>(kMaxProblems);
@@ -2843,6 +2896,10 @@ static HeadsBwdWs carve_heads_bwd(void* ws, const ssdk_head_level* levels, int n
             w.dw_part[i] = c.take<float>((size_t)one.p[0].k_splits * (lv.n_score + lv.n_loc) * 9 * lv.cin);
             w.db_part[i] = c.take<float>((size_t)kColsumBlocks * (lv.n_score + lv.n_loc));
         }
+        if (fast) {
+            w.fast_hi[i] = c.take<__bf16>((size_t)cdiv(lv.cin, 32) * 32 * 9 * npad);
+            w.fast_mid[i] = c.take<__bf16>((size_t)cdiv(lv.cin, 32) * 32 * 9 * npad);
+        }
     }
     if (total) *total = c.off;
     return w;
@@ -2851,6 +2908,11 @@ static HeadsBwdWs carve_heads_bwd(void* ws, const ssdk_head_level* levels, int n
 extern "C" size_t ssdk_heads_bwd_workspace_bytes(const ssdk_head_level* levels, int n_levels, int batch) {
     size_t total = 0;
     if (levels && n_levels > 0 && n_levels <= kMaxProblems) carve_heads_bwd(nullptr, levels, n_levels, batch, &total);
+    return total;
+}
+extern "C" size_t ssdk_heads_bwd_fast_workspace_bytes(const ssdk_head_level* levels, int n_levels, int batch) {
+    size_t total = 0;
+    if (levels && n_levels > 0 && n_levels <= kMaxProblems) carve_heads_bwd(nullptr, levels, n_levels, batch, &total, true);
     return total;
 }
 
@@ -2924,15 +2986,30 @@ static void size_wgrad_splits(WgradGroup& wg, int n, int density_div) {
     wg.total_blocks = begin;
 }
 
+static int heads_bwd_impl(const ssdk_head_level* levels, int n_levels, int batch, const float* dscores, long long scores_batch_stride,
+                          const float* dlocs, long long locs_batch_stride, void* workspace, size_t workspace_bytes, void* stream, bool fast);
 extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int batch, const float* dscores,
                               long long scores_batch_stride, const float* dlocs, long long locs_batch_stride,
                               void* workspace, size_t workspace_bytes, void* stream) {
+    return heads_bwd_impl(levels, n_levels, batch, dscores, scores_batch_stride, dlocs, locs_batch_stride, workspace, workspace_bytes, stream, false);
+}
+extern "C" int ssdk_heads_bwd_fast(const ssdk_head_level* levels, int n_levels, int batch, const float* dscores, long long scores_batch_stride,
+                                   const float* dlocs, long long locs_batch_stride, int terms, void* workspace, size_t workspace_bytes, void* stream) {
+    SSDK_REQUIRE(terms == 3, SSDK_E_UNSUPPORTED, "ssdk_heads_bwd_fast: terms=%d (3 is the one form built)", terms);
+    return heads_bwd_impl(levels, n_levels, batch, dscores, scores_batch_stride, dlocs, locs_batch_stride, workspace, workspace_bytes, stream, true);
+}
+
+static int heads_bwd_impl(const ssdk_head_level* levels, int n_levels, int batch, const float* dscores, long long scores_batch_stride,
+                          const float* dlocs, long long locs_batch_stride, void* workspace, size_t workspace_bytes, void* stream, bool fast) {
     SSDK_REQUIRE(levels && n_levels > 0 && n_levels <= kMaxProblems, SSDK_E_INVALID, "ssdk_heads_bwd: n_levels=%d (1..%d)", n_levels, kMaxProblems);
     SSDK_REQUIRE(dscores, SSDK_E_INVALID, "ssdk_heads_bwd: null dscores");
-    SSDK_REQUIRE(workspace && workspace_bytes >= ssdk_heads_bwd_workspace_bytes(levels, n_levels, batch), SSDK_E_WORKSPACE,
-                 "ssdk_heads_bwd: workspace too small");
+    {
+        size_t need = 0;
+        carve_heads_bwd(nullptr, levels, n_levels, batch, &need, fast);
+        SSDK_REQUIRE(workspace && workspace_bytes >= need, SSDK_E_WORKSPACE, "ssdk_heads_bwd: workspace too small");
+    }
     hipStream_t s = (hipStream_t)stream;
-    HeadsBwdWs w = carve_heads_bwd(workspace, levels, n_levels, batch, nullptr);
+    HeadsBwdWs w = carve_heads_bwd(workspace, levels, n_levels, batch, nullptr, fast);
     LevelTotals h_totals{};
     for (int i = 0; i < n_levels; ++i) {
         int rc = check_level("ssdk_heads_bwd", batch, levels[i]);
@@ -3084,7 +3161,33 @@ extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int b
         SSDK_CHECK_LAUNCH("transpose_group_kernel");
     }
     if (n_dgrad) {
-        int rc = launch_group(dense, n_dgrad, true, s);
+        // fast mode: the DENSE data gradient (what a focal-loss step takes on every level) as the forward convolution of the packed
+        // rows with the mirrored kernel on the split-bf16 GEMM; levels it cannot take stay on the fp32 kernel
+        ConvProblem fdg[kMaxProblems], rest[kMaxProblems];
+        FastProblem ffp[kMaxProblems];
+        SplitGroup fsg{};
+        int n_fdg = 0, n_rest = 0, fsplit_blocks = 0, di = 0;
+        for (int i = 0; i < n_levels; ++i) {
+            const ssdk_head_level& lv = levels[i];
+            if (!lv.dx) continue;
+            ConvProblem g = dense[di++];
+            const int npad = npad_of(lv);
+            if (fast && fast_conv_ok(w.dyp[i], batch, lv.h, lv.w, npad, 3, 1, lv.cin)) {
+                const int rows = cdiv(lv.cin, 32) * 32, K = 9 * npad;
+                ffp[n_fdg].w_hi = w.fast_hi[i]; ffp[n_fdg].w_mid = w.fast_mid[i]; ffp[n_fdg].w_bytes = (unsigned)((size_t)rows * K * 2);
+                SplitJob& J = fsg.j[fsg.count++];
+                J.w0 = w.wd[i]; J.w1 = nullptr; J.n0 = lv.cin; J.n1 = 0; J.n_rows = rows; J.K = K; J.hi = w.fast_hi[i]; J.mid = w.fast_mid[i];
+                J.flip_taps = 9; J.tap_len = npad;
+                J.block_begin = fsplit_blocks;
+                fsplit_blocks += (int)(((long long)rows * K / 4 + 255) / 256);
+                fdg[n_fdg++] = g;   // (pad 1 = 3 - 1 - 1: the mirrored 3 x 3 / pad 1 convolution pads like the forward one)
+            } else {
+                rest[n_rest++] = g;
+            }
+        }
+        int rc = SSDK_OK;
+        if (n_rest) rc = launch_group(rest, n_rest, true, s);
+        if (!rc && n_fdg) rc = launch_fast_group(fdg, ffp, n_fdg, fsg, fsplit_blocks, s);
         if (rc) return rc;
         if (!det) rc = launch_group(sparse, n_dgrad, false, s, false, true, w.vtab[0]);
         if (rc) return rc;
@@ -3293,12 +3396,13 @@ static int conv_wgrad_splits(const ssdk_conv_desc& d, int batch) {
     return one.p[0].k_splits;
 }
 
-extern "C" size_t ssdk_conv2d_bwd_workspace_bytes(const ssdk_conv_desc* descs, int n, int batch) {
+static size_t conv2d_bwd_ws_bytes(const ssdk_conv_desc* descs, int n, int batch, bool fast) {
     size_t total = 0;
     for (int i = 0; i < n; ++i) {
         const ssdk_conv_desc& d = descs[i];
         const size_t wsz = (size_t)d.cin * d.ksize * d.ksize * (size_t)d.cout;
         total += align_up(wsz * sizeof(float), 256);
+        if (fast) total += 2 * align_up((size_t)cdiv(d.cin, 32) * 32 * d.ksize * d.ksize * d.cout * sizeof(__bf16), 256);   // the two split planes of the mirrored kernel
         if (deterministic() && batch > 0 && d.ksize > 0 && d.stride > 0) {   // K-split copies of dw, per-workgroup column sums of db
             if (d.dw) total += align_up((size_t)conv_wgrad_splits(d, batch) * wsz * sizeof(float), 256);
             if (d.db) total += align_up((size_t)kColsumBlocks * d.cout * sizeof(float), 256);
@@ -3306,13 +3410,27 @@ extern "C" size_t ssdk_conv2d_bwd_workspace_bytes(const ssdk_conv_desc* descs, i
     }
     return total;
 }
+extern "C" size_t ssdk_conv2d_bwd_workspace_bytes(const ssdk_conv_desc* descs, int n, int batch) { return conv2d_bwd_ws_bytes(descs, n, batch, false); }
+extern "C" size_t ssdk_conv2d_bwd_fast_workspace_bytes(const ssdk_conv_desc* descs, int n, int batch) { return conv2d_bwd_ws_bytes(descs, n, batch, true); }
 
 // dy: gradient w.r.t. the convolution output (AFTER any fused ReLU has been undone by the caller), [batch,hout,wout,cout]
 // with cout % 4 == 0.  dw / db are ACCUMULATED when `accumulate` != 0 (shared weights across levels), else overwritten.
+static int conv2d_bwd_impl(const ssdk_conv_desc* descs, int n, int batch, int accumulate, void* workspace, size_t workspace_bytes, void* stream,
+                           bool fast);
 extern "C" int ssdk_conv2d_bwd(const ssdk_conv_desc* descs, int n, int batch, int accumulate, void* workspace, size_t workspace_bytes,
                                void* stream) {
+    return conv2d_bwd_impl(descs, n, batch, accumulate, workspace, workspace_bytes, stream, false);
+}
+extern "C" int ssdk_conv2d_bwd_fast(const ssdk_conv_desc* descs, int n, int batch, int accumulate, int terms, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+    SSDK_REQUIRE(terms == 3, SSDK_E_UNSUPPORTED, "ssdk_conv2d_bwd_fast: terms=%d (3 is the one form built)", terms);
+    return conv2d_bwd_impl(descs, n, batch, accumulate, workspace, workspace_bytes, stream, true);
+}
+
+static int conv2d_bwd_impl(const ssdk_conv_desc* descs, int n, int batch, int accumulate, void* workspace, size_t workspace_bytes, void* stream,
+                           bool fast) {
     SSDK_REQUIRE(descs && n > 0 && n <= kMaxProblems, SSDK_E_INVALID, "ssdk_conv2d_bwd: n=%d (1..%d)", n, kMaxProblems);
-    SSDK_REQUIRE(workspace && workspace_bytes >= ssdk_conv2d_bwd_workspace_bytes(descs, n, batch), SSDK_E_WORKSPACE, "ssdk_conv2d_bwd: workspace too small");
+    SSDK_REQUIRE(workspace && workspace_bytes >= conv2d_bwd_ws_bytes(descs, n, batch, fast), SSDK_E_WORKSPACE, "ssdk_conv2d_bwd: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     Carver carve(workspace);
     ConvProblem dgrad[kMaxProblems], scat[kMaxProblems], dgrad_strided[kMaxProblems];
@@ -3325,6 +3443,13 @@ extern "C" int ssdk_conv2d_bwd(const ssdk_conv_desc* descs, int n, int batch, in
     float* dw_part[kMaxProblems] = {};
     float* db_part[kMaxProblems] = {};
     int wg_of[kMaxProblems];
+    // fast mode (ssdk_conv2d_bwd_fast): stride-1 data gradients on the split-bf16 kernel -- the forward convolution of dy with the
+    // mirrored kernel, whose two bf16 planes are split from the re-laid-out weights [cin][tap][cout] with the taps reversed
+    ConvProblem fdg[kMaxProblems];
+    FastProblem ffp[kMaxProblems];
+    SplitGroup fsg{};
+    int n_fdg = 0, fsplit_blocks = 0;
+    const float* fsrc[kMaxProblems];
     for (int i = 0; i < n; ++i) {
         const ssdk_conv_desc& d = descs[i];
         int rc = check_conv("ssdk_conv2d_bwd", batch, d);
@@ -3368,8 +3493,32 @@ extern "C" int ssdk_conv2d_bwd(const ssdk_conv_desc* descs, int n, int batch, in
             g.w0 = wd; g.n0 = d.cin; g.n1 = 0;
             g.o0 = d.dx; g.ob0 = (long long)d.hin * d.win * d.cin; g.os0 = d.cin;
             finish_problem(g);
-            if (maybe_split_k(g)) zl.add(d.dx, (size_t)batch * d.hin * d.win * d.cin);   // (small maps: K = taps * cout is one long chain per tile)
-            dgrad[n_dgrad++] = g;
+            __bf16* const plane_hi = fast ? carve.take<__bf16>((size_t)cdiv(d.cin, 32) * 32 * taps * d.cout) : nullptr;
+            __bf16* const plane_mid = fast ? carve.take<__bf16>((size_t)cdiv(d.cin, 32) * 32 * taps * d.cout) : nullptr;
+            // (at least ~1 GFLOP: below that the split of the weights costs more than the bf16 MFMAs save -- the same bound ops.conv2d applies to the forward)
+            if (fast && 2.0 * batch * d.hin * d.win * (double)d.cin * taps * d.cout >= fast_min_flops() &&
+                fast_conv_ok(d.dy, batch, ho, wo, d.cout, d.ksize, d.ksize - 1 - d.pad, d.cin)) {
+                // forward form: "input" = dy, padding ksize - 1 - pad, "weights" = the mirrored kernel [cin][tap'][cout]
+                g.pad = d.ksize - 1 - d.pad;
+                const int rows = cdiv(d.cin, 32) * 32, K = taps * d.cout;
+                int same = -1;   // (a tower layer's weights are shared by all pyramid levels: split them once)
+                for (int q = 0; q < n_fdg && same < 0; ++q)
+                    if (fsrc[q] == wd) same = q;
+                if (same >= 0) ffp[n_fdg] = ffp[same];
+                else {
+                    ffp[n_fdg].w_hi = plane_hi; ffp[n_fdg].w_mid = plane_mid; ffp[n_fdg].w_bytes = (unsigned)((size_t)rows * K * 2);
+                    SplitJob& J = fsg.j[fsg.count++];
+                    J.w0 = wd; J.w1 = nullptr; J.n0 = d.cin; J.n1 = 0; J.n_rows = rows; J.K = K; J.hi = plane_hi; J.mid = plane_mid;
+                    J.flip_taps = taps; J.tap_len = d.cout;
+                    J.block_begin = fsplit_blocks;
+                    fsplit_blocks += (int)(((long long)rows * K / 4 + 255) / 256);
+                }
+                fsrc[n_fdg] = wd;
+                fdg[n_fdg++] = g;
+            } else {
+                if (maybe_split_k(g)) zl.add(d.dx, (size_t)batch * d.hin * d.win * d.cin);   // (small maps: K = taps * cout is one long chain per tile)
+                dgrad[n_dgrad++] = g;
+            }
         } else if (d.dx) {
             // strided: input stationary.  T[out pixel][tap*cin + c] = dy[out pixel][:] . W[:, tap, c], scatter-added into
             // dx at (yo*stride - pad + ky, xo*stride - pad + kx): no multiply is spent on (pixel, tap) pairs that do not exist
@@ -3450,6 +3599,10 @@ extern "C" int ssdk_conv2d_bwd(const ssdk_conv_desc* descs, int n, int batch, in
     }
     if (n_dgrad_strided) {
         rc = launch_group(dgrad_strided, n_dgrad_strided, true, s);
+        if (rc) return rc;
+    }
+    if (n_fdg) {   // (after the re-layout launches above: the split reads their output)
+        rc = launch_fast_group(fdg, ffp, n_fdg, fsg, fsplit_blocks, s);
         if (rc) return rc;
     }
     if (n_wgrad) {

@@ -166,6 +166,12 @@ def _launch_backward(ctx, dscores, dlocs, needs, s_tot, l_tot):
         out += [gr['dx'], gr['dws'] if need_ws else None, gr['dbs'] if (need_bs and lv['has_bs']) else None,
                 gr['dwl'] if need_wl else None, gr['dbl'] if (need_bl and lv['has_bl']) else None]
     arr = _level_array(levels, grads)
+    if _lib.fast_mode == 'bf16x3':   # the dense data gradients on the split-bf16 GEMM; sparse forms, weight / bias gradients unchanged
+        need = lib.ssdk_heads_bwd_fast_workspace_bytes(arr, len(levels), B)
+        ws = _lib.scratch(need, dev, 'heads_bwd')
+        _lib.check(lib.ssdk_heads_bwd_fast(arr, len(levels), B, _dp(dscores), s_tot, _dp(dlocs), l_tot, 3, _dp(ws), need,
+                                           _lib.current_stream()), 'ssdk_heads_bwd_fast')
+        return out
     need = lib.ssdk_heads_bwd_workspace_bytes(arr, len(levels), B)
     ws = _lib.scratch(need, dev, 'heads_bwd')
     _lib.check(lib.ssdk_heads_bwd(arr, len(levels), B, _dp(dscores), s_tot, _dp(dlocs), l_tot, _dp(ws), need,

@@ -21,6 +21,12 @@ def _out_dim(n, k, s, p):
     return (n + 2 * p - k) // s + 1
 
 
+def _fast_min_flops():
+    """fast mode: smaller launches stay fp32 (the library applies the same bound, from the same variable, to the data gradients)."""
+    e = __import__('os').environ.get('SSDK_FAST_MIN_FLOPS')
+    return float(e) if e else 1.0e9
+
+
 class _ConvFn(torch.autograd.Function):
     """apply(weight, bias, stride, pad, relu, stats, *xs) -> tuple of outputs; the n inputs share `weight` (one grouped launch).
     stats: None, or one fp64 `sums` buffer address (or None) per input: the BatchNorm statistics of that output are accumulated into it."""
@@ -47,7 +53,10 @@ class _ConvFn(torch.autograd.Function):
             d.w, d.bias, d.cout, d.ksize, d.stride, d.pad, d.relu = _dp(w), _dp(b), cout, k, stride, pad, int(bool(relu))
             d.y = _dp(y)
             d.stats = None if stats is None else stats[i]
-        if _lib.fast_mode == 'bf16x3' and cin % 32 == 0:   # opt-in split-bf16 forward (heads.set_fast_mode); the backward below is unchanged
+        # opt-in split-bf16 forward (heads.set_fast_mode) -- for launches of at least ~1 GFLOP: below that the split of the weights and the
+        # statistics pass behind the launch cost more than three bf16 MFMAs save over one fp32 one (the SSD tail's small layers)
+        flops = 2.0 * B * cout * cin * k * k * sum(_out_dim(x.shape[2], k, stride, pad) * _out_dim(x.shape[3], k, stride, pad) for x in xs)
+        if _lib.fast_mode == 'bf16x3' and cin % 32 == 0 and flops >= _fast_min_flops():
             fw = _lib.scratch(lib.ssdk_conv2d_fwd_fast_workspace_bytes(arr, len(xs)), xs[0].device, 'conv_fwd_fast')
             _lib.check(lib.ssdk_conv2d_fwd_fast(arr, len(xs), B, 3, _dp(fw), fw.numel(), _lib.current_stream()), 'ssdk_conv2d_fwd_fast')
         else:
@@ -109,9 +118,7 @@ class _ConvFn(torch.autograd.Function):
                                        stride=stride, pad=pad))
             if all(dx is None for dx in dxs):
                 return (None, None, None, None, None, None) + tuple(dxs)
-        need = lib.ssdk_conv2d_bwd_workspace_bytes(arr, n, B)
-        ws = _lib.scratch(need, w.device, 'conv2d_bwd')
-        _lib.check(lib.ssdk_conv2d_bwd(arr, n, B, 0, _dp(ws), ws.numel(), stream), 'ssdk_conv2d_bwd')
+        _conv2d_bwd(lib, arr, n, B, w.device, stream)
         _forget_transposed_weights(ctx.params[0])
         return (dw, db, None, None, None, None) + tuple(dxs)
 
@@ -127,6 +134,18 @@ def _conv2d_fwd(lib, arr, n, batch, device):
         _lib.check(lib.ssdk_conv2d_fwd_ws(arr, n, batch, _dp(sk), sk.numel(), _lib.current_stream()), 'ssdk_conv2d_fwd')
     else:   # (the library's sticky stream-K error word is checked either way)
         _lib.check(lib.ssdk_conv2d_fwd_ws(arr, n, batch, None, 0, _lib.current_stream()), 'ssdk_conv2d_fwd')
+
+
+def _conv2d_bwd(lib, arr, n, batch, device, stream):
+    """ssdk_conv2d_bwd, or -- in the opt-in fast mode -- ssdk_conv2d_bwd_fast (stride-1 data gradients on the split-bf16 GEMM)."""
+    if _lib.fast_mode == 'bf16x3':
+        need = lib.ssdk_conv2d_bwd_fast_workspace_bytes(arr, n, batch)
+        ws = _lib.scratch(need, device, 'conv2d_bwd')
+        _lib.check(lib.ssdk_conv2d_bwd_fast(arr, n, batch, 0, 3, _dp(ws), ws.numel(), stream), 'ssdk_conv2d_bwd_fast')
+    else:
+        need = lib.ssdk_conv2d_bwd_workspace_bytes(arr, n, batch)
+        ws = _lib.scratch(need, device, 'conv2d_bwd')
+        _lib.check(lib.ssdk_conv2d_bwd(arr, n, batch, 0, _dp(ws), ws.numel(), stream), 'ssdk_conv2d_bwd')
 
 
 class _GroupConvFn(torch.autograd.Function):
@@ -214,9 +233,7 @@ class _GroupConvFn(torch.autograd.Function):
                 _queue_deferred_wgrad(dict(x=x, dy=dy, w=w, weight=weight if need_w else None, bias=bias if need_b else None, stride=stride, pad=pad))
             out += [dx, dw, db]
         if any_launch:
-            need = lib.ssdk_conv2d_bwd_workspace_bytes(arr, n, B)
-            wsb = _lib.scratch(need, ws[0].device, 'conv2d_bwd')
-            _lib.check(lib.ssdk_conv2d_bwd(arr, n, B, 0, _dp(wsb), wsb.numel(), stream), 'ssdk_conv2d_bwd')
+            _conv2d_bwd(lib, arr, n, B, ws[0].device, stream)
         for weight, _ in ctx.params:
             _forget_transposed_weights(weight)
         return tuple(out)

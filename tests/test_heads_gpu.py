@@ -321,11 +321,12 @@ def test_fast_mode_refuses_channel_counts_it_cannot_take():
     (256, 512, 3, 2, 1, False, (19,)),          # ... and its strided 3 x 3
     (64, 40, 3, 1, 1, False, (7,)),             # Cout not a multiple of 32
 ])
-def test_fast_mode_bf16x3_generic_convolutions_vs_fp32(cin, cout, k, stride, pad, relu, sizes):
+def test_fast_mode_bf16x3_generic_convolutions_vs_fp32(cin, cout, k, stride, pad, relu, sizes, monkeypatch):
     """ops.conv2d in the opt-in split-bf16 mode (ssdk_conv2d_fwd_fast) against the fp32 kernel and torch's CPU convolution: within 1e-4
     of the output's scale; the backward pass (fp32, unchanged) gives the same gradients for the same upstream gradient."""
     from single_shot_detection_amd import ops
     from single_shot_detection_amd.detection.modules import heads as heads_mod
+    monkeypatch.setenv('SSDK_FAST_MIN_FLOPS', '0')   # (these small shapes too: by default launches below ~1 GFLOP stay fp32)
     torch.manual_seed(5)
     w = (torch.randn((cout, cin, k, k), device='cuda') * 0.03).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     b = (torch.randn((cout,), device='cuda') * 0.1).requires_grad_(True)
@@ -355,7 +356,12 @@ def test_fast_mode_bf16x3_generic_convolutions_vs_fp32(cin, cout, k, stride, pad
         assert float((a - r).abs().max()) <= 1e-4 * float(r.abs().max()) + 1e-6, (float((a - r).abs().max()), float(r.abs().max()))
 
 
-def test_fast_mode_conv_batch_norm_block_trains_like_fp32():
+def test_fast_mode_conv_batch_norm_block_trains_like_fp32(monkeypatch):
+    monkeypatch.setenv('SSDK_FAST_MIN_FLOPS', '0')
+    _fast_mode_conv_batch_norm_block_trains_like_fp32()
+
+
+def _fast_mode_conv_batch_norm_block_trains_like_fp32():
     """Conv2dBn (conv -> BatchNorm statistics -> apply -> ReLU) with the convolution in the split-bf16 mode: output, running statistics
     and num_batches_tracked of a train() step next to the fp32 block's."""
     import copy
@@ -518,3 +524,64 @@ def test_deterministic_mode_heads_vs_torch_cpu_conv(levels, C, B, density, monke
     from single_shot_detection_amd import ops
     with ops.deterministic():
         _heads_vs_torch_cpu_conv(levels, C, B, density, None, monkeypatch)
+
+
+@pytest.mark.parametrize('cfg_name,batch', [('retina_rn50_500_coco', 2), ('ssd_300_vgg16_voc', 2), ('m2det_512_vgg16_coco', 1)])
+def test_fast_mode_bf16x3_heads_backward_vs_fp32(cfg_name, batch):
+    """heads.fast_mode('bf16x3') in the backward pass (ssdk_heads_bwd_fast): the DENSE data gradient -- what a focal-loss step takes on
+    every level -- as the forward convolution of the packed gradient rows with the mirrored kernel on the split-bf16 GEMM, against the
+    fp32 kernels on the same dense upstream gradient: dx within 1e-4 of its scale on every level (and not identical: it IS another
+    arithmetic); weight and bias gradients stay fp32 (same kernels, atomics: equal up to summation order)."""
+    from single_shot_detection_amd import synthetic as syn
+    from single_shot_detection_amd.detection.modules import heads as heads_mod
+    cfg = syn.CONFIGS[cfg_name]
+    levels, C = cfg['levels'], cfg['num_classes']
+    torch.manual_seed(41)
+    heads = detector_builder.get_heads([l[0] for l in levels], [l[2] for l in levels], C).cuda()
+    with torch.no_grad():
+        for p in heads.parameters():
+            p.copy_(torch.randn_like(p) * (0.03 if p.dim() > 1 else 0.1))
+    xs = [torch.randn((batch, cin, h, h), device='cuda').contiguous(memory_format=torch.channels_last).requires_grad_(True) for cin, h, _ in levels]
+    params = list(heads.parameters())
+    scores, locs = multi_level_heads(xs, xs, heads)
+    gs, gl = torch.randn_like(scores), torch.randn_like(locs)     # dense: every anchor carries a gradient
+    g32 = torch.autograd.grad([scores, locs], xs + params, [gs, gl], retain_graph=True)
+    with heads_mod.fast_mode('bf16x3'):
+        gf = torch.autograd.grad([scores, locs], xs + params, [gs, gl])
+    differs = False
+    for i in range(len(xs)):
+        scale = float(g32[i].abs().max())
+        err = float((gf[i] - g32[i]).abs().max())
+        assert err <= 1e-4 * scale, (i, err, scale)
+        differs = differs or err > 0.0
+    assert differs
+    for a, r in zip(gf[len(xs):], g32[len(xs):]):
+        assert float((a - r).abs().max()) <= 2e-5 * float(r.abs().max()) + 1e-7
+
+
+def test_fast_mode_bf16x3_training_steps_track_fp32():
+    """Four training steps of the RetinaNet hot path (towers + heads, focal loss, dense gradients) with forward AND data gradients in the
+    split-bf16 mode against the fp32 step from the same state: the loss of every step within 1e-4 (relative), the heads' gradients
+    of the first step within 1e-3 of each tensor's scale (both sides in deterministic mode: no atomics noise).  The towers' own gradients
+    are not compared tensor by tensor: conv -> ReLU -> BatchNorm over as few as 32 rows turns a 1e-5 perturbation of the activations into
+    flipped ReLU masks, i.e. discrete changes of small gradients (seen: 2.5e-5 on a tensor whose largest gradient is 1.3e-4); layer by
+    layer the arithmetic is held to 1e-4 by test_fast_mode_bf16x3_generic_convolutions_vs_fp32 / ..._heads_backward_vs_fp32 (the reference's analogue, apex AMP O1, is far coarser)."""
+    import bench
+    from single_shot_detection_amd.detection.modules import heads as heads_mod
+    from test_end_to_end_gpu import _copy_state
+    from single_shot_detection_amd import ops
+    dev = torch.device('cuda:0')
+    with ops.deterministic():   # (no fp32 atomics on either side: what differs is the arithmetic of the GEMMs alone)
+        a, b = bench.HotPath('retina_rn50_500_coco', 2, dev), bench.HotPath('retina_rn50_500_coco', 2, dev)
+        a.train_step()
+        b.train_step()
+        _copy_state(a, b)
+        for k in range(4):
+            la = float(a.train_step().detach())
+            with heads_mod.fast_mode('bf16x3'):
+                lb = float(b.train_step().detach())
+            assert abs(la - lb) <= 1e-4 * abs(la), (k, la, lb)
+            if k == 0:   # one step from the same state: the heads' gradients (the bulk of the parameters) within 1e-3 of each tensor's scale
+                for i, (p, q) in enumerate(zip(a.head_params, b.head_params)):
+                    scale = float(p.grad.abs().max()) + 1e-12
+                    assert float((p.grad - q.grad).abs().max()) <= 1e-3 * scale, (i, tuple(p.shape), float((p.grad - q.grad).abs().max()), scale)
