@@ -188,6 +188,13 @@ int ssdk_multibox_loss_bwd(const ssdk_loss_params* params, const float* scores, 
                            const float* target, const uint8_t* sampled, const float* grad_out, int batch, int num_anchors,
                            int num_classes, float* dscores, float* dlocs, void* workspace, size_t workspace_bytes,
                            void* stream);
+/* ... which also writes row_mask DEV uint8 [batch][num_anchors] (NULL: not wanted): 1 where the anchor's dscores / dlocs rows can be
+ * non-zero (it contributes a classification term, or it is a positive and contributes a box term), 0 where both rows were written as
+ * zeros -- the guarantee ssdk_heads_bwd_ex takes. */
+int ssdk_multibox_loss_bwd_ex(const ssdk_loss_params* params, const float* scores, const float* locs, const float* anchors,
+                              const float* target, const uint8_t* sampled, const float* grad_out, int batch, int num_anchors,
+                              int num_classes, float* dscores, float* dlocs, uint8_t* row_mask, void* workspace, size_t workspace_bytes,
+                              void* stream);
 
 /* detection/box_coder.py:13-34 encode_box (inplace != 0: :22-30, eps after the divide; else :32-34). boxes [n_batch, A, 4]. */
 int ssdk_encode_box(const float* boxes, const float* priors, float* out, int batch, int num_anchors, float xy_scale,
@@ -306,13 +313,25 @@ size_t ssdk_heads_bwd_workspace_bytes(const ssdk_head_level* levels, int n_level
  * backward: bf/training/env.py:87-95, bf/training/callbacks.py:34-40): the DATA gradients that are dense stride-1 convolutions -- the
  * heads' dense form (every level of a focal-loss step), the 3 x 3 / 1 x 1 stride-1 layers of towers, necks and tails -- run as the forward
  * convolution of dy with the mirrored kernel on the split-bf16 GEMM (three cross terms on v_mfma_f32_32x32x16_bf16, fp32 accumulate);
- * the weights' two bf16 planes are split per call from the re-laid-out fp32 weights.  Everything else of ssdk_heads_bwd /
- * ssdk_conv2d_bwd (sparse forms, strided data gradients, weight and bias gradients) is unchanged fp32, as are the arguments; the
+ * the weights' two bf16 planes are split per call from the re-laid-out fp32 weights -- and the WEIGHT gradients (dense, pixel-row and
+ * anchor-row forms alike) run on the split-bf16 form of the K-split GEMM, both operands split in registers after the LDS reads.
+ * Everything else of ssdk_heads_bwd / ssdk_conv2d_bwd (the sparse and strided data gradients, bias gradients, the pack) is unchanged
+ * fp32, as are the arguments; the
  * workspaces are larger (the planes): size them with the _fast_ functions.  A level / layer the kernel cannot take (channels not a
  * multiple of 32, operands beyond 2 GiB) silently stays on the fp32 kernel. */
 size_t ssdk_heads_bwd_fast_workspace_bytes(const ssdk_head_level* levels, int n_levels, int batch);
 int ssdk_heads_bwd_fast(const ssdk_head_level* levels, int n_levels, int batch, const float* dscores, long long scores_batch_stride,
                         const float* dlocs, long long locs_batch_stride, int terms, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ssdk_heads_bwd with what the producer of the gradient knows about its sparsity: row_mask DEV uint8 [batch][num_anchors] (NULL: nothing
+ * known), 0 = the caller GUARANTEES that the score and loc gradient rows of that anchor (anchors numbered like the rows of scores / locs:
+ * level after level, pixel-major, anchor type minor) are entirely zero -- ssdk_multibox_loss_bwd_ex writes exactly this mask for the
+ * gradient it produces (hard-negative mining: ~4 % of the anchors).  The pack pass then reads only the pixels that have a marked anchor
+ * instead of scanning all of dscores for non-zero rows (SSD-300 / 81 classes, batch 32: 88 MB).  fast_terms: 0 = fp32 (ssdk_heads_bwd),
+ * 3 = the dense data gradients in fast mode (ssdk_heads_bwd_fast; size the workspace accordingly). */
+int ssdk_heads_bwd_ex(const ssdk_head_level* levels, int n_levels, int batch, const float* dscores, long long scores_batch_stride,
+                      const float* dlocs, long long locs_batch_stride, const unsigned char* row_mask, int num_anchors, int fast_terms,
+                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* Backward of ssdk_heads_fwd (what autograd derives for detector.py:50-66): dscores / dlocs are the gradients of the
  * concatenated outputs, addressed like scores / locs. */

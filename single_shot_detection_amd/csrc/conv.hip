@@ -1306,7 +1306,12 @@ __device__ __forceinline__ void fast_divmod(int m, int d, float rcp, int& q, int
     if (r >= d) { ++q; r -= d; }
 }
 
-__global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_wgrad_dma_kernel(WgradGroup grp) {
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+// FAST = the opt-in split-bf16 mode (ssdk_heads_bwd_fast / ssdk_conv2d_bwd_fast): both operands are split into bf16 pieces in registers
+// after the LDS reads and every fp32 product becomes a_hi b_hi + a_hi b_mid + a_mid b_hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate):
+// 24 MFMAs of 8 passes per 32-pixel slice instead of 64 of 16.  Staging, tiling, K split and epilogue are the fp32 kernel's.
+template <bool FAST>
+__device__ __forceinline__ void wgrad_dma_body(const WgradGroup& grp) {
     __shared__ __attribute__((aligned(1024))) float s_dy0[32 * 128];
     __shared__ __attribute__((aligned(1024))) float s_dy1[32 * 128];
     __shared__ __attribute__((aligned(1024))) float s_x0[32 * 128];
@@ -1413,7 +1418,7 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_wgrad_dma
         issue(ST ^ 1, dyo1, xo1);                                  // slice sl + 1 lands while slice sl is multiplied
         pixel_offsets(sl + 2, id2, dyo2, xo2);
         id2 = load_id(sl + 3);
-        if (wave_live) {
+        if (wave_live && !FAST) {
             const float* ady = (ST ? s_dy1 : s_dy0) + h * 128 + 4 * r32;
             const float* bx = (ST ? s_x1 : s_x0) + h * 128 + wave * 32 + r32;
             f32x4 av[2];
@@ -1428,6 +1433,42 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_wgrad_dma
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k2 & 1][q], bv[k2 & 1], acc[q], 0, 0, 0);
+            }
+        }
+        if (wave_live && FAST) {
+            // lane (r32, h), K step s2: pixels 16 s2 + 8 h .. + 7 of the slice; A_q[row 4 r32 + q][those pixels] from eight 16-byte reads,
+            // B[those pixels][column wave * 32 + r32] from eight 4-byte reads
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const float* ady = (ST ? s_dy1 : s_dy0) + (16 * s2 + 8 * h) * 128 + 4 * r32;
+                const float* bx = (ST ? s_x1 : s_x0) + (16 * s2 + 8 * h) * 128 + wave * 32 + r32;
+                f32x4 av[8];
+                float bv[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    av[t] = *reinterpret_cast<const f32x4*>(ady + t * 128);
+                    bv[t] = bx[t * 128];
+                }
+                wg_bf16x8 b_hi, b_mid;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const __bf16 hb = (__bf16)bv[t];
+                    b_hi[t] = hb;
+                    b_mid[t] = (__bf16)(bv[t] - (float)hb);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    wg_bf16x8 a_hi, a_mid;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const __bf16 ha = (__bf16)av[t][q];
+                        a_hi[t] = ha;
+                        a_mid[t] = (__bf16)(av[t][q] - (float)ha);
+                    }
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, b_hi, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_mid, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc[q], 0, 0, 0);
+                }
             }
         }
         __syncthreads();
@@ -1462,6 +1503,8 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_wgrad_dma
         }
     }
 }
+__global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_wgrad_dma_kernel(WgradGroup grp) { wgrad_dma_body<false>(grp); }
+__global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_wgrad_bf16x3_kernel(WgradGroup grp) { wgrad_dma_body<true>(grp); }
 
 // ---- dY pack (+ bias gradient) --------------------------------------------------------------------------------------
 // out[m][n] (n < Npad) = n < n0 ? ds[b*sb + p*n0 + n] : (n < n0+n1 ? dl[b*lb + p*n1 + n-n0] : 0);  db += column sums
@@ -1481,6 +1524,10 @@ struct PackLevel {
     int nb, C, Jpad, cap;
     float* ga; int* apix; int* acount;
     const int* mode;   // pack_store_kernel: the level's backward form as decide_sparse_kernel chose it (2 = anchor rows: `out` is not needed)
+    // caller's guarantee (ssdk_heads_bwd_ex): rmask[b * a_total + a_off + pixel * rnb + k] == 0 -> the score and loc gradient rows of that
+    // anchor are entirely zero; a pixel whose rnb anchors are all 0 is not read at all (NULL: every row is read)
+    const unsigned char* rmask;
+    int a_total, a_off, rnb;
 };
 struct PackGroup {
     int count, B;
@@ -1517,6 +1564,15 @@ __device__ __forceinline__ unsigned long long pack_rows(const PackLevel& L, cons
         for (int u = 0; u < U; ++u) {
             const int m = min(m0 + r0 + 4 * u, M - 1);   // (a row past the end re-reads the last one; it is not consumed)
             const int b = m / HW, p = m - b * HW;
+            if (L.rmask) {   // the pixel's anchors are all known to carry no gradient: its row is zeros, nothing is loaded (wave-uniform)
+                const unsigned char* mp = L.rmask + (long long)b * L.a_total + L.a_off + (long long)p * L.rnb;
+                const unsigned char f = lane < L.rnb ? mp[lane] : (unsigned char)0;
+                if (!__ballot(f != 0)) {
+#pragma unroll
+                    for (int k = 0; k < ITERS; ++k) v[u][k] = 0.0f;
+                    continue;
+                }
+            }
             const float* srow = ds + (long long)b * sb + (long long)p * n0;
             const float* lrow = dl ? dl + (long long)b * lb + (long long)p * n1 : srow;
 #pragma unroll
@@ -2920,7 +2976,7 @@ extern "C" size_t ssdk_heads_bwd_fast_workspace_bytes(const ssdk_head_level* lev
 // wave per SIMD: more, shorter workgroups) and no workgroup walks more than 64 slices; each split costs one 64 KB
 // atomic tile, so never fewer than 2 slices per split.
 // picks the LDS-DMA kernel when every problem of the group qualifies (16-byte rows, operands below 2 GiB, pixel count below 2^24)
-static int launch_wgrad(WgradGroup& wg, hipStream_t s) {
+static int launch_wgrad(WgradGroup& wg, hipStream_t s, bool fast = false) {
     bool dma = !getenv("SSDK_CONV_NO_DMA");
     for (int i = 0; i < wg.count && dma; ++i) {
         WgradProblem& g = wg.p[i];
@@ -2931,7 +2987,8 @@ static int launch_wgrad(WgradGroup& wg, hipStream_t s) {
         g.dy_bytes = (unsigned)dy_bytes;
         g.x_bytes = (unsigned)x_bytes;
     }
-    if (dma) hipLaunchKernelGGL(igemm_wgrad_dma_kernel, dim3(wg.total_blocks), dim3(kConvThreads), 0, s, wg);
+    if (dma && fast) hipLaunchKernelGGL(igemm_wgrad_bf16x3_kernel, dim3(wg.total_blocks), dim3(kConvThreads), 0, s, wg);
+    else if (dma) hipLaunchKernelGGL(igemm_wgrad_dma_kernel, dim3(wg.total_blocks), dim3(kConvThreads), 0, s, wg);
     else hipLaunchKernelGGL(igemm_wgrad_kernel, dim3(wg.total_blocks), dim3(kConvThreads), 0, s, wg);
     SSDK_CHECK_LAUNCH("igemm_wgrad_kernel");
     return SSDK_OK;
@@ -2987,7 +3044,16 @@ static void size_wgrad_splits(WgradGroup& wg, int n, int density_div) {
 }
 
 static int heads_bwd_impl(const ssdk_head_level* levels, int n_levels, int batch, const float* dscores, long long scores_batch_stride,
-                          const float* dlocs, long long locs_batch_stride, void* workspace, size_t workspace_bytes, void* stream, bool fast);
+                          const float* dlocs, long long locs_batch_stride, void* workspace, size_t workspace_bytes, void* stream, bool fast,
+                          const unsigned char* row_mask = nullptr, int num_anchors = 0);
+extern "C" int ssdk_heads_bwd_ex(const ssdk_head_level* levels, int n_levels, int batch, const float* dscores, long long scores_batch_stride,
+                                 const float* dlocs, long long locs_batch_stride, const unsigned char* row_mask, int num_anchors, int fast_terms,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    SSDK_REQUIRE(fast_terms == 0 || fast_terms == 3, SSDK_E_UNSUPPORTED, "ssdk_heads_bwd_ex: fast_terms=%d (0 = fp32, 3 = split-bf16)", fast_terms);
+    SSDK_REQUIRE(!row_mask || num_anchors > 0, SSDK_E_INVALID, "ssdk_heads_bwd_ex: a row mask needs num_anchors");
+    return heads_bwd_impl(levels, n_levels, batch, dscores, scores_batch_stride, dlocs, locs_batch_stride, workspace, workspace_bytes, stream,
+                          fast_terms == 3, row_mask, num_anchors);
+}
 extern "C" int ssdk_heads_bwd(const ssdk_head_level* levels, int n_levels, int batch, const float* dscores,
                               long long scores_batch_stride, const float* dlocs, long long locs_batch_stride,
                               void* workspace, size_t workspace_bytes, void* stream) {
@@ -3000,7 +3066,8 @@ extern "C" int ssdk_heads_bwd_fast(const ssdk_head_level* levels, int n_levels, 
 }
 
 static int heads_bwd_impl(const ssdk_head_level* levels, int n_levels, int batch, const float* dscores, long long scores_batch_stride,
-                          const float* dlocs, long long locs_batch_stride, void* workspace, size_t workspace_bytes, void* stream, bool fast) {
+                          const float* dlocs, long long locs_batch_stride, void* workspace, size_t workspace_bytes, void* stream, bool fast,
+                          const unsigned char* row_mask, int num_anchors) {
     SSDK_REQUIRE(levels && n_levels > 0 && n_levels <= kMaxProblems, SSDK_E_INVALID, "ssdk_heads_bwd: n_levels=%d (1..%d)", n_levels, kMaxProblems);
     SSDK_REQUIRE(dscores, SSDK_E_INVALID, "ssdk_heads_bwd: null dscores");
     {
@@ -3066,6 +3133,14 @@ static int heads_bwd_impl(const ssdk_head_level* levels, int n_levels, int batch
             L.ds = dscores + lv.scores_offset; L.dl = lv.n_loc ? dlocs + lv.locs_offset : nullptr;
             L.n0 = lv.n_score; L.n1 = lv.n_loc; L.Npad = npad_of(lv); L.HW = lv.h * lv.w;
             L.out = w.dyp[i]; L.db0 = det ? nullptr : lv.db_score; L.db1 = det ? nullptr : lv.db_loc; L.row_list = w.row_list[i]; L.row_count = w.counts + i;
+            if (row_mask && lv.n_loc > 0 && lv.n_loc % 4 == 0 && lv.n_score % (lv.n_loc / 4) == 0) {
+                // the level's anchors in the caller's [batch][num_anchors] numbering: anchor-major class-minor rows (detector.py:52-63)
+                const int rnb = lv.n_loc / 4, C = lv.n_score / rnb;
+                if (rnb <= kWave && lv.scores_offset % C == 0 && lv.locs_offset == 4 * (lv.scores_offset / C) &&
+                    lv.scores_offset / C + (long long)L.HW * rnb <= num_anchors) {
+                    L.rmask = row_mask; L.a_total = num_anchors; L.a_off = (int)(lv.scores_offset / C); L.rnb = rnb;
+                }
+            }
             if (h_totals.nb[i]) {
                 L.nb = h_totals.nb[i]; L.C = lv.n_score / L.nb; L.Jpad = h_totals.jpad[i]; L.cap = batch * L.HW;
                 L.ga = w.ga[i]; L.apix = w.apix[i]; L.acount = w.acounts + i * kMaxAnchorTypes;
@@ -3228,10 +3303,10 @@ static int heads_bwd_impl(const ssdk_head_level* levels, int n_levels, int batch
     }
     if (n_wgrad) {
         size_wgrad_splits(wd_, n_wgrad, 1);
-        { int rc = launch_wgrad(wd_, s); if (rc) return rc; }
+        { int rc = launch_wgrad(wd_, s, fast); if (rc) return rc; }
         if (!det) {
             size_wgrad_splits(ws_, n_wgrad, 4);  // sparse mode means < 1/4 of the rows
-            int rc = launch_wgrad(ws_, s); if (rc) return rc;
+            int rc = launch_wgrad(ws_, s, fast); if (rc) return rc;
         }
     }
     if (det) {
@@ -3265,7 +3340,7 @@ static int heads_bwd_impl(const ssdk_head_level* levels, int n_levels, int batch
     }
     if (n_wanchor) {
         size_wgrad_splits(wa_, n_wanchor, 16);   // anchor mode: a few % of the anchors of one type
-        { int rc = launch_wgrad(wa_, s); if (rc) return rc; }
+        { int rc = launch_wgrad(wa_, s, fast); if (rc) return rc; }
     }
     return SSDK_OK;
 }
@@ -3607,7 +3682,7 @@ static int conv2d_bwd_impl(const ssdk_conv_desc* descs, int n, int batch, int ac
     }
     if (n_wgrad) {
         size_wgrad_splits(wg, n_wgrad, 1);
-        { int rc2 = launch_wgrad(wg, s); if (rc2) return rc2; }
+        { int rc2 = launch_wgrad(wg, s, fast); if (rc2) return rc2; }
     }
     if (det) {
         for (int i = 0; i < n; ++i) {

@@ -589,7 +589,8 @@ __global__ void __launch_bounds__(kLossThreads) loss_bwd_kernel(LossParams p, in
                                                                 const float* __restrict__ target, const uint8_t* __restrict__ sampled,
                                                                 const float* __restrict__ grad_out, long long n_rows,
                                                                 const float* __restrict__ lse, const LossState* __restrict__ state,
-                                                                float* __restrict__ dscores, float4* __restrict__ dlocs) {
+                                                                float* __restrict__ dscores, float4* __restrict__ dlocs,
+                                                                unsigned char* __restrict__ row_mask) {
     extern __shared__ __attribute__((aligned(16))) float s_tile[];  // kTileRows * C floats
     __shared__ int s_cls[kTileRows];
     __shared__ float s_tscore[kTileRows];
@@ -634,6 +635,8 @@ __global__ void __launch_bounds__(kLossThreads) loss_bwd_kernel(LossParams p, in
                 }
             }
             dlocs[r] = g;
+            // anchors whose gradient rows can be non-zero (a classification term, or a box term): what ssdk_heads_bwd_ex may rely on
+            if (row_mask) row_mask[r] = (want || pos) ? 1 : 0;
         }
         __syncthreads();
         const int nfloat = rows * p.C;
@@ -833,6 +836,14 @@ extern "C" int ssdk_multibox_loss_fwd(const ssdk_loss_params* params, const floa
 extern "C" int ssdk_multibox_loss_bwd(const ssdk_loss_params* params, const float* scores, const float* locs, const float* anchors,
                                       const float* target, const uint8_t* sampled, const float* grad_out, int batch, int num_anchors,
                                       int num_classes, float* dscores, float* dlocs, void* workspace, size_t workspace_bytes, void* stream) {
+    return ssdk_multibox_loss_bwd_ex(params, scores, locs, anchors, target, sampled, grad_out, batch, num_anchors, num_classes, dscores, dlocs,
+                                     nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int ssdk_multibox_loss_bwd_ex(const ssdk_loss_params* params, const float* scores, const float* locs, const float* anchors,
+                                         const float* target, const uint8_t* sampled, const float* grad_out, int batch, int num_anchors,
+                                         int num_classes, float* dscores, float* dlocs, uint8_t* row_mask, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
     int rc = check_loss_common("ssdk_multibox_loss_bwd", scores, batch, num_anchors, num_classes, workspace, workspace_bytes);
     if (rc) return rc;
     rc = check_loss_params("ssdk_multibox_loss_bwd", params);
@@ -850,7 +861,7 @@ extern "C" int ssdk_multibox_loss_bwd(const ssdk_loss_params* params, const floa
     const bool focal = params->cls_kind == SSDK_CLS_SIGMOID_FOCAL || params->cls_kind == SSDK_CLS_SOFTMAX_FOCAL;
     hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)std::min<long long>((n_rows + kTileRows - 1) / kTileRows, 1 << 20)), dim3(kLossThreads), lds, s, p, focal ? params->reduce_mean : 0,
                        params->classification_weight, params->localization_weight, scores, (const float4*)locs, (const float4*)anchors,
-                       num_anchors, target, sampled, grad_out, n_rows, w.lse, w.state, dscores, (float4*)dlocs);
+                       num_anchors, target, sampled, grad_out, n_rows, w.lse, w.state, dscores, (float4*)dlocs, row_mask);
     SSDK_CHECK_LAUNCH("loss_bwd_kernel");
     return SSDK_OK;
 }

@@ -20,6 +20,9 @@ SSDK_LOC_SMOOTH_L1 = 0
 SSDK_LOC_GIOU = 1
 
 
+_NO_ROW_HINT = bool(__import__('os').environ.get('SSDK_NO_ROW_HINT'))   # (measurement knob: the heads scan dscores as before round 4)
+
+
 def _unwrap_sampler(fn):
     """(base function, kwargs) of a possibly functools.partial-wrapped sampler (detection/init.py:90-92)."""
     kwargs = {}
@@ -65,6 +68,7 @@ class _MultiboxLossFn(torch.autograd.Function):
         ctx.save_for_backward(scores, locs, anchors, target, mask, ws)
         ctx.module = module
         ctx.shape = (B, A, C)
+        ctx.sparse_rows = fn is _sampler.hard_negative_mining   # (the gradient rows of the anchors that were not sampled are zeros)
         ctx.mark_non_differentiable(mask)
         return out3[1], out3[2], mask
 
@@ -77,10 +81,16 @@ class _MultiboxLossFn(torch.autograd.Function):
         dscores = torch.empty_like(scores)
         dlocs = torch.empty_like(locs)
         params = module.loss_params()
-        _lib.check(_lib.lib().ssdk_multibox_loss_bwd(ctypes.byref(params), _lib.ptr(scores), _lib.ptr(locs), _lib.ptr(anchors),
-                                                     _lib.ptr(target), _lib.ptr(mask), _lib.ptr(grad_out), B, A, C, _lib.ptr(dscores),
-                                                     _lib.ptr(dlocs), _lib.ptr(ws), ws.numel(), _lib.current_stream()),
+        # under hard-negative mining a few % of the anchors carry a gradient: the kernel also writes which (row_mask), and the heads'
+        # backward of this pass -- if it receives these very tensors -- reads only those rows instead of scanning all of dscores
+        row_mask = torch.empty((B, A), dtype=torch.uint8, device=scores.device) if ctx.sparse_rows and not _NO_ROW_HINT else None
+        _lib.check(_lib.lib().ssdk_multibox_loss_bwd_ex(ctypes.byref(params), _lib.ptr(scores), _lib.ptr(locs), _lib.ptr(anchors),
+                                                        _lib.ptr(target), _lib.ptr(mask), _lib.ptr(grad_out), B, A, C, _lib.ptr(dscores),
+                                                        _lib.ptr(dlocs), _lib.ptr(row_mask), _lib.ptr(ws), ws.numel(), _lib.current_stream()),
                    'ssdk_multibox_loss_bwd')
+        if row_mask is not None:
+            from ..modules import heads as heads_mod
+            heads_mod.gradient_row_hint = heads_mod.RowHint(dscores, dlocs, row_mask)
         return dscores, dlocs, None, None, None
 
 

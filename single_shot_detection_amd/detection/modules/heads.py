@@ -46,6 +46,37 @@ class fast_mode(object):
 launch_events = None
 
 
+# What the producer of the heads' upstream gradient knows about its sparsity (MultiboxLoss's backward under hard-negative mining: ~4 % of
+# the anchors carry a gradient): set by the producer inside a backward pass, taken -- once -- by the heads' backward of the SAME pass,
+# and only for the very tensors the producer returned (same storage, same version: anything autograd added on the way is another tensor).
+class RowHint(object):
+    __slots__ = ('task', 'key', 'mask')
+
+    def __init__(self, dscores, dlocs, mask):
+        self.task = torch._C._current_graph_task_id()
+        self.key = (dscores.data_ptr(), dscores._version, tuple(dscores.shape), dlocs.data_ptr(), dlocs._version, tuple(dlocs.shape))
+        self.mask = mask   # uint8 [B, A]: 0 = the anchor's dscores and dlocs rows are zeros
+
+
+gradient_row_hint = None
+row_hints_taken = 0   # (tests / diagnostics: heads backward calls that ran with a producer's row mask)
+
+
+def take_row_hint(dscores, dlocs):
+    """The row mask for exactly these gradient tensors in this backward pass, or None; the hint is consumed either way."""
+    global gradient_row_hint
+    h, gradient_row_hint = gradient_row_hint, None
+    if h is None or dscores is None or dlocs is None or h.task != torch._C._current_graph_task_id():
+        return None
+    if h.key != (dscores.data_ptr(), dscores._version, tuple(dscores.shape), dlocs.data_ptr(), dlocs._version, tuple(dlocs.shape)):
+        return None
+    if h.mask.shape[0] != dscores.shape[0] or dlocs.shape[1] != 4 * h.mask.shape[1]:
+        return None
+    global row_hints_taken
+    row_hints_taken += 1
+    return h.mask
+
+
 def to_nhwc(x):
     """[B,C,H,W] tensor whose memory is NHWC (zero-copy when the producer already runs channels_last)."""
     x = x.float()
@@ -137,9 +168,10 @@ def _stash_levels(ctx, levels, sinks):
     ctx.sinks = sinks
 
 
-def _launch_backward(ctx, dscores, dlocs, needs, s_tot, l_tot):
+def _launch_backward(ctx, dscores, dlocs, needs, s_tot, l_tot, row_mask=None):
     """dgrad + wgrad + dbias of ctx's levels from their slices of the rows of dscores / dlocs; returns the flat gradient tuple
-    (dx, dw_score, db_score, dw_loc, db_loc) * L.  ``needs``: ctx.needs_input_grad of those 5 L arguments."""
+    (dx, dw_score, db_score, dw_loc, db_loc) * L.  ``needs``: ctx.needs_input_grad of those 5 L arguments.  ``row_mask``: uint8 [B, A],
+    0 = the producer of the gradient guarantees that anchor's rows to be zeros (take_row_hint)."""
     lib = _lib.lib()
     saved = ctx.saved_tensors
     levels = [dict(lv, x=saved[3 * i], ws=saved[3 * i + 1], wl=saved[3 * i + 2], bs=None, bl=None) for i, lv in enumerate(ctx.levels)]
@@ -166,16 +198,13 @@ def _launch_backward(ctx, dscores, dlocs, needs, s_tot, l_tot):
         out += [gr['dx'], gr['dws'] if need_ws else None, gr['dbs'] if (need_bs and lv['has_bs']) else None,
                 gr['dwl'] if need_wl else None, gr['dbl'] if (need_bl and lv['has_bl']) else None]
     arr = _level_array(levels, grads)
-    if _lib.fast_mode == 'bf16x3':   # the dense data gradients on the split-bf16 GEMM; sparse forms, weight / bias gradients unchanged
-        need = lib.ssdk_heads_bwd_fast_workspace_bytes(arr, len(levels), B)
-        ws = _lib.scratch(need, dev, 'heads_bwd')
-        _lib.check(lib.ssdk_heads_bwd_fast(arr, len(levels), B, _dp(dscores), s_tot, _dp(dlocs), l_tot, 3, _dp(ws), need,
-                                           _lib.current_stream()), 'ssdk_heads_bwd_fast')
-        return out
-    need = lib.ssdk_heads_bwd_workspace_bytes(arr, len(levels), B)
+    # fast mode: the dense data gradients on the split-bf16 GEMM; sparse forms, weight / bias gradients unchanged
+    fast = _lib.fast_mode == 'bf16x3'
+    need = (lib.ssdk_heads_bwd_fast_workspace_bytes if fast else lib.ssdk_heads_bwd_workspace_bytes)(arr, len(levels), B)
     ws = _lib.scratch(need, dev, 'heads_bwd')
-    _lib.check(lib.ssdk_heads_bwd(arr, len(levels), B, _dp(dscores), s_tot, _dp(dlocs), l_tot, _dp(ws), need,
-                                  _lib.current_stream()), 'ssdk_heads_bwd')
+    _lib.check(lib.ssdk_heads_bwd_ex(arr, len(levels), B, _dp(dscores), s_tot, _dp(dlocs), l_tot, _dp(row_mask),
+                                     0 if row_mask is None else row_mask.shape[1], 3 if fast else 0, _dp(ws), need, _lib.current_stream()),
+               'ssdk_heads_bwd')
     return out
 
 
@@ -197,9 +226,10 @@ class _HeadsFn(torch.autograd.Function):
     def backward(ctx, dscores, dlocs):
         s_tot, l_tot = ctx.totals
         B, dev = ctx.levels[0]['B'], ctx.saved_tensors[0].device
+        mask = take_row_hint(dscores, dlocs)
         dscores = (torch.zeros((B, s_tot), dtype=torch.float32, device=dev) if dscores is None else dscores.float().contiguous())
         dlocs = (torch.zeros((B, l_tot), dtype=torch.float32, device=dev) if dlocs is None else dlocs.float().contiguous())
-        return tuple(_launch_backward(ctx, dscores, dlocs, ctx.needs_input_grad, s_tot, l_tot))
+        return tuple(_launch_backward(ctx, dscores, dlocs, ctx.needs_input_grad, s_tot, l_tot, mask))
 
 
 # ---- the same heads as TWO independent autograd nodes (dependency split) -------------------------------------------------------------
@@ -212,7 +242,7 @@ class _HeadsShared(object):
     """What the parts of one split heads call share: the output rows while the forward pass runs (dropped once the join has handed them
     on: the join node's outputs would otherwise keep the autograd graph alive through this object), and in the backward pass the
     gradient rows the join received."""
-    __slots__ = ('scores', 'locs', 's_tot', 'l_tot', 'dscores', 'dlocs', 'join_event', 'join_stream', 'pending', 'first_done', 'order')
+    __slots__ = ('scores', 'locs', 's_tot', 'l_tot', 'dscores', 'dlocs', 'join_event', 'join_stream', 'pending', 'first_done', 'order', 'row_mask')
 
     def __init__(self, scores, locs):
         self.scores, self.locs = scores, locs
@@ -221,6 +251,7 @@ class _HeadsShared(object):
         self.pending = []        # levels of parts that left their GEMM to the join (ONE grouped launch of all levels)
         self.first_done = None   # backward: event behind the part that ran first (order = True: the other part waits for it)
         self.order = False
+        self.row_mask = None     # backward: the gradient producer's row mask (take_row_hint), for every part
 
 
 class _HeadsPartFn(torch.autograd.Function):
@@ -253,7 +284,9 @@ class _HeadsPartFn(torch.autograd.Function):
             sh.dlocs.record_stream(cur)
         if sh.order and sh.first_done is not None:
             cur.wait_event(sh.first_done)   # (the part in front of the pyramid tail's backward chain had the chip to itself)
-        out = _launch_backward(ctx, sh.dscores, sh.dlocs, ctx.needs_input_grad[4:], sh.s_tot, sh.l_tot)
+        if sh.row_mask is not None and cur != sh.join_stream:
+            sh.row_mask.record_stream(cur)
+        out = _launch_backward(ctx, sh.dscores, sh.dlocs, ctx.needs_input_grad[4:], sh.s_tot, sh.l_tot, sh.row_mask)
         if sh.order and sh.first_done is None:
             sh.first_done = torch.cuda.Event()
             sh.first_done.record(cur)
@@ -279,6 +312,7 @@ class _HeadsJoinFn(torch.autograd.Function):
     def backward(ctx, dscores, dlocs):
         sh = ctx.shared
         s_shape, l_shape, dev = ctx.meta
+        sh.row_mask = take_row_hint(dscores, dlocs)
         sh.dscores = torch.zeros(s_shape, dtype=torch.float32, device=dev) if dscores is None else dscores.float().contiguous()
         sh.dlocs = torch.zeros(l_shape, dtype=torch.float32, device=dev) if dlocs is None else dlocs.float().contiguous()
         sh.join_stream = torch.cuda.current_stream()
