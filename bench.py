@@ -550,7 +550,7 @@ def fast_mode_legs(device, cfg_name='ssd_300_vgg16_voc', batch=32, steps=10):
     torch.cuda.empty_cache()
     tower = fast_mode_tower_leg(device)
     return {'mode': 'bf16x3', 'tower': tower, 'what': 'forward head GEMM with operands split into bf16 pieces, a_hi b_hi + a_hi b_mid + a_mid b_hi on '
-                                      'v_mfma_f32_32x32x16_bf16, fp32 accumulate; weights split per call (included in the time); backward unchanged (fp32)',
+                                      'v_mfma_f32_32x32x16_bf16, fp32 accumulate; weights split per call (included in the time); in the training step the dense data gradients and the weight gradients take the same mode',
             'workload': f'{cfg_name} batch {batch}', 'heads_fwd_us': usf, 'heads_fwd_fp32_us': us32, 'speedup_vs_fp32_launch': us32 / usf,
             'max_abs_err_over_scale': {'scores': err_s, 'locs': err_l}, 'loss_fp32': losses[0], 'loss_fast': losses[1],
             'loss_abs_diff': abs(losses[0] - losses[1]),
@@ -577,7 +577,7 @@ def fast_mode_tower_leg(device, cfg_name='retina_rn50_500_coco', batch=32):
     with heads_mod.fast_mode('bf16x3'):
         usf = gpu_time_us(fwd, inner=3, reps=3)
         sf, lf = fwd()
-    # the whole training step: fp32 against forward + data gradients in the split-bf16 mode (weight gradients stay fp32)
+    # the whole training step: fp32 against forward + data gradients + weight gradients in the split-bf16 mode
     hp.set_training(True)
 
     def step_ms(n=4):
@@ -597,7 +597,7 @@ def fast_mode_tower_leg(device, cfg_name='retina_rn50_500_coco', batch=32):
             'max_abs_err_over_scale': {'scores': float((sf - s32).abs().max()) / float(s32.abs().max()),
                                        'locs': float((lf - l32).abs().max()) / float(l32.abs().max())},
             'train_step': {'what': 'full training step (towers + heads fwd / bwd, focal loss, SGD): fp32 against forward + data gradients in the '
-                                   'split-bf16 mode, weight gradients fp32', 'fp32_ms': ms32, 'fast_ms': msf, 'speedup': ms32 / msf,
+                                   'split-bf16 mode, weight gradients in it too (igemm_wgrad_bf16x3_kernel)', 'fp32_ms': ms32, 'fast_ms': msf, 'speedup': ms32 / msf,
                            'images_per_sec_fast': batch / (msf * 1e-3)}}
 
 

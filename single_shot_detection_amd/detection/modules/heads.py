@@ -11,12 +11,14 @@ from ...distributed import grad_sink
 
 
 def set_fast_mode(mode):
-    """Opt-in reduced-precision mode of the forward GEMMs (the reference's analogue: apex AMP O1, bf/training/env.py:87-95).
-    ``None`` (default): exact fp32 on v_mfma_f32_32x32x2_f32.  ``'bf16x3'``: operands split into bf16 pieces, three cross terms per product
-    on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- the head GEMM (ssdk_heads_fwd_fast) and every ``ops.conv2d`` whose input has
-    Cin % 32 == 0 (ssdk_conv2d_fwd_fast: RetinaNet's towers, the pyramid tail); outputs within ~1e-5 of their scale; the backward pass is
-    unchanged.  The heads need Cin % 32 == 0 on every level (the call raises otherwise); other convolutions stay fp32 where it does not
-    hold.  Returns the previous setting."""
+    """Opt-in reduced-precision mode of the GEMMs, forward AND backward (the reference's analogue: apex AMP O1, bf/training/env.py:87-95,
+    bf/training/callbacks.py:34-40).  ``None`` (default): exact fp32 on v_mfma_f32_32x32x2_f32.  ``'bf16x3'``: operands split into bf16
+    pieces, three cross terms per product on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- the head GEMM (ssdk_heads_fwd_fast),
+    every ``ops.conv2d`` of at least ~1 GFLOP whose input has Cin % 32 == 0 (ssdk_conv2d_fwd_fast: RetinaNet's towers, necks, the large
+    layers of a pyramid tail), and in the backward pass the dense stride-1 data gradients and every weight gradient (ssdk_heads_bwd_fast,
+    ssdk_conv2d_bwd_fast); bias gradients, the sparse / strided data gradients, norms and losses stay fp32.  Outputs and gradients within
+    ~1e-5 of their scale.  The heads need Cin % 32 == 0 on every level (the forward call raises otherwise); other convolutions stay fp32
+    where it does not hold.  Returns the previous setting."""
     if mode not in (None, 'bf16x3'):
         raise ValueError(f'fast mode {mode!r}: None or "bf16x3"')
     prev, _lib.fast_mode = _lib.fast_mode, mode
