@@ -157,6 +157,7 @@ class HotPath(object):
                       ([p for p in self.tower.parameters()] if self.tower is not None else []) + \
                       ([p for n, p in self.neck.named_parameters() if not n.startswith('base.')] if self.neck is not None else [])
         self.opt = _sgd(self.params, lr=1e-3, momentum=0.9, weight_decay=5e-4)
+        self._one = torch.ones((), dtype=torch.float32, device=device)
         self.exchange = None    # N > 1: distributed.BucketedDataParallel around the path's modules (enable_exchange)
         # exchange step (N > 1): the head gradients are complete as soon as the heads' backward has run, so their ring starts
         # there and overlaps with the backward of the extras / tower; a second, small bucket carries the rest
@@ -270,7 +271,9 @@ class HotPath(object):
         scores, locs = self.forward_heads(timed)
         target = self.assigner.encode_ground_truth(self.resident_ground_truth(), self.anchors)
         loss, class_loss, loc_loss = self.criterion((scores, locs), self.anchors, target)
-        loss.backward()   # (N > 1: the exchange runs inside -- BucketedDataParallel's hooks and end-of-backward callback)
+        # (the root gradient is a resident 1.0: backward() would make a ones_like(loss) with a fill launch every step; N > 1: the exchange
+        # runs inside -- BucketedDataParallel's hooks and end-of-backward callback)
+        loss.backward(self._one)
         self.opt.step()
         return loss
 

@@ -190,9 +190,10 @@ int ssdk_multibox_loss_bwd(const ssdk_loss_params* params, const float* scores, 
                            void* stream);
 /* ... which also writes row_mask DEV uint8 [batch][num_anchors] (NULL: not wanted): 1 where the anchor's dscores / dlocs rows can be
  * non-zero (it contributes a classification term, or it is a positive and contributes a box term), 0 where both rows were written as
- * zeros -- the guarantee ssdk_heads_bwd_ex takes. */
+ * zeros -- the guarantee ssdk_heads_bwd_ex takes.  grad_single != 0: grad_out is ONE device scalar, the upstream gradient of
+ * loss = class_loss + loc_loss (out3[0] of the forward), applied to both terms; 0: grad_out[2] = (d class_loss, d loc_loss). */
 int ssdk_multibox_loss_bwd_ex(const ssdk_loss_params* params, const float* scores, const float* locs, const float* anchors,
-                              const float* target, const uint8_t* sampled, const float* grad_out, int batch, int num_anchors,
+                              const float* target, const uint8_t* sampled, const float* grad_out, int grad_single, int batch, int num_anchors,
                               int num_classes, float* dscores, float* dlocs, uint8_t* row_mask, void* workspace, size_t workspace_bytes,
                               void* stream);
 

@@ -590,14 +590,14 @@ __global__ void __launch_bounds__(kLossThreads) loss_bwd_kernel(LossParams p, in
                                                                 const float* __restrict__ grad_out, long long n_rows,
                                                                 const float* __restrict__ lse, const LossState* __restrict__ state,
                                                                 float* __restrict__ dscores, float4* __restrict__ dlocs,
-                                                                unsigned char* __restrict__ row_mask) {
+                                                                unsigned char* __restrict__ row_mask, int grad_single) {
     extern __shared__ __attribute__((aligned(16))) float s_tile[];  // kTileRows * C floats
     __shared__ int s_cls[kTileRows];
     __shared__ float s_tscore[kTileRows];
     __shared__ int s_any;
     const float divider = state->divider;
     const float g_cls = grad_out[0] * state->scale * cls_w / divider / (reduce_mean ? state->mean_div : 1.0f);
-    const float g_loc = grad_out[1] * loc_w / divider;
+    const float g_loc = grad_out[grad_single ? 0 : 1] * loc_w / divider;   // (grad_single: one upstream scalar, the gradient of class_loss + loc_loss)
     const long long n_tiles = (n_rows + kTileRows - 1) / kTileRows;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -836,12 +836,12 @@ extern "C" int ssdk_multibox_loss_fwd(const ssdk_loss_params* params, const floa
 extern "C" int ssdk_multibox_loss_bwd(const ssdk_loss_params* params, const float* scores, const float* locs, const float* anchors,
                                       const float* target, const uint8_t* sampled, const float* grad_out, int batch, int num_anchors,
                                       int num_classes, float* dscores, float* dlocs, void* workspace, size_t workspace_bytes, void* stream) {
-    return ssdk_multibox_loss_bwd_ex(params, scores, locs, anchors, target, sampled, grad_out, batch, num_anchors, num_classes, dscores, dlocs,
+    return ssdk_multibox_loss_bwd_ex(params, scores, locs, anchors, target, sampled, grad_out, 0, batch, num_anchors, num_classes, dscores, dlocs,
                                      nullptr, workspace, workspace_bytes, stream);
 }
 
 extern "C" int ssdk_multibox_loss_bwd_ex(const ssdk_loss_params* params, const float* scores, const float* locs, const float* anchors,
-                                         const float* target, const uint8_t* sampled, const float* grad_out, int batch, int num_anchors,
+                                         const float* target, const uint8_t* sampled, const float* grad_out, int grad_single, int batch, int num_anchors,
                                          int num_classes, float* dscores, float* dlocs, uint8_t* row_mask, void* workspace,
                                          size_t workspace_bytes, void* stream) {
     int rc = check_loss_common("ssdk_multibox_loss_bwd", scores, batch, num_anchors, num_classes, workspace, workspace_bytes);
@@ -861,7 +861,7 @@ extern "C" int ssdk_multibox_loss_bwd_ex(const ssdk_loss_params* params, const f
     const bool focal = params->cls_kind == SSDK_CLS_SIGMOID_FOCAL || params->cls_kind == SSDK_CLS_SOFTMAX_FOCAL;
     hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)std::min<long long>((n_rows + kTileRows - 1) / kTileRows, 1 << 20)), dim3(kLossThreads), lds, s, p, focal ? params->reduce_mean : 0,
                        params->classification_weight, params->localization_weight, scores, (const float4*)locs, (const float4*)anchors,
-                       num_anchors, target, sampled, grad_out, n_rows, w.lse, w.state, dscores, (float4*)dlocs, row_mask);
+                       num_anchors, target, sampled, grad_out, n_rows, w.lse, w.state, dscores, (float4*)dlocs, row_mask, grad_single ? 1 : 0);
     SSDK_CHECK_LAUNCH("loss_bwd_kernel");
     return SSDK_OK;
 }

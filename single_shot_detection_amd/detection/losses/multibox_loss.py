@@ -70,14 +70,26 @@ class _MultiboxLossFn(torch.autograd.Function):
         ctx.shape = (B, A, C)
         ctx.sparse_rows = fn is _sampler.hard_negative_mining   # (the gradient rows of the anchors that were not sampled are zeros)
         ctx.mark_non_differentiable(mask)
-        return out3[1], out3[2], mask
+        ctx.set_materialize_grads(False)   # (an output nobody differentiated arrives as None, not as a zero tensor made by a fill launch)
+        return out3[0], out3[1], out3[2], mask   # loss = class_loss + loc_loss (summed by the kernel: multibox_loss.py:93), class_loss, loc_loss
 
     @staticmethod
-    def backward(ctx, g_class, g_loc, _g_mask):
+    def backward(ctx, g_total, g_class, g_loc, _g_mask):
         scores, locs, anchors, target, mask, ws = ctx.saved_tensors
         module = ctx.module
         B, A, C = ctx.shape
-        grad_out = torch.stack([g_class.float().reshape(()), g_loc.float().reshape(())]).contiguous()
+        if g_total is None and g_class is None and g_loc is None:
+            return None, None, None, None, None
+        # the usual case: only `loss` was differentiated -- its gradient (one device scalar) goes to the kernel as it is; anything else
+        # (class_loss / loc_loss used on their own in the same backward pass) is combined into the two-element form first
+        single = g_class is None and g_loc is None
+        if single:
+            grad_out = g_total.float().reshape(1).contiguous()
+        else:
+            zero = scores.new_zeros(())
+            gt = zero if g_total is None else g_total.float().reshape(())
+            grad_out = torch.stack([gt + (zero if g_class is None else g_class.float().reshape(())),
+                                    gt + (zero if g_loc is None else g_loc.float().reshape(()))]).contiguous()
         dscores = torch.empty_like(scores)
         dlocs = torch.empty_like(locs)
         params = module.loss_params()
@@ -85,7 +97,7 @@ class _MultiboxLossFn(torch.autograd.Function):
         # backward of this pass -- if it receives these very tensors -- reads only those rows instead of scanning all of dscores
         row_mask = torch.empty((B, A), dtype=torch.uint8, device=scores.device) if ctx.sparse_rows and not _NO_ROW_HINT else None
         _lib.check(_lib.lib().ssdk_multibox_loss_bwd_ex(ctypes.byref(params), _lib.ptr(scores), _lib.ptr(locs), _lib.ptr(anchors),
-                                                        _lib.ptr(target), _lib.ptr(mask), _lib.ptr(grad_out), B, A, C, _lib.ptr(dscores),
+                                                        _lib.ptr(target), _lib.ptr(mask), _lib.ptr(grad_out), 1 if single else 0, B, A, C, _lib.ptr(dscores),
                                                         _lib.ptr(dlocs), _lib.ptr(row_mask), _lib.ptr(ws), ws.numel(), _lib.current_stream()),
                    'ssdk_multibox_loss_bwd')
         if row_mask is not None:
@@ -180,7 +192,6 @@ class MultiboxLoss(nn.Module):
         scores = scores.float().contiguous()
         locs = locs.float().contiguous()
         anchors = anchors.float().contiguous()
-        class_loss, loc_loss, mask = _MultiboxLossFn.apply(scores, locs, anchors, target, self)
+        loss, class_loss, loc_loss, mask = _MultiboxLossFn.apply(scores, locs, anchors, target, self)
         self.last_sampled_mask = mask
-        loss = class_loss + loc_loss
         return loss, class_loss, loc_loss

@@ -77,8 +77,10 @@ def main():
         if rel > worst[0]:
             worst = (rel, '%s |synced| %.3e |mean of locals| %.3e |local| %.3e' % (names[id(p)], float(sg.abs().max()), float(mean.abs().max()), float(p.grad.abs().max())))
         p.grad = sg
-    # (two forward / backward passes of a 50-layer network with fp32 atomics: ~1e-3 of run-to-run noise; a missing or wrong average is O(1))
-    assert worst[0] <= 1e-2, worst
+    # (two forward / backward passes of a 50-layer network with fp32 atomics: ~1e-3 of run-to-run noise, and a hard negative that changes
+    # places between the passes moves single gradients by a few % -- 5 % seen; a missing or wrong average is off by ~|g_0 - g_1| / 2,
+    # i.e. O(1) of this scale)
+    assert worst[0] <= 0.15, worst
     # DistributedDataParallel averaged the gradients: every rank holds the same ones, although the ranks saw different images
     mine = torch.stack([p.grad.double().sum() for p in params] + [loss.detach().double()]).cpu()
     both = [torch.zeros_like(mine) for _ in range(world)]
