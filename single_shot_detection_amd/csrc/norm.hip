@@ -507,22 +507,34 @@ extern "C" int ssdk_upsample_nearest_add_bwd(const float* dout, int batch, int h
 // Reference: bf/modules/features.py:286-298  x = adaptive_avg_pool2d(f, 1); x = fc2(relu(fc1(x))); out = f * sigmoid(x).
 // The two 1x1 "fc" convolutions run on the GEMM kernels; these are the pool and the gate (with their backward).
 namespace ssdk {
-// mean over the HW pixels of each image: x [B][HW][C] -> out [B][C]; one workgroup per (image, 64-float4 column block)
+// mean over the HW pixels of each image: x [B][HW][C] -> out [B][C].  One workgroup per (image, 16-float4 column block): thread
+// (column q of 16, row phase r of 16); a wave instruction reads four rows x 256 contiguous bytes, four row groups are in flight per
+// thread, the 16 phases are folded through LDS.  (Round 3's form -- 64 columns per workgroup, one row in flight per wave -- put M2Det's
+// SFAM pool of a [16, 1024, 64, 64] map, 268 MB, on 64 workgroups: ~600 us; this one uses 256.)
+constexpr int kPoolCols = 16;   // float4 columns per workgroup
 __global__ void __launch_bounds__(256) avgpool_kernel(const float4* __restrict__ x, int HW, int C4, float4* __restrict__ out) {
-    __shared__ float4 s_part[4][64];
-    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c4 = blockIdx.x * 64 + lane;
+    __shared__ float4 s_part[16][kPoolCols];
+    const int b = blockIdx.y, q = threadIdx.x & (kPoolCols - 1), r = threadIdx.x / kPoolCols;
+    const int c4 = blockIdx.x * kPoolCols + q;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c4 < C4)
-        for (int p = wave; p < HW; p += 4) {
-            const float4 v = x[((long long)b * HW + p) * C4 + c4];
+    if (c4 < C4) {
+        const float4* base = x + (long long)b * HW * C4 + c4;
+        int p = r;
+        for (; p + 48 < HW; p += 64) {   // rows p, p + 16, p + 32, p + 48: four loads in flight
+            const float4 v0 = base[(long long)p * C4], v1 = base[(long long)(p + 16) * C4], v2 = base[(long long)(p + 32) * C4], v3 = base[(long long)(p + 48) * C4];
+            a.x += (v0.x + v1.x) + (v2.x + v3.x); a.y += (v0.y + v1.y) + (v2.y + v3.y);
+            a.z += (v0.z + v1.z) + (v2.z + v3.z); a.w += (v0.w + v1.w) + (v2.w + v3.w);
+        }
+        for (; p < HW; p += 16) {
+            const float4 v = base[(long long)p * C4];
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
-    s_part[wave][lane] = a;
+    }
+    s_part[r][q] = a;
     __syncthreads();
-    if (wave == 0 && c4 < C4) {
-        float4 t = s_part[0][lane];
-        for (int w = 1; w < 4; ++w) { const float4 u = s_part[w][lane]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+    if (r == 0 && c4 < C4) {
+        float4 t = s_part[0][q];
+        for (int w = 1; w < 16; ++w) { const float4 u = s_part[w][q]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
         const float inv = 1.0f / (float)HW;
         out[(long long)b * C4 + c4] = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
     }
@@ -549,28 +561,37 @@ __global__ void __launch_bounds__(256) gate_kernel(const float4* __restrict__ x,
         out[i] = make_float4(v.x * sigm(q.x), v.y * sigm(q.y), v.z * sigm(q.z), v.w * sigm(q.w));
     }
 }
-// dx = dout * sigmoid(z);  dz[b][c] = sigmoid'(z) * sum_hw dout * x   (one workgroup per (image, column block))
+// dx = dout * sigmoid(z);  dz[b][c] = sigmoid'(z) * sum_hw dout * x   (one workgroup per (image, 16-float4 column block), as avgpool_kernel)
 __global__ void __launch_bounds__(256) gate_bwd_kernel(const float4* __restrict__ x, const float4* __restrict__ z, const float4* __restrict__ dout,
                                                        int HW, int C4, float4* __restrict__ dx, float4* __restrict__ dz) {
-    __shared__ float4 s_part[4][64];
-    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c4 = blockIdx.x * 64 + lane;
+    __shared__ float4 s_part[16][kPoolCols];
+    const int b = blockIdx.y, q = threadIdx.x & (kPoolCols - 1), r = threadIdx.x / kPoolCols;
+    const int c4 = blockIdx.x * kPoolCols + q;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), sg = a;
     if (c4 < C4) {
-        const float4 q = z[(long long)b * C4 + c4];
-        sg = make_float4(sigm(q.x), sigm(q.y), sigm(q.z), sigm(q.w));
-        for (int p = wave; p < HW; p += 4) {
-            const long long i = ((long long)b * HW + p) * C4 + c4;
+        const float4 zq = z[(long long)b * C4 + c4];
+        sg = make_float4(sigm(zq.x), sigm(zq.y), sigm(zq.z), sigm(zq.w));
+        const long long base = (long long)b * HW * C4 + c4;
+        int p = r;
+        for (; p + 16 < HW; p += 32) {   // two rows (of both operands) in flight
+            const long long i0 = base + (long long)p * C4, i1 = base + (long long)(p + 16) * C4;
+            const float4 g0 = dout[i0], v0 = x[i0], g1 = dout[i1], v1 = x[i1];
+            dx[i0] = make_float4(g0.x * sg.x, g0.y * sg.y, g0.z * sg.z, g0.w * sg.w);
+            dx[i1] = make_float4(g1.x * sg.x, g1.y * sg.y, g1.z * sg.z, g1.w * sg.w);
+            a.x += g0.x * v0.x + g1.x * v1.x; a.y += g0.y * v0.y + g1.y * v1.y; a.z += g0.z * v0.z + g1.z * v1.z; a.w += g0.w * v0.w + g1.w * v1.w;
+        }
+        for (; p < HW; p += 16) {
+            const long long i = base + (long long)p * C4;
             const float4 g = dout[i], v = x[i];
             dx[i] = make_float4(g.x * sg.x, g.y * sg.y, g.z * sg.z, g.w * sg.w);
             a.x += g.x * v.x; a.y += g.y * v.y; a.z += g.z * v.z; a.w += g.w * v.w;
         }
     }
-    s_part[wave][lane] = a;
+    s_part[r][q] = a;
     __syncthreads();
-    if (wave == 0 && c4 < C4) {
-        float4 t = s_part[0][lane];
-        for (int w = 1; w < 4; ++w) { const float4 u = s_part[w][lane]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+    if (r == 0 && c4 < C4) {
+        float4 t = s_part[0][q];
+        for (int w = 1; w < 16; ++w) { const float4 u = s_part[w][q]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
         dz[(long long)b * C4 + c4] = make_float4(t.x * sg.x * (1.f - sg.x), t.y * sg.y * (1.f - sg.y), t.z * sg.z * (1.f - sg.z), t.w * sg.w * (1.f - sg.w));
     }
 }
@@ -585,7 +606,7 @@ extern "C" int ssdk_global_avgpool_fwd(const float* x, int batch, int hw, int ch
     int rc = check_bhwc("ssdk_global_avgpool_fwd", batch, hw, channels);
     if (rc) return rc;
     SSDK_REQUIRE(x && out, SSDK_E_INVALID, "ssdk_global_avgpool_fwd: null pointer");
-    hipLaunchKernelGGL(avgpool_kernel, dim3(cdiv(channels / 4, 64), batch), dim3(256), 0, (hipStream_t)stream, (const float4*)x, hw, channels / 4, (float4*)out);
+    hipLaunchKernelGGL(avgpool_kernel, dim3(cdiv(channels / 4, ssdk::kPoolCols), batch), dim3(256), 0, (hipStream_t)stream, (const float4*)x, hw, channels / 4, (float4*)out);
     SSDK_CHECK_LAUNCH("avgpool_kernel");
     return SSDK_OK;
 }
@@ -612,7 +633,7 @@ extern "C" int ssdk_sigmoid_gate_bwd(const float* x, const float* z, const float
     int rc = check_bhwc("ssdk_sigmoid_gate_bwd", batch, hw, channels);
     if (rc) return rc;
     SSDK_REQUIRE(x && z && dout && dx && dz, SSDK_E_INVALID, "ssdk_sigmoid_gate_bwd: null pointer");
-    hipLaunchKernelGGL(gate_bwd_kernel, dim3(cdiv(channels / 4, 64), batch), dim3(256), 0, (hipStream_t)stream, (const float4*)x, (const float4*)z,
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(cdiv(channels / 4, ssdk::kPoolCols), batch), dim3(256), 0, (hipStream_t)stream, (const float4*)x, (const float4*)z,
                        (const float4*)dout, hw, channels / 4, (float4*)dx, (float4*)dz);
     SSDK_CHECK_LAUNCH("gate_bwd_kernel");
     return SSDK_OK;

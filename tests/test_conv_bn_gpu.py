@@ -682,3 +682,28 @@ def test_prepared_weight_transposes_follow_a_fused_optimizer_step():
         scale = float(xc.grad.abs().max())
         assert float((xi.grad.cpu() - xc.grad).abs().max()) <= 2e-5 * scale, (step, float((xi.grad.cpu() - xc.grad).abs().max()), scale)
         opt.step()   # (moves the weights by half their gradient: a stale layout is off by far more than the bound)
+
+
+@pytest.mark.parametrize('B,C,H', [(2, 1024, 64), (3, 40, 5), (1, 128, 17), (4, 256, 2), (2, 64, 1)])
+def test_global_avg_pool_and_sigmoid_gate_vs_torch(B, C, H):
+    """ops.global_avg_pool / ops.sigmoid_gate (M2Det SFAM, bf/modules/features.py:290-298) against torch on shapes that exercise the
+    kernels' row loops (four rows in flight, then single rows; HW = 1) and column tails (C / 4 not a multiple of the 16-column block)."""
+    import torch.nn.functional as F
+    from single_shot_detection_amd import ops
+    torch.manual_seed(B * 1000 + C + H)
+    x = torch.randn((B, C, H, H), device='cuda').contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    z = torch.randn((B, C, 1, 1), device='cuda').requires_grad_(True)
+    g = torch.randn((B, C, H, H), device='cuda').contiguous(memory_format=torch.channels_last)
+    pooled = ops.global_avg_pool(x)
+    ref = F.adaptive_avg_pool2d(x.detach().double(), 1)
+    assert float((pooled.detach().double() - ref).abs().max()) <= 1e-6 * max(1.0, float(ref.abs().max())) + 1e-6
+    (gx,) = torch.autograd.grad(pooled, [x], torch.ones_like(pooled))
+    assert float((gx - 1.0 / (H * H)).abs().max()) <= 1e-7
+    out = ops.sigmoid_gate(x, z)
+    xr, zr = x.detach().double().requires_grad_(True), z.detach().double().requires_grad_(True)
+    outr = xr * torch.sigmoid(zr)
+    assert float((out.detach().double() - outr.detach()).abs().max()) <= 1e-5
+    dx, dz = torch.autograd.grad(out, [x, z], g)
+    dxr, dzr = torch.autograd.grad(outr, [xr, zr], g.double())
+    assert float((dx.double() - dxr).abs().max()) <= 1e-5
+    assert float((dz.double() - dzr).abs().max()) <= 2e-5 * float(dzr.abs().max()) + 1e-5
