@@ -68,3 +68,4 @@ def graphed_eval(detector, postprocessor, example_images, warmup=3):
             scores, locs, priors = detector(images)
             return postprocessor.postprocess_padded((scores, locs), priors)
     return GraphedCallable(step, [example_images], warmup=warmup)
+

@@ -589,3 +589,4 @@ def test_training_step_hands_the_loss_row_mask_to_the_heads():
     for i, (p, q) in enumerate(zip(a.params, b.params)):
         scale = float(q.grad.abs().max()) + 1e-12
         assert float((p.grad - q.grad).abs().max()) <= 1e-4 * scale, (i, tuple(p.shape))
+
