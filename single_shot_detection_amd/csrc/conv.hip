@@ -1528,6 +1528,7 @@ struct PackLevel {
     // anchor are entirely zero; a pixel whose rnb anchors are all 0 is not read at all (NULL: every row is read)
     const unsigned char* rmask;
     int a_total, a_off, rnb;
+    int block_begin2;   // mask-first pack: first workgroup (mask_scan_kernel) / first chunk (gather_rows_kernel) of the level
 };
 struct PackGroup {
     int count, B;
@@ -1704,23 +1705,178 @@ __global__ void __launch_bounds__(256) pack_dy_kernel(PackGroup grp) {
     }
 }
 
+// ---- the pack when the gradient's producer says which anchors carry one (PackLevel::rmask on every level) -----------------------------
+// pack_dy_kernel finds the non-zero rows by reading all of dscores / dlocs (88 MB at SSD-300 / 81 classes, batch 32) and pays, per
+// 32-row block, its bookkeeping and ~85 same-address bias-gradient atomics whatever it reads (52 us).  With the mask the work is
+// proportional to the MARKED anchors (hard-negative mining: ~4 %):
+//   mask_scan_kernel     one thread per pixel reads its nb mask bytes; per workgroup ONE reservation per anchor type (and one for the
+//                        pixel-row list); writes the anchor lists apix[type][..] and row_list -- what pack_dy's counting half leaves,
+//                        except that a marked row may turn out to be all zeros (harmless: it adds nothing) and that no block ever
+//                        gives up (the lists are sized for every anchor);
+//   decide_sparse_kernel as before, from those counts;
+//   gather_rows_kernel   walks the anchor lists: a wave per listed anchor copies its C + 4 gradient values into the anchor-row
+//                        matrix (levels that took the anchor form) and adds them to the bias gradients (every level: the bias
+//                        gradient IS the sum over the marked anchors), one atomic per (64-row chunk, column);
+//   pack_store_kernel    as before (the dense rows of levels that did not take the anchor form).
+constexpr int kScanPixels = 256;   // pixels per workgroup of mask_scan_kernel
+__global__ void __launch_bounds__(256) mask_scan_kernel(PackGroup grp) {
+    int pi = 0;
+#pragma unroll 1
+    for (int i = 1; i < grp.count; ++i)
+        if ((int)blockIdx.x >= grp.lv[i].block_begin2) pi = i;
+    const PackLevel& L = grp.lv[pi];
+    __shared__ int s_wcnt[4][kMaxAnchorTypes_ + 1];   // per wave: marked anchors per type, [nb] = marked pixel rows
+    __shared__ int s_base[kMaxAnchorTypes_ + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int M = grp.B * L.HW;
+    const int m = (blockIdx.x - L.block_begin2) * kScanPixels + threadIdx.x;
+    unsigned bits = 0;
+    if (m < M) {
+        const int b = m / L.HW, p = m - b * L.HW;
+        const unsigned char* mp = L.rmask + (long long)b * L.a_total + L.a_off + (long long)p * L.rnb;
+        for (int k = 0; k < L.rnb; ++k) bits |= mp[k] ? 1u << k : 0u;
+    }
+#pragma unroll 1
+    for (int k = 0; k < L.rnb; ++k) {   // (every lane takes part in every ballot: no early exits before the end of the kernel)
+        const unsigned long long bk = __ballot((bits >> k) & 1u);
+        if (lane == 0) s_wcnt[wave][k] = __popcll(bk);
+    }
+    const unsigned long long rowbal = __ballot(bits != 0u);
+    if (lane == 0) s_wcnt[wave][L.rnb] = __popcll(rowbal);
+    __syncthreads();
+    if (threadIdx.x <= L.rnb) {
+        const int k = threadIdx.x;
+        const int tot = s_wcnt[0][k] + s_wcnt[1][k] + s_wcnt[2][k] + s_wcnt[3][k];
+        s_base[k] = tot ? atomicAdd(k < L.rnb ? L.acount + k : L.row_count, tot) : 0;
+    }
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll 1
+    for (int k = 0; k < L.rnb; ++k) {
+        const unsigned long long bk = __ballot((bits >> k) & 1u);
+        int off = s_base[k];
+        for (int w = 0; w < wave; ++w) off += s_wcnt[w][k];
+        if ((bits >> k) & 1u) L.apix[(long long)k * L.cap + off + __popcll(bk & below)] = m;
+    }
+    int off = s_base[L.rnb];
+    for (int w = 0; w < wave; ++w) off += s_wcnt[w][L.rnb];
+    if (bits) L.row_list[off + __popcll(rowbal & below)] = m;
+}
+
+constexpr int kGatherRows = 32;   // listed anchors per workgroup of gather_rows_kernel: 8 per wave, 4 in flight
+constexpr int kGtabInts = 2 + kMaxProblems * kMaxAnchorTypes_;   // [0] total chunks, [1 + i * 16 + k] first chunk of (level i, type k), then the end
+// chunk table of gather_rows_kernel from the anchor counts, by one wave: lane l owns entries 2 l and 2 l + 1 of the 8 levels x 16 types
+__device__ __forceinline__ void build_gather_table(const int* __restrict__ acounts, const int* nb, int n, int* __restrict__ gtab) {
+    const int lane = threadIdx.x & 63;
+    int cnt[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int e = 2 * lane + u, i = e / kMaxAnchorTypes_, k = e % kMaxAnchorTypes_;
+        cnt[u] = (i < n && k < nb[i]) ? (acounts[e] + kGatherRows - 1) / kGatherRows : 0;
+    }
+    const int mine = cnt[0] + cnt[1];
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const int t = __shfl_up(incl, d, kWave);
+        if (lane >= d) incl += t;
+    }
+    const int base = incl - mine;
+    gtab[1 + 2 * lane] = base;
+    gtab[2 + 2 * lane] = base + cnt[0];
+    if (lane == kWave - 1) { gtab[1 + kMaxProblems * kMaxAnchorTypes_] = incl; gtab[0] = incl; }
+}
+__global__ void __launch_bounds__(256) gather_rows_kernel(PackGroup grp, const int* __restrict__ gtab) {
+    __shared__ float s_sum[4][256];   // per wave: column sums of its rows (Jpad <= 256)
+    __shared__ int s_tab[kGtabInts];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int t = threadIdx.x; t < kGtabInts; t += 256) s_tab[t] = gtab[t];
+    __syncthreads();
+    const int total = s_tab[0];
+    for (int chunk = blockIdx.x; chunk < total; chunk += gridDim.x) {
+        int e = 0;   // the last (level, type) whose first chunk is <= chunk and that has chunks
+#pragma unroll 1
+        for (int q = 1; q < kMaxProblems * kMaxAnchorTypes_; ++q)
+            if (s_tab[1 + q] <= chunk && s_tab[2 + q] > s_tab[1 + q]) e = q;
+        const int pi = e / kMaxAnchorTypes_, k = e % kMaxAnchorTypes_;
+        const PackLevel& L = grp.lv[pi];
+        const int c = chunk - s_tab[1 + e];
+        const int n = L.acount[k];
+        const bool store = *L.mode == 2;      // the anchor-row matrix is read only by the anchor form
+        const int C = L.C, Jpad = L.Jpad;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};   // this lane's columns lane, lane + 64, ...
+        const int r0 = c * kGatherRows + wave * 8, r_end = min(n, (c + 1) * kGatherRows);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            int mrow[4];
+            float v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + half * 4 + u;
+                mrow[u] = r < r_end ? L.apix[(long long)k * L.cap + r] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int m = mrow[u] < 0 ? 0 : mrow[u];
+                const int b = m / L.HW, p = m - b * L.HW;
+                const float* srow = L.ds + (long long)b * grp.sb + ((long long)p * L.nb + k) * C;
+                const float* lrow = L.dl + (long long)b * grp.lb + ((long long)p * L.nb + k) * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int j = lane + 64 * q;
+                    v[u][q] = (mrow[u] >= 0 && j < C + 4 && j < Jpad) ? (j < C ? srow[j] : lrow[j - C]) : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (mrow[u] < 0) continue;
+                float* grow = L.ga + ((long long)k * L.cap + (r0 + half * 4 + u)) * Jpad;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int j = lane + 64 * q;
+                    if (store && j < Jpad) grow[j] = v[u][q];
+                    acc[q] += v[u][q];
+                }
+            }
+        }
+        __syncthreads();   // (s_sum of the previous chunk has been read)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s_sum[wave][lane + 64 * q] = acc[q];
+        __syncthreads();
+        for (int j = threadIdx.x; j < C + 4; j += 256) {
+            const float t = s_sum[0][j] + s_sum[1][j] + s_sum[2][j] + s_sum[3][j];
+            if (t != 0.0f) {
+                if (j < C) { if (L.db0) atomicAdd(L.db0 + k * C + j, t); }
+                else if (L.db1) atomicAdd(L.db1 + k * 4 + (j - C), t);
+            }
+        }
+    }
+}
+
 // second half of the pack: the dense rows of the levels whose chosen form reads them (mode 0 / 1); a fixed grid walks the row blocks
 template <int ITERS>
 __global__ void __launch_bounds__(256) pack_store_kernel(PackGroup grp, int total_blocks) {
     __shared__ float s_dummy[kPackColIters * 64];
     __shared__ unsigned s_amask[kPackRows];
+    // (all the modes are loaded before any is tested: `any || *mode != 2` short-circuits into one dependent L2 round trip per level --
+    // 12 us for a launch that, under hard-negative mining, has nothing to do)
+    int modes[kMaxProblems];
+#pragma unroll
+    for (int i = 0; i < kMaxProblems; ++i) modes[i] = i < grp.count ? *grp.lv[i].mode : 2;
     bool any = false;
-    for (int i = 0; i < grp.count; ++i) any = any || *grp.lv[i].mode != 2;
+#pragma unroll
+    for (int i = 0; i < kMaxProblems; ++i) any |= modes[i] != 2;
     if (!any) return;
-    for (int blk = blockIdx.x; blk < total_blocks; blk += gridDim.x) {
-        int pi = 0;
-#pragma unroll 1
-        for (int i = 1; i < grp.count; ++i)
-            if (blk >= grp.lv[i].block_begin) pi = i;
-        const PackLevel& L = grp.lv[pi];
-        if (*L.mode == 2) continue;
-        const int M = grp.B * L.HW, m0 = (blk - L.block_begin) * kPackRows;
-        pack_rows<ITERS, true, false>(L, L.ds, L.dl, grp.sb, grp.lb, grp.B, m0, M, s_dummy, s_amask);
+    // level by level, only the levels that read the dense rows (walking ALL row blocks and testing the mode of each cost a dependent L2
+    // round trip per block: 12 us to pack the 128 rows of SSD-300's last level)
+#pragma unroll
+    for (int i = 0; i < kMaxProblems; ++i) {
+        if (i >= grp.count || modes[i] == 2) continue;
+        const PackLevel& L = grp.lv[i];
+        const int nblk = (i + 1 < grp.count ? grp.lv[i + 1].block_begin : total_blocks) - L.block_begin;
+        const int M = grp.B * L.HW;
+        for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x)
+            pack_rows<ITERS, true, false>(L, L.ds, L.dl, grp.sb, grp.lb, grp.B, blk * kPackRows, M, s_dummy, s_amask);
     }
 }
 
@@ -1733,8 +1889,10 @@ __global__ void __launch_bounds__(256) pack_store_kernel(PackGroup grp, int tota
 constexpr int kMaxAnchorTypes = 16;
 static_assert(kVtabSegs == kMaxAnchorTypes + 1 && kMaxAnchorTypes_ == kMaxAnchorTypes, "vtab layout");
 struct LevelTotals { int v[kMaxProblems]; int nb[kMaxProblems]; int jpad[kMaxProblems]; int npad[kMaxProblems]; int force; };
-__global__ void decide_sparse_kernel(const int* __restrict__ counts, const int* __restrict__ acounts, LevelTotals totals, int n, int* __restrict__ mode) {
+__global__ void decide_sparse_kernel(const int* __restrict__ counts, const int* __restrict__ acounts, LevelTotals totals, int n, int* __restrict__ mode,
+                                     int* __restrict__ gtab = nullptr) {
     const int i = threadIdx.x;
+    if (gtab) build_gather_table(acounts, totals.nb, n, gtab);   // (the whole wave; the table does not depend on the modes)
     if (i >= n) return;
     int m = ((long long)counts[i] * 10 < (long long)totals.v[i] * 7) ? 1 : 0;
     if (totals.nb[i] > 0) {
@@ -2898,6 +3056,7 @@ struct HeadsBwdWs {
     int* counts;  // [kMaxProblems] non-zero gradient rows per level
     int* totals;  // [kMaxProblems] pixel rows per level
     int* mode;    // [kMaxProblems] 1 = sparse backward, 0 = dense
+    int* gtab;    // [kGtabInts] chunk table of gather_rows_kernel (mask-first pack)
     // deterministic mode only: per level the K-split copies of the weight gradient [k_splits][N][9*Cin] and the per-workgroup column sums
     // of the bias gradient [kColsumBlocks][N]
     float* dw_part[kMaxProblems];
@@ -2930,6 +3089,7 @@ static HeadsBwdWs carve_heads_bwd(void* ws, const ssdk_head_level* levels, int n
     w.vtab[1] = c.take<int>(kVtabInts);
     w.totals = c.take<int>(kMaxProblems);
     w.mode = c.take<int>(kMaxProblems);
+    w.gtab = c.take<int>(kGtabInts);
     for (int i = 0; i < n_levels; ++i) {
         const ssdk_head_level& lv = levels[i];
         const size_t npad = (size_t)npad_of(lv), M = (size_t)batch * lv.h * lv.w;
@@ -3154,7 +3314,15 @@ static int heads_bwd_impl(const ssdk_head_level* levels, int n_levels, int batch
         // two-stage when every level can take the anchor form (then the dense rows are usually not needed at all); else the one-pass form
         bool two_stage = !getenv("SSDK_PACK_ONE_PASS");
         for (int i = 0; i < n_levels; ++i) two_stage = two_stage && h_totals.nb[i] > 0;
-        if (two_stage) {
+        // mask-first: every level has the producer's row mask, in the numbering of its own anchor types (see mask_scan_kernel)
+        bool mask_first = two_stage && row_mask && !getenv("SSDK_PACK_SCAN");
+        for (int i = 0; i < n_levels; ++i)
+            mask_first = mask_first && pg.lv[i].rmask && pg.lv[i].rnb == pg.lv[i].nb && pg.lv[i].Jpad <= 256 && pg.lv[i].dl;
+        if (mask_first) {
+            int scan_blocks = 0;
+            for (int i = 0; i < n_levels; ++i) { pg.lv[i].block_begin2 = scan_blocks; scan_blocks += cdiv(batch * pg.lv[i].HW, kScanPixels); }
+            hipLaunchKernelGGL(mask_scan_kernel, dim3(scan_blocks), dim3(256), 0, s, pg);
+        } else if (two_stage) {
             if (max_npad <= 384) hipLaunchKernelGGL((pack_dy_kernel<6, false>), dim3(begin), dim3(256), 0, s, pg);
             else if (max_npad <= 512) hipLaunchKernelGGL((pack_dy_kernel<8, false>), dim3(begin), dim3(256), 0, s, pg);
             else hipLaunchKernelGGL((pack_dy_kernel<12, false>), dim3(begin), dim3(256), 0, s, pg);
@@ -3164,11 +3332,17 @@ static int heads_bwd_impl(const ssdk_head_level* levels, int n_levels, int batch
             else hipLaunchKernelGGL((pack_dy_kernel<12, true>), dim3(begin), dim3(256), 0, s, pg);
         }
         SSDK_CHECK_LAUNCH("pack_dy_kernel");
-        hipLaunchKernelGGL(decide_sparse_kernel, dim3(1), dim3(64), 0, s, w.counts, w.acounts, h_totals, n_levels, w.mode);
+        hipLaunchKernelGGL(decide_sparse_kernel, dim3(1), dim3(64), 0, s, w.counts, w.acounts, h_totals, n_levels, w.mode, mask_first ? w.gtab : nullptr);
         SSDK_CHECK_LAUNCH("decide_sparse_kernel");
         if (two_stage) {
             for (int i = 0; i < n_levels; ++i) pg.lv[i].mode = w.mode + i;
-            const int grid = std::min(begin, 4096);
+            if (mask_first) {
+                long long worst = 0;
+                for (int i = 0; i < n_levels; ++i) worst += (long long)pg.lv[i].nb * cdiv(pg.lv[i].cap, kGatherRows);
+                hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)std::min<long long>(worst, 1024)), dim3(256), 0, s, pg, w.gtab);
+                SSDK_CHECK_LAUNCH("gather_rows_kernel");
+            }
+            const int grid = std::min(begin, mask_first ? 256 : 4096);   // (mask-first: under hard-negative mining no level needs the dense rows; a small grid walks them when one does)
             if (max_npad <= 384) hipLaunchKernelGGL(pack_store_kernel<6>, dim3(grid), dim3(256), 0, s, pg, begin);
             else if (max_npad <= 512) hipLaunchKernelGGL(pack_store_kernel<8>, dim3(grid), dim3(256), 0, s, pg, begin);
             else hipLaunchKernelGGL(pack_store_kernel<12>, dim3(grid), dim3(256), 0, s, pg, begin);
