@@ -1093,7 +1093,7 @@ __device__ __forceinline__ int wave_collect(const KeySpace& ks, const u64* s_all
 __global__ void __launch_bounds__(kWave) post_tau_kernel(const u64* __restrict__ cand, long long list_cap, int seg_off, int seg_cap,
                                                          const int* __restrict__ segcnt, int nseg_all, int seg0, int nseg, int K,
                                                          u64* __restrict__ top, int* __restrict__ topcnt, unsigned* __restrict__ tau,
-                                                         int hot_rank, unsigned* __restrict__ hotb, int* __restrict__ tophot) {
+                                                         int hot_rank, unsigned* __restrict__ hotb, int* __restrict__ tophot, int* __restrict__ nall_out) {
     __shared__ unsigned s_hist[256];
     __shared__ int s_pref[kWave + 1];
     __shared__ u64 s_cache[kTauCache];
@@ -1103,6 +1103,9 @@ __global__ void __launch_bounds__(kWave) post_tau_kernel(const u64* __restrict__
     KeySpace ks;
     ks.top = nullptr; ks.ntop = 0; ks.segs = cand + (size_t)pc * list_cap + seg_off; ks.seg_cap = seg_cap; ks.nseg = nseg; ks.s_pref = s_pref; ks.s_hot = nullptr;
     ks.n = wave_prefix_to_lds(mycnt, nseg, s_pref);
+    // the sample holds every key above the score threshold of every kSampleStride-th tile, unpruned: an estimate of the whole list's
+    // length that does not depend on the bound the main pass prunes with (post_density_hint)
+    if (lane == 0 && nall_out) nall_out[pc] = ks.n * kSampleStride;
     u64* out = top + (size_t)pc * K;
     u64 prefix = 0;
     const u64* s_all = nullptr;
@@ -1167,6 +1170,7 @@ struct NmsSrc {
     const u64* top;       // [npc][K] the sample pass's survivors (NULL: none), hot ones first
     const int* topcnt;
     const int* tophot;
+    int* nall_out;        // [npc] (MODE 0 / 1) keys of the whole list: what the next call's plan is chosen from (post_density_hint)
 };
 
 // single-instruction min / max (fminf / fmaxf canonicalise every operand that may be a signalling NaN: four extra v_max per IoU here)
@@ -1235,6 +1239,7 @@ __global__ void __launch_bounds__(kWave) post_nms_wave_kernel(const float4* __re
             pc_count[pc] = 0;
             pc_m[pc] = 0;
             if (MODE == 1) head_last[pc] = 0u;
+            if (MODE != 2 && src.nall_out) src.nall_out[pc] = 0;
         }
         return;
     }
@@ -1269,6 +1274,7 @@ __global__ void __launch_bounds__(kWave) post_nms_wave_kernel(const float4* __re
     }
     __syncthreads();
     int m = min(cnt, Kuse);   // box_utils.py:186-188
+    if (MODE != 2 && lane == 0 && src.nall_out) src.nall_out[pc] = n_all;
     if (MODE == 1 && lane == 0) {
         pc_m[pc] = min(n_all, K);   // boxes that enter NMS in the reference, whatever part of the work the bound spares
         head_last[pc] = n_all > Khead ? (unsigned)(s_sorted[Khead - 1] >> 32) + 1u : 0u;
@@ -1405,7 +1411,8 @@ __global__ void __launch_bounds__(256) post_img_tau_kernel(int ncls, int K, int 
 __global__ void __launch_bounds__(1024) post_merge2_kernel(int ncls, int K, int max_total, const float* __restrict__ pc_rows,
                                                            const float* __restrict__ pc_score, const int* __restrict__ pc_count,
                                                            const int* __restrict__ pc_m, float* __restrict__ out, int out_cap,
-                                                           int* __restrict__ counts, long long* __restrict__ nms_candidates) {
+                                                           int* __restrict__ counts, long long* __restrict__ nms_candidates,
+                                                           const int* __restrict__ pc_nall, unsigned* __restrict__ host_hint) {
     __shared__ u64 s_keys[kMergeCap];
     __shared__ unsigned s_hist[256];
     __shared__ u64 s_misc[4];
@@ -1433,6 +1440,17 @@ __global__ void __launch_bounds__(1024) post_merge2_kernel(int ncls, int K, int 
         struct AddLL { __device__ __forceinline__ long long operator()(long long a, long long b) const { return a + b; } };
         run = wave_allreduce(run, AddLL());
         if (tid == kWave) nms_candidates[i] = run;
+    } else if (tid >= 2 * kWave && tid < 3 * kWave && host_hint && i == 0) {
+        // image 0's keys above the score threshold, all classes: a sample of how dense this workload's score lists are, left in pinned
+        // host memory for the NEXT call's choice of plan (post_density_hint) -- never read back by this call
+        long long run = 0;
+        for (int c = tid - 2 * kWave; c < ncls; c += kWave) run += pc_nall[c];
+        struct AddLL2 { __device__ __forceinline__ long long operator()(long long a, long long b) const { return a + b; } };
+        run = wave_allreduce(run, AddLL2());
+        if (tid == 2 * kWave) {
+            const unsigned avg = (unsigned)min(run / (long long)(ncls > 0 ? ncls : 1), 0x7FFFFFFFLL);
+            __hip_atomic_store(host_hint, avg + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (+ 1: 0 means "nothing seen yet")
+        }
     }
     __syncthreads();
     const int T = s_prefix[ncls];
@@ -1537,7 +1555,38 @@ struct PostPlan {
     int nseg;
 };
 
-static PostPlan make_plan(int batch, int A, int C, int softmax, int K, int max_total) {
+// Average keys per (image, class) list of image 0 of the last postprocess call that finished (+ 1; 0: none yet), written by
+// post_merge2_kernel into pinned host memory.  The sample pass + per-class bound (two extra launches and a second read of 1 / 8 of the
+// scores) pays when the lists are long -- random logits: 8 108 keys per list, 165 against 281 us at batch 64 -- and costs when they are
+// short -- trained-like scores: ~580 keys per list, 130 against 117 us.  Both plans are exact, so a stale or missing hint only costs time.
+static unsigned* g_post_hint = nullptr;
+static bool g_post_hint_tried = false;
+static unsigned* post_hint_word(hipStream_t s) {
+    if (!g_post_hint && !g_post_hint_tried) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (st != hipStreamCaptureStatusNone) return nullptr;
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && p) {
+            *static_cast<volatile unsigned*>(p) = 0u;
+            g_post_hint = static_cast<unsigned*>(p);
+        } else {
+            (void)hipGetLastError();
+        }
+        g_post_hint_tried = true;
+    }
+    return g_post_hint;
+}
+static bool post_wants_sample_pass(int K) {
+    if (getenv("SSDK_POST_NO_SAMPLE")) return false;
+    if (getenv("SSDK_POST_SAMPLE") || !g_post_hint) return true;
+    const unsigned v = *static_cast<volatile unsigned*>(g_post_hint);
+    // nothing seen yet: the plan that is safe for long lists.  Crossover measured at batch 64, K = 100 (tools/bench_post.py bg<shift>):
+    // 1 264 keys per list: 153 with / 168 us without the sample pass; 580: 130 / 117; 38: 96 / 77
+    return v == 0u || (long long)(v - 1u) > 8LL * K;
+}
+
+static PostPlan make_plan(int batch, int A, int C, int softmax, int K, int max_total, bool sample = true) {
     PostPlan p;
     memset(&p, 0, sizeof(p));
     const int ncls = ncls_of(C, softmax);
@@ -1545,7 +1594,7 @@ static PostPlan make_plan(int batch, int A, int C, int softmax, int K, int max_t
     p.tiles = cdiv(A, kPostTileRows);
     const int ns = cdiv(p.tiles, kSampleStride);
     // sample pass + per-class bound only where the sample can hold well over max_per_class candidates
-    p.ns = ((long long)ns * kPostTileRows >= 4LL * K && p.tiles - ns > 0 && !getenv("SSDK_POST_NO_SAMPLE")) ? ns : 0;
+    p.ns = ((long long)ns * kPostTileRows >= 4LL * K && p.tiles - ns > 0 && sample) ? ns : 0;
     const int target_wgs = getenv("SSDK_POST_WGS") ? atoi(getenv("SSDK_POST_WGS")) : 768;   // (three resident workgroups per CU: measured best of 384 .. 2048 at batch 64, tools/r03_post_wgs.sh)
     int per_image = cdiv(target_wgs, batch);   // about five resident workgroups per CU over the whole grid ...
     per_image = per_image < 1 ? 1 : (per_image > kWave ? kWave : per_image);   // ... and at most one segment counter per lane of the consumer
@@ -1579,6 +1628,7 @@ struct PostWs2 {
     int* pc_m;        // [npc]
     unsigned* head_last;  // [npc]   two-pass NMS (post_nms_wave_kernel MODE 1 / 2)
     unsigned* img_tau;    // [batch]
+    int* pc_nall;         // [npc]   keys of the whole list (post_density_hint)
 };
 
 // Head size of the two-pass NMS: about 2.5 x the share of max_total a class would get if the image's detections were spread evenly
@@ -1609,6 +1659,7 @@ static PostWs2 carve_post_ws2(void* ws, size_t npc, size_t K, const PostPlan& p,
     w.pc_m = c.take<int>(npc);
     w.head_last = c.take<unsigned>(npc);
     w.img_tau = c.take<unsigned>(npc);   // (one per image needed; npc >= batch)
+    w.pc_nall = c.take<int>(npc);
     if (total) *total = c.off;
     return w;
 }
@@ -1653,8 +1704,12 @@ extern "C" size_t ssdk_postprocess_workspace_bytes(int batch, int num_anchors, i
     }
     size_t total = 0, total2 = 0;
     carve_post_ws(nullptr, (size_t)batch, (size_t)num_anchors, ncls, (size_t)max_per_class, &total);
-    const PostPlan p = make_plan(batch, num_anchors, num_classes, softmax, max_per_class, max_total);
-    if (p.ok) carve_post_ws2(nullptr, (size_t)batch * ncls, (size_t)max_per_class, p, &total2);
+    for (int sample = 0; sample < 2; ++sample) {   // (the plan is chosen per call: the workspace fits either)
+        const PostPlan p = make_plan(batch, num_anchors, num_classes, softmax, max_per_class, max_total, sample != 0);
+        size_t t = 0;
+        if (p.ok) carve_post_ws2(nullptr, (size_t)batch * ncls, (size_t)max_per_class, p, &t);
+        total2 = t > total2 ? t : total2;
+    }
     return total > total2 ? total : total2;   // (soft-NMS takes the general pipeline: the caller may ask for either)
 }
 
@@ -1701,7 +1756,7 @@ static int postprocess_v2(const PostPlan& p, const float* scores, const float* l
         // Khead the head wants (5 / 16 of Khead: 3 % of the lists come out short and take the whole list, 8 % exceed the head's 64 slots)
         const int hot_rank = (khead_plan && !getenv("SSDK_POST_NO_HOT")) ? (5 * khead_plan + 15) / 16 : 0;
         hipLaunchKernelGGL(post_tau_kernel, dim3(npc), dim3(kWave), 0, s, w.cand, p.list_cap, 0, p.Ts * kPostTileRows, w.segcnt, p.nseg, 0, p.Gs,
-                           max_per_class, w.top, w.topcnt, w.tau, hot_rank, w.hotb, w.tophot);
+                           max_per_class, w.top, w.topcnt, w.tau, hot_rank, w.hotb, w.tophot, post_hint_word(s) ? w.pc_nall : nullptr);
         SSDK_CHECK_LAUNCH("post_tau_kernel");
         rc = launch(2, p.tiles - p.ns, p.Gm, p.Tm, seg_off_main, p.Gs, w.tau, hot_rank ? w.hotb : nullptr);
         if (rc) return rc;
@@ -1720,6 +1775,8 @@ static int postprocess_v2(const PostPlan& p, const float* scores, const float* l
     src.cand = w.cand; src.list_cap = p.list_cap; src.seg_off = p.ns ? seg_off_main : 0; src.seg_cap = p.Tm * kPostTileRows;
     src.segcnt = w.segcnt; src.seghot = w.seghot; src.nseg_all = p.nseg; src.seg0 = p.Gs; src.nseg = p.Gm;
     src.top = p.ns ? w.top : nullptr; src.topcnt = w.topcnt; src.tophot = w.tophot;
+    unsigned* const hint = post_hint_word(s);
+    src.nall_out = (hint && !p.ns) ? w.pc_nall : nullptr;   // (with a sample pass the estimate is the tau kernel's: the main pass' lists are pruned)
     const int nms_stop = getenv("SSDK_NMS_STOP") ? atoi(getenv("SSDK_NMS_STOP")) : 0;
     const int khead = nms_stop ? 0 : nms_head_size(ncls, max_per_class, max_total);
 #define SSDK_NMS(TIE, MODE)                                                                                                                     \
@@ -1740,7 +1797,7 @@ static int postprocess_v2(const PostPlan& p, const float* scores, const float* l
     }
 #undef SSDK_NMS
     hipLaunchKernelGGL(post_merge2_kernel, dim3(batch), dim3(1024), sizeof(int) * (size_t)(ncls + 1), s, ncls, max_per_class, max_total,
-                       w.pc_rows, w.pc_score, w.pc_count, w.pc_m, out, out_cap, counts, (long long*)nms_candidates);
+                       w.pc_rows, w.pc_score, w.pc_count, w.pc_m, out, out_cap, counts, (long long*)nms_candidates, w.pc_nall, hint);
     SSDK_CHECK_LAUNCH("post_merge2_kernel");
     return SSDK_OK;
 }
@@ -1767,7 +1824,7 @@ extern "C" int ssdk_postprocess(const float* scores, const float* locs, const fl
                  SSDK_E_WORKSPACE, "ssdk_postprocess: workspace too small");
     SSDK_REQUIRE((long long)batch * ncls < 2147483647LL && batch <= 65535, SSDK_E_INVALID, "ssdk_postprocess: grid too large");
     hipStream_t s = (hipStream_t)stream;
-    const PostPlan plan = make_plan(batch, num_anchors, num_classes, softmax, max_per_class, max_total);
+    const PostPlan plan = make_plan(batch, num_anchors, num_classes, softmax, max_per_class, max_total, post_wants_sample_pass(max_per_class));
     if (plan.ok && !soft_nms && !any_k)
         return postprocess_v2(plan, scores, locs, priors, batch, num_anchors, num_classes, softmax, score_threshold, max_per_class, nms_threshold,
                               max_total, xy_scale, wh_scale, out, out_cap, counts, nms_candidates, workspace, s);

@@ -24,6 +24,8 @@ A, C = anchors.shape[0], cfg['num_classes']
 softmax = cfg['score_converter'] == 'SOFTMAX'
 g = torch.Generator(device=dev).manual_seed(5)
 logits = torch.randn((B, A, C), device=dev, generator=g)
+if variant.startswith('bg'):   # bg<shift>: background logit + shift (the density knob between "worst" = 0 and "trained" = 6)
+    logits[..., 0] += float(variant[2:])
 if variant == 'trained':
     if softmax:
         logits[..., 0] += 6.0
