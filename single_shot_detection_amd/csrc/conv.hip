@@ -2491,9 +2491,11 @@ static void narrow_for_atomics(ConvProblem& g) {
 
 // decides the kernel (LDS-DMA or register staged; 128- or 256-pixel tiles), orders the problems by decreasing work per
 // workgroup (longest first), assigns block ranges, launches
+constexpr int kStreamKWgs = 512;   // two 64 KB-LDS workgroups per CU x 256 CUs: the most a stream-K launch uses, and the size its workspace is laid out for
 struct StreamKWs {
     float* partial;
-    unsigned* flags;
+    unsigned* flags;   // [kStreamKWgs + 2]: a flag per workgroup, then the timeout counter at [kStreamKWgs] (a FIXED place: a launch capped
+                       // below kStreamKWgs workgroups -- ssdk_heads_fwd_ex -- shares the workspace with uncapped ones)
     int nwg;
 };
 // does a column space of N end in a tile of at most 16 columns?
@@ -2659,7 +2661,7 @@ static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t 
         if (worth) {
             sk.partial = skws->partial;
             sk.flags = skws->flags;
-            sk.timeouts = skws->flags + skws->nwg;   // (behind the flags of the largest launch)
+            sk.timeouts = skws->flags + kStreamKWgs;   // (behind the flags of the largest launch)
             sk.host_err = streamk_host_err_word(s);
             sk.epoch = __atomic_add_fetch(&g_streamk_epoch, 1u, __ATOMIC_RELAXED);
             if (sk.epoch == 0) sk.epoch = __atomic_add_fetch(&g_streamk_epoch, 1u, __ATOMIC_RELAXED);   // (0 is what a fresh workspace holds)
@@ -2713,7 +2715,6 @@ static inline int anchor_types_of(const ssdk_head_level& lv) {
 }
 static inline int jpad_of(const ssdk_head_level& lv) { return cdiv(lv.n_score / (lv.n_loc / 4) + 4, 32) * 32; }
 
-constexpr int kStreamKWgs = 512;   // two 64 KB-LDS workgroups per CU x 256 CUs
 extern "C" size_t ssdk_heads_fwd_workspace_bytes(void) {
     return align_up((size_t)(kStreamKWgs + 1) * (4 * kMaxTN * 4 * 64 * 4) * sizeof(float), 256) + align_up((size_t)(kStreamKWgs + 2) * sizeof(unsigned), 256);
 }
