@@ -32,6 +32,17 @@ class Boundaries(object):
     def near(self, a, b):
         return abs(a - b) <= 1e-5 * max(abs(a), abs(b)) + 1e-9
 
+    def threshold_ties(self, image):
+        """(anchor, class) pairs of ``image`` whose probability sits within 1e-5 relative of the score threshold: each may or may not be
+        a candidate, depending on the last ulp of an exp() -- the slack of a per-image candidate COUNT."""
+        x = self.logits[image].astype(np.float64).reshape(-1, self.num_classes)
+        if self.softmax:
+            e = np.exp(x - x.max(1, keepdims=True))
+            p = (e / e.sum(1, keepdims=True))[:, 1:]
+        else:
+            p = 1.0 / (1.0 + np.exp(-x))
+        return int((np.abs(p - self.thr) <= 1e-5 * self.thr + 1e-9).sum())
+
     def explains(self, image, cls, score, num_classes, last_scores):
         x = self.logits[image].astype(np.float64).reshape(-1, num_classes)
         if self.softmax:

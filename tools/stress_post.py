@@ -55,8 +55,13 @@ for case in range(cases):
         out = post.postprocess((torch.from_numpy(lg.reshape(B, -1)).cuda(), torch.from_numpy(lc.reshape(B, -1)).cuda()), torch.from_numpy(pri).cuda())
         ref, cand = oracle.postprocess(lg.reshape(B, -1), lc.reshape(B, -1), pri, softmax=softmax, score_thr=thr, max_per_class=mpc, nms_thr=nms_thr,
                                        max_total=mt, return_cand=True, **(dict(soft=True, sigma=0.5) if soft else {}))
-        compare(out, ref, boundaries=Boundaries(lg.reshape(B, -1), C, softmax, thr, mpc, mt))
-        assert np.array_equal(post.last_nms_candidates.cpu().numpy(), cand), (post.last_nms_candidates.cpu().numpy(), cand)
+        bounds = Boundaries(lg.reshape(B, -1), C, softmax, thr, mpc, mt)
+        compare(out, ref, boundaries=bounds)
+        got = post.last_nms_candidates.cpu().numpy()
+        # (candidates entering NMS: exact, except that a probability within 1e-5 relative of the score threshold may fall on either side --
+        # seed 43, case 73: 3 675 against 3 676 on one image, one such probability)
+        for i in range(B):
+            assert abs(int(got[i]) - int(cand[i])) <= bounds.threshold_ties(i), (i, got, cand, bounds.threshold_ties(i))
     except Exception as e:   # noqa: BLE001
         bad += 1
         print('FAIL', tag, type(e).__name__, str(e)[:300], flush=True)
