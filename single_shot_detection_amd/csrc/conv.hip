@@ -516,22 +516,23 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
                 const int y = r / g.Wout, x = r % g.Wout;
                 unsigned mask = 0;
                 int by, bx;
+                // (the taps that exist = existing kernel rows x existing kernel columns: 2 * ks compares, no division by ks -- the tap-by-tap
+                // loop with t / ks and t % ks was 3.5 us of a 3 x 3 tile's 6 us prologue, tools/phase_conv.py)
+                unsigned colbits = 0;
                 if (!MIRROR) {
                     by = y * g.stride - g.pad;
                     bx = x * g.stride - g.pad;
-                    for (int t = 0; t < taps; ++t) {
-                        const int iy = by + t / ks, ix = bx + t % ks;
-                        if (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) mask |= 1u << t;
-                    }
+                    for (int kx = 0; kx < ks; ++kx) colbits |= ((unsigned)(bx + kx) < (unsigned)g.Win ? 1u : 0u) << kx;
+                    for (int ky = 0; ky < ks; ++ky)
+                        if ((unsigned)(by + ky) < (unsigned)g.Hin) mask |= colbits << (ky * ks);
                     by += g.pad;   // relative to the shifted base
                     bx += g.pad;
                 } else {
                     by = y + g.pad;
                     bx = x + g.pad;
-                    for (int t = 0; t < taps; ++t) {
-                        const int ty = by - t / ks, tx = bx - t % ks;
-                        if (ty >= 0 && tx >= 0 && ty < g.Hin && tx < g.Win) mask |= 1u << t;   // stride 1 only
-                    }
+                    for (int kx = 0; kx < ks; ++kx) colbits |= ((unsigned)(bx - kx) < (unsigned)g.Win ? 1u : 0u) << kx;   // stride 1 only
+                    for (int ky = 0; ky < ks; ++ky)
+                        if ((unsigned)(by - ky) < (unsigned)g.Hin) mask |= colbits << (ky * ks);
                 }
                 a_vo[i] = (unsigned)(b * (int)g.a_bstride + by * win_ps + bx * a_ps + src_chunk * 4) * 4u;
                 a_nmask[i] = ~mask;
@@ -2258,10 +2259,10 @@ __device__ __forceinline__ void fast_tile(const ConvProblem& g, const FastProble
             const int y = r / g.Wout, x = r % g.Wout;
             unsigned mask = 0;
             int by = y * g.stride - g.pad, bx = x * g.stride - g.pad;
-            for (int t = 0; t < taps; ++t) {
-                const int iy = by + t / ks, ix = bx + t % ks;
-                if (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) mask |= 1u << t;
-            }
+            unsigned colbits = 0;   // (existing kernel rows x existing kernel columns, as dma_tile)
+            for (int kx = 0; kx < ks; ++kx) colbits |= ((unsigned)(bx + kx) < (unsigned)g.Win ? 1u : 0u) << kx;
+            for (int ky = 0; ky < ks; ++ky)
+                if ((unsigned)(by + ky) < (unsigned)g.Hin) mask |= colbits << (ky * ks);
             by += g.pad;
             bx += g.pad;
             a_vo[i] = (unsigned)(b * (int)g.a_bstride + by * win_ps + bx * a_ps + src_chunk * 4) * 4u;
@@ -2587,6 +2588,29 @@ static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t 
         if (!g.forced) {
             g.n_blocks = cdiv(g.tiles_n, tn6 ? 6 : kMaxTN);
             if (!vtab && (scatter || g.k_splits > 1)) narrow_for_atomics(g);
+        }
+    }
+    // A launch smaller than the chip, whatever its epilogue: halve the columns per workgroup while the workgroups still fit one per CU.
+    // A 128 x 128 x 32 slice is 1.7 us of MFMA on one CU, so the 1 x 1 data gradients of the pyramid tail (K = 128: 4 slices, 6 .. 100
+    // workgroups of 128 columns) spent 9 us in the K loop and 6.6 us storing four column tiles on a chip that was 60-98 % idle
+    // (tools/phase_conv.py bwd); at 32 columns a slice costs its DMA latency (~0.85 us) instead.  The column partition does not change
+    // any sum's order: same bits.
+    // (not for the heads' forward launch: its stream-K partition is sized from the 128-column blocks)
+    if (!vtab && !skws && !getenv("SSDK_CONV_NO_NARROW")) {
+        long long total = 0;
+        for (int i = 0; i < count; ++i) total += (long long)probs[i].m_tiles * probs[i].n_blocks * probs[i].k_splits;
+        for (bool again = true; again && total < 256;) {
+            again = false;
+            for (int i = 0; i < count; ++i) {
+                ConvProblem& g = probs[i];
+                if (g.forced || g.n_blocks >= g.tiles_n) continue;
+                const int nb = std::min(g.tiles_n, g.n_blocks * 2);
+                const long long grown = total + (long long)g.m_tiles * (nb - g.n_blocks) * g.k_splits;
+                if (grown > 256) continue;
+                g.n_blocks = nb;
+                total = grown;
+                again = true;
+            }
         }
     }
     // 8-wave / 256-pixel tiling: measured 3 % (B=128) to 14 % (B=32) MORE cycles than two 4-wave workgroups per CU on the

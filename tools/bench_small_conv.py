@@ -33,5 +33,16 @@ for cin, cout, k, s, p, h in LAYERS:
             e[3].record()
             torch.cuda.synchronize()
             cold.append(e[2].elapsed_time(e[3]) * 1e3)
+    # backward-data only (the weight does not ask for a gradient): one re-layout up front, as a prepared step does
+    xg = x.clone().requires_grad_(True)
+    y = ops.conv2d(xg, w, None, s, p)
+    dy = torch.randn_like(y)
+    for _ in range(3): torch.autograd.grad(y, xg, dy, retain_graph=True)
+    torch.cuda.synchronize()
+    e[0].record()
+    for _ in range(20): torch.autograd.grad(y, xg, dy, retain_graph=True)
+    e[1].record()
+    torch.cuda.synchronize()
+    bwd = e[0].elapsed_time(e[1]) / 20 * 1e3
     flops = 2.0 * B * ((h + 2 * p - k) // s + 1) ** 2 * cin * k * k * cout
-    print(f'{cin:5d}->{cout:4d} k{k} s{s} {h:2d}x{h:<2d}: warm {warm:6.1f} us/launch ({flops / warm / 1e6:6.1f} TFLOP/s)   cold {min(cold):6.1f}..{max(cold):6.1f} us')
+    print(f'{cin:5d}->{cout:4d} k{k} s{s} {h:2d}x{h:<2d}: warm {warm:6.1f} us/launch ({flops / warm / 1e6:6.1f} TFLOP/s)   cold {min(cold):6.1f}..{max(cold):6.1f} us   dgrad (incl. re-layout) {bwd:6.1f} us')
