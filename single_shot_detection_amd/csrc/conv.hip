@@ -2597,16 +2597,17 @@ static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t 
     // any sum's order: same bits.
     // (not for the heads' forward launch: its stream-K partition is sized from the 128-column blocks)
     if (!vtab && !skws && !getenv("SSDK_CONV_NO_NARROW")) {
+        static const long long fill = []() { const char* e = getenv("SSDK_CONV_NARROW_TO"); const long long v = e ? atoll(e) : 0; return v > 0 ? v : 256LL; }();   // (measurement knob)
         long long total = 0;
         for (int i = 0; i < count; ++i) total += (long long)probs[i].m_tiles * probs[i].n_blocks * probs[i].k_splits;
-        for (bool again = true; again && total < 256;) {
+        for (bool again = true; again && total < fill;) {
             again = false;
             for (int i = 0; i < count; ++i) {
                 ConvProblem& g = probs[i];
                 if (g.forced || g.n_blocks >= g.tiles_n) continue;
                 const int nb = std::min(g.tiles_n, g.n_blocks * 2);
                 const long long grown = total + (long long)g.m_tiles * (nb - g.n_blocks) * g.k_splits;
-                if (grown > 256) continue;
+                if (grown > fill) continue;
                 g.n_blocks = nb;
                 total = grown;
                 again = true;
