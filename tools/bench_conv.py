@@ -19,6 +19,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--fwd-only', action='store_true')
+    ap.add_argument('--cold', type=int, default=0, help='forward only: MB copied between two launches (evicts L2 / the memory-side cache), each launch timed alone')
     ap.add_argument('--sparse', type=float, default=0.0, help='fraction of zero dY rows (per anchor) in the backward input')
     args = ap.parse_args()
     cfg = syn.CONFIGS[args.config]
@@ -41,6 +42,22 @@ def main():
         return e0.elapsed_time(e1) / reps
 
     t_fwd = timed(lambda: multi_level_heads(xs, xs, heads), args.reps)
+    if args.cold:
+        big = torch.empty(args.cold << 18, dtype=torch.float32, device=dev)
+        big2 = torch.empty_like(big)
+        ts = []
+        with torch.no_grad():
+            for _ in range(args.reps):
+                big2.copy_(big)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                multi_level_heads(xs, xs, heads)
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+        ts.sort()
+        print(f'{args.config} B={B}: fwd back to back {t_fwd:.3f} ms | behind a {args.cold} MB copy: median {ts[len(ts) // 2]:.3f} ms, min {ts[0]:.3f}, max {ts[-1]:.3f}')
+        return
     if args.fwd_only:
         print(f'{args.config} B={B}: fwd {t_fwd:.3f} ms = {flops / t_fwd / 1e9:.1f} TFLOP/s')
         return
