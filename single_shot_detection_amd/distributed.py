@@ -196,6 +196,7 @@ class BucketedDataParallel(torch.nn.Module):
         self._arrived = [0] * len(self.buckets)
         self._started = [False] * len(self.buckets)
         self._callback_queued = False
+        self._task = None              # the autograd graph task the queued callback belongs to
         self.require_sync = True
         self.start_order = []          # (diagnostics / tests: bucket indices in the order their rings started in the last backward pass)
         self.started_early = []        # ... and which of them started from a hook, i.e. before the backward pass had ended
@@ -227,8 +228,19 @@ class BucketedDataParallel(torch.nn.Module):
     def _on_grad(self, param):
         if not self._active():
             return
+        task = torch._C._current_graph_task_id()
+        if self._callback_queued and task != self._task:
+            # the pass that queued the callback never reached it (its backward raised): its arrival counts and "started" marks are
+            # not this pass's -- without this the next pass would neither queue a callback nor finish its rings (stale gradients, silently)
+            for b, started in zip(self.buckets, self._started):
+                if started:
+                    b.finish_(self.process_group)   # (a ring that pass had started: let it land before its buffer is written again)
+            self._arrived = [0] * len(self.buckets)
+            self._started = [False] * len(self.buckets)
+            self._callback_queued = False
         if not self._callback_queued:
             self._callback_queued = True
+            self._task = task
             self.start_order, self.started_early = [], []
             torch.autograd.Variable._execution_engine.queue_callback(self._finish_all)
         i = self._bucket_of[id(param)]

@@ -252,6 +252,33 @@ def _bdp_worker(rank, world, port, out_dir):
         p.grad = None
     net(x).square().sum().backward()
     assert net.start_order == [0, 1]
+    # a backward pass that RAISES behind the heads (their ring has started, the end-of-backward callback never runs) must not leave the
+    # wrapper deaf: the next pass resets the counters, finishes the orphaned ring, and exchanges as before
+    class _Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.view_as(t)
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError('boom')
+    for p in params:
+        p.grad = None
+    hook = net.module.features.register_forward_hook(lambda m, i, o: _Boom.apply(o))
+    try:
+        net(x).square().sum().backward()
+        raise AssertionError('the backward pass should have raised')
+    except RuntimeError as e:
+        assert 'boom' in str(e)
+    hook.remove()
+    for p in params:
+        p.grad = None
+    net(x).square().sum().backward()
+    assert net.start_order == [0, 1] and 0 in net.started_early, (net.start_order, net.started_early)
+    for i, p in enumerate(params):
+        if gathered[0][i] is not None:
+            want = sum(torch.from_numpy(gathered[r][i]) for r in range(world)) / world
+            assert torch.allclose(p.grad, want, atol=1e-6, rtol=1e-5), (rank, i)
     np.save(os.path.join(out_dir, f'bdp{rank}.npy'), np.array([1]))
     dist.destroy_process_group()
 
