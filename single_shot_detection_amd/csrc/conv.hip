@@ -2453,7 +2453,11 @@ static bool maybe_split_k(ConvProblem& g) {
 static bool maybe_split_k_any(ConvProblem& g) {
     const int blocks = cdiv(g.m_tiles, 8) * 8 * g.n_blocks;
     const int slices = g.ksize * g.ksize * cdiv(g.Cc, kBK);
-    if (g.relu || blocks >= 256 || slices < 8) return false;
+    static const bool old_rules = getenv("SSDK_CONV_OLD_SPLIT") != nullptr;   // (measurement knob: the rules before round 4's sweep)
+    // A K chain of eight slices is not worth cutting: a split saves at most ~3 us of it and costs a zero-fill launch, an atomic epilogue
+    // and -- for a convolution in front of a BatchNorm -- the statistics pass that a complete tile does in its epilogue
+    // (tools/conv_decomp_sweep.py m2det: 1 x 1 256 -> 256 at 16 x 16, batch 16: 19.4 -> 13.6 us with 32-column workgroups and no split)
+    if (g.relu || blocks >= 256 || slices < (old_rules ? 8 : 9)) return false;
     // Many row tiles, few column blocks (the SSD-300 tail's 1 x 1 512 -> 256 at 18 x 18, batch 32: 81 x 2 tiles of 128 x 128): 64-column
     // workgroups fill the chip WITHOUT splitting K -- no atomic epilogue (3 x the output through 1.3 TB/s of atomics), no zero-fill
     // launch: 57 -> 44 us (tools/conv_decomp_sweep.py; the other tail layers stay within 15 % of their best split)
@@ -2465,10 +2469,15 @@ static bool maybe_split_k_any(ConvProblem& g) {
     // Few row tiles and a deep K (the 3 x 3 / 2 layers on 16 x 16 .. 4 x 4 maps: M <= 1 024 rows, 36 .. 72 slices): 32-column workgroups
     // first, then only as many K splits as bring the launch to ~256 workgroups with at least 8 slices each -- the rule below split the
     // M2Det TUM's 256 -> 256 layer at 16 x 16 eighteen ways (49 us; 26 us with 8 column blocks x 4 splits), tools/conv_decomp_sweep.py
-    if (g.m_tiles >= 3 && g.m_tiles <= 8 && slices >= 32) {   // (one or two row tiles: the rule below measured as good or better)
+    // (round 4: up to 32 row tiles when tiles x column tiles still fit one per CU -- the M2Det TUM's 256 -> 256 layer at 32 x 32 -> 16 x 16,
+    // batch 16, took the rule below: 2 column blocks x 8 splits, 73.5 us; 8 column blocks x 2 splits: 52.6)
+    static const int wide = []() { const char* e = getenv("SSDK_CONV_SPLIT_WIDE"); return e ? atoi(e) : 256; }();   // (measurement knob)
+    if (g.m_tiles >= 3 && (g.m_tiles <= 8 || (!old_rules && g.m_tiles <= 32 && g.m_tiles * g.tiles_n <= wide)) && slices >= 32) {   // (one or two row tiles: the rule below measured as good or better)
         g.n_blocks = g.tiles_n;
         int ks = std::max(2, 256 / std::max(1, g.m_tiles * g.n_blocks));
         ks = std::min(ks, slices / 8);
+        if (!old_rules && g.m_tiles > 8 && g.m_tiles * g.n_blocks * ks > 512) ks = 512 / (g.m_tiles * g.n_blocks);   // (never more than two workgroups per CU)
+        if (!old_rules && g.m_tiles > 8 && ks < 2) { g.forced = 1; return false; }   // one 32-column workgroup per tile, whole K: no atomics, statistics in the epilogue
         if (ks >= 2) {
             g.k_splits = ks;
             g.forced = 1;
