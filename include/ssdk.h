@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SSDK_VERSION 111
+#define SSDK_VERSION 112
 
 #define SSDK_OK 0
 #define SSDK_E_INVALID (-1)   /* bad argument / shape */
@@ -479,6 +479,23 @@ int ssdk_global_avgpool_bwd(const float* dout, int batch, int hw, int channels, 
 int ssdk_sigmoid_gate_fwd(const float* x, const float* z, int batch, int hw, int channels, float* out, void* stream);
 int ssdk_sigmoid_gate_bwd(const float* x, const float* z, const float* dout, int batch, int hw, int channels, float* dx,
                           float* dz, void* stream);
+
+/* The same gate over PIECES (round 4): the maps the reference concatenates in front of the gate (features.py:385, torch.cat of the eight
+ * TUM outputs of a scale, each [batch, hw, piece_channels]) are read where they are -- the concatenated map is never built.
+ * `pieces`: n_pieces (<= 8) device pointers, 16-byte aligned, all of the same shape; columns k * piece_channels .. of pooled / z / out / dout /
+ * dpool belong to piece k.
+ *   pool_fwd:         pooled [batch, n * pc] = mean over the pixels                                  (features.py:288)
+ *   gate_fwd:         out [batch, hw, n * pc] = piece * sigmoid(z)                                   (:296-298)
+ *   gate_bwd_reduce:  dz [batch, n * pc] = sigmoid'(z) * sum_hw dout * piece                         (first half of the backward: feeds fc2 / fc1)
+ *   gate_bwd_apply:   dpieces[k] [batch, hw, pc] = dout[.., k * pc ..] * sigmoid(z) + dpool / hw     (second half: the gate's and the pool's
+ *                     gradient of a piece in one pass, each piece's gradient a contiguous map) */
+int ssdk_sfam_pool_fwd(const float* const* pieces, int n_pieces, int batch, int hw, int piece_channels, float* pooled, void* stream);
+int ssdk_sfam_gate_fwd(const float* const* pieces, int n_pieces, int batch, int hw, int piece_channels, const float* z, float* out,
+                       void* stream);
+int ssdk_sfam_gate_bwd_reduce(const float* const* pieces, int n_pieces, int batch, int hw, int piece_channels, const float* z,
+                              const float* dout, float* dz, void* stream);
+int ssdk_sfam_gate_bwd_apply(float* const* dpieces, int n_pieces, int batch, int hw, int piece_channels, const float* z, const float* dout,
+                             const float* dpool, void* stream);
 
 /* ---- depthwise convolution (bf/modules/conv.py:39-85 DepthwiseConv2dBn: depthwise k x k, groups = channels, then a 1x1 pointwise
  * convolution; `use_depthwise` configs such as samples/ssd_mb2_voc.py).  NHWC activations, weights [channels][k*k] (= the memory of

@@ -192,6 +192,16 @@ class ScalewiseFeatureAggregationModule(nn.Module):
             result.append(ops.sigmoid_gate(feature, x))             # feature * sigmoid(x)
         return result
 
+    def forward_pieces(self, pieces):
+        """forward([torch.cat(p, dim=1) for p in pieces]) for per-scale LISTS of maps (the TUM outputs features.py:385 concatenates): on
+        libssdk the concatenated maps are never built (ops.sfam_pieces); anything the kernels do not take goes through torch.cat and
+        forward().  SSDK_SFAM_CAT=1 forces that path (measurement / tests)."""
+        import os
+        assert len(pieces) == len(self.fc1)
+        if not os.environ.get('SSDK_SFAM_CAT') and ops.sfam_pieces_ok(pieces, list(self.fc1), list(self.fc2)):
+            return ops.sfam_pieces(pieces, list(self.fc1), list(self.fc2))
+        return self.forward([torch.cat(p, dim=1) for p in pieces])
+
 
 class MultilevelFeaturePyramid(Features):
     """M2Det MLFPN neck -- restatement of bf/modules/features.py:303-393."""
@@ -250,8 +260,7 @@ class MultilevelFeaturePyramid(Features):
             x = torch.cat([features[-1][-1], reduced], dim=1)                                      # :378-380
             for i, feature in enumerate(tum(x)):
                 features[i].append(feature)
-        features = [torch.cat(f, dim=1) for f in reversed(features)]                              # :385
-        features = self.sfam(features)
+        features = self.sfam.forward_pieces(list(reversed(features)))                              # :385 torch.cat per scale + :387 sfam
         return features, features[-1]
 
     def _reducers_merged(self, base_features):

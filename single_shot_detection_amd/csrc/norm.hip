@@ -651,6 +651,174 @@ extern "C" int ssdk_sigmoid_gate_bwd(const float* x, const float* z, const float
     return SSDK_OK;
 }
 
+// ---- SFAM over PIECES ------------------------------------------------------------------------------------------------------------
+// The reference concatenates the eight TUM outputs of a scale (features.py:385, torch.cat of [B, 128, H, W] maps) and hands the
+// [B, 1024, H, W] map to the gate (:286-298).  The concatenated map is never needed as such: the pool and the gate read the pieces where
+// they are and the gate writes the one map the heads read; the backward pass writes each piece's gradient as its own contiguous map --
+// dout * sigmoid(z) + dpool / HW in ONE pass (torch.cat's backward made eight strided slices that every consumer first copied, and
+// autograd added the pool's and the gate's gradient maps with one more pass).
+namespace ssdk {
+constexpr int kMaxPieces = 8;
+struct Pieces {
+    const float4* p[kMaxPieces];
+    int n, Cp4;   // pieces, float4 columns per piece
+};
+struct PiecesOut {
+    float4* p[kMaxPieces];
+    int n, Cp4;
+};
+// mean over the pixels of every image: pieces [B][HW][Cp] -> out [B][n * Cp]   (avgpool_kernel's layout of the work)
+__global__ void __launch_bounds__(256) pool_pieces_kernel(Pieces ps, int HW, float4* __restrict__ out) {
+    __shared__ float4 s_part[16][kPoolCols];
+    const int C4 = ps.n * ps.Cp4;
+    const int b = blockIdx.y, q = threadIdx.x & (kPoolCols - 1), r = threadIdx.x / kPoolCols;
+    const int c4 = blockIdx.x * kPoolCols + q;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < C4) {
+        const int k = c4 / ps.Cp4, w = c4 - k * ps.Cp4;
+        const int Cp4 = ps.Cp4;
+        const float4* base = ps.p[k] + (long long)b * HW * Cp4 + w;
+        int p = r;
+        for (; p + 48 < HW; p += 64) {
+            const float4 v0 = base[(long long)p * Cp4], v1 = base[(long long)(p + 16) * Cp4], v2 = base[(long long)(p + 32) * Cp4], v3 = base[(long long)(p + 48) * Cp4];
+            a.x += (v0.x + v1.x) + (v2.x + v3.x); a.y += (v0.y + v1.y) + (v2.y + v3.y);
+            a.z += (v0.z + v1.z) + (v2.z + v3.z); a.w += (v0.w + v1.w) + (v2.w + v3.w);
+        }
+        for (; p < HW; p += 16) {
+            const float4 v = base[(long long)p * Cp4];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    }
+    s_part[r][q] = a;
+    __syncthreads();
+    if (r == 0 && c4 < C4) {
+        float4 t = s_part[0][q];
+        for (int w = 1; w < 16; ++w) { const float4 u = s_part[w][q]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        const float inv = 1.0f / (float)HW;
+        out[(long long)b * C4 + c4] = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+    }
+}
+// out [B][HW][n * Cp] = piece * sigmoid(z[b][c])
+__global__ void __launch_bounds__(256) gate_pieces_kernel(Pieces ps, const float4* __restrict__ z, int B, int HW, float4* __restrict__ out) {
+    const int C4 = ps.n * ps.Cp4, Cp4 = ps.Cp4;
+    const long long total = (long long)B * HW * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / C4;
+        const int c = (int)(i - row * C4);
+        const int b = (int)(row / HW);
+        const int k = c / Cp4, w = c - k * Cp4;
+        const float4 v = ps.p[k][row * Cp4 + w], q = z[(long long)b * C4 + c];
+        out[i] = make_float4(v.x * sigm(q.x), v.y * sigm(q.y), v.z * sigm(q.z), v.w * sigm(q.w));
+    }
+}
+// dz[b][c] = sigmoid'(z) * sum_hw dout * piece   (gate_bwd_kernel's reduction; the data gradient waits for dpool: gate_bwd_pieces_kernel)
+__global__ void __launch_bounds__(256) gate_bwd_reduce_pieces_kernel(Pieces ps, const float4* __restrict__ z, const float4* __restrict__ dout, int HW,
+                                                                     float4* __restrict__ dz) {
+    __shared__ float4 s_part[16][kPoolCols];
+    const int C4 = ps.n * ps.Cp4, Cp4 = ps.Cp4;
+    const int b = blockIdx.y, q = threadIdx.x & (kPoolCols - 1), r = threadIdx.x / kPoolCols;
+    const int c4 = blockIdx.x * kPoolCols + q;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < C4) {
+        const int k = c4 / Cp4, w = c4 - k * Cp4;
+        const float4* xb = ps.p[k] + (long long)b * HW * Cp4 + w;
+        const float4* gb = dout + (long long)b * HW * C4 + c4;
+        int p = r;
+        for (; p + 16 < HW; p += 32) {
+            const float4 g0 = gb[(long long)p * C4], v0 = xb[(long long)p * Cp4], g1 = gb[(long long)(p + 16) * C4], v1 = xb[(long long)(p + 16) * Cp4];
+            a.x += g0.x * v0.x + g1.x * v1.x; a.y += g0.y * v0.y + g1.y * v1.y; a.z += g0.z * v0.z + g1.z * v1.z; a.w += g0.w * v0.w + g1.w * v1.w;
+        }
+        for (; p < HW; p += 16) {
+            const float4 g = gb[(long long)p * C4], v = xb[(long long)p * Cp4];
+            a.x += g.x * v.x; a.y += g.y * v.y; a.z += g.z * v.z; a.w += g.w * v.w;
+        }
+    }
+    s_part[r][q] = a;
+    __syncthreads();
+    if (r == 0 && c4 < C4) {
+        float4 t = s_part[0][q];
+        for (int w = 1; w < 16; ++w) { const float4 u = s_part[w][q]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        const float4 zq = z[(long long)b * C4 + c4];
+        const float4 sg = make_float4(sigm(zq.x), sigm(zq.y), sigm(zq.z), sigm(zq.w));
+        dz[(long long)b * C4 + c4] = make_float4(t.x * sg.x * (1.f - sg.x), t.y * sg.y * (1.f - sg.y), t.z * sg.z * (1.f - sg.z), t.w * sg.w * (1.f - sg.w));
+    }
+}
+// dpiece_k [B][HW][Cp] = dout[.., k * Cp + c] * sigmoid(z) + dpool[b][k * Cp + c] / HW   (the gate's and the pool's gradient in one pass)
+__global__ void __launch_bounds__(256) gate_bwd_pieces_kernel(PiecesOut ds, const float4* __restrict__ z, const float4* __restrict__ dout,
+                                                              const float4* __restrict__ dpool, int B, int HW) {
+    const int C4 = ds.n * ds.Cp4, Cp4 = ds.Cp4;
+    const long long total = (long long)B * HW * C4;
+    const float inv = 1.0f / (float)HW;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / C4;
+        const int c = (int)(i - row * C4);
+        const int b = (int)(row / HW);
+        const int k = c / Cp4, w = c - k * Cp4;
+        const float4 g = dout[i], q = z[(long long)b * C4 + c], dp = dpool[(long long)b * C4 + c];
+        ds.p[k][row * Cp4 + w] = make_float4(g.x * sigm(q.x) + dp.x * inv, g.y * sigm(q.y) + dp.y * inv, g.z * sigm(q.z) + dp.z * inv, g.w * sigm(q.w) + dp.w * inv);
+    }
+}
+}  // namespace ssdk
+
+static int check_pieces(const char* fn, const float* const* pieces, int n_pieces, int batch, int hw, int piece_channels) {
+    SSDK_REQUIRE(pieces && n_pieces > 0 && n_pieces <= ssdk::kMaxPieces, SSDK_E_INVALID, "%s: n_pieces=%d (1..%d)", fn, n_pieces, ssdk::kMaxPieces);
+    SSDK_REQUIRE(batch > 0 && batch <= 65535 && hw > 0 && piece_channels > 0 && piece_channels % 4 == 0, SSDK_E_INVALID,
+                 "%s: batch=%d hw=%d piece_channels=%d (%% 4 == 0)", fn, batch, hw, piece_channels);
+    for (int k = 0; k < n_pieces; ++k)
+        SSDK_REQUIRE(pieces[k] && ((uintptr_t)pieces[k] & 15) == 0, SSDK_E_INVALID, "%s: piece %d is null or not 16-byte aligned", fn, k);
+    return SSDK_OK;
+}
+extern "C" int ssdk_sfam_pool_fwd(const float* const* pieces, int n_pieces, int batch, int hw, int piece_channels, float* pooled, void* stream) {
+    int rc = check_pieces("ssdk_sfam_pool_fwd", pieces, n_pieces, batch, hw, piece_channels);
+    if (rc) return rc;
+    SSDK_REQUIRE(pooled, SSDK_E_INVALID, "ssdk_sfam_pool_fwd: null output");
+    ssdk::Pieces ps{};
+    ps.n = n_pieces; ps.Cp4 = piece_channels / 4;
+    for (int k = 0; k < n_pieces; ++k) ps.p[k] = (const float4*)pieces[k];
+    hipLaunchKernelGGL(pool_pieces_kernel, dim3(cdiv(n_pieces * piece_channels / 4, ssdk::kPoolCols), batch), dim3(256), 0, (hipStream_t)stream, ps, hw, (float4*)pooled);
+    SSDK_CHECK_LAUNCH("pool_pieces_kernel");
+    return SSDK_OK;
+}
+extern "C" int ssdk_sfam_gate_fwd(const float* const* pieces, int n_pieces, int batch, int hw, int piece_channels, const float* z, float* out,
+                                  void* stream) {
+    int rc = check_pieces("ssdk_sfam_gate_fwd", pieces, n_pieces, batch, hw, piece_channels);
+    if (rc) return rc;
+    SSDK_REQUIRE(z && out, SSDK_E_INVALID, "ssdk_sfam_gate_fwd: null pointer");
+    ssdk::Pieces ps{};
+    ps.n = n_pieces; ps.Cp4 = piece_channels / 4;
+    for (int k = 0; k < n_pieces; ++k) ps.p[k] = (const float4*)pieces[k];
+    hipLaunchKernelGGL(gate_pieces_kernel, dim3(stream_blocks((long long)batch * hw * n_pieces * piece_channels / 4, 256)), dim3(256), 0, (hipStream_t)stream, ps,
+                       (const float4*)z, batch, hw, (float4*)out);
+    SSDK_CHECK_LAUNCH("gate_pieces_kernel");
+    return SSDK_OK;
+}
+extern "C" int ssdk_sfam_gate_bwd_reduce(const float* const* pieces, int n_pieces, int batch, int hw, int piece_channels, const float* z,
+                                         const float* dout, float* dz, void* stream) {
+    int rc = check_pieces("ssdk_sfam_gate_bwd_reduce", pieces, n_pieces, batch, hw, piece_channels);
+    if (rc) return rc;
+    SSDK_REQUIRE(z && dout && dz, SSDK_E_INVALID, "ssdk_sfam_gate_bwd_reduce: null pointer");
+    ssdk::Pieces ps{};
+    ps.n = n_pieces; ps.Cp4 = piece_channels / 4;
+    for (int k = 0; k < n_pieces; ++k) ps.p[k] = (const float4*)pieces[k];
+    hipLaunchKernelGGL(gate_bwd_reduce_pieces_kernel, dim3(cdiv(n_pieces * piece_channels / 4, ssdk::kPoolCols), batch), dim3(256), 0, (hipStream_t)stream, ps,
+                       (const float4*)z, (const float4*)dout, hw, (float4*)dz);
+    SSDK_CHECK_LAUNCH("gate_bwd_reduce_pieces_kernel");
+    return SSDK_OK;
+}
+extern "C" int ssdk_sfam_gate_bwd_apply(float* const* dpieces, int n_pieces, int batch, int hw, int piece_channels, const float* z, const float* dout,
+                                        const float* dpool, void* stream) {
+    int rc = check_pieces("ssdk_sfam_gate_bwd_apply", (const float* const*)dpieces, n_pieces, batch, hw, piece_channels);
+    if (rc) return rc;
+    SSDK_REQUIRE(z && dout && dpool, SSDK_E_INVALID, "ssdk_sfam_gate_bwd_apply: null pointer");
+    ssdk::PiecesOut ds{};
+    ds.n = n_pieces; ds.Cp4 = piece_channels / 4;
+    for (int k = 0; k < n_pieces; ++k) ds.p[k] = (float4*)dpieces[k];
+    hipLaunchKernelGGL(gate_bwd_pieces_kernel, dim3(stream_blocks((long long)batch * hw * n_pieces * piece_channels / 4, 256)), dim3(256), 0, (hipStream_t)stream, ds,
+                       (const float4*)z, (const float4*)dout, (const float4*)dpool, batch, hw);
+    SSDK_CHECK_LAUNCH("gate_bwd_pieces_kernel");
+    return SSDK_OK;
+}
+
 // ---- depthwise convolution (bf/modules/conv.py:39-85) ----------------------------------------------------------------------
 // HBM-bound stencils on NHWC maps: a thread owns 4 consecutive channels of one output pixel (16-byte loads / stores, the k*k
 // weights of its channels in registers).  Backward-weights: every thread accumulates its pixels' products for its 4 channels,

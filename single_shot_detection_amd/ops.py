@@ -886,6 +886,147 @@ def sigmoid_gate(x, z):
     return _GateFn.apply(x, z)
 
 
+class _SfamFn(torch.autograd.Function):
+    """M2Det SFAM over PIECES: apply(n_scales, n_pieces, *pieces (scale-major), *(fc1.weight, fc1.bias, fc2.weight, fc2.bias per scale))
+    -> n_scales gated maps [B, n_pieces * Cp, H_s, W_s].  What bf/modules/features.py:385 + :286-298 compute -- torch.cat of a scale's TUM
+    outputs, adaptive_avg_pool2d, fc1 + ReLU, fc2, sigmoid gate -- without ever building the concatenated map: the pool and the gate read
+    the pieces where they are (ssdk_sfam_*), the two 1 x 1 "fc" convolutions of all scales run as grouped launches, and the backward pass
+    writes each piece's gradient (gate's part + pool's part) as its own contiguous map in one pass."""
+
+    @staticmethod
+    def forward(ctx, n_scales, n_pieces, *flat):
+        import ctypes
+        lib = _lib.lib()
+        stream = _lib.current_stream()
+        pieces = [[_nhwc(flat[s * n_pieces + k]) for k in range(n_pieces)] for s in range(n_scales)]
+        params = flat[n_scales * n_pieces:]
+        _lib.require_cuda(*[p for ps in pieces for p in ps])
+        w1 = [params[4 * s].float().contiguous(memory_format=torch.channels_last) for s in range(n_scales)]
+        b1 = [None if params[4 * s + 1] is None else params[4 * s + 1].float().contiguous() for s in range(n_scales)]
+        w2 = [params[4 * s + 2].float().contiguous(memory_format=torch.channels_last) for s in range(n_scales)]
+        b2 = [None if params[4 * s + 3] is None else params[4 * s + 3].float().contiguous() for s in range(n_scales)]
+        B, Cp = pieces[0][0].shape[0], pieces[0][0].shape[1]
+        C, Hc = n_pieces * Cp, w1[0].shape[0]
+        dev = pieces[0][0].device
+        for s in range(n_scales):
+            shape = pieces[s][0].shape
+            assert all(p.shape == shape for p in pieces[s]) and shape[0] == B and shape[1] == Cp, 'the pieces of a scale must share one shape'
+            assert tuple(w1[s].shape) == (Hc, C, 1, 1) and tuple(w2[s].shape) == (C, Hc, 1, 1), (tuple(w1[s].shape), tuple(w2[s].shape))
+        pooled = torch.empty((n_scales, B, C), dtype=torch.float32, device=dev)
+        hidden = torch.empty((n_scales, B, Hc), dtype=torch.float32, device=dev)
+        z = torch.empty((n_scales, B, C), dtype=torch.float32, device=dev)
+        ptrs = [(ctypes.c_void_p * n_pieces)(*[p.data_ptr() for p in pieces[s]]) for s in range(n_scales)]
+        hw = [pieces[s][0].shape[2] * pieces[s][0].shape[3] for s in range(n_scales)]
+        for s in range(n_scales):
+            _lib.check(lib.ssdk_sfam_pool_fwd(ptrs[s], n_pieces, B, hw[s], Cp, pooled[s].data_ptr(), stream), 'ssdk_sfam_pool_fwd')
+        for x, w, b, y, relu in ((pooled, w1, b1, hidden, 1), (hidden, w2, b2, z, 0)):   # fc1 + F.relu, fc2: one grouped launch each
+            arr = (_lib.ConvDesc * n_scales)()
+            for s in range(n_scales):
+                d = arr[s]
+                d.x, d.hin, d.win, d.cin = x[s].data_ptr(), 1, 1, x.shape[2]
+                d.w, d.bias, d.cout, d.ksize, d.stride, d.pad, d.relu = w[s].data_ptr(), _dp(b[s]), y.shape[2], 1, 1, 0, relu
+                d.y = y[s].data_ptr()
+            _conv2d_fwd(lib, arr, n_scales, B, dev)
+        outs = []
+        for s in range(n_scales):
+            out = torch.empty((B, C) + tuple(pieces[s][0].shape[2:]), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+            _lib.check(lib.ssdk_sfam_gate_fwd(ptrs[s], n_pieces, B, hw[s], Cp, z[s].data_ptr(), _dp(out), stream), 'ssdk_sfam_gate_fwd')
+            outs.append(out)
+        ctx.save_for_backward(pooled, hidden, z, *w1, *w2, *[p for ps in pieces for p in ps])
+        ctx.meta = (n_scales, n_pieces, [b is not None for b in b1], [b is not None for b in b2])
+        ctx.params = params
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        import ctypes
+        lib = _lib.lib()
+        stream = _lib.current_stream()
+        n_scales, n_pieces, has_b1, has_b2 = ctx.meta
+        saved = ctx.saved_tensors
+        pooled, hidden, z = saved[:3]
+        w1, w2 = saved[3:3 + n_scales], saved[3 + n_scales:3 + 2 * n_scales]
+        flat_pieces = saved[3 + 2 * n_scales:]
+        pieces = [flat_pieces[s * n_pieces:(s + 1) * n_pieces] for s in range(n_scales)]
+        B, Cp = pieces[0][0].shape[0], pieces[0][0].shape[1]
+        C, Hc = n_pieces * Cp, hidden.shape[2]
+        dev = pooled.device
+        hw = [pieces[s][0].shape[2] * pieces[s][0].shape[3] for s in range(n_scales)]
+        ptrs = [(ctypes.c_void_p * n_pieces)(*[p.data_ptr() for p in pieces[s]]) for s in range(n_scales)]
+        douts = [torch.zeros((B, C) + tuple(pieces[s][0].shape[2:]), dtype=torch.float32, device=dev).contiguous(memory_format=torch.channels_last)
+                 if g is None else _nhwc(g) for s, g in enumerate(douts)]
+        # 1. dz = sigmoid'(z) * sum_hw dout * piece
+        dz = torch.empty_like(z)
+        for s in range(n_scales):
+            _lib.check(lib.ssdk_sfam_gate_bwd_reduce(ptrs[s], n_pieces, B, hw[s], Cp, z[s].data_ptr(), _dp(douts[s]), dz[s].data_ptr(), stream),
+                       'ssdk_sfam_gate_bwd_reduce')
+        # 2. fc2 and fc1 backward (data, weight and bias gradients; one grouped call each), the ReLU between them
+        d_hidden = torch.empty_like(hidden)
+        dpool = torch.empty_like(pooled)
+        dw1 = [torch.empty_like(w, memory_format=torch.channels_last) for w in w1]
+        dw2 = [torch.empty_like(w, memory_format=torch.channels_last) for w in w2]
+        db1 = [torch.empty((Hc,), dtype=torch.float32, device=dev) if h else None for h in has_b1]
+        db2 = [torch.empty((C,), dtype=torch.float32, device=dev) if h else None for h in has_b2]
+
+        def conv_bwd(x, w, dy, dx, dw, db):
+            arr = (_lib.ConvDesc * n_scales)()
+            for s in range(n_scales):
+                d = arr[s]
+                d.x, d.hin, d.win, d.cin = x[s].data_ptr(), 1, 1, x.shape[2]
+                d.w, d.bias, d.cout, d.ksize, d.stride, d.pad, d.relu = w[s].data_ptr(), None, dy.shape[2], 1, 1, 0, 0
+                d.dy, d.dx, d.dw, d.db = dy[s].data_ptr(), dx[s].data_ptr(), dw[s].data_ptr(), _dp(db[s])
+            _conv2d_bwd(lib, arr, n_scales, B, dev, stream)
+        conv_bwd(hidden, w2, dz, d_hidden, dw2, db2)
+        g_hidden = torch.empty_like(d_hidden)
+        _lib.check(lib.ssdk_relu_bwd(_dp(hidden), _dp(d_hidden), hidden.numel(), _dp(g_hidden), stream), 'ssdk_relu_bwd')
+        conv_bwd(pooled, w1, g_hidden, dpool, dw1, db1)
+        # 3. every piece's gradient: dout * sigmoid(z) + dpool / HW, one pass
+        dpieces = []
+        for s in range(n_scales):
+            ds = [torch.empty_like(p, memory_format=torch.channels_last) for p in pieces[s]]
+            darr = (ctypes.c_void_p * n_pieces)(*[t.data_ptr() for t in ds])
+            _lib.check(lib.ssdk_sfam_gate_bwd_apply(darr, n_pieces, B, hw[s], Cp, z[s].data_ptr(), _dp(douts[s]), dpool[s].data_ptr(), stream),
+                       'ssdk_sfam_gate_bwd_apply')
+            dpieces += ds
+        need = ctx.needs_input_grad
+        grads = [g if need[2 + i] else None for i, g in enumerate(dpieces)]
+        base = 2 + n_scales * n_pieces
+        for s in range(n_scales):
+            for j, g in enumerate((dw1[s], db1[s], dw2[s], db2[s])):
+                grads.append(g if need[base + 4 * s + j] else None)
+        return (None, None) + tuple(grads)
+
+
+def sfam_pieces(pieces, fc1, fc2):
+    """[cat(pieces_s, 1) * sigmoid(fc2_s(relu(fc1_s(avgpool(cat(pieces_s, 1)))))) for every scale s] (bf/modules/features.py:385, :286-298)
+    with no concatenated map (``_SfamFn``).  ``pieces``: per scale the list of [B, Cp, H_s, W_s] maps; ``fc1`` / ``fc2``: per scale the 1 x 1
+    nn.Conv2d layers.  ``sfam_pieces_ok`` says whether the kernels take the arguments."""
+    n_scales, n_pieces = len(pieces), len(pieces[0])
+    flat = [p for ps in pieces for p in ps]
+    for a, b in zip(fc1, fc2):
+        flat += [a.weight, a.bias, b.weight, b.bias]
+    return list(_SfamFn.apply(n_scales, n_pieces, *flat))
+
+
+def sfam_pieces_ok(pieces, fc1, fc2):
+    if not pieces or len(pieces) != len(fc1) or len(pieces) != len(fc2) or len(pieces) > 8:
+        return False
+    n = len(pieces[0])
+    if not (0 < n <= 8) or any(len(ps) != n for ps in pieces):
+        return False
+    first = pieces[0][0]
+    Cp, B = first.shape[1], first.shape[0]
+    for ps, a, b in zip(pieces, fc1, fc2):
+        if any((not p.is_cuda) or p.dim() != 4 or p.dtype != torch.float32 or p.shape != ps[0].shape or p.shape[1] != Cp or p.shape[0] != B for p in ps):
+            return False
+        for m in (a, b):
+            if not isinstance(m, torch.nn.Conv2d) or m.kernel_size != (1, 1) or m.stride != (1, 1) or m.padding != (0, 0) or m.groups != 1:
+                return False
+        if a.in_channels != n * Cp or b.out_channels != n * Cp or a.out_channels != b.in_channels or a.out_channels != fc1[0].out_channels:
+            return False
+    return Cp % 4 == 0 and fc1[0].out_channels % 4 == 0 and (B * fc1[0].out_channels * len(pieces)) % 4 == 0
+
+
 class _DepthwiseFn(torch.autograd.Function):
     """Depthwise k x k convolution (groups = channels) on libssdk; weight is torch's [C, 1, k, k] parameter."""
 

@@ -707,3 +707,58 @@ def test_global_avg_pool_and_sigmoid_gate_vs_torch(B, C, H):
     dxr, dzr = torch.autograd.grad(outr, [xr, zr], g.double())
     assert float((dx.double() - dxr).abs().max()) <= 1e-5
     assert float((dz.double() - dzr).abs().max()) <= 2e-5 * float(dzr.abs().max()) + 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,n_pieces,Cp,sizes', [(2, 8, 16, (9, 5, 3, 1)), (3, 3, 8, (17, 4)), (1, 1, 32, (6,)), (4, 8, 128, (8, 2))])
+def test_sfam_over_pieces_vs_torch(B, n_pieces, Cp, sizes):
+    """ops.sfam_pieces (M2Det SFAM without the concatenated maps: ssdk_sfam_pool_fwd / gate_fwd / gate_bwd_reduce / gate_bwd_apply + the
+    grouped 1 x 1 fc convolutions) against the reference's arithmetic in torch fp64 -- torch.cat, adaptive_avg_pool2d, fc1 + relu, fc2,
+    x * sigmoid (bf/modules/features.py:385, :286-298) -- outputs, every piece's gradient, the fc weights' and biases' gradients; and the
+    module's own torch.cat path (SSDK_SFAM_CAT=1) gives the same numbers."""
+    import os
+    import torch.nn.functional as F
+    from single_shot_detection_amd import ops
+    from single_shot_detection_amd.bf.modules.features import ScalewiseFeatureAggregationModule
+    torch.manual_seed(B * 100 + n_pieces * 10 + Cp)
+    C = n_pieces * Cp
+    sfam = ScalewiseFeatureAggregationModule(C, len(sizes), reduction_ratio=2).cuda()
+    pieces = [[torch.randn((B, Cp, h, h), device='cuda').contiguous(memory_format=torch.channels_last).requires_grad_(True) for _ in range(n_pieces)]
+              for h in sizes]
+    gouts = [torch.randn((B, C, h, h), device='cuda').contiguous(memory_format=torch.channels_last) for h in sizes]
+    assert ops.sfam_pieces_ok(pieces, list(sfam.fc1), list(sfam.fc2))
+    params = [p for p in sfam.parameters()]
+    flat = [p for ps in pieces for p in ps]
+
+    def run():
+        outs = sfam.forward_pieces(pieces)
+        grads = torch.autograd.grad(outs, flat + params, gouts)
+        return [o.detach() for o in outs], grads
+    outs, grads = run()
+    # reference arithmetic, fp64
+    ref_pieces = [[p.detach().double().requires_grad_(True) for p in ps] for ps in pieces]
+    ref_params = [p.detach().double().requires_grad_(True) for p in params]
+    n = len(sizes)
+    ref_outs = []
+    for s in range(n):
+        f = torch.cat(ref_pieces[s], dim=1)
+        # (ModuleList order of the parameters: fc1.0.weight, fc1.0.bias, fc1.1.weight, ..., then fc2.*)
+        w1, b1, w2, b2 = ref_params[2 * s], ref_params[2 * s + 1], ref_params[2 * n + 2 * s], ref_params[2 * n + 2 * s + 1]
+        x = F.adaptive_avg_pool2d(f, 1)
+        x = F.relu(F.conv2d(x, w1, b1))
+        x = F.conv2d(x, w2, b2)
+        ref_outs.append(f * torch.sigmoid(x))
+    ref_grads = torch.autograd.grad(ref_outs, [p for ps in ref_pieces for p in ps] + ref_params, [g.double() for g in gouts])
+    for o, r in zip(outs, ref_outs):
+        assert float((o.double() - r.detach()).abs().max()) <= 2e-5 * max(1.0, float(r.detach().abs().max()))
+    for i, (g, r) in enumerate(zip(grads, ref_grads)):
+        assert g.shape == r.shape
+        assert float((g.double() - r).abs().max()) <= 5e-5 * max(1.0, float(r.abs().max())), i
+    # the torch.cat path of the module (the pre-round-4 form) agrees
+    os.environ['SSDK_SFAM_CAT'] = '1'
+    try:
+        outs2, grads2 = run()
+    finally:
+        del os.environ['SSDK_SFAM_CAT']
+    for a, b in zip(outs + list(grads), outs2 + list(grads2)):
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Per-call durations of the BatchNorm kernels (and the other elementwise kernels) in M2Det training steps, from a rocprofv3 kernel trace:
+# Per-call durations of the kernels of M2Det training steps (the 22 largest by total time), from a rocprofv3 kernel trace:
 # which calls carry the time?   bash tools/m2det_bn_calls.sh  (on the GPU box; output gpurun_out/m2det_bn_calls.txt)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
@@ -15,8 +15,11 @@ rows = db.execute(f"select s.display_name, d.end - d.start, d.grid_size_x, d.gri
 by = collections.defaultdict(list)
 for name, du, gx, gy in rows:
     short = name.split('(')[0].replace('void ', '').replace('ssdk::', '')
+    if 'at::native' in name: short = 'torch ' + ('add' if 'Functor_add' in name or 'OnSelf_add' in name else 'cat' if 'CatArray' in name else 'copy' if 'nocast' in name or 'copy' in name.lower() else 'sgd' if 'multi_tensor' in name else name[:60])
     by[short].append((du / 1e3, gx, gy))
-for k in ('bn_reduce_kernel<1>', 'bn_bwd_apply_kernel', 'bn_apply_kernel', 'bn_reduce_kernel<0>', 'zero_many_kernel', 'upsample_add_kernel', 'gate_kernel', 'gate_bwd_kernel', 'avgpool_kernel'):
+tot_all = sum(c[0] for v in by.values() for c in v)
+print(f'all kernels: {tot_all / 1e3:.1f} ms in {sum(len(v) for v in by.values())} launches')
+for k in sorted(by, key=lambda k: -sum(c[0] for c in by[k]))[:22]:
     calls = by.get(k, [])
     if not calls: continue
     calls.sort(reverse=True)
