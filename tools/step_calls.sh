@@ -1,11 +1,12 @@
 #!/bin/bash
-# Per-call durations of the kernels of M2Det training steps (the 22 largest by total time), from a rocprofv3 kernel trace:
-# which calls carry the time?   bash tools/m2det_bn_calls.sh  (on the GPU box; output gpurun_out/m2det_bn_calls.txt)
+# Per-call durations of the kernels of a config's training steps (the 22 largest by total time), from a rocprofv3 kernel trace:
+# which calls carry the time?   bash tools/step_calls.sh [config] [batch]  (on the GPU box; output gpurun_out/step_calls_<config>.txt)
 R=${GRAFT_REPO_ROOT:-/root/repo}
+CFG=${1:-m2det_512_vgg16_coco}; B=${2:-16}
 cd /tmp && export TMPDIR=/tmp
-W=/tmp/m2det_calls; rm -rf $W; mkdir -p $W $R/gpurun_out
-timeout -k 10 400 rocprofv3 --kernel-trace -d $W -o p -- python3 $R/bench.py --config m2det_512_vgg16_coco --batch 16 --steps 3 --warmup 1 --no-cpu-baseline --no-extra-legs > $W/run.log 2>&1
-python3 - $W/p_results.db > $R/gpurun_out/m2det_bn_calls.txt <<'PY'
+W=/tmp/step_calls; rm -rf $W; mkdir -p $W $R/gpurun_out
+timeout -k 10 400 rocprofv3 --kernel-trace -d $W -o p -- python3 $R/bench.py --config $CFG --batch $B --steps 3 --warmup 1 --no-cpu-baseline --no-extra-legs > $W/run.log 2>&1
+python3 - $W/p_results.db > $R/gpurun_out/step_calls_$CFG.txt <<'PY'
 import sqlite3, sys, collections
 db = sqlite3.connect(sys.argv[1])
 tabs = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
@@ -33,4 +34,4 @@ for k in sorted(by, key=lambda k: -sum(c[0] for c in by[k]))[:22]:
         lo = e
     print('   longest:', ', '.join(f'{c[0]:.0f}us(grid {c[1]}x{c[2]})' for c in calls[:8]))
 PY
-cat $R/gpurun_out/m2det_bn_calls.txt
+cat $R/gpurun_out/step_calls_$CFG.txt
