@@ -287,6 +287,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvProblem& g, const f32x16
     }
     const unsigned lo0 = (unsigned)(unsigned long long)off0, hi0 = (unsigned)((unsigned long long)off0 >> 32);
     const unsigned lo1 = (unsigned)(unsigned long long)off1, hi1 = (unsigned)((unsigned long long)off1 >> 32);
+    // The bias values are in their registers HERE: left to itself the compiler waits for the loads at their first use inside the
+    // element loop -- behind branches it can no longer tell them from the stores / atomics issued since, so every element waited
+    // vmcnt(0), i.e. for the previous element's store to complete (seen in the one-column-tile instantiation: 17 waits per tile).
+#pragma unroll
+    for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(biasj[j]));
     double* const stats = (!split && s_red) ? g.stats : nullptr;   // (uniform over the workgroup)
     float cs1[NT], cs2[NT];
 #pragma unroll
@@ -324,7 +329,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvProblem& g, const f32x16
         const bool ok = n < N && !(second && n < n0_pad);
         const int col = second ? n - n0_pad : n;
         const float* bias = second ? g.bias1 : g.bias0;
-        const float bv = (ok && bias && ksp == 0) ? bias[col] : 0.0f;
+        float bv = (ok && bias && ksp == 0) ? bias[col] : 0.0f;
+        asm volatile("" : "+v"(bv));   // (as above: the load is waited for here, not in front of every store)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -453,6 +459,11 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
     __shared__ __attribute__((aligned(1024))) float s_a1[BM * kBK];
     __shared__ __attribute__((aligned(1024))) float s_b0[MAXTN * 32 * kBK];
     __shared__ __attribute__((aligned(1024))) float s_b1[MAXTN * 32 * kBK];
+    // MAXTN == 1 (one 32-column tile per workgroup: the launches smaller than the chip, whose K loop runs at the latency of the DMA --
+    // ~0.75 us per slice against 0.43 us of MFMA, tools/phase_conv.py): THREE stages of 16 + 4 KB, the DMA issued two slices ahead
+    constexpr int kStages = MAXTN == 1 ? 3 : 2;
+    __shared__ __attribute__((aligned(1024))) float s_a2[kStages == 3 ? BM * kBK : 4];
+    __shared__ __attribute__((aligned(1024))) float s_b2[kStages == 3 ? MAXTN * 32 * kBK : 4];
 
     const int Cc = g.Cc;
     const int ks = g.ksize;
@@ -581,11 +592,11 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
         ld_chunk += wrap_t ? 1 : 0;
     };
     auto stage_piece = [&](int DST, int i) {   // DST is a literal at every call site (folds after inlining)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)((DST ? s_a1 : s_a0) + (wave * 32 + kRowsPerPiece * i) * kBK), 16,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)((DST == 2 ? s_a2 : DST ? s_a1 : s_a0) + (wave * 32 + kRowsPerPiece * i) * kBK), 16,
                                                  a_vo[i] | ((a_nmask[i] >> tap_bit) << 31), so_a, 0, 0);
     };
     auto stage_w_piece = [&](int DST, int i) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_seg1[i] ? rsrc_w1 : rsrc_w0, (lds_ptr_t)((DST ? s_b1 : s_b0) + ((wave * ((MAXTN * 32 / (1024 / (BK * 4))) / WAVES) + i) * (1024 / (BK * 4))) * kBK), 16, w_vo[i],
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_seg1[i] ? rsrc_w1 : rsrc_w0, (lds_ptr_t)((DST == 2 ? s_b2 : DST ? s_b1 : s_b0) + ((wave * ((MAXTN * 32 / (1024 / (BK * 4))) / WAVES) + i) * (1024 / (BK * 4))) * kBK), 16, w_vo[i],
                                                  so_w, 0, 0);
     };
 
@@ -676,13 +687,71 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
             }
         }
     } else {
-        switch (tn) {
-            case 6: if constexpr (MAXTN >= 6) { k_loop(std::integral_constant<int, 6>{}, std::false_type{}); } break;
-            case 5: if constexpr (MAXTN >= 6) { k_loop(std::integral_constant<int, 5>{}, std::false_type{}); } break;
-            case 4: k_loop(std::integral_constant<int, 4>{}, std::false_type{}); break;
-            case 3: k_loop(std::integral_constant<int, 3>{}, std::false_type{}); break;
-            case 2: k_loop(std::integral_constant<int, 2>{}, std::false_type{}); break;
-            default: k_loop(std::integral_constant<int, 1>{}, std::false_type{}); break;
+        if constexpr (MAXTN == 1) {
+            // Three stages: slice i is read from stage i % 3 while the DMA of slice i + 2 goes into stage (i + 2) % 3 (last read in iteration
+            // i - 1, behind that iteration's barrier).  The end of an iteration waits for the wave's own DMAs of slice i + 1 only -- the
+            // kAPieces + kWPieces issued in this iteration stay in flight (vmcnt counts down in issue order) -- then the barrier.
+            constexpr int kPer = kAPieces + kWPieces;
+            static_assert(kPer < 16, "vmcnt immediate below");
+            if (slice_begin + 1 < n_slices) {   // slice_begin + 1 into stage 1 (slice_begin is in stage 0, landed: the barrier above)
+                slice_offsets(slice_begin + 2 < n_slices);
+#pragma unroll
+                for (int i = 0; i < kAPieces; ++i) stage_piece(1, i);
+#pragma unroll
+                for (int i = 0; i < kWPieces; ++i) stage_w_piece(1, i);
+            }
+            auto body3 = [&](auto st_c, int slice) {
+                constexpr int ST = decltype(st_c)::value;
+                constexpr int NX = (ST + 2) % 3;
+                const float* const sa = ST == 2 ? s_a2 : ST ? s_a1 : s_a0;
+                const float* const sb = ST == 2 ? s_b2 : ST ? s_b1 : s_b0;
+                const bool more = slice + 2 < n_slices;   // (uniform) is there a slice to stage?  Past the end nothing is issued: the launch would end waiting for it
+                if (more) slice_offsets(slice + 3 < n_slices);   // the slice staged now is slice + 2
+                f32x4 av[2], bv[2];
+                auto read_frags = [&](int buf, int gk) {
+                    const int pos = (pos0 ^ (2 * gk)) * 4;
+                    av[buf] = *reinterpret_cast<const f32x4*>(&sa[a_row + pos]);
+                    bv[buf] = *reinterpret_cast<const f32x4*>(&sb[b_row + pos]);
+                };
+                read_frags(0, 0);
+#pragma unroll
+                for (int gk = 0; gk < kBK / 8; ++gk) {
+                    if (gk + 1 < kBK / 8) read_frags((gk + 1) & 1, gk + 1);
+                    if (gk == 0 && more) {
+#pragma unroll
+                        for (int i = 0; i < kAPieces; ++i) stage_piece(NX, i);
+#pragma unroll
+                        for (int i = 0; i < kWPieces; ++i) stage_w_piece(NX, i);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[gk & 1][kk], bv[gk & 1][kk], acc[0], 0, 0, 0);
+                }
+                // s_waitcnt vmcnt(n) lgkmcnt(0): simm16 = vmcnt[3:0] | expcnt (7: no wait) << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14;
+                // n = what this iteration issued (everything older -- slice + 1 -- has then landed)
+                if (more) __builtin_amdgcn_s_waitcnt(kPer | (7 << 4));
+                else __builtin_amdgcn_s_waitcnt(0 | (7 << 4));
+                __builtin_amdgcn_s_barrier();
+            };
+            int slice = slice_begin;
+            for (; slice + 2 < n_slices; slice += 3) {
+                body3(std::integral_constant<int, 0>{}, slice);
+                body3(std::integral_constant<int, 1>{}, slice + 1);
+                body3(std::integral_constant<int, 2>{}, slice + 2);
+            }
+            if (slice < n_slices) {
+                body3(std::integral_constant<int, 0>{}, slice);
+                if (slice + 1 < n_slices) body3(std::integral_constant<int, 1>{}, slice + 1);
+            }
+        } else {
+            switch (tn) {
+                case 6: if constexpr (MAXTN >= 6) { k_loop(std::integral_constant<int, 6>{}, std::false_type{}); } break;
+                case 5: if constexpr (MAXTN >= 6) { k_loop(std::integral_constant<int, 5>{}, std::false_type{}); } break;
+                case 4: k_loop(std::integral_constant<int, 4>{}, std::false_type{}); break;
+                case 3: k_loop(std::integral_constant<int, 3>{}, std::false_type{}); break;
+                case 2: k_loop(std::integral_constant<int, 2>{}, std::false_type{}); break;
+                default: k_loop(std::integral_constant<int, 1>{}, std::false_type{}); break;
+            }
         }
     }
     PHASE(2)
@@ -2706,7 +2775,14 @@ static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t 
             hipLaunchKernelGGL((igemm_dma_kernel<false, false, false, 4>), dim3(begin), dim3(kConvThreads), 0, s, grp);
         }
     } else if (dma) {
-        if (scatter) hipLaunchKernelGGL((igemm_dma_kernel<false, false, true, 4>), dim3(begin), dim3(kConvThreads), 0, s, grp);
+        // every workgroup of the launch owns ONE 32-column tile (the launches narrowed above, the atomic-epilogue launches of the small
+        // maps): the three-stage instantiation -- its K loop does not wait for a DMA issued one slice earlier but two
+        bool one_tile = !bk16 && !tn6 && !getenv("SSDK_CONV_NO_3STAGE");
+        for (int i = 0; i < count && one_tile; ++i) one_tile = grp.p[i].n_blocks == grp.p[i].tiles_n && !grp.p[i].half_last;
+        if (one_tile && scatter) hipLaunchKernelGGL((igemm_dma_kernel<false, false, true, 4, 32, 1>), dim3(begin), dim3(kConvThreads), 0, s, grp);
+        else if (one_tile && mirror) hipLaunchKernelGGL((igemm_dma_kernel<true, false, false, 4, 32, 1>), dim3(begin), dim3(kConvThreads), 0, s, grp);
+        else if (one_tile && generic) hipLaunchKernelGGL((igemm_dma_kernel<false, true, false, 4, 32, 1>), dim3(begin), dim3(kConvThreads), 0, s, grp);
+        else if (scatter) hipLaunchKernelGGL((igemm_dma_kernel<false, false, true, 4>), dim3(begin), dim3(kConvThreads), 0, s, grp);
         else if (mirror) hipLaunchKernelGGL((igemm_dma_kernel<true, false, false, 4>), dim3(begin), dim3(kConvThreads), 0, s, grp);
         else if (generic) hipLaunchKernelGGL((igemm_dma_kernel<false, true, false, 4>), dim3(begin), dim3(kConvThreads), 0, s, grp);
         else if (bk16) hipLaunchKernelGGL((igemm_dma_kernel<false, false, false, 4, 16>), dim3(begin), dim3(kConvThreads), 0, s, grp);
