@@ -101,14 +101,16 @@ __global__ void __launch_bounds__(256) bn_reduce_kernel(const float* __restrict_
 
 // sums != NULL (training): mean / rstd come straight from the fp64 sums of bn_reduce_kernel<0> (no separate finalize
 // launch); workgroup 0 also publishes save_mean / save_rstd for the backward and updates the running statistics.
-__device__ __forceinline__ void stats_from_sums(const double* sums, long long rows, int C, int c, float eps, float& m, float& rs, float& var_out) {
-    const double n = (double)rows;
-    const double mu = sums[c] / n;
-    double var = sums[C + c] / n - mu * mu;
+// (inv_n = 1 / rows and unbias = rows / (rows - 1) once per thread, multiplications and one reciprocal square root per channel: the
+// form with three fp64 divisions and a square root per channel was ~600 instructions in front of a thread's first load -- every thread of
+// every apply launch derives its four channels' constants this way)
+__device__ __forceinline__ void stats_from_sums(const double* sums, double inv_n, double unbias, int C, int c, float eps, float& m, float& rs, float& var_out) {
+    const double mu = sums[c] * inv_n;
+    double var = sums[C + c] * inv_n - mu * mu;
     if (var < 0.0) var = 0.0;
     m = (float)mu;
-    rs = (float)(1.0 / sqrt(var + (double)eps));
-    var_out = (float)(rows > 1 ? var * n / (n - 1.0) : var);
+    rs = (float)rsqrt(var + (double)eps);
+    var_out = (float)(var * unbias);
 }
 
 __global__ void __launch_bounds__(256) bn_apply_kernel(const float4* __restrict__ x, long long n4, int C4, const float4* __restrict__ mean,
@@ -124,10 +126,11 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float4* __restrict_
         for (int c = threadIdx.x; c < 2 * C + 2; c += blockDim.x) zero_after[c] = 0.0;
     if (sums && count_on_device) rows = (long long)sums[2 * C];   // synchronised statistics: the row count of all ranks travels with the sums
     if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
+    const double inv_n = sums ? 1.0 / (double)rows : 0.0, unbias = rows > 1 ? (double)rows / ((double)rows - 1.0) : 1.0;
     if (sums && blockIdx.x == 0) {
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
             float m, rs, uv;
-            stats_from_sums(sums, rows, C, c, eps, m, rs, uv);
+            stats_from_sums(sums, inv_n, unbias, C, c, eps, m, rs, uv);
             save_mean[c] = m;
             save_rstd[c] = rs;
             if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * m;
@@ -148,10 +151,10 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float4* __restrict_
     auto load_consts = [&](int c) {
         if (sums) {
             float uv;
-            stats_from_sums(sums, rows, C, 4 * c + 0, eps, m.x, rs.x, uv);
-            stats_from_sums(sums, rows, C, 4 * c + 1, eps, m.y, rs.y, uv);
-            stats_from_sums(sums, rows, C, 4 * c + 2, eps, m.z, rs.z, uv);
-            stats_from_sums(sums, rows, C, 4 * c + 3, eps, m.w, rs.w, uv);
+            stats_from_sums(sums, inv_n, unbias, C, 4 * c + 0, eps, m.x, rs.x, uv);
+            stats_from_sums(sums, inv_n, unbias, C, 4 * c + 1, eps, m.y, rs.y, uv);
+            stats_from_sums(sums, inv_n, unbias, C, 4 * c + 2, eps, m.z, rs.z, uv);
+            stats_from_sums(sums, inv_n, unbias, C, 4 * c + 3, eps, m.w, rs.w, uv);
         } else if (mean) {
             m = mean[c];
             rs = rstd[c];
