@@ -2526,7 +2526,8 @@ static bool maybe_split_k_any(ConvProblem& g) {
     // A K chain of eight slices is not worth cutting: a split saves at most ~3 us of it and costs a zero-fill launch, an atomic epilogue
     // and -- for a convolution in front of a BatchNorm -- the statistics pass that a complete tile does in its epilogue
     // (tools/conv_decomp_sweep.py m2det: 1 x 1 256 -> 256 at 16 x 16, batch 16: 19.4 -> 13.6 us with 32-column workgroups and no split)
-    if (g.relu || blocks >= 256 || slices < (old_rules ? 8 : 9)) return false;
+    static const int no_split_upto = []() { const char* e = getenv("SSDK_CONV_NO_SPLIT_UPTO"); return e ? atoi(e) : 8; }();   // (measurement knob: 16 and 24 measured within noise of 8 on SSD-300 / SSD-512 / M2Det)
+    if (g.relu || blocks >= 256 || slices < (old_rules ? 8 : no_split_upto + 1)) return false;
     // Many row tiles, few column blocks (the SSD-300 tail's 1 x 1 512 -> 256 at 18 x 18, batch 32: 81 x 2 tiles of 128 x 128): 64-column
     // workgroups fill the chip WITHOUT splitting K -- no atomic epilogue (3 x the output through 1.3 TB/s of atomics), no zero-fill
     // launch: 57 -> 44 us (tools/conv_decomp_sweep.py; the other tail layers stay within 15 % of their best split)
