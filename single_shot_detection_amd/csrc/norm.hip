@@ -25,7 +25,9 @@ static inline int bn_rows_per_block(long long rows) {
     // (rocprofv3, tools/bnrows_retina.sh): 64 rows everywhere 53.4 us; 256 rows everywhere 30.2 (the small levels then take 17 instead of
     // 6 us); 64 rows until the launch has N workgroups, then more rows per workgroup: N = 1536: 42.3, 1024: 36.6, 768: 32.3, 512: 29.1,
     // 384: 24.8, 256: 23.0, 192: 23.1 (backward statistics alike: 60.7 -> 28.9).  retina_rn50_500_coco step 52.97 -> 50.17 ms.
-    const long long target = getenv("SSDK_BN_WGS") ? atoll(getenv("SSDK_BN_WGS")) : 256;
+    // (round 4, tools/ab_step.sh SSDK_BN_WGS 256 128 64 on one box: M2Det 31.45 / 31.28 / 31.73 ms per step, RetinaNet 46.57 / 46.53 / 46.82, SSD-300
+    // unchanged: 128 -- the mid-size maps of the M2Det neck, 16 k rows, spent ~20 of their 36 us in the 256-way atomics)
+    const long long target = getenv("SSDK_BN_WGS") ? atoll(getenv("SSDK_BN_WGS")) : 128;
     long long r = (rows + target - 1) / target;
     r = (r + 15) / 16 * 16;
     return (int)(r < kBnRows ? kBnRows : (r > 4096 ? 4096 : r));
