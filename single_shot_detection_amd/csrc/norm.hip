@@ -43,21 +43,27 @@ __global__ void __launch_bounds__(256) bn_reduce_kernel(const float* __restrict_
     const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C4 = C >> 2;
+    // Rows of at most 32 float4 (C <= 128: the 128-channel smoothing layers of the M2Det neck, 48 of its 131 norms): a wave instruction
+    // takes 64 / C4 consecutive rows instead of one row on half (a quarter, ...) of its lanes; the lanes that share a column are folded
+    // with cross-lane adds at the end.
+    const bool packed = C4 <= 32 && (64 % C4) == 0;
+    const int rpw = packed ? 64 / C4 : 1;          // rows per wave instruction
+    const int sub = packed ? lane / C4 : 0;        // this lane's row inside them
     if (blockIdx.x == 0 && threadIdx.x == 0) sums[2 * C] = (double)rows;   // (slot 2C: the count behind the sums)
     for (int cbase = 0; cbase < C4; cbase += 64) {
-        const int c4 = cbase + lane;
+        const int c4 = packed ? lane - sub * C4 : cbase + lane;
         float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
         if (c4 < C4) {
             float4 m4 = a0, rs4 = a0;
             if (MODE == 1) { m4 = reinterpret_cast<const float4*>(mean)[c4]; rs4 = reinterpret_cast<const float4*>(rstd)[c4]; }
-            // four rows per trip, all their loads issued before the first is consumed (a row per trip made every wave wait one
+            // four row groups per trip, all their loads issued before the first is consumed (a row per trip made every wave wait one
             // memory round trip per row: 10-24 us on the small pyramid maps); rows past the end re-read the last row, weight 0
-            for (long long r = r0 + wave; r < r1; r += 16) {
+            for (long long v = wave; r0 + v * rpw < r1; v += 16) {
                 float4 xv[4], gv[4], yv[4];
                 float wgt[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const long long ru = r + 4 * u;
+                    const long long ru = r0 + (v + 4 * u) * rpw + sub;
                     wgt[u] = ru < r1 ? 1.0f : 0.0f;
                     const long long rr = ru < r1 ? ru : r1 - 1;
                     xv[u] = reinterpret_cast<const float4*>(x + rr * C)[c4];
@@ -88,14 +94,20 @@ __global__ void __launch_bounds__(256) bn_reduce_kernel(const float* __restrict_
                 }
             }
         }
+        if (packed) {   // (uniform) lanes c4, c4 + C4, c4 + 2 C4, ... hold the same column: fold them into lane c4
+            for (int d = C4; d < 64; d <<= 1) {
+                a0.x += __shfl_xor(a0.x, d, 64); a0.y += __shfl_xor(a0.y, d, 64); a0.z += __shfl_xor(a0.z, d, 64); a0.w += __shfl_xor(a0.w, d, 64);
+                a1.x += __shfl_xor(a1.x, d, 64); a1.y += __shfl_xor(a1.y, d, 64); a1.z += __shfl_xor(a1.z, d, 64); a1.w += __shfl_xor(a1.w, d, 64);
+            }
+        }
         __syncthreads();
         s_part[0][wave][lane] = a0;
         s_part[1][wave][lane] = a1;
         __syncthreads();
-        if (wave < 2 && c4 < C4) {  // wave 0 folds the s0 partials, wave 1 the s1 partials
+        if (wave < 2 && (packed ? lane < C4 : c4 < C4)) {  // wave 0 folds the s0 partials, wave 1 the s1 partials
             float4 t = s_part[wave][0][lane];
             for (int w = 1; w < 4; ++w) { const float4 u = s_part[wave][w][lane]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
-            double* dst = sums + (size_t)wave * C + (size_t)c4 * 4;
+            double* dst = sums + (size_t)wave * C + (size_t)(packed ? lane : c4) * 4;
             atomicAdd(dst + 0, (double)t.x); atomicAdd(dst + 1, (double)t.y); atomicAdd(dst + 2, (double)t.z); atomicAdd(dst + 3, (double)t.w);
         }
     }
