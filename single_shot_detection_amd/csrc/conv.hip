@@ -2595,7 +2595,11 @@ static bool streamk_would_take(const ConvProblem* probs, int count, bool generic
     // generic convolutions: OFF unless asked for (SSDK_CONV_STREAMK_GENERIC=1).  Measured on the SSD-300 tail at batch 32
     // (tools/r03_sk_sweep.sh): the 1 x 1 512 -> 256 layer 56 -> 92-115 us and the 3 x 3 / 2 256 -> 512 layer 85 -> 140 us with ranges of
     // 8 .. 32 units -- a launch of ONE round has no tail to even out, and every workgroup then parks and fixes up a 64 KB partial tile
-    if (getenv("SSDK_CONV_NO_STREAMK") || (generic && !getenv("SSDK_CONV_STREAMK_GENERIC"))) return false;
+    // Round 4: launches of TWO rounds of tiles and more do take it (the RetinaNet tower's grouped launches: 2 664 tiles of 128 x 128 on 512
+    // slots -- the last, partly filled round is what stream-K evens out: 46.40 -> 45.94 ms per step); SSDK_CONV_STREAMK_GENERIC=1: every
+    // generic launch that qualifies like a heads launch, =0: none
+    static const int generic_mode = []() { const char* e = getenv("SSDK_CONV_STREAMK_GENERIC"); return !e ? -1 : (atoi(e) ? 1 : 0); }();
+    if (getenv("SSDK_CONV_NO_STREAMK") || (generic && generic_mode == 0)) return false;
     long long units = 0, blocks = 0;
     for (int i = 0; i < count; ++i) {
         const ConvProblem& g = probs[i];
@@ -2607,6 +2611,9 @@ static bool streamk_would_take(const ConvProblem* probs, int count, bool generic
     }
     const long long min_range = generic ? streamk_generic_min_range() : kStreamKMinRange;
     const long long nwg = std::min<long long>(512, units / (2 * min_range) / 8 * 8);
+    // (two rounds and more, the last one at most three quarters full: a launch of whole rounds -- the M2Det neck's 2 048- and 3 584-tile
+    // layers -- has no tail to even out and measured 0.1 ms slower per step with the fix-up traffic)
+    if (generic && generic_mode < 0 && (blocks < 2 * kStreamKWgs || blocks % kStreamKWgs == 0 || blocks % kStreamKWgs > 3 * kStreamKWgs / 4)) return false;
     return nwg >= kStreamKMinWgs && blocks <= 16 * nwg;
 }
 static unsigned g_streamk_epoch = 0;   // (a launch counter: tells this launch's flags from an earlier launch's in the same workspace)

@@ -123,9 +123,10 @@ class _ConvFn(torch.autograd.Function):
         return (dw, db, None, None, None, None) + tuple(dxs)
 
 
-# stream-K for the generic convolutions is an opt-in of the library (SSDK_CONV_STREAMK_GENERIC, conv.hip streamk_would_take: measured
-# slower on the one-round launches of a pyramid tail); read once: only then do these calls carry the heads' 33 MB stream-K workspace
-_GENERIC_STREAMK = bool(__import__('os').environ.get('SSDK_CONV_STREAMK_GENERIC'))
+# stream-K for the generic convolutions: the library takes it for launches of two rounds of tiles and more (conv.hip streamk_would_take:
+# the RetinaNet tower, the large maps of the M2Det neck; slower on the one-round launches of a pyramid tail), so these calls carry the
+# heads' 33 MB stream-K workspace (one cached buffer per device and stream); SSDK_CONV_STREAMK_GENERIC=0: never, no workspace.  Read once
+_GENERIC_STREAMK = __import__('os').environ.get('SSDK_CONV_STREAMK_GENERIC', '') != '0'
 
 
 def _conv2d_fwd(lib, arr, n, batch, device):
