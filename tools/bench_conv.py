@@ -19,6 +19,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--fwd-only', action='store_true')
+    ap.add_argument('--relu-inputs', action='store_true', help='source maps max(N(0,1), 0) (post-ReLU backbone features: half the operand zeros) instead of N(0,1)')
     ap.add_argument('--cold', type=int, default=0, help='forward only: MB copied between two launches (evicts L2 / the memory-side cache), each launch timed alone')
     ap.add_argument('--sparse', type=float, default=0.0, help='fraction of zero dY rows (per anchor) in the backward input')
     args = ap.parse_args()
@@ -28,6 +29,8 @@ def main():
     heads = detector_builder.get_heads([l[0] for l in levels], [l[2] for l in levels], C).to(dev)
     xs = [torch.from_numpy(x).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
           for x in syn.make_feature_maps(B, levels)]
+    if args.relu_inputs:
+        xs = [x.detach().clamp_min(0).requires_grad_(True) for x in xs]
     flops = sum(2.0 * h * h * 9 * cin * nb * (C + 4) for cin, h, nb in levels) * B
 
     def timed(fn, reps):
