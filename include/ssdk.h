@@ -286,6 +286,11 @@ int ssdk_streamk_poisoned(void);
  * raises its flag (-1: none), and an owner gives up after `spin_limit` polls (0: the default 2^22).  Used by
  * tests/streamk_fault_worker.py in a child process; never by the product path. */
 int ssdk_debug_streamk_fault(int drop_workgroup, unsigned spin_limit);
+/* TEST HOOK: byte offsets, inside the workspace of ssdk_heads_bwd / ssdk_heads_bwd_ex, of the intermediates the ordered anchor-row backward
+ * keeps for level `level` (fp32 mode): out[0..7] = ga (rows [type][B*H*W][Jpad]), T (rows [row][9*Cin]), aidx (int [type][B*H*W]: T row or -1),
+ * apix (int [type][B*H*W]: pixel of row r), acounts (int[16]: rows per type), plan (int[34]: first T row per type, then first 128-row
+ * tile per type), mode (int: 2 = anchor rows, 0 = dense), T capacity in rows.  -3 when these levels do not take that pipeline. */
+int ssdk_debug_heads_bwd_layout(const ssdk_head_level* levels, int n_levels, int batch, int level, unsigned long long* out);
 int ssdk_heads_fwd(const ssdk_head_level* levels, int n_levels, int batch, float* scores, long long scores_batch_stride,
                    float* locs, long long locs_batch_stride, void* workspace, size_t workspace_bytes, void* stream);
 /* The same with a cap on the persistent workgroups of the stream-K form (0 = the library's choice: 512 = every 64 KB LDS slot of the

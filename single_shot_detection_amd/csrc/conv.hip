@@ -1217,6 +1217,9 @@ struct WgradProblem {
     // dw1 = dw0 + n0 * taps * Cc, consecutive copies det_stride floats apart) instead of adding into dw with atomics;
     // reduce_partials_kernel then adds the copies in split order
     long long det_stride;
+    // != 0: the workgroup STORES its tile (into copy ksp when det_stride != 0, into dw itself when k_splits == 1) instead of adding it with
+    // atomics, and a split whose row range is empty stores zeros: the outputs need no zero-fill and every copy is always complete
+    int ordered;
 };
 struct WgradGroup {
     int count;
@@ -1380,7 +1383,10 @@ typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
 // FAST = the opt-in split-bf16 mode (ssdk_heads_bwd_fast / ssdk_conv2d_bwd_fast): both operands are split into bf16 pieces in registers
 // after the LDS reads and every fp32 product becomes a_hi b_hi + a_hi b_mid + a_mid b_hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate):
 // 24 MFMAs of 8 passes per 32-pixel slice instead of 64 of 16.  Staging, tiling, K split and epilogue are the fp32 kernel's.
-template <bool FAST>
+// ROW32 (anchor rows: Npad = Jpad is 32 .. 128): MFMA q owns output rows n_begin + 32 q .. + 31 -- lane (r, h) reads dY[pixel][r + 32 q] with a
+// ds_read_b32 per q -- and only the ceil(rows / 32) MFMAs that have rows are issued (Jpad = 96: 3 of 4; 21-class heads, Jpad = 32: 1 of 4).
+// The default map (MFMA q owns rows 4 i + q: one ds_read_b128 feeds four MFMAs) always issues four.
+template <bool FAST, bool ROW32 = false>
 __device__ __forceinline__ void wgrad_dma_body(const WgradGroup& grp) {
     __shared__ __attribute__((aligned(1024))) float s_dy0[32 * 128];
     __shared__ __attribute__((aligned(1024))) float s_dy1[32 * 128];
@@ -1422,12 +1428,13 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradGroup& grp) {
     const int slices_total = (M + 31) / 32;
     const int per = (slices_total + g.k_splits - 1) / g.k_splits;
     const int s_begin = ksp * per, s_end = min(slices_total, s_begin + per);
-    if (s_begin >= s_end) return;
+    if (s_begin >= s_end && !g.ordered) return;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r32 = lane & 31, h = lane >> 5;
     const bool wave_live = wave < tn;
+    const int nq = ROW32 ? min(4, (g.Npad - n_begin + 31) / 32) : 4;   // MFMAs per K step that have output rows
 
     const __amdgpu_buffer_rsrc_t rsrc_dy = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(dy_p), 0, (int)g.dy_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(g.x), 0, (int)g.x_bytes, 0x00020000);
@@ -1488,7 +1495,26 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradGroup& grp) {
         issue(ST ^ 1, dyo1, xo1);                                  // slice sl + 1 lands while slice sl is multiplied
         pixel_offsets(sl + 2, id2, dyo2, xo2);
         id2 = load_id(sl + 3);
-        if (wave_live && !FAST) {
+        if (wave_live && !FAST && ROW32) {
+            const float* ady = (ST ? s_dy1 : s_dy0) + h * 128 + r32;
+            const float* bx = (ST ? s_x1 : s_x0) + h * 128 + wave * 32 + r32;
+            float av[2][4], bv[2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) av[0][q] = q < nq ? ady[32 * q] : 0.0f;
+            bv[0] = bx[0];
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) {
+                if (k2 + 1 < 16) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) av[(k2 + 1) & 1][q] = q < nq ? ady[(k2 + 1) * 256 + 32 * q] : 0.0f;
+                    bv[(k2 + 1) & 1] = bx[(k2 + 1) * 256];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (q < nq) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k2 & 1][q], bv[k2 & 1], acc[q], 0, 0, 0);
+            }
+        }
+        if (wave_live && !FAST && !ROW32) {
             const float* ady = (ST ? s_dy1 : s_dy0) + h * 128 + 4 * r32;
             const float* bx = (ST ? s_x1 : s_x0) + h * 128 + wave * 32 + r32;
             f32x4 av[2];
@@ -1557,17 +1583,17 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradGroup& grp) {
     const int n0 = g.n0;
     float* const base0 = dw0_p + (long long)tap * Cc + c + (long long)ksp * g.det_stride;
     float* const base1 = dw1_p ? dw1_p + (long long)tap * Cc + c - (long long)n0 * K + (long long)ksp * g.det_stride : base0;
-    const bool ordered = g.det_stride != 0;   // deterministic mode: this split's own copy, plain stores
+    const bool ordered = g.det_stride != 0 || g.ordered;   // this split's own copy (or the output itself), plain stores
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int i = (e & 3) + 8 * (e >> 2) + 4 * h;
-        const int nq = n_begin + 4 * i;
-        const long long nK = (long long)nq * K;
+        const int nrow = n_begin + (ROW32 ? i : 4 * i);
+        const long long nK = (long long)nrow * K;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int n = nq + q;   // MFMA q, row i
+            const int n = nrow + (ROW32 ? 32 * q : q);   // MFMA q, row i
             if (n >= N) continue;
-            float* const dst = (n < n0 ? base0 : base1) + nK + q * K;
+            float* const dst = (n < n0 ? base0 : base1) + nK + (long long)(ROW32 ? 32 * q : q) * K;
             if (ordered) *dst = acc[q][e];
             else atomicAdd(dst, acc[q][e]);
         }
@@ -1575,6 +1601,7 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradGroup& grp) {
 }
 __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_wgrad_dma_kernel(WgradGroup grp) { wgrad_dma_body<false>(grp); }
 __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_wgrad_bf16x3_kernel(WgradGroup grp) { wgrad_dma_body<true>(grp); }
+__global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_wgrad_rows_kernel(WgradGroup grp) { wgrad_dma_body<false, true>(grp); }
 
 // ---- dY pack (+ bias gradient) --------------------------------------------------------------------------------------
 // out[m][n] (n < Npad) = n < n0 ? ds[b*sb + p*n0 + n] : (n < n0+n1 ? dl[b*lb + p*n1 + n-n0] : 0);  db += column sums
@@ -1599,6 +1626,10 @@ struct PackLevel {
     const unsigned char* rmask;
     int a_total, a_off, rnb;
     int block_begin2;   // mask-first pack: first workgroup (mask_scan_kernel) / first chunk (gather_rows_kernel) of the level
+    // ordered pipeline: gather_rows_kernel STORES the column sums of chunk c of type k into dbp[(k * chunks_cap + c) * Jpad + j]
+    // (anchor_dbias_kernel adds them in chunk order) instead of adding them into db0 / db1 with atomics
+    float* dbp;
+    int chunks_cap;
 };
 struct PackGroup {
     int count, B;
@@ -1915,7 +1946,9 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(PackGroup grp, const i
         __syncthreads();
         for (int j = threadIdx.x; j < C + 4; j += 256) {
             const float t = s_sum[0][j] + s_sum[1][j] + s_sum[2][j] + s_sum[3][j];
-            if (t != 0.0f) {
+            if (L.dbp) {
+                L.dbp[((long long)k * L.chunks_cap + c) * Jpad + j] = t;
+            } else if (t != 0.0f) {
                 if (j < C) { if (L.db0) atomicAdd(L.db0 + k * C + j, t); }
                 else if (L.db1) atomicAdd(L.db1 + k * 4 + (j - C), t);
             }
@@ -2002,14 +2035,438 @@ __global__ void build_vtab_kernel(VtabArgs a) {
     vt[0] = v;
 }
 
+// =====================================================================================================================
+// Ordered anchor-row backward (the sparse form of the heads' backward; no atomics anywhere, the same bits on every run).
+//
+// Under hard-negative mining ~4 % of the anchors carry a gradient (detection/sampler.py:12-25, detection/losses/multibox_loss.py:60-90).
+// Row = one such anchor: its C score gradients and 4 box gradients (Jpad = C + 4 rounded up to 32), multiplied with the weight rows of its
+// anchor TYPE k only (detector_builder.py:111-137: output channel k * C + c of the score head, k * 4 + q of the loc head).
+//   anchor_mask_kernel    (only when the caller has no row mask) which anchors carry a gradient, from dscores / dlocs themselves;
+//   anchor_count_kernel   per 256-pixel block and anchor type: marked anchors;
+//   anchor_plan_kernel    ONE workgroup: exclusive scan of the block counts per (level, type) -- rows are numbered in PIXEL ORDER, whatever
+//                         order the blocks ran in --, the level's backward form (2 = anchor rows when they fit the T buffer, else 0 = dense),
+//                         row bases of the types inside the level's T buffer, the tile list of the row GEMM, the chunk table of
+//                         gather_rows_kernel;
+//   anchor_fill_kernel    pixel id of every row (apix) and, inverted, the T row of every (type, pixel) (aidx; -1: no gradient);
+//   gather_rows_kernel    copies the rows' C + 4 values into the compact matrix ga[type][row][Jpad]; per 32-row chunk column sums
+//                         (stored, not added: anchor_dbias_kernel adds them in chunk order);
+//   anchor_rowgemm_kernel T[row][tap * Cin + c] = sum_j ga[row][j] * W_type[j][tap][c] -- every contribution row is STORED once (plain
+//                         stores run at 4-5 x the rate of float atomics, MI355X_MICROARCH.md "Global float atomics");
+//   anchor_dx_kernel      dX[pixel][c] = sum over the (tap, type) pairs whose source anchor exists, in that fixed order, of its T row
+//                         (the inverted index is aidx: at most 9 * nb lookups per pixel); writes EVERY pixel, so dX needs no zero-fill;
+//   igemm_wgrad_dma_kernel<.., ROW32> over the rows (K = rows in pixel order, split over workgroups by a host-side rule; every split stores
+//                         its own copy, reduce_partials_kernel adds the copies in split order).
+constexpr int kAT = kMaxAnchorTypes;
+constexpr int kAnchorBlk = 256;                       // pixels per workgroup of the count / fill kernels
+constexpr int kRgRows = 128;                          // rows per workgroup of the row GEMM
+constexpr int kRgStepCols = 64;                       // T columns per step (two 32-column MFMA tiles)
+constexpr int kRgChunkCols = 512;                     // T columns per work item (8 steps)
+// device-side plan (ints): [0] row GEMM items, [1 + i] first item of level i (i = 0 .. count), then per level kPlanStride ints:
+// [0 .. kAT] first T row of type k (entry nb: rows of the level), [kAT + 1 .. 2 kAT + 1] first 128-row tile of type k
+constexpr int kPlanHead = 1 + kMaxProblems + 1;
+constexpr int kPlanStride = 2 * (kAT + 1);
+constexpr int kPlanInts = kPlanHead + kMaxProblems * kPlanStride;
+
+struct AnchorLevel {
+    const unsigned char* rmask;   // mask byte of (image b, pixel p, type k): rmask[b * a_total + a_off + p * nb + k]
+    int a_total, a_off;
+    int nb, HW, cap;              // cap = B * HW pixels = rows a type can have
+    int blk_begin, nblk;          // workgroups of the count / fill grids
+    int* blk;                     // [nblk][kAT]: marked anchors per block and type -> (anchor_plan_kernel) first row of the block
+    int* apix;                    // [nb][cap] pixel id of row r of type k
+    int* aidx;                    // [nb][cap] T row of (type k, pixel m), -1: none
+    int tcap;                     // rows the level's T buffer holds
+    int items_per_tile;           // column chunks of the row GEMM per row tile (0: no data gradient wanted)
+};
+struct AnchorGroup {
+    int count, force;
+    int* acounts;   // [kMaxProblems][kAT]
+    int* plan;      // [kPlanInts]
+    int* mode;      // [kMaxProblems]
+    int* gtab;      // chunk table of gather_rows_kernel
+    float* zeros;   // 64 floats of zeros (source of the row GEMM's padding lanes)
+    AnchorLevel lv[kMaxProblems];
+};
+
+__device__ __forceinline__ unsigned anchor_bits(const AnchorLevel& L, int m) {
+    unsigned bits = 0;
+    if (m < L.cap) {
+        const int b = m / L.HW, p = m - b * L.HW;
+        const unsigned char* mp = L.rmask + (long long)b * L.a_total + L.a_off + (long long)p * L.nb;
+        for (int k = 0; k < L.nb; ++k) bits |= mp[k] ? 1u << k : 0u;
+    }
+    return bits;
+}
+
+__global__ void __launch_bounds__(kAnchorBlk) anchor_count_kernel(AnchorGroup grp) {
+    int pi = 0;
+#pragma unroll 1
+    for (int i = 1; i < grp.count; ++i)
+        if ((int)blockIdx.x >= grp.lv[i].blk_begin) pi = i;
+    const AnchorLevel& L = grp.lv[pi];
+    __shared__ int s_w[4][kAT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int blk = blockIdx.x - L.blk_begin;
+    const unsigned bits = anchor_bits(L, blk * kAnchorBlk + threadIdx.x);
+#pragma unroll 1
+    for (int k = 0; k < L.nb; ++k) {
+        const unsigned long long bk = __ballot((bits >> k) & 1u);
+        if (lane == 0) s_w[wave][k] = __popcll(bk);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < L.nb) L.blk[blk * kAT + threadIdx.x] = s_w[0][threadIdx.x] + s_w[1][threadIdx.x] + s_w[2][threadIdx.x] + s_w[3][threadIdx.x];
+}
+
+__global__ void __launch_bounds__(1024) anchor_plan_kernel(AnchorGroup grp) {
+    __shared__ int s_cnt[kMaxProblems * kAT];
+    __shared__ int s_nb[kMaxProblems];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 64) grp.zeros[threadIdx.x] = 0.0f;
+    if (threadIdx.x < kMaxProblems) s_nb[threadIdx.x] = (int)threadIdx.x < grp.count ? grp.lv[threadIdx.x].nb : 0;
+#pragma unroll 1
+    for (int p = wave; p < kMaxProblems * kAT; p += 16) {
+        const int li = p / kAT, k = p % kAT;
+        int run = 0;
+        if (li < grp.count && k < grp.lv[li].nb) {
+            const AnchorLevel& L = grp.lv[li];
+#pragma unroll 1
+            for (int c0 = 0; c0 < L.nblk; c0 += kWave) {
+                const int i = c0 + lane;
+                const int v = i < L.nblk ? L.blk[i * kAT + k] : 0;
+                const int incl = wave_inclusive_scan(v, OpAddI());
+                if (i < L.nblk) L.blk[i * kAT + k] = run + incl - v;
+                run += __shfl(incl, kWave - 1, kWave);
+            }
+        }
+        if (lane == 0) { s_cnt[p] = run; grp.acounts[p] = run; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int items = 0;
+        for (int li = 0; li < grp.count; ++li) {
+            const AnchorLevel& L = grp.lv[li];
+            int* pl = grp.plan + kPlanHead + li * kPlanStride;
+            long long rows = 0;
+            for (int k = 0; k < L.nb; ++k) rows += s_cnt[li * kAT + k];
+            int m = rows <= (long long)L.tcap ? 2 : 0;
+            if (grp.force == 0) m = 0;
+            int base = 0, tiles = 0;
+            for (int k = 0; k <= L.nb; ++k) {
+                pl[k] = base;
+                pl[kAT + 1 + k] = tiles;
+                if (k < L.nb && m == 2) { base += s_cnt[li * kAT + k]; tiles += (s_cnt[li * kAT + k] + kRgRows - 1) / kRgRows; }
+            }
+            grp.plan[1 + li] = items;
+            items += tiles * L.items_per_tile;
+            grp.mode[li] = m;
+        }
+        for (int li = grp.count; li <= kMaxProblems; ++li) grp.plan[1 + li] = items;
+        grp.plan[0] = items;
+    }
+    if (wave == 0 && grp.gtab) build_gather_table(s_cnt, s_nb, grp.count, grp.gtab);
+}
+
+__global__ void __launch_bounds__(kAnchorBlk) anchor_fill_kernel(AnchorGroup grp) {
+    int pi = 0;
+#pragma unroll 1
+    for (int i = 1; i < grp.count; ++i)
+        if ((int)blockIdx.x >= grp.lv[i].blk_begin) pi = i;
+    const AnchorLevel& L = grp.lv[pi];
+    __shared__ int s_w[4][kAT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int blk = blockIdx.x - L.blk_begin;
+    const int m = blk * kAnchorBlk + threadIdx.x;
+    const unsigned bits = anchor_bits(L, m);
+#pragma unroll 1
+    for (int k = 0; k < L.nb; ++k) {
+        const unsigned long long bk = __ballot((bits >> k) & 1u);
+        if (lane == 0) s_w[wave][k] = __popcll(bk);
+    }
+    __syncthreads();
+    const int* tbase = grp.plan + kPlanHead + pi * kPlanStride;
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll 1
+    for (int k = 0; k < L.nb; ++k) {
+        const unsigned long long bk = __ballot((bits >> k) & 1u);
+        int off = L.blk[blk * kAT + k];
+        for (int w = 0; w < wave; ++w) off += s_w[w][k];
+        off += __popcll(bk & below);
+        const bool on = (bits >> k) & 1u;
+        if (on) L.apix[(long long)k * L.cap + off] = m;
+        if (m < L.cap) L.aidx[(long long)k * L.cap + m] = on ? tbase[k] + off : -1;
+    }
+}
+
+// Which anchors carry a gradient, from the gradient itself (callers without a row mask): out[(b * HW + p) * nb + k] = any of the C score
+// values or 4 box values of anchor (p, k) of image b is non-zero.  A wave per pixel row, lanes over the nb * (C + 4) columns.
+struct MaskLevel { const float* ds; const float* dl; unsigned char* out; int nb, C, HW, blk_begin; };
+struct MaskGroup { int count, B; long long sb, lb; MaskLevel lv[kMaxProblems]; };
+constexpr int kMaskRows = 16;   // pixel rows per workgroup
+__global__ void __launch_bounds__(256) anchor_mask_kernel(MaskGroup grp) {
+    int pi = 0;
+#pragma unroll 1
+    for (int i = 1; i < grp.count; ++i)
+        if ((int)blockIdx.x >= grp.lv[i].blk_begin) pi = i;
+    const MaskLevel& L = grp.lv[pi];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int M = grp.B * L.HW, n0 = L.nb * L.C, n1 = L.nb * 4;
+    const float inv_c = 1.0f / (float)L.C;
+    const int m0 = (blockIdx.x - L.blk_begin) * kMaskRows;
+#pragma unroll 1
+    for (int r = wave; r < kMaskRows; r += 4) {
+        const int m = m0 + r;
+        if (m >= M) break;
+        const int b = m / L.HW, p = m - b * L.HW;
+        const float* srow = L.ds + (long long)b * grp.sb + (long long)p * n0;
+        const float* lrow = L.dl + (long long)b * grp.lb + (long long)p * n1;
+        unsigned mine = 0u;
+        for (int n = lane; n < n0; n += kWave) {
+            const int a = (int)(((float)n + 0.5f) * inv_c);   // n / C, exact for n < 2^20
+            mine |= srow[n] != 0.0f ? 1u << a : 0u;
+        }
+        for (int n = lane; n < n1; n += kWave) mine |= lrow[n] != 0.0f ? 1u << (n >> 2) : 0u;
+        unsigned char v = 0;
+        for (int k = 0; k < L.nb; ++k) {
+            const bool any = __ballot((mine >> k) & 1u) != 0ull;
+            if (lane == k) v = any ? 1 : 0;
+        }
+        if (lane < L.nb) L.out[(long long)m * L.nb + lane] = v;
+    }
+}
+
+// db of every (level, type): the column sums gather_rows_kernel stored per 32-row chunk, added in chunk order
+struct DbiasLevel { const float* part; float* db0; float* db1; int nb, C, Jpad, chunks_cap; };
+struct DbiasGroup { int count; const int* acounts; DbiasLevel lv[kMaxProblems]; };
+__global__ void __launch_bounds__(128) anchor_dbias_kernel(DbiasGroup grp) {
+    const int li = blockIdx.x / kAT, k = blockIdx.x % kAT;
+    if (li >= grp.count) return;
+    const DbiasLevel& L = grp.lv[li];
+    if (k >= L.nb) return;
+    const int chunks = (grp.acounts[li * kAT + k] + 31) / 32;
+    const float* p = L.part + (long long)k * L.chunks_cap * L.Jpad;
+    for (int j = threadIdx.x; j < L.C + 4; j += blockDim.x) {
+        float s = 0.0f;
+        int c = 0;
+        for (; c + 8 <= chunks; c += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(long long)(c + u) * L.Jpad + j];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; c < chunks; ++c) s += p[(long long)c * L.Jpad + j];
+        if (j < L.C) { if (L.db0) L.db0[k * L.C + j] = s; }
+        else if (L.db1) L.db1[k * 4 + (j - L.C)] = s;
+    }
+}
+
+// ---- the row GEMM -------------------------------------------------------------------------------------------------------
+// T[row][n] = sum_j ga[row][j] * Wk[j][n], n = tap * Cin + c in [0, 9 Cin), Wk[j] = row k * C + j of the score weights (j < C), row
+// k * 4 + j - C of the loc weights (j < C + 4), zeros above: the weights are read where they lie ([n][tap][cin] IS [j][tap * Cin + c]).
+// K = Jpad <= 128 is short, so the A operand never leaves registers: a wave holds its 32 rows x Jpad (Jpad / 2 registers) while the
+// workgroup walks its columns in steps of 64; the B slice [Jpad][64] of a step travels global -> LDS by global_load_lds_dwordx4 (one
+// piece = 4 rows j x 256 B; a lane whose row or column does not exist reads the zero line), two stages.  MFMA step s = 4 g + e takes
+// K index 8 g + 4 h + e from lane half h: the lane's A values are float4 number 2 g + h of its row, its B values lie in piece 2 g + h.
+// LDS image of a step: the piece PAIR g at float g * 544, its odd piece 288 floats (256 + 32) further on, so that the two halves of a
+// ds_read_b32 (same column, rows 4 apart) hit banks 32 apart (and the odd piece ends where the next pair begins).
+struct RowGemmLevel {
+    const float* ga; const float* ws; const float* wl;
+    float* T;
+    int nb, C, cap, K9, n_chunks;
+};
+struct RowGemmGroup { int count; const int* plan; const int* acounts; const float* zeros; RowGemmLevel lv[kMaxProblems]; };
+typedef const __attribute__((address_space(1))) void* g_void_ptr_t;
+
+template <int KQ>   // Jpad = 32 KQ
+__global__ void __launch_bounds__(256, KQ <= 3 ? 3 : 2) anchor_rowgemm_kernel(RowGemmGroup grp) {
+    constexpr int Jpad = 32 * KQ, G = Jpad / 8, kPieces = Jpad / 4, kPerWave = kPieces / 4;
+    constexpr int kPair = 544, kOdd = 288;
+    constexpr int kStageFloats = G * kPair;
+    __shared__ __attribute__((aligned(1024))) float s_b0[kStageFloats];
+    __shared__ __attribute__((aligned(1024))) float s_b1[kStageFloats];
+    const int* plan = grp.plan;
+    const int total = plan[0];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, h = lane >> 5;
+#pragma unroll 1
+    for (int item = blockIdx.x; item < total; item += gridDim.x) {
+        int li = 0;
+#pragma unroll 1
+        for (int i = 1; i < grp.count; ++i)
+            if (item >= plan[1 + i]) li = i;
+        const RowGemmLevel& L = grp.lv[li];
+        const int local = item - plan[1 + li];
+        const int chunk = local % L.n_chunks, tile = local / L.n_chunks;
+        const int* pl = plan + kPlanHead + li * kPlanStride;
+        int k = 0;
+#pragma unroll 1
+        for (int q = 1; q < L.nb; ++q)
+            if (tile >= pl[kAT + 1 + q]) k = q;
+        const int r0 = (tile - pl[kAT + 1 + k]) * kRgRows;
+        const int cnt = grp.acounts[li * kAT + k];
+        const int K9 = L.K9, C = L.C;
+        const int col_begin = chunk * kRgChunkCols, col_end = min(K9, col_begin + kRgChunkCols);
+        const int nsteps = (col_end - col_begin + kRgStepCols - 1) / kRgStepCols;
+        const int nvalid = min(32, max(0, cnt - r0 - wave * 32));   // rows of this wave that exist (uniform)
+
+        // A: this lane's row, float4 number 2 g + h
+        f32x4 a[G];
+        {
+            const int r = r0 + wave * 32 + n;
+            const float* arow = L.ga + ((long long)k * L.cap + (r < cnt ? r : 0)) * Jpad + 4 * h;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                a[g] = *reinterpret_cast<const f32x4*>(arow + 8 * g);
+                if (r >= cnt) a[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        // B staging: piece p = wave + 4 i holds rows j = 4 p .. 4 p + 3; lane l: row 4 p + l / 16, float4 column l % 16
+        const float* src[kPerWave];
+        const int colq = (lane & 15) * 4;
+#pragma unroll
+        for (int i = 0; i < kPerWave; ++i) {
+            const int j = 4 * (wave + 4 * i) + (lane >> 4);
+            src[i] = j < C ? L.ws + ((long long)k * C + j) * K9 : (j < C + 4 ? L.wl + ((long long)k * 4 + (j - C)) * K9 : nullptr);
+        }
+        auto stage = [&](int DST, int st) {   // DST is a literal at the call sites
+            const int col = col_begin + st * kRgStepCols + colq;
+#pragma unroll
+            for (int i = 0; i < kPerWave; ++i) {
+                const int p = wave + 4 * i;
+                const float* s = (src[i] && col < col_end) ? src[i] + col : grp.zeros;
+                __builtin_amdgcn_global_load_lds((g_void_ptr_t)s, (lds_ptr_t)((DST ? s_b1 : s_b0) + (p >> 1) * kPair + (p & 1) * kOdd), 16, 0, 0);
+            }
+        };
+        __syncthreads();   // (the previous item's last step has been read)
+        stage(0, 0);
+        __builtin_amdgcn_s_waitcnt(0 | (7 << 4));   // vmcnt(0): this wave's pieces have landed
+        __builtin_amdgcn_s_barrier();
+
+        float* const tile_ptr = L.T + (long long)(pl[k] + r0 + wave * 32) * K9;
+        const int lane_off = 4 * h * K9 + n;
+        auto body = [&](auto st_c, int st) {
+            constexpr int ST = decltype(st_c)::value;
+            if (st + 1 < nsteps) stage(ST ^ 1, st + 1);
+            const int col0 = col_begin + st * kRgStepCols;
+            f32x16 acc[2];
+            if (nvalid > 0) {
+                const float* sb = (ST ? s_b1 : s_b0) + h * kOdd + n;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[ct][e] = 0.0f;
+                // the B values of group g + 1 are read BEFORE the eight MFMAs of group g (pinned: left alone the compiler reads a pair,
+                // waits, issues its two MFMAs, reads the next pair into the same registers ...)
+                float b[2][4][2];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    b[0][e][0] = sb[e * 64];
+                    b[0][e][1] = sb[e * 64 + 32];
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    if (g + 1 < G) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            b[(g + 1) & 1][e][0] = sb[(g + 1) * kPair + e * 64];
+                            b[(g + 1) & 1][e][1] = sb[(g + 1) * kPair + e * 64 + 32];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g][e], b[g & 1][e][0], acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g][e], b[g & 1][e][1], acc[1], 0, 0, 0);
+                    }
+                }
+            }
+            // vmcnt(0): the next step's pieces (issued a step of MFMAs ago) and the PREVIOUS step's stores; this step's stores are issued
+            // behind the barrier and stay in flight under the next step's MFMAs
+            __builtin_amdgcn_s_waitcnt(0 | (7 << 4));
+            __builtin_amdgcn_s_barrier();
+            if (nvalid > 0) {
+                // C/D map of the 32 x 32 MFMA: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    if (col0 + ct * 32 + n >= col_end) continue;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = (e & 3) + 8 * (e >> 2);
+                        if (row + 4 * h < nvalid) tile_ptr[(long long)row * K9 + col0 + ct * 32 + lane_off] = acc[ct][e];
+                    }
+                }
+            }
+        };
+#pragma unroll 1
+        for (int st = 0; st < nsteps; st += 2) {
+            body(std::integral_constant<int, 0>{}, st);
+            if (st + 1 < nsteps) body(std::integral_constant<int, 1>{}, st + 1);
+        }
+    }
+}
+
+// ---- the sum pass ----------------------------------------------------------------------------------------------------------
+// dX[m][c] = sum over taps t = (ky, kx) in order, over types k in order, of T[aidx[k][m']][t * Cin + c], m' = the output pixel that tap
+// connects to input pixel m: (y + 1 - ky, x + 1 - kx) (3 x 3, pad 1, stride 1).  A wave per pixel; the hits go through LDS.
+struct DxLevel { const int* aidx; const float* T; float* dx; const int* mode; int nb, H, W, cin, cap, blk_begin; };
+struct DxGroup { int count; DxLevel lv[kMaxProblems]; };
+constexpr int kDxHits = 9 * kAT;
+__global__ void __launch_bounds__(256) anchor_dx_kernel(DxGroup grp) {
+    int pi = 0;
+#pragma unroll 1
+    for (int i = 1; i < grp.count; ++i)
+        if ((int)blockIdx.x >= grp.lv[i].blk_begin) pi = i;
+    const DxLevel& L = grp.lv[pi];
+    if (*L.mode != 2) return;
+    __shared__ unsigned s_hit[4][kDxHits];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = (blockIdx.x - L.blk_begin) * 4 + wave;
+    if (m >= L.cap) return;   // (whole waves; no workgroup barrier below)
+    const int HW = L.H * L.W;
+    const int b = m / HW, p = m - b * HW, y = p / L.W, x = p - y * L.W;
+    const int nq = 9 * L.nb, K9 = 9 * L.cin;
+    const float inv_nb = 1.0f / (float)L.nb;
+    int nh = 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll 1
+    for (int q0 = 0; q0 < nq; q0 += kWave) {
+        const int q = q0 + lane;
+        const int t = (int)(((float)q + 0.5f) * inv_nb), k = q - t * L.nb;   // q / nb, exact for q < 2^20
+        const int ky = t / 3, kx = t - 3 * ky;
+        const int yo = y + 1 - ky, xo = x + 1 - kx;
+        int row = -1;
+        if (q < nq && (unsigned)yo < (unsigned)L.H && (unsigned)xo < (unsigned)L.W) row = L.aidx[(long long)k * L.cap + b * HW + yo * L.W + xo];
+        const unsigned long long hit = __ballot(row >= 0);
+        if (row >= 0) s_hit[wave][nh + __popcll(hit & below)] = (unsigned)row * (unsigned)K9 + (unsigned)(t * L.cin);
+        nh += __popcll(hit);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float* const out = L.dx + (long long)m * L.cin;
+    for (int c0 = lane * 4; c0 < L.cin; c0 += 4 * kWave) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        int i = 0;
+        for (; i + 4 <= nh; i += 4) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(L.T + s_hit[wave][i] + c0), v1 = *reinterpret_cast<const f32x4*>(L.T + s_hit[wave][i + 1] + c0);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(L.T + s_hit[wave][i + 2] + c0), v3 = *reinterpret_cast<const f32x4*>(L.T + s_hit[wave][i + 3] + c0);
+            acc += v0; acc += v1; acc += v2; acc += v3;
+        }
+        for (; i < nh; ++i) acc += *reinterpret_cast<const f32x4*>(L.T + s_hit[wave][i] + c0);
+        *reinterpret_cast<f32x4*>(out + c0) = acc;
+    }
+}
+
 // Deterministic mode: out[e] (+)= sum_k src[k * stride + e], k = 0 .. n_src - 1 IN THAT ORDER (the partial tiles of a K-split weight
 // gradient, the per-workgroup column sums of a bias gradient): the fixed-order second half of what the atomics do in any order.
 struct ReduceJob {
     float* dst; const float* src;
     long long elems, stride;
-    int n_src, accumulate, block_begin, pad_;
+    int n_src, accumulate, block_begin, want_mode;
+    const int* mode;   // the job runs only when *mode == want_mode (NULL: always)
 };
-constexpr int kMaxReduceJobs = 40;
+constexpr int kMaxReduceJobs = 36;   // (56 bytes each: the group stays inside the 4 KB of kernel arguments with room to spare)
 struct ReduceGroup { int count; ReduceJob j[kMaxReduceJobs]; };
 __global__ void __launch_bounds__(256) reduce_partials_kernel(ReduceGroup grp) {
     int ji = 0;
@@ -2017,6 +2474,7 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(ReduceGroup grp) {
     for (int i = 1; i < grp.count; ++i)
         if ((int)blockIdx.x >= grp.j[i].block_begin) ji = i;
     const ReduceJob& J = grp.j[ji];
+    if (J.mode && *J.mode != J.want_mode) return;
     const long long e4 = ((long long)(blockIdx.x - J.block_begin) * 256 + threadIdx.x) * 4;
     if (e4 >= J.elems) return;
     if (e4 + 4 <= J.elems && ((J.stride | (long long)((uintptr_t)J.src >> 2) | (long long)((uintptr_t)J.dst >> 2)) & 3) == 0) {
@@ -3240,22 +3698,12 @@ static HeadsBwdWs carve_heads_bwd(void* ws, const ssdk_head_level* levels, int n
     return w;
 }
 
-extern "C" size_t ssdk_heads_bwd_workspace_bytes(const ssdk_head_level* levels, int n_levels, int batch) {
-    size_t total = 0;
-    if (levels && n_levels > 0 && n_levels <= kMaxProblems) carve_heads_bwd(nullptr, levels, n_levels, batch, &total);
-    return total;
-}
-extern "C" size_t ssdk_heads_bwd_fast_workspace_bytes(const ssdk_head_level* levels, int n_levels, int batch) {
-    size_t total = 0;
-    if (levels && n_levels > 0 && n_levels <= kMaxProblems) carve_heads_bwd(nullptr, levels, n_levels, batch, &total, true);
-    return total;
-}
 
 // K (= pixel rows) is split so that every problem contributes >= ~256 workgroups (tiny maps are latency bound at one
 // wave per SIMD: more, shorter workgroups) and no workgroup walks more than 64 slices; each split costs one 64 KB
 // atomic tile, so never fewer than 2 slices per split.
 // picks the LDS-DMA kernel when every problem of the group qualifies (16-byte rows, operands below 2 GiB, pixel count below 2^24)
-static int launch_wgrad(WgradGroup& wg, hipStream_t s, bool fast = false) {
+static int launch_wgrad(WgradGroup& wg, hipStream_t s, bool fast = false, bool rows32 = false) {
     bool dma = !getenv("SSDK_CONV_NO_DMA");
     for (int i = 0; i < wg.count && dma; ++i) {
         WgradProblem& g = wg.p[i];
@@ -3266,7 +3714,10 @@ static int launch_wgrad(WgradGroup& wg, hipStream_t s, bool fast = false) {
         g.dy_bytes = (unsigned)dy_bytes;
         g.x_bytes = (unsigned)x_bytes;
     }
+    for (int i = 0; i < wg.count; ++i)
+        SSDK_REQUIRE(dma || !(wg.p[i].ordered && !wg.p[i].det_stride) , SSDK_E_UNSUPPORTED, "launch_wgrad: ordered stores need the LDS-DMA kernel");
     if (dma && fast) hipLaunchKernelGGL(igemm_wgrad_bf16x3_kernel, dim3(wg.total_blocks), dim3(kConvThreads), 0, s, wg);
+    else if (dma && rows32) hipLaunchKernelGGL(igemm_wgrad_rows_kernel, dim3(wg.total_blocks), dim3(kConvThreads), 0, s, wg);
     else if (dma) hipLaunchKernelGGL(igemm_wgrad_dma_kernel, dim3(wg.total_blocks), dim3(kConvThreads), 0, s, wg);
     else hipLaunchKernelGGL(igemm_wgrad_kernel, dim3(wg.total_blocks), dim3(kConvThreads), 0, s, wg);
     SSDK_CHECK_LAUNCH("igemm_wgrad_kernel");
@@ -3278,11 +3729,13 @@ struct ReduceList {
     ReduceGroup g;
     int blocks;
     ReduceList() : blocks(0) { g.count = 0; }
-    int add(float* dst, const float* src, long long elems, long long stride, int n_src, int accumulate, hipStream_t s) {
+    int add(float* dst, const float* src, long long elems, long long stride, int n_src, int accumulate, hipStream_t s, const int* mode = nullptr,
+            int want_mode = 0) {
         if (!dst || elems <= 0 || n_src <= 0) return SSDK_OK;
         if (g.count == kMaxReduceJobs) { const int rc = launch(s); if (rc) return rc; }
         ReduceJob& J = g.j[g.count++];
-        J.dst = dst; J.src = src; J.elems = elems; J.stride = stride; J.n_src = n_src; J.accumulate = accumulate; J.block_begin = blocks; J.pad_ = 0;
+        J.dst = dst; J.src = src; J.elems = elems; J.stride = stride; J.n_src = n_src; J.accumulate = accumulate; J.block_begin = blocks;
+        J.mode = mode; J.want_mode = want_mode;
         blocks += (int)((elems + 1023) / 1024);
         return SSDK_OK;
     }
@@ -3322,6 +3775,355 @@ static void size_wgrad_splits(WgradGroup& wg, int n, int density_div) {
     wg.total_blocks = begin;
 }
 
+// ---- the ordered pipeline (every level has anchor structure: a loc head with nb = n_loc / 4 anchor types, n_score = nb * C, C + 4 <= 128) ----
+// Per level the DEVICE picks the form (anchor_plan_kernel): 2 = anchor rows (see "Ordered anchor-row backward" above) when the rows fit the
+// level's T buffer, else 0 = dense.  Both forms sum in an order fixed by the launch: no atomics, no zero-fill, the same bits on every run
+// and in a HIP-graph replay, whatever ssdk_set_deterministic says (it governs the legacy pipeline below and the generic convolutions).
+static int heads_t_div() {
+    static const int v = []() { const char* e = getenv("SSDK_HEADS_T_DIV"); const int d = e ? atoi(e) : 0; return d >= 1 ? d : 4; }();
+    return v;
+}
+// rows of a level's T buffer: a quarter of its anchors (hard-negative mining marks ~4 %), never fewer than 4 096 (small maps always fit)
+static inline long long t_rows_of(const ssdk_head_level& lv, int batch) {
+    const long long all = (long long)anchor_types_of(lv) * batch * lv.h * lv.w;
+    return std::min(all, std::max<long long>(4096, (all + heads_t_div() - 1) / heads_t_div()));
+}
+static bool ordered_heads_ok(const ssdk_head_level* levels, int n_levels, int batch) {
+    if (getenv("SSDK_CONV_NO_DMA") || getenv("SSDK_HEADS_BWD_LEGACY")) return false;
+    const char* f = getenv("SSDK_HEADS_BWD_MODE");
+    if (f && atoi(f) == 1) return false;   // (the pixel-row form exists in the legacy pipeline only)
+    for (int i = 0; i < n_levels; ++i) {
+        const ssdk_head_level& lv = levels[i];
+        const int nb = anchor_types_of(lv);
+        if (!nb || lv.cin % 4 || ((uintptr_t)lv.x & 15)) return false;
+        const long long M = (long long)batch * lv.h * lv.w, jpad = jpad_of(lv);
+        if (jpad > 128 || M >= (1 << 24) || M * jpad * 4 >= (1LL << 31) - 65536 || M * lv.cin * 4 >= (1LL << 31) - 65536 ||
+            M * npad_of(lv) * 4 >= (1LL << 31) - 65536) return false;   // (every operand of the LDS-DMA weight-gradient kernel below 2 GiB)
+        if (t_rows_of(lv, batch) * 9 * lv.cin >= (1LL << 32)) return false;
+        if (npad_of(lv) > kPackColIters * 64) return false;
+    }
+    return true;
+}
+// K splits of the anchor-row weight gradient of a level: sized for 1 / 16 of the anchors of a type carrying a gradient, ~16 slices of 32 rows
+// per split, at most 8 (every split stores a full copy of the level's weight gradient)
+static inline int anchor_wgrad_splits(const ssdk_head_level& lv, int batch) {
+    const int slices = cdiv(cdiv(batch * lv.h * lv.w, 16), 32);
+    return std::max(1, std::min(8, cdiv(slices, 16)));
+}
+struct OrderedWs {
+    int* acounts; int* plan; int* mode; int* gtab; float* zeros;
+    unsigned char* imask[kMaxProblems];
+    int* blk[kMaxProblems]; int* apix[kMaxProblems]; int* aidx[kMaxProblems];
+    float* ga[kMaxProblems]; float* T[kMaxProblems]; float* dbp[kMaxProblems];
+    float* dyp[kMaxProblems]; float* wd[kMaxProblems];
+    float* dw_part[kMaxProblems];
+    int dense_splits[kMaxProblems], anchor_splits[kMaxProblems];
+    long long tcap[kMaxProblems];
+    __bf16* fast_hi[kMaxProblems];
+    __bf16* fast_mid[kMaxProblems];
+};
+static OrderedWs carve_heads_ordered(void* ws, const ssdk_head_level* levels, int n_levels, int batch, size_t* total, bool fast) {
+    Carver c(ws);
+    OrderedWs w{};
+    w.acounts = c.take<int>(kMaxProblems * kAT);
+    w.plan = c.take<int>(kPlanInts);
+    w.mode = c.take<int>(kMaxProblems);
+    w.gtab = c.take<int>(kGtabInts);
+    w.zeros = c.take<float>(64);
+    for (int i = 0; i < n_levels; ++i) {
+        const ssdk_head_level& lv = levels[i];
+        const size_t M = (size_t)batch * lv.h * lv.w, nb = (size_t)anchor_types_of(lv), jpad = (size_t)jpad_of(lv), npad = (size_t)npad_of(lv);
+        const size_t N = (size_t)lv.n_score + lv.n_loc, K9 = (size_t)9 * lv.cin;
+        w.imask[i] = c.take<unsigned char>(M * nb);
+        w.blk[i] = c.take<int>((size_t)cdiv((int)M, kAnchorBlk) * kAT);
+        w.apix[i] = c.take<int>(nb * M);
+        w.aidx[i] = c.take<int>(nb * M);
+        w.ga[i] = c.take<float>(nb * M * jpad);
+        w.tcap[i] = t_rows_of(lv, batch);
+        w.T[i] = c.take<float>((size_t)w.tcap[i] * K9);
+        w.dbp[i] = c.take<float>(nb * (size_t)cdiv((int)M, kGatherRows) * jpad);
+        w.dyp[i] = c.take<float>(M * npad);
+        w.wd[i] = c.take<float>((size_t)lv.cin * 9 * npad);
+        {   // the K-split copies of the weight gradient: the dense form's or the anchor form's, whichever is larger (a level takes one)
+            WgradGroup one{};
+            one.p[0] = heads_wgrad_problem(lv, batch);
+            size_wgrad_splits(one, 1, 1);
+            w.dense_splits[i] = one.p[0].k_splits;
+            w.anchor_splits[i] = anchor_wgrad_splits(lv, batch);
+            w.dw_part[i] = c.take<float>((size_t)std::max(w.dense_splits[i], w.anchor_splits[i] > 1 ? w.anchor_splits[i] : 0) * N * K9);
+        }
+        if (fast) {
+            w.fast_hi[i] = c.take<__bf16>((size_t)cdiv(lv.cin, 32) * 32 * 9 * npad);
+            w.fast_mid[i] = c.take<__bf16>((size_t)cdiv(lv.cin, 32) * 32 * 9 * npad);
+        }
+    }
+    if (total) *total = c.off;
+    return w;
+}
+
+// TEST HOOK: where the ordered pipeline keeps its intermediates of level `level` inside the workspace (byte offsets), so that tests can hold
+// the row matrix, the inverted index and the T rows against a CPU restatement.  out[0..7] = ga, T, aidx, apix, acounts (of this level),
+// plan (of this level: T row base / tile base per type), mode (of this level), T capacity in rows.  Returns 0, or -3 when these levels do
+// not take the ordered pipeline.
+extern "C" int ssdk_debug_heads_bwd_layout(const ssdk_head_level* levels, int n_levels, int batch, int level, unsigned long long* out) {
+    SSDK_REQUIRE(levels && out && n_levels > 0 && n_levels <= kMaxProblems && level >= 0 && level < n_levels && batch > 0, SSDK_E_INVALID, "ssdk_debug_heads_bwd_layout: bad arguments");
+    if (!ordered_heads_ok(levels, n_levels, batch)) return SSDK_E_UNSUPPORTED;
+    char* const base = reinterpret_cast<char*>(0x1000);   // (never dereferenced: the carver only adds offsets)
+    const OrderedWs w = carve_heads_ordered(base, levels, n_levels, batch, nullptr, false);
+    auto off = [&](const void* p) { return (unsigned long long)(reinterpret_cast<const char*>(p) - base); };
+    out[0] = off(w.ga[level]); out[1] = off(w.T[level]); out[2] = off(w.aidx[level]); out[3] = off(w.apix[level]);
+    out[4] = off(w.acounts + level * kAT); out[5] = off(w.plan + kPlanHead + level * kPlanStride); out[6] = off(w.mode + level);
+    out[7] = (unsigned long long)w.tcap[level];
+    return SSDK_OK;
+}
+
+static int heads_bwd_ordered(const ssdk_head_level* levels, int n_levels, int batch, const float* dscores, long long scores_batch_stride,
+                             const float* dlocs, long long locs_batch_stride, void* workspace, hipStream_t s, bool fast,
+                             const unsigned char* row_mask, int num_anchors) {
+    OrderedWs w = carve_heads_ordered(workspace, levels, n_levels, batch, nullptr, fast);
+    // 1. which anchors carry a gradient: the caller's mask where it covers the level in the level's own numbering, else derived
+    AnchorGroup ag{};
+    ag.count = n_levels;
+    {
+        const char* f = getenv("SSDK_HEADS_BWD_MODE");
+        ag.force = f ? atoi(f) : -1;
+    }
+    ag.acounts = w.acounts; ag.plan = w.plan; ag.mode = w.mode; ag.gtab = w.gtab; ag.zeros = w.zeros;
+    MaskGroup mg{};
+    mg.B = batch; mg.sb = scores_batch_stride; mg.lb = locs_batch_stride;
+    int blk_begin = 0, mask_blocks = 0;
+    for (int i = 0; i < n_levels; ++i) {
+        const ssdk_head_level& lv = levels[i];
+        int rc = check_level("ssdk_heads_bwd", batch, lv);
+        if (rc) return rc;
+        SSDK_REQUIRE(dlocs, SSDK_E_INVALID, "ssdk_heads_bwd: null dlocs");
+        const int nb = anchor_types_of(lv), C = lv.n_score / nb, hw = lv.h * lv.w;
+        AnchorLevel& L = ag.lv[i];
+        L.nb = nb; L.HW = hw; L.cap = batch * hw;
+        L.blk_begin = blk_begin; L.nblk = cdiv(L.cap, kAnchorBlk);
+        blk_begin += L.nblk;
+        L.blk = w.blk[i]; L.apix = w.apix[i]; L.aidx = w.aidx[i];
+        L.tcap = (int)std::min<long long>(w.tcap[i], 0x7fffffff);
+        L.items_per_tile = lv.dx ? cdiv(9 * lv.cin, kRgChunkCols) : 0;
+        const bool covered = row_mask && lv.scores_offset % C == 0 && lv.locs_offset == 4 * (lv.scores_offset / C) &&
+                             lv.scores_offset / C + (long long)hw * nb <= num_anchors;
+        if (covered && !getenv("SSDK_PACK_SCAN")) {
+            L.rmask = row_mask; L.a_total = num_anchors; L.a_off = (int)(lv.scores_offset / C);
+        } else {
+            L.rmask = w.imask[i]; L.a_total = hw * nb; L.a_off = 0;
+            MaskLevel& Q = mg.lv[mg.count++];
+            Q.ds = dscores + lv.scores_offset; Q.dl = dlocs + lv.locs_offset; Q.out = w.imask[i]; Q.nb = nb; Q.C = C; Q.HW = hw;
+            Q.blk_begin = mask_blocks;
+            mask_blocks += cdiv(L.cap, kMaskRows);
+        }
+    }
+    if (mg.count) {
+        hipLaunchKernelGGL(anchor_mask_kernel, dim3(mask_blocks), dim3(256), 0, s, mg);
+        SSDK_CHECK_LAUNCH("anchor_mask_kernel");
+    }
+    hipLaunchKernelGGL(anchor_count_kernel, dim3(blk_begin), dim3(kAnchorBlk), 0, s, ag);
+    SSDK_CHECK_LAUNCH("anchor_count_kernel");
+    hipLaunchKernelGGL(anchor_plan_kernel, dim3(1), dim3(1024), 0, s, ag);
+    SSDK_CHECK_LAUNCH("anchor_plan_kernel");
+    hipLaunchKernelGGL(anchor_fill_kernel, dim3(blk_begin), dim3(kAnchorBlk), 0, s, ag);
+    SSDK_CHECK_LAUNCH("anchor_fill_kernel");
+
+    // 2. the rows' values (anchor form) and the bias gradients (every form: the bias gradient IS the sum over the marked anchors)
+    PackGroup pg{};
+    pg.count = n_levels; pg.B = batch; pg.sb = scores_batch_stride; pg.lb = locs_batch_stride;
+    int pack_blocks = 0, max_npad = 0;
+    long long worst_chunks = 0;
+    DbiasGroup dbg{};
+    dbg.count = n_levels; dbg.acounts = w.acounts;
+    for (int i = 0; i < n_levels; ++i) {
+        const ssdk_head_level& lv = levels[i];
+        PackLevel& L = pg.lv[i];
+        L.ds = dscores + lv.scores_offset; L.dl = dlocs + lv.locs_offset;
+        L.n0 = lv.n_score; L.n1 = lv.n_loc; L.Npad = npad_of(lv); L.HW = lv.h * lv.w;
+        L.out = w.dyp[i];
+        L.nb = ag.lv[i].nb; L.C = lv.n_score / L.nb; L.Jpad = jpad_of(lv); L.cap = batch * L.HW;
+        L.ga = w.ga[i]; L.apix = w.apix[i]; L.acount = w.acounts + i * kAT;
+        L.mode = w.mode + i;
+        L.dbp = w.dbp[i]; L.chunks_cap = cdiv(L.cap, kGatherRows);
+        L.block_begin = pack_blocks;
+        pack_blocks += cdiv(batch * L.HW, kPackRows);
+        max_npad = std::max(max_npad, L.Npad);
+        worst_chunks += (long long)L.nb * L.chunks_cap;
+        DbiasLevel& D = dbg.lv[i];
+        D.part = w.dbp[i]; D.db0 = lv.db_score; D.db1 = lv.db_loc; D.nb = L.nb; D.C = L.C; D.Jpad = L.Jpad; D.chunks_cap = L.chunks_cap;
+    }
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)std::min<long long>(worst_chunks, 1024)), dim3(256), 0, s, pg, w.gtab);
+    SSDK_CHECK_LAUNCH("gather_rows_kernel");
+    hipLaunchKernelGGL(anchor_dbias_kernel, dim3(n_levels * kAT), dim3(128), 0, s, dbg);
+    SSDK_CHECK_LAUNCH("anchor_dbias_kernel");
+    {   // the dense rows [pixel][Npad] of the levels that took the dense form (a small grid: usually none does)
+        const int grid = std::min(pack_blocks, 256);
+        if (max_npad <= 384) hipLaunchKernelGGL(pack_store_kernel<6>, dim3(grid), dim3(256), 0, s, pg, pack_blocks);
+        else if (max_npad <= 512) hipLaunchKernelGGL(pack_store_kernel<8>, dim3(grid), dim3(256), 0, s, pg, pack_blocks);
+        else hipLaunchKernelGGL(pack_store_kernel<12>, dim3(grid), dim3(256), 0, s, pg, pack_blocks);
+        SSDK_CHECK_LAUNCH("pack_store_kernel");
+    }
+
+    // 3. data gradients.  Anchor form: row GEMM into T, then the sum pass; dense form: the forward kernel with mirrored taps
+    {
+        RowGemmGroup rg{};
+        DxGroup dg{};
+        rg.plan = w.plan; rg.acounts = w.acounts; rg.zeros = w.zeros;
+        rg.count = n_levels;
+        int dx_blocks = 0, kq = 1;
+        bool any_dx = false;
+        for (int i = 0; i < n_levels; ++i) {
+            const ssdk_head_level& lv = levels[i];
+            RowGemmLevel& R = rg.lv[i];
+            R.ga = w.ga[i]; R.ws = lv.w_score; R.wl = lv.w_loc; R.T = w.T[i];
+            R.nb = ag.lv[i].nb; R.C = lv.n_score / R.nb; R.cap = batch * lv.h * lv.w; R.K9 = 9 * lv.cin; R.n_chunks = cdiv(9 * lv.cin, kRgChunkCols);
+            kq = std::max(kq, jpad_of(lv) / 32);
+            if (!lv.dx) continue;
+            any_dx = true;
+            DxLevel& D = dg.lv[dg.count++];
+            D.aidx = w.aidx[i]; D.T = w.T[i]; D.dx = lv.dx; D.mode = w.mode + i; D.nb = R.nb; D.H = lv.h; D.W = lv.w; D.cin = lv.cin; D.cap = R.cap;
+            D.blk_begin = dx_blocks;
+            dx_blocks += cdiv(R.cap, 4);
+        }
+        for (int i = 0; i < n_levels; ++i)
+            SSDK_REQUIRE(jpad_of(levels[i]) / 32 == kq, SSDK_E_UNSUPPORTED, "ssdk_heads_bwd: the levels' class counts differ (C + 4 rounded up to 32: %d vs %d)",
+                         jpad_of(levels[i]), kq * 32);
+        if (any_dx) {
+            const int grid = kq <= 3 ? 768 : 512;   // (what is resident at once: 3 / 2 workgroups per CU)
+            if (kq == 1) hipLaunchKernelGGL(anchor_rowgemm_kernel<1>, dim3(grid), dim3(256), 0, s, rg);
+            else if (kq == 2) hipLaunchKernelGGL(anchor_rowgemm_kernel<2>, dim3(grid), dim3(256), 0, s, rg);
+            else if (kq == 3) hipLaunchKernelGGL(anchor_rowgemm_kernel<3>, dim3(grid), dim3(256), 0, s, rg);
+            else hipLaunchKernelGGL(anchor_rowgemm_kernel<4>, dim3(grid), dim3(256), 0, s, rg);
+            SSDK_CHECK_LAUNCH("anchor_rowgemm_kernel");
+            hipLaunchKernelGGL(anchor_dx_kernel, dim3(dx_blocks), dim3(256), 0, s, dg);
+            SSDK_CHECK_LAUNCH("anchor_dx_kernel");
+        }
+    }
+    {   // dense form (mode 0)
+        TransposeGroup tg{};
+        int t_blocks = 0;
+        ConvProblem rest[kMaxProblems], fdg[kMaxProblems];
+        FastProblem ffp[kMaxProblems];
+        SplitGroup fsg{};
+        int n_rest = 0, n_fdg = 0, fsplit_blocks = 0;
+        for (int i = 0; i < n_levels; ++i) {
+            const ssdk_head_level& lv = levels[i];
+            if (!lv.dx) continue;
+            const int npad = npad_of(lv), hw = lv.h * lv.w;
+            TransposeJob& J = tg.j[tg.count++];
+            J.w0 = lv.w_score; J.w1 = lv.w_loc; J.out = w.wd[i];
+            J.kind = 0; J.n0 = lv.n_score; J.n1 = lv.n_loc; J.Npad = npad; J.taps = 9; J.Cc = lv.cin; J.mode = w.mode + i;
+            J.tiles_x = cdiv(npad, 32); J.tiles_y = cdiv(lv.cin, 32); J.block_begin = t_blocks;
+            t_blocks += J.tiles_x * J.tiles_y * kTrDepth;
+            ConvProblem g{};
+            g.a = w.dyp[i]; g.a_bstride = (long long)hw * npad; g.a_pstride = npad; g.Cc = npad;
+            g.B = batch; g.Hout = lv.h; g.Wout = lv.w; g.Hin = lv.h; g.Win = lv.w; g.ksize = 3; g.stride = 1; g.pad = 1;
+            g.w0 = w.wd[i]; g.n0 = lv.cin; g.n1 = 0;
+            g.o0 = lv.dx; g.ob0 = (long long)hw * lv.cin; g.os0 = lv.cin;
+            g.mode = w.mode + i; g.want_mode = 0;
+            finish_problem(g);
+            if (fast && fast_conv_ok(w.dyp[i], batch, lv.h, lv.w, npad, 3, 1, lv.cin)) {
+                const int rows = cdiv(lv.cin, 32) * 32, K = 9 * npad;
+                ffp[n_fdg].w_hi = w.fast_hi[i]; ffp[n_fdg].w_mid = w.fast_mid[i]; ffp[n_fdg].w_bytes = (unsigned)((size_t)rows * K * 2);
+                SplitJob& SJ = fsg.j[fsg.count++];
+                SJ.w0 = w.wd[i]; SJ.w1 = nullptr; SJ.n0 = lv.cin; SJ.n1 = 0; SJ.n_rows = rows; SJ.K = K; SJ.hi = w.fast_hi[i]; SJ.mid = w.fast_mid[i];
+                SJ.flip_taps = 9; SJ.tap_len = npad;
+                SJ.block_begin = fsplit_blocks;
+                fsplit_blocks += (int)(((long long)rows * K / 4 + 255) / 256);
+                fdg[n_fdg++] = g;
+            } else {
+                rest[n_rest++] = g;
+            }
+        }
+        if (tg.count) {
+            hipLaunchKernelGGL(transpose_group_kernel, dim3(t_blocks), dim3(256), 0, s, tg);
+            SSDK_CHECK_LAUNCH("transpose_group_kernel");
+        }
+        int rc = SSDK_OK;
+        if (n_rest) rc = launch_group(rest, n_rest, true, s);
+        if (!rc && n_fdg) rc = launch_fast_group(fdg, ffp, n_fdg, fsg, fsplit_blocks, s);
+        if (rc) return rc;
+    }
+
+    // 4. weight gradients: dense (mode 0) and anchor rows (mode 2), every K split into its own copy; then the copies in split order
+    WgradGroup wd_{}, wa_{};
+    int n_wgrad = 0;
+    int idx_of[kMaxProblems];
+    for (int i = 0; i < n_levels; ++i) {
+        const ssdk_head_level& lv = levels[i];
+        if (!lv.dw_score) continue;
+        SSDK_REQUIRE(lv.dw_loc, SSDK_E_INVALID, "ssdk_heads_bwd: dw_loc missing");
+        const long long K9 = (long long)9 * lv.cin, N = lv.n_score + lv.n_loc;
+        WgradProblem g = heads_wgrad_problem(lv, batch);
+        g.dy = w.dyp[i];
+        g.mode = w.mode + i; g.want_mode = 0;
+        g.dw0 = w.dw_part[i];
+        g.dw1 = w.dw_part[i] + (size_t)lv.n_score * K9;
+        g.det_stride = N * K9;
+        g.ordered = 1;
+        wd_.p[n_wgrad] = g;
+        const int nb = ag.lv[i].nb, C = lv.n_score / nb, ks = w.anchor_splits[i];
+        WgradProblem a = heads_wgrad_problem(lv, batch);
+        a.dy = w.ga[i]; a.Npad = jpad_of(lv); a.n0 = C; a.n1 = 4; a.n_tiles = 1;
+        a.mode = w.mode + i; a.want_mode = 2;
+        a.row_list = w.apix[i]; a.row_count = nullptr;
+        a.seg_count = w.acounts + i * kAT; a.segs = nb; a.seg_cap = batch * lv.h * lv.w;
+        a.dw0_seg = (long long)C * K9; a.dw1_seg = (long long)4 * K9;
+        a.ordered = 1;
+        if (ks > 1) {
+            a.dw0 = w.dw_part[i]; a.dw1 = w.dw_part[i] + (size_t)lv.n_score * K9; a.det_stride = N * K9;
+        } else {
+            a.dw0 = lv.dw_score; a.dw1 = lv.dw_loc; a.det_stride = 0;
+        }
+        wa_.p[n_wgrad] = a;
+        idx_of[n_wgrad] = i;
+        ++n_wgrad;
+    }
+    if (n_wgrad) {
+        size_wgrad_splits(wd_, n_wgrad, 1);
+        { int rc = launch_wgrad(wd_, s, fast); if (rc) return rc; }
+        // anchor rows: 128-channel workgroups, the host-side split rule of anchor_wgrad_splits (a fixed function of the shapes)
+        int begin = 0;
+        for (int q = 0; q < n_wgrad; ++q) {
+            WgradProblem& a = wa_.p[q];
+            a.k_splits = w.anchor_splits[idx_of[q]];
+            a.block_begin = begin;
+            begin += a.ksize * a.ksize * a.n_tiles * a.c_blocks * a.segs * a.k_splits;
+        }
+        wa_.count = n_wgrad;
+        wa_.total_blocks = begin;
+        { int rc = launch_wgrad(wa_, s, fast, true); if (rc) return rc; }
+        ReduceList rl;
+        for (int q = 0; q < n_wgrad; ++q) {
+            const int i = idx_of[q];
+            const ssdk_head_level& lv = levels[i];
+            const long long K9 = (long long)9 * lv.cin, N = lv.n_score + lv.n_loc;
+            const WgradProblem& g = wd_.p[q];
+            SSDK_REQUIRE(g.k_splits == w.dense_splits[i], SSDK_E_WORKSPACE, "ssdk_heads_bwd: the workspace was sized for another split rule");
+            const int used = wgrad_used_splits(g);
+            int rc = rl.add(lv.dw_score, w.dw_part[i], (long long)lv.n_score * K9, N * K9, used, 0, s, w.mode + i, 0);
+            if (!rc) rc = rl.add(lv.dw_loc, w.dw_part[i] + (size_t)lv.n_score * K9, (long long)lv.n_loc * K9, N * K9, used, 0, s, w.mode + i, 0);
+            const int ks = w.anchor_splits[i];
+            if (!rc && ks > 1) rc = rl.add(lv.dw_score, w.dw_part[i], (long long)lv.n_score * K9, N * K9, ks, 0, s, w.mode + i, 2);
+            if (!rc && ks > 1) rc = rl.add(lv.dw_loc, w.dw_part[i] + (size_t)lv.n_score * K9, (long long)lv.n_loc * K9, N * K9, ks, 0, s, w.mode + i, 2);
+            if (rc) return rc;
+        }
+        const int rc = rl.launch(s);
+        if (rc) return rc;
+    }
+    return SSDK_OK;
+}
+
+static size_t heads_bwd_ws_bytes(const ssdk_head_level* levels, int n_levels, int batch, bool fast) {
+    size_t total = 0;
+    if (!levels || n_levels <= 0 || n_levels > kMaxProblems || batch <= 0) return 0;
+    if (ordered_heads_ok(levels, n_levels, batch)) carve_heads_ordered(nullptr, levels, n_levels, batch, &total, fast);
+    else carve_heads_bwd(nullptr, levels, n_levels, batch, &total, fast);
+    return total;
+}
+extern "C" size_t ssdk_heads_bwd_workspace_bytes(const ssdk_head_level* levels, int n_levels, int batch) { return heads_bwd_ws_bytes(levels, n_levels, batch, false); }
+extern "C" size_t ssdk_heads_bwd_fast_workspace_bytes(const ssdk_head_level* levels, int n_levels, int batch) { return heads_bwd_ws_bytes(levels, n_levels, batch, true); }
+
 static int heads_bwd_impl(const ssdk_head_level* levels, int n_levels, int batch, const float* dscores, long long scores_batch_stride,
                           const float* dlocs, long long locs_batch_stride, void* workspace, size_t workspace_bytes, void* stream, bool fast,
                           const unsigned char* row_mask = nullptr, int num_anchors = 0);
@@ -3349,12 +4151,14 @@ static int heads_bwd_impl(const ssdk_head_level* levels, int n_levels, int batch
                           const unsigned char* row_mask, int num_anchors) {
     SSDK_REQUIRE(levels && n_levels > 0 && n_levels <= kMaxProblems, SSDK_E_INVALID, "ssdk_heads_bwd: n_levels=%d (1..%d)", n_levels, kMaxProblems);
     SSDK_REQUIRE(dscores, SSDK_E_INVALID, "ssdk_heads_bwd: null dscores");
+    SSDK_REQUIRE(batch > 0, SSDK_E_INVALID, "ssdk_heads_bwd: batch=%d", batch);
+    hipStream_t s = (hipStream_t)stream;
     {
-        size_t need = 0;
-        carve_heads_bwd(nullptr, levels, n_levels, batch, &need, fast);
+        const size_t need = heads_bwd_ws_bytes(levels, n_levels, batch, fast);
         SSDK_REQUIRE(workspace && workspace_bytes >= need, SSDK_E_WORKSPACE, "ssdk_heads_bwd: workspace too small");
     }
-    hipStream_t s = (hipStream_t)stream;
+    if (ordered_heads_ok(levels, n_levels, batch))
+        return heads_bwd_ordered(levels, n_levels, batch, dscores, scores_batch_stride, dlocs, locs_batch_stride, workspace, s, fast, row_mask, num_anchors);
     HeadsBwdWs w = carve_heads_bwd(workspace, levels, n_levels, batch, nullptr, fast);
     LevelTotals h_totals{};
     for (int i = 0; i < n_levels; ++i) {
