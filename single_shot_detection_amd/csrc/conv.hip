@@ -2065,7 +2065,8 @@ constexpr int kRgChunkCols = 512;                     // T columns per work item
 // [0 .. kAT] first T row of type k (entry nb: rows of the level), [kAT + 1 .. 2 kAT + 1] first 128-row tile of type k
 constexpr int kPlanHead = 1 + kMaxProblems + 1;
 constexpr int kPlanStride = 2 * (kAT + 1);
-constexpr int kPlanInts = kPlanHead + kMaxProblems * kPlanStride;
+constexpr int kPlanQueue = kPlanHead + kMaxProblems * kPlanStride;   // head of the row GEMM's work queue (zeroed by anchor_plan_kernel)
+constexpr int kPlanInts = kPlanQueue + 1;
 
 struct AnchorLevel {
     const unsigned char* rmask;   // mask byte of (image b, pixel p, type k): rmask[b * a_total + a_off + p * nb + k]
@@ -2123,9 +2124,11 @@ __global__ void __launch_bounds__(1024) anchor_plan_kernel(AnchorGroup grp) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x < 64) grp.zeros[threadIdx.x] = 0.0f;
     if (threadIdx.x < kMaxProblems) s_nb[threadIdx.x] = (int)threadIdx.x < grp.count ? grp.lv[threadIdx.x].nb : 0;
+    // (pair p = wave + 16 i is level p % 8, type p / 8: the few types a level has are spread over the waves -- with level-major pairs
+    // the waves 0 .. nb - 1 scanned every level one after the other and the rest idled)
 #pragma unroll 1
-    for (int p = wave; p < kMaxProblems * kAT; p += 16) {
-        const int li = p / kAT, k = p % kAT;
+    for (int q = wave; q < kMaxProblems * kAT; q += 16) {
+        const int li = q % kMaxProblems, k = q / kMaxProblems, p = li * kAT + k;
         int run = 0;
         if (li < grp.count && k < grp.lv[li].nb) {
             const AnchorLevel& L = grp.lv[li];
@@ -2162,6 +2165,7 @@ __global__ void __launch_bounds__(1024) anchor_plan_kernel(AnchorGroup grp) {
         }
         for (int li = grp.count; li <= kMaxProblems; ++li) grp.plan[1 + li] = items;
         grp.plan[0] = items;
+        grp.plan[kPlanQueue] = 0;
     }
     if (wave == 0 && grp.gtab) build_gather_table(s_cnt, s_nb, grp.count, grp.gtab);
 }
@@ -2274,9 +2278,19 @@ struct RowGemmLevel {
     float* T;
     int nb, C, cap, K9, n_chunks;
 };
-struct RowGemmGroup { int count; const int* plan; const int* acounts; const float* zeros; RowGemmLevel lv[kMaxProblems]; };
-typedef const __attribute__((address_space(1))) void* g_void_ptr_t;
+struct RowGemmGroup { int count; int* plan; const int* acounts; const float* zeros; int probe; RowGemmLevel lv[kMaxProblems]; };   // probe: measurement knob (1: T stores dropped)
 
+#ifdef SSDK_RG_STAMPS
+// experiment only (never built into the shipped library; tools/rg_stamps.py): per workgroup, 100 MHz wall-clock sums of the phases of its items
+__device__ unsigned long long g_rg_stamp[1024 * 8];
+extern "C" int ssdk_debug_read_rg_stamps(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rg_stamp), sizeof(unsigned long long) * 1024 * 8); }
+extern "C" int ssdk_debug_zero_rg_stamps() { static unsigned long long z[1024 * 8]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_rg_stamp), z, sizeof(z)); }
+#define RG_STAMP(var) unsigned long long var = 0; if (threadIdx.x == 0) { __builtin_amdgcn_sched_barrier(0); var = wall_clock64(); __builtin_amdgcn_sched_barrier(0); }
+#define RG_ADD(slot, a, b) if (threadIdx.x == 0 && blockIdx.x < 1024) g_rg_stamp[blockIdx.x * 8 + (slot)] += (b) - (a);
+#else
+#define RG_STAMP(var)
+#define RG_ADD(slot, a, b)
+#endif
 template <int KQ>   // Jpad = 32 KQ
 __global__ void __launch_bounds__(256, KQ <= 3 ? 3 : 2) anchor_rowgemm_kernel(RowGemmGroup grp) {
     constexpr int Jpad = 32 * KQ, G = Jpad / 8, kPieces = Jpad / 4, kPerWave = kPieces / 4;
@@ -2284,13 +2298,20 @@ __global__ void __launch_bounds__(256, KQ <= 3 ? 3 : 2) anchor_rowgemm_kernel(Ro
     constexpr int kStageFloats = G * kPair;
     __shared__ __attribute__((aligned(1024))) float s_b0[kStageFloats];
     __shared__ __attribute__((aligned(1024))) float s_b1[kStageFloats];
+    __shared__ int s_item;
     const int* plan = grp.plan;
+    const int* acounts = grp.acounts;
     const int total = plan[0];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, h = lane >> 5;
+    // Items are handed out by a queue (one returning atomic per ~20 us item), heaviest levels first: with a fixed stride the workgroups
+    // that started with the largest tiles also got the second round (PMC: 1.9 of 3 wave slots busy on average).  Which workgroup
+    // computes an item does not change a bit of it.
+    int item = blockIdx.x;
 #pragma unroll 1
-    for (int item = blockIdx.x; item < total; item += gridDim.x) {
+    while (item < total) {
+        RG_STAMP(t_item)
         int li = 0;
 #pragma unroll 1
         for (int i = 1; i < grp.count; ++i)
@@ -2304,11 +2325,14 @@ __global__ void __launch_bounds__(256, KQ <= 3 ? 3 : 2) anchor_rowgemm_kernel(Ro
         for (int q = 1; q < L.nb; ++q)
             if (tile >= pl[kAT + 1 + q]) k = q;
         const int r0 = (tile - pl[kAT + 1 + k]) * kRgRows;
-        const int cnt = grp.acounts[li * kAT + k];
+        const int cnt = acounts[li * kAT + k];
         const int K9 = L.K9, C = L.C;
+
         const int col_begin = chunk * kRgChunkCols, col_end = min(K9, col_begin + kRgChunkCols);
         const int nsteps = (col_end - col_begin + kRgStepCols - 1) / kRgStepCols;
-        const int nvalid = min(32, max(0, cnt - r0 - wave * 32));   // rows of this wave that exist (uniform)
+        // rows of this wave that exist (uniform; through readfirstlane so that the store descriptor below is built in scalar registers --
+        // the counts come from vector loads, and a descriptor the compiler takes for divergent costs a waterfall loop per store)
+        const int nvalid = __builtin_amdgcn_readfirstlane(min(32, max(0, cnt - r0 - wave * 32)));
 
         // A: this lane's row, float4 number 2 g + h
         f32x4 a[G];
@@ -2329,27 +2353,50 @@ __global__ void __launch_bounds__(256, KQ <= 3 ? 3 : 2) anchor_rowgemm_kernel(Ro
             const int j = 4 * (wave + 4 * i) + (lane >> 4);
             src[i] = j < C ? L.ws + ((long long)k * C + j) * K9 : (j < C + 4 ? L.wl + ((long long)k * 4 + (j - C)) * K9 : nullptr);
         }
+        // The LDS-DMA is issued from an asm statement (M0 = the piece's LDS address, saved and restored inside the statement:
+        // cdna_hip_programming.md, "M0 ... is compiler-reserved"): as a builtin the compiler sees an LDS write in flight and puts
+        // s_waitcnt vmcnt(0) in front of the next step's fragment reads -- which also waits for the T stores of the step before.  Hidden
+        // from its bookkeeping, the pieces are waited for by the counted waits below; a wait the compiler inserts for its own loads can
+        // only be longer for them, never shorter (vmcnt counts down in issue order).
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)s_b0);
+        const unsigned lds1 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)s_b1);
         auto stage = [&](int DST, int st) {   // DST is a literal at the call sites
             const int col = col_begin + st * kRgStepCols + colq;
 #pragma unroll
             for (int i = 0; i < kPerWave; ++i) {
                 const int p = wave + 4 * i;
                 const float* s = (src[i] && col < col_end) ? src[i] + col : grp.zeros;
-                __builtin_amdgcn_global_load_lds((g_void_ptr_t)s, (lds_ptr_t)((DST ? s_b1 : s_b0) + (p >> 1) * kPair + (p & 1) * kOdd), 16, 0, 0);
+                const unsigned dst = __builtin_amdgcn_readfirstlane((DST ? lds1 : lds0) + (unsigned)((p >> 1) * kPair + (p & 1) * kOdd) * 4u);
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(s), "s"(dst) : "memory");
             }
         };
+        // T rows of this wave through a buffer descriptor that ends behind its last existing row (built before the first piece is
+        // issued: its operands come from vector loads, and a wait for those would wait for the pieces as well)
+        const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)uniform_ptr(L.T + (long long)(pl[k] + r0 + wave * 32) * K9), 0, __builtin_amdgcn_readfirstlane(grp.probe == 1 ? 0 : nvalid * K9 * 4), 0x00020000);
         __syncthreads();   // (the previous item's last step has been read)
         stage(0, 0);
-        __builtin_amdgcn_s_waitcnt(0 | (7 << 4));   // vmcnt(0): this wave's pieces have landed
+        __builtin_amdgcn_s_waitcnt(0 | (7 << 4));   // vmcnt(0): this wave's pieces have landed (and the previous item's stores are done)
         __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int g = 0; g < G; ++g) asm volatile("" : "+v"(a[g]));   // (the A rows are waited for HERE, where nothing else is in flight)
+        if (nsteps > 1) stage(1, 1);
+        RG_STAMP(t_pro)
+        RG_ADD(0, t_item, t_pro)
+#ifdef SSDK_RG_STAMPS
+        if (threadIdx.x == 0 && blockIdx.x < 1024) { g_rg_stamp[blockIdx.x * 8 + 5] += 1; g_rg_stamp[blockIdx.x * 8 + 6] += (unsigned long long)nsteps; }
+#endif
 
-        float* const tile_ptr = L.T + (long long)(pl[k] + r0 + wave * 32) * K9;
-        const int lane_off = 4 * h * K9 + n;
+        // (the stores of rows that do not exist are dropped by the descriptor's range check -- no predicates, and EVERY wave with rows
+        // issues exactly 32 stores per step, 16 when only one column tile of the step exists: what the counted wait below relies on)
+        const unsigned lane_off = (unsigned)(4 * h * K9 + n) * 4u;
         auto body = [&](auto st_c, int st) {
             constexpr int ST = decltype(st_c)::value;
-            if (st + 1 < nsteps) stage(ST ^ 1, st + 1);
             const int col0 = col_begin + st * kRgStepCols;
             f32x16 acc[2];
+            RG_STAMP(t_a)
             if (nvalid > 0) {
                 const float* sb = (ST ? s_b1 : s_b0) + h * kOdd + n;
 #pragma unroll
@@ -2381,28 +2428,44 @@ __global__ void __launch_bounds__(256, KQ <= 3 ? 3 : 2) anchor_rowgemm_kernel(Ro
                     }
                 }
             }
-            // vmcnt(0): the next step's pieces (issued a step of MFMAs ago) and the PREVIOUS step's stores; this step's stores are issued
-            // behind the barrier and stay in flight under the next step's MFMAs
-            __builtin_amdgcn_s_waitcnt(0 | (7 << 4));
-            __builtin_amdgcn_s_barrier();
+            RG_STAMP(t_b)
+            RG_ADD(1, t_a, t_b)
+            if (st + 1 < nsteps) {
+                // The next step's pieces must have landed: vmcnt(0).  That also waits for the T stores of the PREVIOUS step, which have had
+                // this step's MFMAs to complete (a counted wait that leaves them in flight measured the same: 122.9 vs 124.3 us).
+                __builtin_amdgcn_s_waitcnt(0 | (7 << 4));   // s_waitcnt simm16 = vmcnt[3:0] | expcnt << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14
+                __builtin_amdgcn_s_barrier();
+                RG_STAMP(t_c)
+                RG_ADD(2, t_b, t_c)
+                if (st + 2 < nsteps) stage(ST, st + 2);   // into the stage every wave has just finished reading
+            }
+            RG_STAMP(t_d)
             if (nvalid > 0) {
                 // C/D map of the 32 x 32 MFMA: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
-                    if (col0 + ct * 32 + n >= col_end) continue;
+                    if (col0 + ct * 32 >= col_end) continue;   // (uniform: 9 Cin is a multiple of 32; only an item's last step can be half)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int row = (e & 3) + 8 * (e >> 2);
-                        if (row + 4 * h < nvalid) tile_ptr[(long long)row * K9 + col0 + ct * 32 + lane_off] = acc[ct][e];
+                        const float v = acc[ct][e];   // (a named float: __builtin_bit_cast on the vector element stored element 0 sixteen times)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_t, lane_off + (unsigned)(row * K9 + col0 + ct * 32) * 4u, 0, 0);
                     }
                 }
             }
+            RG_STAMP(t_e)
+            RG_ADD(3, t_d, t_e)
         };
 #pragma unroll 1
         for (int st = 0; st < nsteps; st += 2) {
             body(std::integral_constant<int, 0>{}, st);
             if (st + 1 < nsteps) body(std::integral_constant<int, 1>{}, st + 1);
         }
+        if (tid == 0) s_item = (int)gridDim.x + atomicAdd(grp.plan + kPlanQueue, 1);
+        __syncthreads();
+        item = s_item;
+        RG_STAMP(t_end)
+        RG_ADD(4, t_item, t_end)
     }
 }
 
@@ -3795,7 +3858,7 @@ static bool ordered_heads_ok(const ssdk_head_level* levels, int n_levels, int ba
     for (int i = 0; i < n_levels; ++i) {
         const ssdk_head_level& lv = levels[i];
         const int nb = anchor_types_of(lv);
-        if (!nb || lv.cin % 4 || ((uintptr_t)lv.x & 15)) return false;
+        if (!nb || lv.cin % 4 || ((uintptr_t)lv.x & 15) || ((uintptr_t)lv.w_score & 15) || ((uintptr_t)lv.w_loc & 15)) return false;
         const long long M = (long long)batch * lv.h * lv.w, jpad = jpad_of(lv);
         if (jpad > 128 || M >= (1 << 24) || M * jpad * 4 >= (1LL << 31) - 65536 || M * lv.cin * 4 >= (1LL << 31) - 65536 ||
             M * npad_of(lv) * 4 >= (1LL << 31) - 65536) return false;   // (every operand of the LDS-DMA weight-gradient kernel below 2 GiB)
@@ -3808,7 +3871,8 @@ static bool ordered_heads_ok(const ssdk_head_level* levels, int n_levels, int ba
 // per split, at most 8 (every split stores a full copy of the level's weight gradient)
 static inline int anchor_wgrad_splits(const ssdk_head_level& lv, int batch) {
     const int slices = cdiv(cdiv(batch * lv.h * lv.w, 16), 32);
-    return std::max(1, std::min(8, cdiv(slices, 16)));
+    static const int per = []() { const char* e = getenv("SSDK_ANCHOR_WGRAD_SLICES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 16; }();   // (measurement knob)
+    return std::max(1, std::min(8, cdiv(slices, per)));
 }
 struct OrderedWs {
     int* acounts; int* plan; int* mode; int* gtab; float* zeros;
@@ -3969,6 +4033,7 @@ static int heads_bwd_ordered(const ssdk_head_level* levels, int n_levels, int ba
         RowGemmGroup rg{};
         DxGroup dg{};
         rg.plan = w.plan; rg.acounts = w.acounts; rg.zeros = w.zeros;
+        { const char* e = getenv("SSDK_RG_PROBE"); rg.probe = e ? atoi(e) : 0; }
         rg.count = n_levels;
         int dx_blocks = 0, kq = 1;
         bool any_dx = false;
@@ -3989,7 +4054,8 @@ static int heads_bwd_ordered(const ssdk_head_level* levels, int n_levels, int ba
             SSDK_REQUIRE(jpad_of(levels[i]) / 32 == kq, SSDK_E_UNSUPPORTED, "ssdk_heads_bwd: the levels' class counts differ (C + 4 rounded up to 32: %d vs %d)",
                          jpad_of(levels[i]), kq * 32);
         if (any_dx) {
-            const int grid = kq <= 3 ? 768 : 512;   // (what is resident at once: 3 / 2 workgroups per CU)
+            // what is resident at once: 3 / 2 workgroups per CU (measured at 512 / 768 / 1 024 workgroups: 127 / 120 / 126 us)
+            const int grid = kq <= 3 ? 768 : 512;
             if (kq == 1) hipLaunchKernelGGL(anchor_rowgemm_kernel<1>, dim3(grid), dim3(256), 0, s, rg);
             else if (kq == 2) hipLaunchKernelGGL(anchor_rowgemm_kernel<2>, dim3(grid), dim3(256), 0, s, rg);
             else if (kq == 3) hipLaunchKernelGGL(anchor_rowgemm_kernel<3>, dim3(grid), dim3(256), 0, s, rg);

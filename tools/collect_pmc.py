@@ -11,7 +11,8 @@ KEYS = {   # json key suffix -> substring of the kernel name
     'igemm_fwd_heads': 'igemm_streamk_kernel',
     'igemm_fwd_heads_tiles': 'igemm_dma_kernel<false, false, false, 4',
     'igemm_scatter_dgrad': 'igemm_dma_kernel<false, false, true, 4',
-    'igemm_wgrad': 'igemm_wgrad_dma_kernel',
+    'igemm_wgrad': 'igemm_wgrad_dma_kernel', 'wgrad_rows': 'igemm_wgrad_rows_kernel', 'anchor_rowgemm': 'anchor_rowgemm_kernel',
+    'anchor_dx': 'anchor_dx_kernel', 'gather_rows': 'gather_rows_kernel', 'anchor_plan': 'anchor_plan_kernel', 'reduce_partials': 'reduce_partials_kernel',
     'loss_bwd': 'loss_bwd_kernel', 'loss_fwd': 'loss_fwd_kernel', 'hnm_rows': 'hnm_rows_kernel', 'hnm_select': 'hnm_select_kernel',
     'pack_dy': 'pack_dy_kernel', 'assign': 'assign_kernel', 'gt_argmax': 'gt_argmax_kernel',
     'post_select': 'post_select2_kernel', 'post_nms': 'post_nms_wave_kernel', 'post_merge': 'post_merge2_kernel', 'post_tau': 'post_tau_kernel',

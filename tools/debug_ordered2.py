@@ -75,3 +75,5 @@ some = lambda B, P, nb, rng: [(b, p, k) for b in range(B) for p in range(P) for 
 for cfg in ((32, 4, 2, 4, 1), (32, 4, 2, 5, 1), (32, 4, 2, 12, 1), (32, 4, 2, 28, 1)):
     run(*cfg, one)
 run(64, 6, 4, 21, 2, some)
+every = lambda B, P, nb, rng: [(b, p, k) for b in range(B) for p in range(P) for k in range(nb)]
+run(512, 18, 6, 81, 2, every)
