@@ -90,11 +90,6 @@ struct ConvProblem {
     const int* row_list;
     const int* row_count;
     int sc_cin;  // scatter: output channels per tap (n = tap * sc_cin + c)
-    // SCATTER, segmented rows (anchor-granular sparse backward): the row space is `segs` segments of seg_cap rows, of which the
-    // first seg_count[s] exist; segment s multiplies with the weight block w0 + s * w_seg_stride
-    const int* seg_count;
-    int seg_cap, segs;
-    long long w_seg_stride;
     // column index space: [0, n0) = rows of w0, [n0, n0_pad) unused, [n0_pad, n0_pad + n1) = rows of w1.  n0_pad = n0 except for
     // the LDS-DMA kernel, which rounds it up to 8 so that every 8-row DMA piece reads ONE weight tensor (one descriptor)
     int n0_pad;
@@ -477,18 +472,9 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
     const int K = taps * Cc;
     const int N = g.n0_pad + g.n1;
     const int hw = g.Hout * g.Wout;
-    int M = (SCATTER && g.row_list && !g.seg_count) ? *g.row_count : g.B * hw;   // one past the last existing row
+    int M = (SCATTER && g.row_list) ? *g.row_count : g.B * hw;   // one past the last existing row
     int m_base = m_tile * BM;                                                     // first row of this workgroup
-    const float* w0p = g.w0;
-    if (SCATTER && g.seg_count) {
-        const int tiles_per_seg = (g.seg_cap + BM - 1) / BM;
-        const int seg = m_tile / tiles_per_seg, local = m_tile % tiles_per_seg;
-        const int cnt = g.seg_count[seg];
-        if (local * BM >= cnt) return;
-        m_base = seg * g.seg_cap + local * BM;
-        M = seg * g.seg_cap + cnt;
-        w0p += (long long)seg * g.w_seg_stride;
-    }
+    const float* const w0p = g.w0;
     if (SCATTER && m_base >= M) return;
 
     const int base_t = g.tiles_n / g.n_blocks, rem_t = g.tiles_n % g.n_blocks;
@@ -520,8 +506,8 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
         a_nmask[i] = 0;
         if (m < M) {
             if (SCATTER) {
-                // (pixel-sparse rows index the dense packed dY through row_list; segmented rows are stored compacted)
-                a_vo[i] = (unsigned)((g.seg_count ? m : (g.row_list ? g.row_list[m] : m)) * a_ps + src_chunk * 4) * 4u;
+                // (pixel-sparse rows index the dense packed dY through row_list)
+                a_vo[i] = (unsigned)((g.row_list ? g.row_list[m] : m) * a_ps + src_chunk * 4) * 4u;
             } else {
                 const int b = m / hw, r = m % hw;
                 const int y = r / g.Wout, x = r % g.Wout;
@@ -563,7 +549,7 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
     }
 
     // buffer descriptors (wave-uniform): A window starts `shift` elements before the tensor, W window spans both segments
-    const long long a_records = (SCATTER && g.seg_count) ? (long long)g.segs * g.seg_cap * a_ps * 4 : ((long long)g.B * g.a_bstride - shift) * 4;
+    const long long a_records = ((long long)g.B * g.a_bstride - shift) * 4;
     const __amdgpu_buffer_rsrc_t rsrc_a =
         __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(g.a + shift), 0, (int)(a_records > 0x7FFFFFFFLL ? 0x7FFFFFFFLL : a_records), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_w0 = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(w0p), 0, (int)g.w0_bytes, 0x00020000);
@@ -830,13 +816,11 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
 }
 
 
-// vtab (sparse backward only): a compact list of the row tiles that exist, built on the device after the rows were counted --
-//   [0] number of virtual workgroups, [1 + p] first virtual workgroup of problem p (p = 0 .. count), then per problem
-//   kMaxAnchorTypes + 1 tile prefixes over its segments.  Without it the grid must cover the worst case (every anchor sampled):
-//   72 000 workgroups for the SSD-300 heads, of which ~4 000 have rows, and a workgroup that only finds out that it has
-//   nothing to do still occupies one of the two 64 KB LDS slots of a CU for ~2 us (measured: 350 of the 480 us of the launch).
-constexpr int kVtabSegs = 16 + 1;
-constexpr int kVtabInts = 1 + (kMaxProblems + 1) + kMaxProblems * kVtabSegs;
+// vtab (pixel-sparse backward only): the row tiles that exist, counted on the device after the rows were listed --
+//   [0] number of virtual workgroups, [1 + p] first virtual workgroup of problem p (p = 0 .. count).  Without it the grid must cover
+//   the worst case (every pixel row listed), and a workgroup that only finds out that it has nothing to do still occupies one of the two
+//   64 KB LDS slots of a CU for ~2 us.
+constexpr int kVtabInts = 1 + (kMaxProblems + 1);
 
 template <bool MIRROR, bool GENERIC, bool SCATTER, int WAVES, int BK = 32, int MAXTN = kMaxTN>
 __global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? (BK == 16 ? 3 : SSDK_CONV_WAVES) : 1) igemm_dma_kernel(ConvGroup grp) {
@@ -851,13 +835,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? (BK == 16 ? 3 : SSDK_
             const ConvProblem& g = grp.p[pi];
             const int local = vb - vt[1 + pi];
             const int n_block = local % g.n_blocks, t = local / g.n_blocks;
-            const int* tp = vt + 1 + (kMaxProblems + 1) + pi * kVtabSegs;
-            int seg = 0;
-#pragma unroll 1
-            for (int q = 1; q < (g.seg_count ? g.segs : 1); ++q)
-                if (t >= tp[q]) seg = q;
-            const int tiles_per_seg = ((g.seg_count ? g.seg_cap : g.B * g.Hout * g.Wout) + 32 * WAVES - 1) / (32 * WAVES);
-            dma_tile<MIRROR, GENERIC, SCATTER, WAVES, BK, MAXTN>(g, pi, seg * tiles_per_seg + (t - tp[seg]), n_block, 0);
+            dma_tile<MIRROR, GENERIC, SCATTER, WAVES, BK, MAXTN>(g, pi, t, n_block, 0);
             __syncthreads();   // the next tile's first DMA overwrites LDS stage 0
         }
         return;
@@ -1207,7 +1185,7 @@ struct WgradProblem {
     int want_mode;
     const int* row_list;   // sparse: contract only over these pixel ids (*row_count of them)
     const int* row_count;
-    // segmented (anchor-granular sparse backward): `segs` independent problems that share x: segment s has seg_count[s] rows of dy at
+    // segmented (the anchor rows of the ordered pipeline: segment = anchor type): `segs` independent problems that share x: segment s has seg_count[s] rows of dy at
     // dy + s * seg_cap * Npad, their pixel ids at row_list + s * seg_cap, and adds into dw0 + s * dw0_seg / dw1 + s * dw1_seg
     const int* seg_count;
     int segs, seg_cap;
@@ -1616,20 +1594,20 @@ struct PackLevel {
     float* out; float* db0; float* db1;
     int* row_list; int* row_count;
     int block_begin;
-    // anchor-granular rows (ga == NULL: not produced): anchor type k of a pixel owns C score columns [k*C, (k+1)*C) and 4 loc
-    // columns; every anchor with a non-zero gradient becomes one row [Jpad] of segment k: C scores, 4 locs, zero padding
+    // ordered pipeline (gather_rows_kernel, pack_store_kernel): anchor type k of a pixel owns C score columns [k*C, (k+1)*C) and 4 loc
+    // columns; every anchor with a gradient is one row [Jpad] of ga[k]: C scores, 4 locs, zero padding; apix = the rows' pixel ids,
+    // acount = rows per type (both written by anchor_plan_kernel / anchor_fill_kernel)
     int nb, C, Jpad, cap;
-    float* ga; int* apix; int* acount;
-    const int* mode;   // pack_store_kernel: the level's backward form as decide_sparse_kernel chose it (2 = anchor rows: `out` is not needed)
-    // caller's guarantee (ssdk_heads_bwd_ex): rmask[b * a_total + a_off + pixel * rnb + k] == 0 -> the score and loc gradient rows of that
-    // anchor are entirely zero; a pixel whose rnb anchors are all 0 is not read at all (NULL: every row is read)
-    const unsigned char* rmask;
-    int a_total, a_off, rnb;
-    int block_begin2;   // mask-first pack: first workgroup (mask_scan_kernel) / first chunk (gather_rows_kernel) of the level
-    // ordered pipeline: gather_rows_kernel STORES the column sums of chunk c of type k into dbp[(k * chunks_cap + c) * Jpad + j]
-    // (anchor_dbias_kernel adds them in chunk order) instead of adding them into db0 / db1 with atomics
+    float* ga; const int* apix; const int* acount;
+    const int* mode;   // the level's backward form as anchor_plan_kernel chose it (2 = anchor rows: `out` is not needed; else `ga` is not)
+    // gather_rows_kernel STORES the column sums of chunk c of type k into dbp[(k * chunks_cap + c) * Jpad + j] (anchor_dbias_kernel adds
+    // them in chunk order)
     float* dbp;
     int chunks_cap;
+    // legacy pipeline, caller's guarantee (ssdk_heads_bwd_ex): rmask[b * a_total + a_off + pixel * rnb + k] == 0 -> the score and loc gradient
+    // rows of that anchor are entirely zero; a pixel whose rnb anchors are all 0 is not read at all (NULL: every row is read)
+    const unsigned char* rmask;
+    int a_total, a_off, rnb;
 };
 struct PackGroup {
     int count, B;
@@ -1643,20 +1621,12 @@ struct PackGroup {
 // Returns the mask of this wave's rows that are not entirely zero; leaves the wave's column sums in `sum`.
 template <int ITERS, bool STORE, bool COUNT>
 __device__ __forceinline__ unsigned long long pack_rows(const PackLevel& L, const float* __restrict__ ds, const float* __restrict__ dl, long long sb,
-                                              long long lb, int B, int m0, int M, float* __restrict__ sum, unsigned* __restrict__ s_amask) {
+                                              long long lb, int B, int m0, int M, float* __restrict__ sum) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: row bases stay in SGPRs)
     const int n0 = L.n0, n1 = L.n1, N = n0 + n1, Npad = L.Npad, HW = L.HW;
-    // per lane and trip: 4 bits of anchor type (kept packed: registers are what bounds the rows in flight)
-    unsigned long long anchor_of = 0ull;
     float acc[ITERS];
-    const float inv_c = 1.0f / (float)(L.C > 0 ? L.C : 1);
 #pragma unroll
-    for (int k = 0; k < ITERS; ++k) {
-        const int n = k * 64 + lane;
-        const int a = n < n0 ? (int)(((float)n + 0.5f) * inv_c) : (n - n0) >> 2;   // n / C, exact for n < 2^20
-        anchor_of |= (unsigned long long)((L.ga && n < N) ? a : 15) << (4 * k);    // (type 15 does not exist: nb <= 15)
-        acc[k] = 0.0f;
-    }
+    for (int k = 0; k < ITERS; ++k) acc[k] = 0.0f;
     unsigned long long mine = 0ull;
     constexpr int U = ITERS <= 8 ? 2 : 1;   // rows of the wave in flight
     for (int r0 = wave; r0 < kPackRows; r0 += 4 * U) {
@@ -1692,24 +1662,18 @@ __device__ __forceinline__ unsigned long long pack_rows(const PackLevel& L, cons
             const int r = r0 + 4 * u, m = m0 + r;
             if (m >= M) continue;
             float* orow = L.out + (long long)m * Npad;
-            unsigned amask = 0u;   // anchor types of this row that carry a gradient (as seen by this lane)
+            bool any = false;   // this lane saw a non-zero value of the row
 #pragma unroll
             for (int k = 0; k < ITERS; ++k) {
                 const float x = v[u][k];
                 if (STORE && k * 64 + lane < Npad) orow[k * 64 + lane] = x;
                 if (COUNT) {
                     acc[k] += x;
-                    amask |= x != 0.0f ? ((1u << ((unsigned)(anchor_of >> (4 * k)) & 15u)) | 0x80000000u) : 0u;
+                    any = any || x != 0.0f;
                 }
             }
             if (!COUNT) continue;
-            if (__ballot(amask != 0u)) mine |= 1ull << r;
-            if (L.ga) {   // which anchor types of this row carry a gradient (wave-wide OR of the lanes' masks)
-                unsigned row_mask = 0u;
-                for (int a = 0; a < L.nb; ++a)
-                    if (__ballot((amask >> a) & 1u)) row_mask |= 1u << a;
-                if (lane == 0) s_amask[r] = row_mask;
-            }
+            if (__ballot(any)) mine |= 1ull << r;
         }
     }
     if (COUNT) {
@@ -1719,10 +1683,8 @@ __device__ __forceinline__ unsigned long long pack_rows(const PackLevel& L, cons
     return mine;
 }
 
-// STORE = false: the counting half alone (bias gradients, row lists, anchor rows) -- the dense [pixel][Npad] rows, which only the dense and
-// the pixel-sparse backward read, are then written by pack_store_kernel AFTER decide_sparse_kernel, and only for levels that did not take
-// the anchor form: with hard-negative mining (4 % of the anchors) that is no level, and 92 MB of writes per SSD-300 step are not made.
-template <int ITERS, bool STORE>
+// (legacy pipeline) packs the rows, sums the bias gradients, lists the pixel rows that carry a gradient
+template <int ITERS>
 __global__ void __launch_bounds__(256) pack_dy_kernel(PackGroup grp) {
     int pi = 0;
 #pragma unroll 1
@@ -1743,18 +1705,13 @@ __global__ void __launch_bounds__(256) pack_dy_kernel(PackGroup grp) {
     __shared__ unsigned long long s_flag;
     __shared__ int s_base;
     __shared__ float s_sum[4][kPackColIters * 64];
-    __shared__ unsigned s_amask[kPackRows];       // anchor types with a gradient, per row of the block
-    __shared__ unsigned long long s_acol[kMaxAnchorTypes_]; // per anchor type: which rows of the block have it
-    __shared__ int s_abase[kMaxAnchorTypes_];     // per anchor type: first row index reserved in its segment (-1: not stored)
     const int M = B * HW;
     const int m0 = block * kPackRows;
     const int N = n0 + n1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_flag = 0ull;
-    if (threadIdx.x < kPackRows) s_amask[threadIdx.x] = 0u;
     __syncthreads();
-    unsigned long long mine = 0ull;
-    mine = pack_rows<ITERS, STORE, true>(L, ds, dl, sb, lb, B, m0, M, s_sum[wave], s_amask);
+    const unsigned long long mine = pack_rows<ITERS, true, true>(L, ds, dl, sb, lb, B, m0, M, s_sum[wave]);
     if (lane == 0 && mine) atomicOr(&s_flag, mine);
     __syncthreads();
     for (int n = threadIdx.x; n < N; n += 256) {
@@ -1769,101 +1726,11 @@ __global__ void __launch_bounds__(256) pack_dy_kernel(PackGroup grp) {
     __syncthreads();
     if (threadIdx.x < kPackRows && ((flags >> threadIdx.x) & 1ull))
         row_list[s_base + __popcll(flags & ((1ull << threadIdx.x) - 1ull))] = m0 + (int)threadIdx.x;
-    if (!L.ga) return;
-    // anchor-granular rows: ONE atomic per (block, anchor type) reserves the block's rows in segment k (an atomic per anchor
-    // serialises on 4..9 counters: 2 ms at full density), then the waves copy the C + 4 values of every listed anchor.
-    // A block in which more than half of the anchors carry a gradient is not "sparse": it stores nothing and marks the level
-    // (acount[kMaxAnchorTypes - 1] != 0 -> decide_sparse_kernel never picks the anchor form for it).
-    if (wave == 0) {   // lane a = anchor type a: its rows of the block, its reservation (the nb atomics travel together)
-        unsigned long long col = 0ull;
-        if (lane < L.nb)
-            for (int r = 0; r < kPackRows; ++r) col |= (unsigned long long)((s_amask[r] >> lane) & 1u) << r;
-        const int c = __popcll(col);
-        const int total = wave_allreduce(c, OpAddI());
-        const bool dense = 2 * total > kPackRows * L.nb;
-        if (lane == 0 && dense) atomicOr(L.acount + (kMaxAnchorTypes_ - 1), 1);
-        if (lane < L.nb) {
-            s_acol[lane] = col;
-            s_abase[lane] = (!dense && c) ? atomicAdd(L.acount + lane, c) : -1;
-        }
-    }
-    __syncthreads();
-    for (int r = wave; r < kPackRows; r += 4) {
-        const unsigned row_mask = s_amask[r];
-        if (!row_mask) continue;
-        const int m = m0 + r;
-        const int b = m / HW, p = m % HW;
-        const float* srow = ds + (long long)b * sb + (long long)p * n0;
-        const float* lrow = dl + (long long)b * lb + (long long)p * n1;
-        for (int a = 0; a < L.nb; ++a) {
-            if (!((row_mask >> a) & 1u) || s_abase[a] < 0) continue;
-            const int idx = s_abase[a] + __popcll(s_acol[a] & ((1ull << r) - 1ull));
-            float* grow = L.ga + ((long long)a * L.cap + idx) * L.Jpad;
-            for (int j = lane; j < L.Jpad; j += kWave)
-                grow[j] = j < L.C ? srow[a * L.C + j] : (j < L.C + 4 ? lrow[a * 4 + j - L.C] : 0.0f);
-            if (lane == 0) L.apix[(long long)a * L.cap + idx] = m;
-        }
-    }
 }
 
-// ---- the pack when the gradient's producer says which anchors carry one (PackLevel::rmask on every level) -----------------------------
-// pack_dy_kernel finds the non-zero rows by reading all of dscores / dlocs (88 MB at SSD-300 / 81 classes, batch 32) and pays, per
-// 32-row block, its bookkeeping and ~85 same-address bias-gradient atomics whatever it reads (52 us).  With the mask the work is
-// proportional to the MARKED anchors (hard-negative mining: ~4 %):
-//   mask_scan_kernel     one thread per pixel reads its nb mask bytes; per workgroup ONE reservation per anchor type (and one for the
-//                        pixel-row list); writes the anchor lists apix[type][..] and row_list -- what pack_dy's counting half leaves,
-//                        except that a marked row may turn out to be all zeros (harmless: it adds nothing) and that no block ever
-//                        gives up (the lists are sized for every anchor);
-//   decide_sparse_kernel as before, from those counts;
-//   gather_rows_kernel   walks the anchor lists: a wave per listed anchor copies its C + 4 gradient values into the anchor-row
-//                        matrix (levels that took the anchor form) and adds them to the bias gradients (every level: the bias
-//                        gradient IS the sum over the marked anchors), one atomic per (64-row chunk, column);
-//   pack_store_kernel    as before (the dense rows of levels that did not take the anchor form).
-constexpr int kScanPixels = 256;   // pixels per workgroup of mask_scan_kernel
-__global__ void __launch_bounds__(256) mask_scan_kernel(PackGroup grp) {
-    int pi = 0;
-#pragma unroll 1
-    for (int i = 1; i < grp.count; ++i)
-        if ((int)blockIdx.x >= grp.lv[i].block_begin2) pi = i;
-    const PackLevel& L = grp.lv[pi];
-    __shared__ int s_wcnt[4][kMaxAnchorTypes_ + 1];   // per wave: marked anchors per type, [nb] = marked pixel rows
-    __shared__ int s_base[kMaxAnchorTypes_ + 1];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int M = grp.B * L.HW;
-    const int m = (blockIdx.x - L.block_begin2) * kScanPixels + threadIdx.x;
-    unsigned bits = 0;
-    if (m < M) {
-        const int b = m / L.HW, p = m - b * L.HW;
-        const unsigned char* mp = L.rmask + (long long)b * L.a_total + L.a_off + (long long)p * L.rnb;
-        for (int k = 0; k < L.rnb; ++k) bits |= mp[k] ? 1u << k : 0u;
-    }
-#pragma unroll 1
-    for (int k = 0; k < L.rnb; ++k) {   // (every lane takes part in every ballot: no early exits before the end of the kernel)
-        const unsigned long long bk = __ballot((bits >> k) & 1u);
-        if (lane == 0) s_wcnt[wave][k] = __popcll(bk);
-    }
-    const unsigned long long rowbal = __ballot(bits != 0u);
-    if (lane == 0) s_wcnt[wave][L.rnb] = __popcll(rowbal);
-    __syncthreads();
-    if (threadIdx.x <= L.rnb) {
-        const int k = threadIdx.x;
-        const int tot = s_wcnt[0][k] + s_wcnt[1][k] + s_wcnt[2][k] + s_wcnt[3][k];
-        s_base[k] = tot ? atomicAdd(k < L.rnb ? L.acount + k : L.row_count, tot) : 0;
-    }
-    __syncthreads();
-    const unsigned long long below = (1ull << lane) - 1ull;
-#pragma unroll 1
-    for (int k = 0; k < L.rnb; ++k) {
-        const unsigned long long bk = __ballot((bits >> k) & 1u);
-        int off = s_base[k];
-        for (int w = 0; w < wave; ++w) off += s_wcnt[w][k];
-        if ((bits >> k) & 1u) L.apix[(long long)k * L.cap + off + __popcll(bk & below)] = m;
-    }
-    int off = s_base[L.rnb];
-    for (int w = 0; w < wave; ++w) off += s_wcnt[w][L.rnb];
-    if (bits) L.row_list[off + __popcll(rowbal & below)] = m;
-}
-
+// ---- gather_rows_kernel (ordered pipeline) walks the anchor lists anchor_fill_kernel wrote: a wave per listed anchor copies its C + 4
+// gradient values into the anchor-row matrix (levels that took the anchor form) and sums them per 32-row chunk for the bias gradients
+// (every level: the bias gradient IS the sum over the marked anchors).
 constexpr int kGatherRows = 32;   // listed anchors per workgroup of gather_rows_kernel: 8 per wave, 4 in flight
 constexpr int kGtabInts = 2 + kMaxProblems * kMaxAnchorTypes_;   // [0] total chunks, [1 + i * 16 + k] first chunk of (level i, type k), then the end
 // chunk table of gather_rows_kernel from the anchor counts, by one wave: lane l owns entries 2 l and 2 l + 1 of the 8 levels x 16 types
@@ -1946,12 +1813,7 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(PackGroup grp, const i
         __syncthreads();
         for (int j = threadIdx.x; j < C + 4; j += 256) {
             const float t = s_sum[0][j] + s_sum[1][j] + s_sum[2][j] + s_sum[3][j];
-            if (L.dbp) {
-                L.dbp[((long long)k * L.chunks_cap + c) * Jpad + j] = t;
-            } else if (t != 0.0f) {
-                if (j < C) { if (L.db0) atomicAdd(L.db0 + k * C + j, t); }
-                else if (L.db1) atomicAdd(L.db1 + k * 4 + (j - C), t);
-            }
+            L.dbp[((long long)k * L.chunks_cap + c) * Jpad + j] = t;   // (stored, not added: anchor_dbias_kernel adds the chunks in order)
         }
     }
 }
@@ -1960,7 +1822,6 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(PackGroup grp, const i
 template <int ITERS>
 __global__ void __launch_bounds__(256) pack_store_kernel(PackGroup grp, int total_blocks) {
     __shared__ float s_dummy[kPackColIters * 64];
-    __shared__ unsigned s_amask[kPackRows];
     // (all the modes are loaded before any is tested: `any || *mode != 2` short-circuits into one dependent L2 round trip per level --
     // 12 us for a launch that, under hard-negative mining, has nothing to do)
     int modes[kMaxProblems];
@@ -1979,40 +1840,28 @@ __global__ void __launch_bounds__(256) pack_store_kernel(PackGroup grp, int tota
         const int nblk = (i + 1 < grp.count ? grp.lv[i + 1].block_begin : total_blocks) - L.block_begin;
         const int M = grp.B * L.HW;
         for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x)
-            pack_rows<ITERS, true, false>(L, L.ds, L.dl, grp.sb, grp.lb, grp.B, blk * kPackRows, M, s_dummy, s_amask);
+            pack_rows<ITERS, true, false>(L, L.ds, L.dl, grp.sb, grp.lb, grp.B, blk * kPackRows, M, s_dummy);
     }
 }
 
-// mode[i] = 1 (sparse backward) when fewer than 70 % of the level's pixel rows carry a gradient, else 0 (dense).
-// The sparse forms never do more multiplies than the dense ones; what they add is the scatter's atomic traffic
+// (legacy pipeline) mode[i] = 1 (pixel-sparse backward) when fewer than 70 % of the level's pixel rows carry a gradient, else 0 (dense).
+// The sparse form never does more multiplies than the dense one; what it adds is the scatter's atomic traffic
 // (rows * 9 * Cin * 4 bytes), which costs about a third of the dense GEMM time at full density.
-// Mode 2 (anchor-granular rows): a row is one ANCHOR with a non-zero gradient -- C + 4 columns instead of the nb * (C + 4) of
-// its pixel -- multiplied with the weight rows of its anchor type only.  With hard-negative mining a pixel rarely has more than
-// one sampled anchor, so this does 1/nb of the multiplies of mode 1.  Chosen when rows * Jpad < 0.8 * pixel_rows * Npad.
 constexpr int kMaxAnchorTypes = 16;
-static_assert(kVtabSegs == kMaxAnchorTypes + 1 && kMaxAnchorTypes_ == kMaxAnchorTypes, "vtab layout");
-struct LevelTotals { int v[kMaxProblems]; int nb[kMaxProblems]; int jpad[kMaxProblems]; int npad[kMaxProblems]; int force; };
-__global__ void decide_sparse_kernel(const int* __restrict__ counts, const int* __restrict__ acounts, LevelTotals totals, int n, int* __restrict__ mode,
-                                     int* __restrict__ gtab = nullptr) {
+static_assert(kMaxAnchorTypes_ == kMaxAnchorTypes, "anchor types");
+struct LevelTotals { int v[kMaxProblems]; int force; };
+__global__ void decide_sparse_kernel(const int* __restrict__ counts, LevelTotals totals, int n, int* __restrict__ mode) {
     const int i = threadIdx.x;
-    if (gtab) build_gather_table(acounts, totals.nb, n, gtab);   // (the whole wave; the table does not depend on the modes)
     if (i >= n) return;
     int m = ((long long)counts[i] * 10 < (long long)totals.v[i] * 7) ? 1 : 0;
-    if (totals.nb[i] > 0) {
-        long long rows = 0;
-        for (int k = 0; k < totals.nb[i]; ++k) rows += acounts[i * kMaxAnchorTypes + k];
-        const bool complete = acounts[i * kMaxAnchorTypes + kMaxAnchorTypes - 1] == 0;   // no block gave up storing its anchors
-        if (complete && m == 1 && rows * totals.jpad[i] * 10 < (long long)counts[i] * totals.npad[i] * 8) m = 2;
-        if (complete && totals.force == 2) m = 2;
-    }
     if (totals.force == 0 || totals.force == 1) m = totals.force;
     mode[i] = m;
 }
 
-// builds the compact tile list of a sparse scatter launch (igemm_dma_kernel, vtab): one thread, <= 8 problems x 16 segments
+// builds the tile list of a pixel-sparse scatter launch (igemm_dma_kernel, vtab): one thread, <= 8 problems
 struct VtabArgs {
     int count;
-    struct { const int* counts; int segs; const int* mode; int want; int n_blocks; } p[kMaxProblems];
+    struct { const int* counts; const int* mode; int want; int n_blocks; } p[kMaxProblems];
     int* vtab;
 };
 __global__ void build_vtab_kernel(VtabArgs a) {
@@ -2021,15 +1870,8 @@ __global__ void build_vtab_kernel(VtabArgs a) {
     int v = 0;
     for (int i = 0; i < a.count; ++i) {
         vt[1 + i] = v;
-        int* tp = vt + 1 + (kMaxProblems + 1) + i * kVtabSegs;
-        int t = 0;
         const bool on = !a.p[i].mode || *a.p[i].mode == a.p[i].want;
-        for (int k = 0; k < a.p[i].segs; ++k) {
-            tp[k] = t;
-            if (on) t += (a.p[i].counts[k] + kBM - 1) / kBM;
-        }
-        tp[a.p[i].segs] = t;
-        v += t * a.p[i].n_blocks;
+        if (on) v += (*a.p[i].counts + kBM - 1) / kBM * a.p[i].n_blocks;
     }
     vt[1 + a.count] = v;
     vt[0] = v;
@@ -2643,20 +2485,17 @@ __global__ void __launch_bounds__(256) transpose_tapmajor_kernel(const float* __
 
 // All weight re-layouts of one heads backward in ONE launch (18 launches of ~5 us each before): a job table, 32x32 tiles.
 //   kind 0: out[c][tap][n]  (n < Npad)  = W[n][tap][c]   (dense dgrad)          kind 1: out[tap][c][n] = W[n][tap][c]  (scatter dgrad)
-//   kind 2: out[k][tap*Cc + c][j] (j < Jpad) = anchor type k's C score rows + 4 loc rows (anchor-granular scatter dgrad)
 struct TransposeJob {
     const float* w0; const float* w1; float* out;
-    int kind, n0, n1, Npad, taps, Cc, C, Jpad;
+    int kind, n0, n1, Npad, taps, Cc;
     const int* mode;   // the layout is produced only when *mode == kind (backward mode of the level: 0 dense, 1 pixel rows, 2 anchor rows)
-    int tiles_x, tiles_y, block_begin;   // tiles_x * tiles_y * depth blocks, depth = kTrDepth (kinds 0, 1) or anchor types (kind 2)
+    int tiles_x, tiles_y, block_begin;   // tiles_x * tiles_y * kTrDepth blocks
 };
-constexpr int kMaxTransposeJobs = 3 * kMaxProblems;
+constexpr int kMaxTransposeJobs = 3 * kMaxProblems;   // (ssdk_conv2d_transpose_weights takes up to this many weights per launch)
 constexpr int kTrDepth = 3;   // kinds 0, 1: workgroups per (n, c) tile, each walks taps / kTrDepth taps
-constexpr int kTrJ = 96;   // rows (C + 4 columns of one anchor type, padded) a kind-2 workgroup moves at once
 struct TransposeGroup { int count; TransposeJob j[kMaxTransposeJobs]; };
 __global__ void __launch_bounds__(256) transpose_group_kernel(TransposeGroup grp) {
-    __shared__ float tile2[kTrJ][65];               // kind 2
-    float (*tile)[33] = reinterpret_cast<float (*)[33]>(&tile2[0][0]);   // kinds 0, 1: 32 x 33
+    __shared__ float tile[32][33];
     int ji = 0;
 #pragma unroll 1
     for (int i = 1; i < grp.count; ++i)
@@ -2668,30 +2507,6 @@ __global__ void __launch_bounds__(256) transpose_group_kernel(TransposeGroup grp
     const int by = id % J.tiles_y; id /= J.tiles_y;
     const int bz = id;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    if (J.kind == 2) {
-        // one workgroup = kTrJ rows j (all of them when Jpad <= kTrJ) x 64 columns n of anchor type k: wave-wide 256-byte row
-        // segments in (branch-free, several in flight), ONE contiguous 64 x Jpad block out
-        const int K = J.taps * J.Cc, k = bz, jb = bx * kTrJ, nb_ = by * 64, C = J.C;
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int n = nb_ + lane;
-#pragma unroll 8
-        for (int i = 0; i < kTrJ / 4; ++i) {
-            const int jl = wave + 4 * i, j = jb + jl;
-            const bool real = j < C + 4 && n < K;
-            const float* row = j < C ? J.w0 + ((long long)k * C + (real ? j : 0)) * K : J.w1 + ((long long)k * 4 + (real ? j - C : 0)) * K;
-            const float v = row[real ? n : 0];
-            tile2[jl][lane] = real ? v : 0.0f;
-        }
-        __syncthreads();
-        const int jw = min(kTrJ, J.Jpad - jb);
-        const float inv_jw = 1.0f / (float)jw;
-        float* out = J.out + ((long long)k * K + nb_) * J.Jpad + jb;
-        for (int e = threadIdx.x; e < 64 * jw; e += 256) {
-            const int nl = (int)(((float)e + 0.5f) * inv_jw), jl = e - nl * jw;   // e / jw, exact for e < 2^20
-            if (nb_ + nl < K) out[(long long)nl * J.Jpad + jl] = tile2[jl][nl];
-        }
-        return;
-    }
     // kinds 0, 1: a workgroup walks a third of the taps of its 32 x 32 (n, c) tile.  (A workgroup per tap: 9x the workgroups, which
     // in the usual sparse step are launched only to find their layout is not wanted; one workgroup for all taps: 18 dependent
     // memory round trips, the long pole of the launch whenever a small level does want the layout.)
@@ -3245,8 +3060,6 @@ static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t 
     grp.count = count;
     grp.total_blocks = begin;
     grp.vtab = nullptr;
-    for (int i = 0; i < count; ++i)
-        SSDK_REQUIRE(dma || !grp.p[i].seg_count, SSDK_E_UNSUPPORTED, "segmented scatter rows need the LDS-DMA kernel");
     if (dma && w8) {
         if (mirror) hipLaunchKernelGGL((igemm_dma_kernel<true, false, false, 8>), dim3(begin), dim3(512), 0, s, grp);
         else if (generic) hipLaunchKernelGGL((igemm_dma_kernel<false, true, false, 8>), dim3(begin), dim3(512), 0, s, grp);
@@ -3258,8 +3071,7 @@ static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t 
         va.vtab = vtab;
         for (int i = 0; i < count; ++i) {
             const ConvProblem& g = grp.p[i];
-            va.p[i].counts = g.seg_count ? g.seg_count : g.row_count;
-            va.p[i].segs = g.seg_count ? g.segs : 1;
+            va.p[i].counts = g.row_count;
             va.p[i].mode = g.mode; va.p[i].want = g.want_mode; va.p[i].n_blocks = g.n_blocks;
             SSDK_REQUIRE(va.p[i].counts && g.k_splits == 1, SSDK_E_INVALID, "launch_group: a tile list needs device-side row counts and no split-K");
         }
@@ -3683,20 +3495,16 @@ static bool fast_conv_ok(const float* a, int batch, int h, int w, int ch, int ks
 
 constexpr int kColsumBlocks = 256;   // deterministic bias gradients: at most this many per-workgroup partial column sums per tensor
 
+// workspace of the legacy pipeline (levels without anchor structure, or SSDK_HEADS_BWD_MODE=1): dense or pixel-row backward
 struct HeadsBwdWs {
     float* dyp[kMaxProblems];
     float* wd[kMaxProblems];
     float* wt[kMaxProblems];
     int* row_list[kMaxProblems];
-    float* ga[kMaxProblems];    // anchor-granular gradient rows [nb][B*HW][Jpad] (NULL: level has no loc head -> no anchor mode)
-    int* apix[kMaxProblems];    // their pixel ids [nb][B*HW]
-    float* wa[kMaxProblems];    // per-anchor-type transposed weights [nb][9*Cin][Jpad]
-    int* acounts;               // [kMaxProblems][kMaxAnchorTypes]
-    int* vtab[2];               // compact tile lists of the two sparse scatter launches
+    int* vtab;    // tile list of the pixel-sparse scatter launch
     int* counts;  // [kMaxProblems] non-zero gradient rows per level
     int* totals;  // [kMaxProblems] pixel rows per level
-    int* mode;    // [kMaxProblems] 1 = sparse backward, 0 = dense
-    int* gtab;    // [kGtabInts] chunk table of gather_rows_kernel (mask-first pack)
+    int* mode;    // [kMaxProblems] 1 = pixel-sparse backward, 0 = dense
     // deterministic mode only: per level the K-split copies of the weight gradient [k_splits][N][9*Cin] and the per-workgroup column sums
     // of the bias gradient [kColsumBlocks][N]
     float* dw_part[kMaxProblems];
@@ -3724,22 +3532,12 @@ static HeadsBwdWs carve_heads_bwd(void* ws, const ssdk_head_level* levels, int n
     Carver c(ws);
     HeadsBwdWs w{};
     w.counts = c.take<int>(kMaxProblems);
-    w.acounts = c.take<int>(kMaxProblems * kMaxAnchorTypes);
-    w.vtab[0] = c.take<int>(kVtabInts);
-    w.vtab[1] = c.take<int>(kVtabInts);
+    w.vtab = c.take<int>(kVtabInts);
     w.totals = c.take<int>(kMaxProblems);
     w.mode = c.take<int>(kMaxProblems);
-    w.gtab = c.take<int>(kGtabInts);
     for (int i = 0; i < n_levels; ++i) {
         const ssdk_head_level& lv = levels[i];
         const size_t npad = (size_t)npad_of(lv), M = (size_t)batch * lv.h * lv.w;
-        const int nb = anchor_types_of(lv);
-        if (nb) {
-            const size_t jpad = (size_t)jpad_of(lv);
-            w.ga[i] = c.take<float>((size_t)nb * M * jpad);
-            w.apix[i] = c.take<int>((size_t)nb * M);
-            w.wa[i] = c.take<float>((size_t)nb * 9 * lv.cin * jpad);
-        }
         w.dyp[i] = c.take<float>(M * npad);
         w.wd[i] = c.take<float>((size_t)lv.cin * 9 * npad);
         w.wt[i] = c.take<float>((size_t)lv.cin * 9 * npad);
@@ -3760,7 +3558,6 @@ static HeadsBwdWs carve_heads_bwd(void* ws, const ssdk_head_level* levels, int n
     if (total) *total = c.off;
     return w;
 }
-
 
 // K (= pixel rows) is split so that every problem contributes >= ~256 workgroups (tiny maps are latency bound at one
 // wave per SIMD: more, shorter workgroups) and no workgroup walks more than 64 slices; each split costs one 64 KB
@@ -4225,6 +4022,11 @@ static int heads_bwd_impl(const ssdk_head_level* levels, int n_levels, int batch
     }
     if (ordered_heads_ok(levels, n_levels, batch))
         return heads_bwd_ordered(levels, n_levels, batch, dscores, scores_batch_stride, dlocs, locs_batch_stride, workspace, s, fast, row_mask, num_anchors);
+
+    // ---- the legacy pipeline: levels without anchor structure (score and loc towers as two single-head calls, detector.py:50-66 behind a
+    // SharedConvPredictor), class counts above 124, channel counts that are not multiples of 32, operands of 2 GiB and more, or
+    // SSDK_HEADS_BWD_MODE=1.  Two forms per level, picked on the device from the number of pixel rows with a gradient: 0 dense, 1 rows =
+    // pixels with a gradient (scatter-added data gradient: fp32 atomics).  Deterministic mode takes the dense form on every level.
     HeadsBwdWs w = carve_heads_bwd(workspace, levels, n_levels, batch, nullptr, fast);
     LevelTotals h_totals{};
     for (int i = 0; i < n_levels; ++i) {
@@ -4235,29 +4037,21 @@ static int heads_bwd_impl(const ssdk_head_level* levels, int n_levels, int batch
         SSDK_REQUIRE(npad_of(levels[i]) <= kPackColIters * 64, SSDK_E_UNSUPPORTED, "ssdk_heads_bwd: n_score + n_loc = %d exceeds %d",
                      levels[i].n_score + levels[i].n_loc, kPackColIters * 64);
         h_totals.v[i] = batch * levels[i].h * levels[i].w;
-        h_totals.nb[i] = anchor_types_of(levels[i]);
-        // (the anchor-granular form exists on the LDS-DMA kernel only: operands below 2 GiB)
-        if (getenv("SSDK_CONV_NO_DMA") || (long long)h_totals.nb[i] * h_totals.v[i] * (h_totals.nb[i] ? jpad_of(levels[i]) : 0) * 4 >= (1LL << 31) - 65536) h_totals.nb[i] = 0;
-        h_totals.jpad[i] = h_totals.nb[i] ? jpad_of(levels[i]) : 0;
-        h_totals.npad[i] = npad_of(levels[i]);
     }
-    {   // test / experiment hook: SSDK_HEADS_BWD_MODE = 0 dense, 1 pixel-sparse, 2 anchor-granular (where available), unset: by density
+    {   // test / experiment hook: SSDK_HEADS_BWD_MODE = 0 dense, 1 pixel-sparse, unset: by density (2 = anchor rows exists in the ordered pipeline only: by density here)
         const char* f = getenv("SSDK_HEADS_BWD_MODE");
         h_totals.force = f ? atoi(f) : -1;
+        if (h_totals.force > 1) h_totals.force = -1;
     }
-    // Deterministic mode: the sparse forms scatter-add into dX with fp32 atomics and list their rows in the order the pack's workgroups
+    // Deterministic mode: the pixel-sparse form scatter-adds into dX with fp32 atomics and lists its rows in the order the pack's workgroups
     // finish -- the dense (output-stationary) data gradient and a dense weight gradient whose K splits are added in split order take
-    // their place; the bias gradients are column sums of the packed rows in two fixed-order stages
+    // its place; the bias gradients are column sums of the packed rows in two fixed-order stages
     const bool det = deterministic();
-    if (det) {
-        h_totals.force = 0;
-        for (int i = 0; i < n_levels; ++i) { h_totals.nb[i] = 0; h_totals.jpad[i] = 0; }
-    }
-    // 0. zero everything the atomics of this call add into, in one launch (two when > 32 buffers); the row / anchor counters ride along
+    if (det) h_totals.force = 0;
+    // 0. zero everything the atomics of this call add into, in one launch (two when > 32 buffers); the row counters ride along
     {
         ZeroList zl;
         zl.add(reinterpret_cast<float*>(w.counts), kMaxProblems);
-        zl.add(reinterpret_cast<float*>(w.acounts), (size_t)kMaxProblems * kMaxAnchorTypes);
         for (int i = 0; i < n_levels; ++i) {
             const ssdk_head_level& lv = levels[i];
             const size_t hw = (size_t)lv.h * lv.w;
@@ -4283,16 +4077,13 @@ static int heads_bwd_impl(const ssdk_head_level* levels, int n_levels, int batch
             L.n0 = lv.n_score; L.n1 = lv.n_loc; L.Npad = npad_of(lv); L.HW = lv.h * lv.w;
             L.out = w.dyp[i]; L.db0 = det ? nullptr : lv.db_score; L.db1 = det ? nullptr : lv.db_loc; L.row_list = w.row_list[i]; L.row_count = w.counts + i;
             if (row_mask && lv.n_loc > 0 && lv.n_loc % 4 == 0 && lv.n_score % (lv.n_loc / 4) == 0) {
-                // the level's anchors in the caller's [batch][num_anchors] numbering: anchor-major class-minor rows (detector.py:52-63)
+                // the level's anchors in the caller's [batch][num_anchors] numbering: anchor-major class-minor rows (detector.py:52-63);
+                // a pixel whose anchors are all unmarked is not read
                 const int rnb = lv.n_loc / 4, C = lv.n_score / rnb;
                 if (rnb <= kWave && lv.scores_offset % C == 0 && lv.locs_offset == 4 * (lv.scores_offset / C) &&
                     lv.scores_offset / C + (long long)L.HW * rnb <= num_anchors) {
                     L.rmask = row_mask; L.a_total = num_anchors; L.a_off = (int)(lv.scores_offset / C); L.rnb = rnb;
                 }
-            }
-            if (h_totals.nb[i]) {
-                L.nb = h_totals.nb[i]; L.C = lv.n_score / L.nb; L.Jpad = h_totals.jpad[i]; L.cap = batch * L.HW;
-                L.ga = w.ga[i]; L.apix = w.apix[i]; L.acount = w.acounts + i * kMaxAnchorTypes;
             }
             L.block_begin = begin;
             begin += cdiv(batch * L.HW, kPackRows);
@@ -4300,52 +4091,20 @@ static int heads_bwd_impl(const ssdk_head_level* levels, int n_levels, int batch
         // one instantiation per launch: column trips of the widest level (6 / 8 / 12: Npad <= 384 / 512 / 768)
         int max_npad = 0;
         for (int i = 0; i < n_levels; ++i) max_npad = std::max(max_npad, pg.lv[i].Npad);
-        // two-stage when every level can take the anchor form (then the dense rows are usually not needed at all); else the one-pass form
-        bool two_stage = !getenv("SSDK_PACK_ONE_PASS");
-        for (int i = 0; i < n_levels; ++i) two_stage = two_stage && h_totals.nb[i] > 0;
-        // mask-first: every level has the producer's row mask, in the numbering of its own anchor types (see mask_scan_kernel)
-        bool mask_first = two_stage && row_mask && !getenv("SSDK_PACK_SCAN");
-        for (int i = 0; i < n_levels; ++i)
-            mask_first = mask_first && pg.lv[i].rmask && pg.lv[i].rnb == pg.lv[i].nb && pg.lv[i].Jpad <= 256 && pg.lv[i].dl;
-        if (mask_first) {
-            int scan_blocks = 0;
-            for (int i = 0; i < n_levels; ++i) { pg.lv[i].block_begin2 = scan_blocks; scan_blocks += cdiv(batch * pg.lv[i].HW, kScanPixels); }
-            hipLaunchKernelGGL(mask_scan_kernel, dim3(scan_blocks), dim3(256), 0, s, pg);
-        } else if (two_stage) {
-            if (max_npad <= 384) hipLaunchKernelGGL((pack_dy_kernel<6, false>), dim3(begin), dim3(256), 0, s, pg);
-            else if (max_npad <= 512) hipLaunchKernelGGL((pack_dy_kernel<8, false>), dim3(begin), dim3(256), 0, s, pg);
-            else hipLaunchKernelGGL((pack_dy_kernel<12, false>), dim3(begin), dim3(256), 0, s, pg);
-        } else {
-            if (max_npad <= 384) hipLaunchKernelGGL((pack_dy_kernel<6, true>), dim3(begin), dim3(256), 0, s, pg);
-            else if (max_npad <= 512) hipLaunchKernelGGL((pack_dy_kernel<8, true>), dim3(begin), dim3(256), 0, s, pg);
-            else hipLaunchKernelGGL((pack_dy_kernel<12, true>), dim3(begin), dim3(256), 0, s, pg);
-        }
+        if (max_npad <= 384) hipLaunchKernelGGL(pack_dy_kernel<6>, dim3(begin), dim3(256), 0, s, pg);
+        else if (max_npad <= 512) hipLaunchKernelGGL(pack_dy_kernel<8>, dim3(begin), dim3(256), 0, s, pg);
+        else hipLaunchKernelGGL(pack_dy_kernel<12>, dim3(begin), dim3(256), 0, s, pg);
         SSDK_CHECK_LAUNCH("pack_dy_kernel");
-        hipLaunchKernelGGL(decide_sparse_kernel, dim3(1), dim3(64), 0, s, w.counts, w.acounts, h_totals, n_levels, w.mode, mask_first ? w.gtab : nullptr);
+        hipLaunchKernelGGL(decide_sparse_kernel, dim3(1), dim3(64), 0, s, w.counts, h_totals, n_levels, w.mode);
         SSDK_CHECK_LAUNCH("decide_sparse_kernel");
-        if (two_stage) {
-            for (int i = 0; i < n_levels; ++i) pg.lv[i].mode = w.mode + i;
-            if (mask_first) {
-                long long worst = 0;
-                for (int i = 0; i < n_levels; ++i) worst += (long long)pg.lv[i].nb * cdiv(pg.lv[i].cap, kGatherRows);
-                hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)std::min<long long>(worst, 1024)), dim3(256), 0, s, pg, w.gtab);
-                SSDK_CHECK_LAUNCH("gather_rows_kernel");
-            }
-            const int grid = std::min(begin, mask_first ? 256 : 4096);   // (mask-first: under hard-negative mining no level needs the dense rows; a small grid walks them when one does)
-            if (max_npad <= 384) hipLaunchKernelGGL(pack_store_kernel<6>, dim3(grid), dim3(256), 0, s, pg, begin);
-            else if (max_npad <= 512) hipLaunchKernelGGL(pack_store_kernel<8>, dim3(grid), dim3(256), 0, s, pg, begin);
-            else hipLaunchKernelGGL(pack_store_kernel<12>, dim3(grid), dim3(256), 0, s, pg, begin);
-            SSDK_CHECK_LAUNCH("pack_store_kernel");
-        }
     }
 
     // 2. backward-data.  dense: dX[m][c] = sum_(tap,n) dY[m + pad - tap][n] * W[n][tap][c] (output stationary);
     //    sparse: T[row][tap*Cin + c] = dY[row][:] . W[:, tap, c] for the non-zero rows only, scatter-added into dX.
-    ConvProblem dense[kMaxProblems], sparse[kMaxProblems], anchor[kMaxProblems];
-    int n_dgrad = 0, n_anchor = 0;
+    ConvProblem dense[kMaxProblems], sparse[kMaxProblems];
+    int n_dgrad = 0;
     TransposeGroup tg{};
     int t_blocks = 0;
-    // (the tap-walking jobs first: where one of them is wanted its workgroups are the long ones and must not start last)
     for (int i = 0; i < n_levels; ++i) {
         const ssdk_head_level& lv = levels[i];
         if (!lv.dx) continue;
@@ -4376,23 +4135,6 @@ static int heads_bwd_impl(const ssdk_head_level* levels, int n_levels, int batch
         finish_problem(q);  // m_tiles for the worst case; workgroups past the real row count exit at once
         sparse[n_dgrad] = q;
         ++n_dgrad;
-        if (h_totals.nb[i]) {   // anchor-granular rows: segment k = anchor type k, weights Wa[k]
-            const int nb = h_totals.nb[i], jpad = h_totals.jpad[i], C = lv.n_score / nb;
-            TransposeJob& J = tg.j[tg.count++];
-            J.w0 = lv.w_score; J.w1 = lv.w_loc; J.out = w.wa[i];
-            J.kind = 2; J.taps = 9; J.Cc = lv.cin; J.C = C; J.Jpad = jpad; J.mode = w.mode + i;
-            J.tiles_x = cdiv(jpad, kTrJ); J.tiles_y = cdiv(9 * lv.cin, 64); J.block_begin = t_blocks;
-            t_blocks += J.tiles_x * J.tiles_y * nb;
-            ConvProblem r = q;
-            r.a = w.ga[i]; r.a_pstride = jpad; r.Cc = jpad; r.a_bstride = (long long)hw * jpad * nb;
-            r.w0 = w.wa[i]; r.row_list = w.apix[i]; r.row_count = nullptr;
-            r.seg_count = w.acounts + i * kMaxAnchorTypes; r.seg_cap = batch * hw; r.segs = nb; r.w_seg_stride = (long long)9 * lv.cin * jpad;
-            r.want_mode = 2;
-            finish_problem(r);
-            r.m_tiles = nb * cdiv(batch * hw, kBM);
-            r.m_tiles256 = nb * cdiv(batch * hw, 256);
-            anchor[n_anchor++] = r;
-        }
     }
     if (tg.count) {
         hipLaunchKernelGGL(transpose_group_kernel, dim3(t_blocks), dim3(256), 0, s, tg);
@@ -4427,17 +4169,13 @@ static int heads_bwd_impl(const ssdk_head_level* levels, int n_levels, int batch
         if (n_rest) rc = launch_group(rest, n_rest, true, s);
         if (!rc && n_fdg) rc = launch_fast_group(fdg, ffp, n_fdg, fsg, fsplit_blocks, s);
         if (rc) return rc;
-        if (!det) rc = launch_group(sparse, n_dgrad, false, s, false, true, w.vtab[0]);
-        if (rc) return rc;
-    }
-    if (n_anchor) {
-        int rc = launch_group(anchor, n_anchor, false, s, false, true, w.vtab[1]);
+        if (!det) rc = launch_group(sparse, n_dgrad, false, s, false, true, w.vtab);
         if (rc) return rc;
     }
 
     // 3. backward-weights, dense (all pixels) or sparse (only the listed rows)
-    WgradGroup wd_{}, ws_{}, wa_{};
-    int n_wgrad = 0, n_wanchor = 0;
+    WgradGroup wd_{}, ws_{};
+    int n_wgrad = 0;
     for (int i = 0; i < n_levels; ++i) {
         const ssdk_head_level& lv = levels[i];
         if (!lv.dw_score) continue;
@@ -4454,15 +4192,6 @@ static int heads_bwd_impl(const ssdk_head_level* levels, int n_levels, int batch
         g.want_mode = 1; g.row_list = w.row_list[i]; g.row_count = w.counts + i;
         ws_.p[n_wgrad] = g;
         ++n_wgrad;
-        if (h_totals.nb[i]) {
-            const int nb = h_totals.nb[i], C = lv.n_score / nb;
-            WgradProblem a = g;
-            a.dy = w.ga[i]; a.Npad = h_totals.jpad[i]; a.n0 = C; a.n1 = 4; a.n_tiles = 1;
-            a.row_list = w.apix[i]; a.row_count = nullptr; a.want_mode = 2;
-            a.seg_count = w.acounts + i * kMaxAnchorTypes; a.segs = nb; a.seg_cap = batch * lv.h * lv.w;
-            a.dw0_seg = (long long)C * 9 * lv.cin; a.dw1_seg = (long long)4 * 9 * lv.cin;
-            wa_.p[n_wanchor++] = a;
-        }
     }
     if (n_wgrad) {
         size_wgrad_splits(wd_, n_wgrad, 1);
@@ -4500,10 +4229,6 @@ static int heads_bwd_impl(const ssdk_head_level* levels, int n_levels, int batch
         }
         const int rc = rl.launch(s);
         if (rc) return rc;
-    }
-    if (n_wanchor) {
-        size_wgrad_splits(wa_, n_wanchor, 16);   // anchor mode: a few % of the anchors of one type
-        { int rc = launch_wgrad(wa_, s, fast); if (rc) return rc; }
     }
     return SSDK_OK;
 }
