@@ -3664,11 +3664,13 @@ static bool ordered_heads_ok(const ssdk_head_level* levels, int n_levels, int ba
     }
     return true;
 }
-// K splits of the anchor-row weight gradient of a level: sized for 1 / 16 of the anchors of a type carrying a gradient, ~16 slices of 32 rows
-// per split, at most 8 (every split stores a full copy of the level's weight gradient)
+// K splits of the anchor-row weight gradient of a level: a fixed function of the shapes (sized for 1 / 16 of the anchors of a type carrying a
+// gradient, ~64 slices of 32 rows per split, at most 8; every split stores a full copy of the level's weight gradient).  Measured on
+// SSD-300 / 81 classes, batch 32 (level 0: ~55 slices per type; kernel + reduction, us): 1 split 224 + 10, 2 splits 160 + 15, 3: 208 + 15,
+// 6: 173 + 20, 8: 179 + 22 (tools/r05_stats.sh with SSDK_ANCHOR_WGRAD_SLICES = 128 / 64 / 32 / 16 / 8)
 static inline int anchor_wgrad_splits(const ssdk_head_level& lv, int batch) {
     const int slices = cdiv(cdiv(batch * lv.h * lv.w, 16), 32);
-    static const int per = []() { const char* e = getenv("SSDK_ANCHOR_WGRAD_SLICES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 16; }();   // (measurement knob)
+    static const int per = []() { const char* e = getenv("SSDK_ANCHOR_WGRAD_SLICES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 64; }();   // (measurement knob)
     return std::max(1, std::min(8, cdiv(slices, per)));
 }
 struct OrderedWs {

@@ -644,3 +644,100 @@ def test_heads_backward_with_a_row_mask_equals_the_full_scan(cfg_name, batch):
     ref2 = torch.autograd.grad([scores, locs], xs + params, [gs + 1e-3, gl])
     for a, r in zip(got, ref2):
         assert float((a - r).abs().max()) <= 2e-5 * float(r.abs().max()) + 1e-7
+
+
+def _ordered_layout(levels_meta, heads, xs, batch, level):
+    """ssdk_debug_heads_bwd_layout for one level of a heads call -> (offsets, workspace bytes as numpy)."""
+    import ctypes as C
+    from single_shot_detection_amd import _lib
+    from single_shot_detection_amd.detection.modules import heads as H
+    lvs, s_off, l_off = [], 0, 0
+    for (cin, h, nb), head, x in zip(levels_meta, heads, xs):
+        ws, wl = H.weight_khwc(head['score'].weight.detach()), H.weight_khwc(head['loc'].weight.detach())
+        lvs.append(dict(x=H.to_nhwc(x.detach()), H=h, W=h, cin=cin, ws=ws, bs=None, wl=wl, bl=None, ns=ws.shape[0], nl=wl.shape[0], s_off=s_off, l_off=l_off))
+        s_off += h * h * ws.shape[0]
+        l_off += h * h * wl.shape[0]
+    arr = H._level_array(lvs)
+    out = (C.c_ulonglong * 8)()
+    rc = _lib.lib().ssdk_debug_heads_bwd_layout(arr, len(lvs), batch, level, out)
+    assert rc == 0, rc
+    return [int(v) for v in out], _lib.scratch(0, xs[0].device, 'heads_bwd').cpu().numpy()
+
+
+@pytest.mark.parametrize('levels,C,B,density', [([(64, 6, 4), (32, 3, 6)], 21, 2, 0.1), ([(512, 18, 6)], 81, 2, 1.0), ([(96, 19, 4), (1280, 10, 6)], 21, 2, 0.05)])
+def test_ordered_backward_intermediates(levels, C, B, density, monkeypatch):
+    """The intermediates of the ordered anchor-row backward, through ssdk_debug_heads_bwd_layout: rows numbered in PIXEL order per anchor
+    type (whatever order the workgroups ran in), the inverted index aidx = the rows' T positions and -1 elsewhere, the row matrix = the
+    anchors' C + 4 gradient values, and T[row] = row . W_type against numpy in fp64 -- the contribution rows anchor_dx_kernel sums
+    (detection/detector.py:50-66 backward; detection/losses/multibox_loss.py:60-90 decides which anchors carry a gradient)."""
+    monkeypatch.delenv('SSDK_HEADS_BWD_MODE', raising=False)
+    rng = np.random.default_rng(5)
+    weights, xs_np = {}, []
+    for i, (cin, h, nb) in enumerate(levels):
+        xs_np.append(rng.standard_normal((B, cin, h, h), dtype=np.float32))
+        for k, nout in (('score', nb * C), ('loc', nb * 4)):
+            weights[(k, i)] = (rng.standard_normal((nout, cin, 3, 3), dtype=np.float32) * np.float32(0.05), np.zeros((nout,), np.float32))
+    heads = build_heads(levels, C, weights)
+    xs = [torch.from_numpy(x).cuda().requires_grad_(True) for x in xs_np]
+    scores, locs = multi_level_heads(xs, xs, heads)
+    A = scores.shape[1] // C
+    keep = rng.random((B, A)) < density
+    gs = (rng.standard_normal((B, A, C), dtype=np.float32) * keep[..., None]).astype(np.float32)
+    gl = (rng.standard_normal((B, A, 4), dtype=np.float32) * keep[..., None]).astype(np.float32)
+    torch.autograd.grad([scores, locs], xs, [torch.from_numpy(gs).view(B, -1).cuda(), torch.from_numpy(gl).view(B, -1).cuda()])
+    torch.cuda.synchronize()
+    a_off = 0
+    for li, (cin, h, nb) in enumerate(levels):
+        off, wsb = _ordered_layout(levels, heads, xs, B, li)
+        M, K9, Jpad = B * h * h, 9 * cin, (C + 4 + 31) // 32 * 32
+        i32 = lambda o, n: wsb[o:o + 4 * n].view(np.int32)
+        f32 = lambda o, n: wsb[o:o + 4 * n].view(np.float32)
+        counts, plan, mode = i32(off[4], 16), i32(off[5], 34), int(i32(off[6], 1)[0])
+        g_s = gs[:, a_off:a_off + h * h * nb].reshape(B * h * h, nb, C)
+        g_l = gl[:, a_off:a_off + h * h * nb].reshape(B * h * h, nb, 4)
+        marked = keep[:, a_off:a_off + h * h * nb].reshape(B * h * h, nb)
+        a_off += h * h * nb
+        assert mode == 2, (li, mode)
+        ga = f32(off[0], nb * M * Jpad).reshape(nb, M, Jpad)
+        apix, aidx = i32(off[3], nb * M).reshape(nb, M), i32(off[2], nb * M).reshape(nb, M)
+        rows = int(plan[nb])
+        assert rows == int(marked.sum()) and rows <= off[7]
+        T = f32(off[1], rows * K9).reshape(rows, K9)
+        wsk = weights[('score', li)][0].transpose(0, 2, 3, 1).reshape(nb, C, K9)      # [type][j][tap * Cin + c]
+        wlk = weights[('loc', li)][0].transpose(0, 2, 3, 1).reshape(nb, 4, K9)
+        for k in range(nb):
+            n = int(counts[k])
+            pix = np.nonzero(marked[:, k])[0]
+            assert n == len(pix) and np.array_equal(apix[k, :n], pix), 'rows are the marked pixels of the type, in pixel order'
+            assert np.array_equal(aidx[k, pix], plan[k] + np.arange(n)) and int((aidx[k] >= 0).sum()) == n and np.all(aidx[k][~marked[:, k]] == -1)
+            if not n:
+                continue
+            ref_rows = np.concatenate([g_s[pix, k], g_l[pix, k]], 1)
+            assert np.array_equal(ga[k, :n, :C + 4], ref_rows) and np.all(ga[k, :n, C + 4:] == 0)
+            Wk = np.concatenate([wsk[k], wlk[k]], 0)
+            Tref = ref_rows.astype(np.float64) @ Wk.astype(np.float64)
+            np.testing.assert_allclose(T[plan[k]:plan[k] + n], Tref, rtol=1e-5, atol=2e-6 * np.sqrt(C + 4) * float(np.abs(Tref).max()))
+
+
+@pytest.mark.parametrize('cfg_name,batch', [('ssd_300_vgg16_voc', 8), ('ssd_mb2_voc', 2)])
+def test_heads_backward_is_bitwise_reproducible_by_default(cfg_name, batch):
+    """The ordered pipeline sums in an order fixed by the launch -- rows in pixel order, taps and anchor types in order, K splits added
+    in split order, bias chunks in chunk order -- so the heads' backward gives the same bits on every run WITHOUT ops.deterministic()
+    (the reference runs cudnn.deterministic = True, bf/training/env.py:74-76), with the row mask derived from the gradient or given."""
+    from single_shot_detection_amd import synthetic as syn
+    cfg = syn.CONFIGS[cfg_name]
+    levels, C = cfg['levels'], cfg['num_classes']
+    torch.manual_seed(47)
+    heads = detector_builder.get_heads([l[0] for l in levels], [l[2] for l in levels], C).cuda()
+    xs = [torch.randn((batch, cin, h, h), device='cuda').contiguous(memory_format=torch.channels_last).requires_grad_(True) for cin, h, _ in levels]
+    params = list(heads.parameters())
+    scores, locs = multi_level_heads(xs, xs, heads)
+    A = scores.shape[1] // C
+    keep = torch.rand((batch, A), device='cuda') < 0.04
+    gs = (torch.randn_like(scores).view(batch, A, C) * keep[..., None]).view(batch, -1)
+    gl = (torch.randn_like(locs).view(batch, A, 4) * keep[..., None]).view(batch, -1)
+    first = [g.clone() for g in torch.autograd.grad([scores, locs], xs + params, [gs, gl], retain_graph=True)]
+    for _ in range(3):
+        again = torch.autograd.grad([scores, locs], xs + params, [gs, gl], retain_graph=True)
+        for a, r in zip(again, first):
+            assert torch.equal(a, r)
