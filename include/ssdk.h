@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SSDK_VERSION 112
+#define SSDK_VERSION 113
 
 #define SSDK_OK 0
 #define SSDK_E_INVALID (-1)   /* bad argument / shape */
@@ -47,6 +47,34 @@ extern "C" {
 #define SSDK_LOC_GIOU 1      /* GeneralizedIoULoss, losses.py:109-114, on decoded corners (multibox_loss.py:77-79) */
 
 int ssdk_version(void);
+
+/*
+ * bf/utils/box_utils.py:16-194 as a callable surface (every array DEV fp32; boxes 16-byte aligned rows of 4; no workspace unless said).
+ *   ssdk_box_to_corners    :16-23   [cx,cy,w,h] -> [c - wh/2, c + wh/2]                                  box, out [n,4] (out may be box)
+ *   ssdk_box_to_centroids  :25-36   inplace_form = 0: [(max+min)/2, max-min] (:36); != 0: wh = max-min, c = min + wh/2 (:33-34) -- the two
+ *                                   forms round the centre differently, both as the reference does
+ *   ssdk_box_area          :38-46   clamp(x2-x1, 0) * clamp(y2-y1, 0)                                     out [n]
+ *   ssdk_box_intersection  :49-80   cat([max of the min corners, min of the max corners]); cartesian != 0: out [na,nb,4], else na == nb and
+ *                                   out [na,4]; zero_incorrect != 0: rows with max < min in any coordinate become 0
+ *   ssdk_box_iou           :83-101 (generalized = 0) / :104-143 (generalized != 0): cartesian != 0: out [na,nb], else out [na].  No +1, no
+ *                                   epsilon: two degenerate boxes give NaN like the reference.  The [G,A] matrix ssdk_match_per_prediction takes.
+ *   ssdk_nms               :145-194 ONE problem (n <= 65536; the batched fused path is ssdk_postprocess): max_per_class in 1..n-1 first keeps
+ *                                   the max_per_class best scores (:186-188 topk(sorted=False): the reference defines the SET; here it is kept
+ *                                   in descending score order, ties by ascending index); then soft == 0: hard NMS per torchvision.ops.nms's
+ *                                   documented contract (:193; PARITY UNPINNED: torchvision is not vendored), soft != 0: _soft_nms (:145-163,
+ *                                   incl. its loop condition mask.nonzero().sum()).  picked DEV int64 [>= min(n, cap)]: positions, in pick
+ *                                   order, in the array the NMS ran on (the input, or the top-k subset when a cap applied); picked_boxes
+ *                                   DEV [.,4] / picked_scores DEV [.] (NULL: not wanted): boxes[picked] / scores[picked]; count DEV int32.
+ */
+int ssdk_box_to_corners(const float* box, float* out, long long n, void* stream);
+int ssdk_box_to_centroids(const float* box, float* out, long long n, int inplace_form, void* stream);
+int ssdk_box_area(const float* box, float* out, long long n, void* stream);
+int ssdk_box_intersection(const float* a, int na, const float* b, int nb, int cartesian, int zero_incorrect, float* out, void* stream);
+int ssdk_box_iou(const float* a, int na, const float* b, int nb, int cartesian, int generalized, float* out, void* stream);
+size_t ssdk_nms_workspace_bytes(int n);
+int ssdk_nms(const float* boxes, const float* scores, int n, float overlap_threshold, float score_threshold, int max_per_class, int soft,
+             float sigma, long long* picked, float* picked_boxes, float* picked_scores, int* count, void* workspace, size_t workspace_bytes,
+             void* stream);
 
 /*
  * DETERMINISTIC MODE (process-wide; default off, or SSDK_DETERMINISTIC=1 in the environment).  The reference runs every GPU job with

@@ -467,8 +467,14 @@ int orc_nms_soft(const float* boxes, const float* scores, int n, float score_thr
         int64_t idxsum = 0;
         for (int i = 0; i < n; ++i) if (mask[i]) idxsum += i;
         if (idxsum == 0) break;
+        /* :152 argmax: first max; torch.argmax ranks NaN above everything (first NaN wins) -- a score turns NaN when a degenerate box
+         * (zero area) meets the picked box with zero intersection: 0 / 0 in :158 (tests/golden/box_utils.npz has four such boxes) */
         int best = 0;
-        for (int i = 1; i < n; ++i) if (sc[i] > sc[best]) best = i; /* :152 argmax: first max */
+        for (int i = 1; i < n; ++i) {
+            const int best_nan = sc[best] != sc[best];
+            if (best_nan) break;
+            if (sc[i] != sc[i] || sc[i] > sc[best]) best = i;
+        }
         sc[best] = 0.0f;
         picked[k++] = best;
         for (int i = 0; i < n; ++i) mask[i] = sc[i] > score_thr; /* :156 */

@@ -72,6 +72,14 @@ _SIGNATURES = {
     'ssdk_heads_fwd_timeouts': (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     'ssdk_streamk_poisoned': (C.c_int, []),
     'ssdk_debug_streamk_fault': (C.c_int, [C.c_int, C.c_uint]),
+    'ssdk_box_to_corners': (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
+    'ssdk_box_to_centroids': (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]),
+    'ssdk_box_area': (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
+    'ssdk_box_intersection': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'ssdk_box_iou': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'ssdk_nms_workspace_bytes': (C.c_size_t, [C.c_int]),
+    'ssdk_nms': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                           C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'ssdk_debug_heads_bwd_layout': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]),
     'ssdk_heads_bwd_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     'ssdk_heads_bwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong,

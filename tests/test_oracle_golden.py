@@ -281,3 +281,15 @@ def test_oracle_ssd_anchor_generator_options_vs_reference(name):
     got = oracle.ssd_anchor_generator(img_wh, fmap_wh, **kw)
     assert got.shape == g[name].shape and got.shape[2] == int(g[name + '_num_boxes'])
     assert np.array_equal(got.view(np.uint32), g[name].view(np.uint32))
+
+
+def test_box_utils_golden_nms():
+    """tests/golden/box_utils.npz (the reference's nms wrapper on 300 clustered boxes, four of them degenerate): the oracle's hard NMS
+    (contract) and soft NMS -- incl. torch.argmax's NaN-first rule, which the 40-box kat11 case never reaches."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'box_utils.npz'))
+    b, s = g['nms_boxes'], g['nms_scores']
+    assert np.array_equal(oracle.nms_hard(b, s, 0.45), g['nms_hard_picked'])   # contract golden (unpinned)
+    assert np.array_equal(oracle.nms_soft(b, s, 0.05, 0.5), g['nms_soft_picked'])
+    w = oracle.iou(g['a'], g['b'])
+    nan = np.isnan(g['iou'])
+    assert np.array_equal(np.isnan(w), nan) and np.array_equal(bits(w)[~nan], bits(g['iou'])[~nan])

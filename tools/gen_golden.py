@@ -534,6 +534,59 @@ def gen_blocks(out_dir):
     print(f'blocks -> {path} ({os.path.getsize(path) / 1e3:.1f} KB, {len(res)} arrays)')
 
 
+def gen_box_utils(out_dir):
+    """bf/utils/box_utils.py:16-194 as a callable surface: seeded boxes through the reference's to_corners /
+    to_centroids / area / intersection / iou / generalized_iou / nms (hard NMS: the documented-contract stand-in above; soft: its own)."""
+    rng = np.random.default_rng(29)
+
+    def boxes(n, lo=0.0, hi=300.0):
+        xy = rng.uniform(lo, hi * 0.7, size=(n, 2)).astype(np.float32)
+        wh = rng.uniform(2.0, hi * 0.5, size=(n, 2)).astype(np.float32)
+        return torch.from_numpy(np.concatenate([xy, xy + wh], 1))
+    res = {}
+    a, b = boxes(37), boxes(211)
+    a[3] = b[5]                       # an identical pair (IoU 1)
+    a[4] = torch.tensor([10., 10., 10., 10.])   # degenerate: zero area
+    b[7] = torch.tensor([10., 10., 10., 10.])   # ... against a degenerate one: NaN
+    b[9] = torch.tensor([50., 60., 40., 30.])   # "incorrect" corners (max < min)
+    res['a'], res['b'] = a.numpy(), b.numpy()
+    res['iou'] = box_utils.iou(a, b).numpy()
+    res['giou'] = box_utils.generalized_iou(a, b).numpy()
+    res['intersection'] = box_utils.intersection(a, b).numpy()
+    res['intersection_zero'] = box_utils.intersection(a, b, zero_incorrect=True).numpy()
+    c = boxes(37)
+    res['c'] = c.numpy()
+    res['iou_pair'] = box_utils.iou(a, c, cartesian=False).numpy()
+    res['giou_pair'] = box_utils.generalized_iou(a, c, cartesian=False).numpy()
+    res['intersection_pair'] = box_utils.intersection(a, c, cartesian=False).numpy()
+    res['area_b'] = box_utils.area(b).numpy()
+    cen = box_utils.to_centroids(b)
+    res['centroids_b'] = cen.numpy()
+    inpl = b.clone(); box_utils.to_centroids(inpl, inplace=True)
+    res['centroids_inplace_b'] = inpl.numpy()
+    res['corners_of_centroids_b'] = box_utils.to_corners(cen).numpy()
+    batched = torch.stack([boxes(16), boxes(16)])
+    res['batched'] = batched.numpy()
+    res['batched_corners'] = box_utils.to_corners(batched).numpy()
+    res['batched_centroids'] = box_utils.to_centroids(batched).numpy()
+    res['batched_area'] = box_utils.area(batched).numpy()
+    # nms: 300 clustered boxes, scores with ties
+    base = boxes(30, hi=200.0)
+    nb_ = torch.cat([base + torch.from_numpy(rng.uniform(-6, 6, size=(30, 4)).astype(np.float32)) for _ in range(10)])
+    sc = torch.from_numpy(np.round(rng.uniform(0.0, 1.0, size=(300,)), 2).astype(np.float32))
+    res['nms_boxes'], res['nms_scores'] = nb_.numpy(), sc.numpy()
+    (pb, ps), pk = box_utils.nms(nb_, sc, 0.45, 0.05)
+    res['nms_hard_picked'], res['nms_hard_boxes'], res['nms_hard_scores'] = pk.numpy(), pb.numpy(), ps.numpy()   # nms_contract
+    (pb, ps), pk = box_utils.nms(nb_, sc, 0.45, 0.05, soft=True, sigma=0.5)
+    res['nms_soft_picked'], res['nms_soft_boxes'], res['nms_soft_scores'] = pk.numpy(), pb.numpy(), ps.numpy()
+    # with a cap the reference takes topk(sorted=False) first: the SET is defined, its order is not -- record boxes / scores as sets
+    (pb, ps), pk = box_utils.nms(nb_, sc, 0.45, 0.05, max_per_class=100)
+    res['nms_hard_cap_boxes'], res['nms_hard_cap_scores'] = pb.numpy(), ps.numpy()
+    path = os.path.join(out_dir, 'box_utils.npz')
+    np.savez_compressed(path, **res)
+    print(f'box_utils -> {path} ({os.path.getsize(path) / 1e3:.1f} KB)')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(REPO, 'tests', 'golden'))
@@ -542,6 +595,8 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     batches = {'ssd_mb2_voc': 2, 'ssd_300_vgg16_voc': 4, 'ssd_512_vgg16_coco': 2,
                'retina_rn50_500_coco': 2, 'm2det_512_vgg16_coco': 2}
+    if args.only in (None, 'box_utils'):
+        gen_box_utils(args.out)
     if args.only in (None, 'kats'):
         gen_kats(args.out)
     if args.only in (None, 'heads'):
