@@ -259,6 +259,7 @@ class HotPath(object):
                     p.requires_grad_(False)
             groups = [g for g in (self.head_params, self.rest_params) if g]
             self.exchange = BucketedDataParallel(mods, groups=groups, process_group=process_group)
+            self.exchange.collect_timing = True   # three events per bucket and step: the line says how long each ring took and how long its join stalled
             self.bucket_heads = self.exchange.buckets[0]
             self.bucket_rest = self.exchange.buckets[1] if len(self.exchange.buckets) > 1 else None
         return self.exchange
@@ -850,6 +851,7 @@ def main():
 
     if rank == 0:
         A = hp.anchors.shape[0]
+        ex_timing = hp.exchange.exchange_timing() if hp.exchange is not None else []
         out = {
             'metric': 'images/sec (train step) + NMS boxes/sec, SSD-300 VGG16 batch 32 @1/2/4/8 GPU',
             'value': value, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -867,7 +869,12 @@ def main():
                                   'all-reduces started in the last step, those started from a gradient hook (before the backward pass ended), and the '
                                   'head gradients that had to be copied into their bucket slots (0 = the kernels wrote them there)',
                           'start_order': hp.exchange.start_order, 'started_early': hp.exchange.started_early,
-                          'heads_copied': int(getattr(hp.bucket_heads, 'copied_last', -1))}),
+                          'heads_copied': int(getattr(hp.bucket_heads, 'copied_last', -1)),
+                          # of the LAST timed step, per bucket (heads first): ring_ms = all-reduce started -> joined on the device timeline (an
+                          # upper bound of the ring itself: the joining stream may have had work queued); exposed_ms = how long the join at
+                          # the end of backward() stalled that stream (gloo: the host) -- 0 means the ring was hidden under the tail's backward
+                          'buckets': ex_timing, 'ring_ms': [b['ring_ms'] for b in ex_timing], 'exposed_ms': [b['exposed_ms'] for b in ex_timing],
+                          'recovered_steps': hp.exchange.recovered_steps}),
             'nms_boxes_per_sec': world * cand / dtp, 'postprocess_images_per_sec': world * args.batch / dtp,
             'eval_images_per_sec': world * args.batch / dte, 'nms_candidates_per_image': cand / args.batch,
             'postprocess_trained_like': {'images_per_sec': world * args.batch / dtp_tl, 'nms_boxes_per_sec': world * cand_tl / dtp_tl,

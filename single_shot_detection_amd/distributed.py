@@ -62,6 +62,12 @@ class GradBucket(object):
         self.flat = None
         self.views = None
         self._work = None
+        # timing of the last collective (BucketedDataParallel.collect_timing): device events on the stream the collective was started /
+        # joined on, and the host time finish_() blocked (what a host-synchronous backend -- gloo -- costs instead)
+        self.timing = False
+        self._ev = None
+        self.ring_ms = None       # start_ -> joined (an UPPER bound of the ring's own duration: it includes whatever the stream still had queued)
+        self.exposed_ms = None    # how long the joining stream (or, on gloo, the host) stalled for the ring
 
     @property
     def nbytes(self):
@@ -111,16 +117,38 @@ class GradBucket(object):
                 op = dist.ReduceOp.AVG
             else:
                 self._post_div = world
+        if self.timing and self.flat.is_cuda:
+            self._ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            self._ev[0].record()
         self._work = dist.all_reduce(self.flat, op=op, group=group, async_op=True)
 
     def finish_(self, group=None):
         """Waits for the collective ``start_`` began (the average was chosen there: ReduceOp.AVG, or a division here on gloo)."""
         if self._work is None:
             return
-        self._work.wait()
+        import time
+        t0 = time.perf_counter()
+        if self._ev is not None:
+            self._ev[1].record()
+        self._work.wait()       # (nccl: the current stream waits, the host does not; gloo: the host waits)
+        if self._ev is not None:
+            self._ev[2].record()
+        self._host_wait_ms = (time.perf_counter() - t0) * 1e3
         if self._post_div:
             self.flat.div_(self._post_div)
         self._work = None
+
+    def read_timing_(self):
+        """ring_ms / exposed_ms of the last collective (synchronises with its events; call outside the timed region)."""
+        if self._ev is not None:
+            self._ev[2].synchronize()
+            self.ring_ms = self._ev[0].elapsed_time(self._ev[2])
+            self.exposed_ms = self._ev[1].elapsed_time(self._ev[2])
+            self._ev = None
+        elif self.timing and getattr(self, '_host_wait_ms', None) is not None:
+            self.ring_ms = None
+            self.exposed_ms = self._host_wait_ms
+        return self.ring_ms, self.exposed_ms
 
 
 def shard_batch(items, rank, world):
@@ -161,10 +189,15 @@ class BucketedDataParallel(torch.nn.Module):
 
     ``groups``: lists of parameters in the order their gradients complete during the backward pass; default: the heads' parameters
     (``module.heads``; complete as soon as the heads' backward node has run, i.e. first) and everything else.  A
-    post-accumulate-grad hook per parameter counts arrivals; when a bucket is complete its all-reduce STARTS (async), so the heads' ring
-    runs under the backward pass of the pyramid tail / towers / backbone; a callback at the end of the backward pass starts whatever has
-    not started (parameters that took no part in the step count as zero gradients) and waits for all rings, so ``backward()`` returns
-    with averaged gradients like DDP's does.  Producers that write a parameter's gradient into its bucket slot (``grad_sink``: the
+    post-accumulate-grad hook per parameter counts arrivals; when a bucket is complete AND every bucket in front of it has started, its
+    all-reduce STARTS (async) -- collectives are issued in bucket-index order on every rank, whatever order the gradients arrive in (ranks
+    whose unused parameters differ would otherwise pair different buckets' rings) --, so the heads' ring runs under the backward pass of
+    the pyramid tail / towers / backbone; a callback at the end of the backward pass starts whatever has not started (parameters that took
+    no part in the step count as zero gradients: unlike apex / torch DDP, which leave such a ``.grad`` None, the optimizer then sees a zero
+    gradient -- weight decay and momentum still move the parameter) and waits for all rings, so ``backward()`` returns with averaged
+    gradients like DDP's does.  A backward pass that RAISES after some rings have started leaves this rank's collective count short of its
+    peers'; the next pass (or ``abort_step_()``) first issues the missing collectives, so that the ranks stay paired -- the gradients of
+    the failed step are meaningless, but nothing hangs and nothing pairs a 36 MB ring with a 9 MB one.  Producers that write a parameter's gradient into its bucket slot (``grad_sink``: the
     heads' / convolutions' weight-gradient kernels) make the exchange zero-copy.  ``no_sync()`` skips the exchange (gradient
     accumulation).  Parameters and buffers are broadcast from rank 0 at construction.  ``state_dict`` keys carry the ``module.`` prefix
     like DDP's."""
@@ -200,6 +233,8 @@ class BucketedDataParallel(torch.nn.Module):
         self.require_sync = True
         self.start_order = []          # (diagnostics / tests: bucket indices in the order their rings started in the last backward pass)
         self.started_early = []        # ... and which of them started from a hook, i.e. before the backward pass had ended
+        self.recovered_steps = 0       # backward passes that raised and whose missing collectives were issued afterwards
+        self.collect_timing = False    # bench.py: event-timed ring duration / exposed wait per bucket (exchange_timing())
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for b in self.buckets for p in b.params]
         for b in self.buckets:
             for p in b.params:
@@ -232,12 +267,7 @@ class BucketedDataParallel(torch.nn.Module):
         if self._callback_queued and task != self._task:
             # the pass that queued the callback never reached it (its backward raised): its arrival counts and "started" marks are
             # not this pass's -- without this the next pass would neither queue a callback nor finish its rings (stale gradients, silently)
-            for b, started in zip(self.buckets, self._started):
-                if started:
-                    b.finish_(self.process_group)   # (a ring that pass had started: let it land before its buffer is written again)
-            self._arrived = [0] * len(self.buckets)
-            self._started = [False] * len(self.buckets)
-            self._callback_queued = False
+            self.abort_step_()
         if not self._callback_queued:
             self._callback_queued = True
             self._task = task
@@ -245,14 +275,46 @@ class BucketedDataParallel(torch.nn.Module):
             torch.autograd.Variable._execution_engine.queue_callback(self._finish_all)
         i = self._bucket_of[id(param)]
         self._arrived[i] += 1
-        if self._arrived[i] == len(self.buckets[i].params) and not self._started[i]:
-            self._start(i, early=True)
+        # strictly in index order: bucket i starts from a hook only once every bucket in front of it has started; a bucket that completes
+        # out of order waits for its predecessors (or for the end of the pass)
+        j = 0
+        while j < len(self.buckets) and self._started[j]:
+            j += 1
+        while j < len(self.buckets) and self._arrived[j] == len(self.buckets[j].params):
+            self._start(j, early=True)
+            j += 1
+
+    def abort_step_(self):
+        """After a backward pass that raised: issue the collectives that pass never reached (with whatever the buckets hold), wait for all of
+        them, reset the counters.  The peers issued theirs; this keeps the per-rank collective count -- and the pairing of the rings -- equal.
+        Called by the next pass' first gradient hook; a trainer that catches the exception may call it itself."""
+        if not self._callback_queued:
+            return
+        # (parameters without a gradient get a zero one for the owed collective and lose it again afterwards: the pass that follows must
+        # not accumulate into the failed step's leftovers)
+        none_before = [p for i, b in enumerate(self.buckets) if not self._started[i] for p in b.params if p.grad is None]
+        try:
+            for i in range(len(self.buckets)):
+                if not self._started[i]:
+                    self._start(i, early=False)
+        finally:
+            try:
+                for b in self.buckets:
+                    b.finish_(self.process_group)
+            finally:
+                for p in none_before:
+                    p.grad = None
+                self._arrived = [0] * len(self.buckets)
+                self._started = [False] * len(self.buckets)
+                self._callback_queued = False
+                self.recovered_steps += 1
 
     def _start(self, i, early):
         b = self.buckets[i]
         for p, v in zip(b.params, b.views):
             if p.grad is None:   # took no part in this step: a zero gradient on every rank that agrees, the others' share otherwise
                 p.grad = v.zero_().detach()
+        b.timing = self.collect_timing
         b.start_(self.process_group)
         self._started[i] = True
         self.start_order.append(i)
@@ -260,17 +322,39 @@ class BucketedDataParallel(torch.nn.Module):
             self.started_early.append(i)
 
     def _finish_all(self):
+        # Whatever raises on the way, every bucket's collective is issued and waited for before the counters go back: a rank that skipped
+        # one would leave its peers waiting in it (and pair its next ring with their previous one), and a ring that is not waited for may
+        # still be writing the buffer when the next start_ overwrites its handle.  The first error is raised at the end.
+        err = None
         try:
             # weight gradients deferred to the end of the backward pass (ops.defer_weight_gradients) are written now, before the buckets
             # they belong to start: this callback was queued by the FIRST gradient of the pass, the deferred flush's own callback later
             from . import ops
             ops._flush_weight_gradients()
-            for i in range(len(self.buckets)):
-                if not self._started[i]:
+        except BaseException as e:   # noqa: B902
+            err = e
+        for i in range(len(self.buckets)):
+            if not self._started[i]:
+                try:
                     self._start(i, early=False)
-            for b in self.buckets:
+                except BaseException as e:   # noqa: B902
+                    err = err or e
+        for b in self.buckets:
+            try:
                 b.finish_(self.process_group)
-        finally:
-            self._arrived = [0] * len(self.buckets)
-            self._started = [False] * len(self.buckets)
-            self._callback_queued = False
+            except BaseException as e:   # noqa: B902
+                err = err or e
+        self._arrived = [0] * len(self.buckets)
+        self._started = [False] * len(self.buckets)
+        self._callback_queued = False
+        if err is not None:
+            raise err
+
+    def exchange_timing(self):
+        """Per bucket of the last exchanged step (collect_timing = True): {'ring_ms': start -> joined on the device timeline (upper bound of
+        the ring), 'exposed_ms': how long the join stalled the stream (gloo: the host)}.  Synchronises with the step's events."""
+        out = []
+        for b in self.buckets:
+            ring, exposed = b.read_timing_()
+            out.append({'bytes': b.nbytes, 'ring_ms': ring, 'exposed_ms': exposed})
+        return out

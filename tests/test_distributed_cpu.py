@@ -290,3 +290,87 @@ def test_bucketed_data_parallel_gloo_world2(tmp_path):
     world = 2
     mp.spawn(_bdp_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f'bdp{r}.npy') for r in range(world))
+
+
+def _bdp_one_rank_raises_worker(rank, world, port, out_dir):
+    """Only rank 1's backward pass raises (behind the heads: its first ring has started, its second has not); rank 0 finishes its step.
+    Rank 1's next pass first issues the collective it owes, so the ranks stay paired: no hang, and the following step averages correctly."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world, timeout=__import__('datetime').timedelta(seconds=60))
+    from single_shot_detection_amd.distributed import BucketedDataParallel
+    torch.manual_seed(5)
+    net = BucketedDataParallel(_ToyPredictor())
+    params = [p for p in net.parameters()]
+    x = torch.randn((2, 3, 9, 9), generator=torch.Generator().manual_seed(17 + rank))
+    with net.no_sync():
+        net(x).square().sum().backward()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, [None if p.grad is None else p.grad.numpy().copy() for p in params])
+    for p in params:
+        p.grad = None
+
+    class _Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.view_as(t)
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError('boom')
+    if rank == 1:
+        hook = net.module.features.register_forward_hook(lambda m, i, o: _Boom.apply(o))
+        try:
+            net(x).square().sum().backward()
+            raise AssertionError('the backward pass should have raised')
+        except RuntimeError as e:
+            assert 'boom' in str(e)
+        hook.remove()
+    else:
+        net(x).square().sum().backward()      # waits in bucket 1's all-reduce until rank 1 issues the one it owes
+    for p in params:
+        p.grad = None
+    net(x).square().sum().backward()          # rank 1: abort_step_() first (the missing collective), then an ordinary step
+    assert net.recovered_steps == (1 if rank == 1 else 0)
+    assert net.start_order == [0, 1] and 0 in net.started_early
+    for i, p in enumerate(params):
+        if gathered[0][i] is not None:
+            want = sum(torch.from_numpy(gathered[r][i]) for r in range(world)) / world
+            assert torch.allclose(p.grad, want, atol=1e-6, rtol=1e-5), (rank, i)
+    np.save(os.path.join(out_dir, f'one{rank}.npy'), np.array([1]))
+    dist.destroy_process_group()
+
+
+def test_bucketed_data_parallel_one_rank_raises(tmp_path):
+    """Advisor (round 4): a backward pass that raises on ONE rank must not leave the ranks' collectives unpaired."""
+    world = 2
+    mp.spawn(_bdp_one_rank_raises_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f'one{r}.npy') for r in range(world))
+
+
+def _bdp_order_worker(rank, world, port, out_dir):
+    """Buckets whose gradients complete in another order than their indices: the rings still start in index order on every rank (and none
+    early past an unfinished predecessor); timing fields are filled when asked for."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from single_shot_detection_amd.distributed import BucketedDataParallel
+    torch.manual_seed(9)
+    toy = _ToyPredictor()
+    groups = [list(toy.features.parameters()), list(toy.heads.parameters()), list(toy.unused.parameters())]   # the features complete LAST
+    net = BucketedDataParallel(toy, groups=groups)
+    net.collect_timing = True
+    x = torch.randn((2, 3, 9, 9), generator=torch.Generator().manual_seed(27 + rank))
+    net(x).square().sum().backward()
+    assert net.start_order == [0, 1, 2], net.start_order
+    assert 2 not in net.started_early                      # (the heads were complete first, but started only behind bucket 0, in the hook of ITS last gradient)
+    t = net.exchange_timing()
+    assert len(t) == 3 and all(e['exposed_ms'] is not None and e['exposed_ms'] >= 0.0 for e in t) and t[0]['bytes'] == net.buckets[0].nbytes
+    np.save(os.path.join(out_dir, f'ord{rank}.npy'), np.array([1]))
+    dist.destroy_process_group()
+
+
+def test_bucketed_data_parallel_index_order_and_timing(tmp_path):
+    world = 2
+    mp.spawn(_bdp_order_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f'ord{r}.npy') for r in range(world))

@@ -481,6 +481,11 @@ def test_bench_n2_path_on_one_gpu_over_gloo():
     assert line['streamk_timeouts'] == 0   # two ranks time-slicing one card: every stream-K partner still arrived
     # the exchange detection.init(distributed=True) runs: heads' ring first and from a hook (under the tail's backward), zero-copy
     assert line['exchange']['start_order'] == [0, 1] and 0 in line['exchange']['started_early'] and line['exchange']['heads_copied'] == 0
+    # ... and the line explains itself: per bucket the ring's start -> join time and how long the join stalled (device events)
+    ex = line['exchange']
+    assert len(ex['buckets']) == 2 and ex['buckets'][0]['bytes'] == 36046848 and ex['recovered_steps'] == 0
+    assert all(t is not None and t >= 0.0 for t in ex['exposed_ms']) and all(t is not None and t > 0.0 for t in ex['ring_ms'])
+    assert all(e <= r + 1e-3 for e, r in zip(ex['exposed_ms'], ex['ring_ms']))
 
 
 def test_hot_path_scopes_its_process_wide_switches():
