@@ -596,3 +596,21 @@ def test_training_step_hands_the_loss_row_mask_to_the_heads():
         scale = float(q.grad.abs().max()) + 1e-12
         assert float((p.grad - q.grad).abs().max()) <= 1e-4 * scale, (i, tuple(p.shape))
 
+
+def test_split_heads_step_captures_into_a_hip_graph():
+    """Regression guard for the abort of round 4 (hipStreamEndCapture crashed while capturing the split-heads step: a reference cycle kept
+    earlier steps' default-stream AccumulateGrad nodes alive): two eager split steps, two warm-up steps on the capture stream, capture,
+    one replay, in a child process (a crash there is a failed test, not a dead test run); the replayed step -- the fifth from the
+    initial state -- has the loss of the fifth single-stream eager step from the same state."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(repo, 'tests', 'capture_split_worker.py')], cwd=repo, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.returncode, out.stderr[-2000:])
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert res['timeouts'] == 0
+    # the split only re-orders launches: eager split steps follow the single-stream ones, and the replay is step 5
+    assert all(abs(a - b) <= 2e-4 * abs(b) for a, b in zip(res['eager'], res['ref'][:2])), res
+    assert abs(res['replay'] - res['ref'][4]) <= 2e-4 * abs(res['ref'][4]), res
