@@ -313,7 +313,11 @@ int ssdk_streamk_poisoned(void);
 /* TEST HOOK (fault injection, process-wide, synchronises the device): the stream-K workgroup with range index `drop_workgroup` never
  * raises its flag (-1: none), and an owner gives up after `spin_limit` polls (0: the default 2^22).  Used by
  * tests/streamk_fault_worker.py in a child process; never by the product path. */
-int ssdk_debug_streamk_fault(int drop_workgroup, unsigned spin_limit);
+int ssdk_debug_streamk_fault(int drop_workgroup, unsigned spin_limit);   /* refused (-3) unless SSDK_ENABLE_FAULT_INJECTION=1 is in the environment */
+/* Recovery after SSDK_E_STREAMK_TIMEOUT (e.g. a trainer that goes back to a checkpoint inside the process): synchronises `stream`, clears
+ * the flags and the timeout counter of this ssdk_heads_fwd / ssdk_conv2d_fwd_ws workspace and the process-wide sticky word, so that
+ * ssdk_heads_fwd runs again and captured graphs replay healthy launches.  The outputs of the step that timed out are lost (NaN). */
+int ssdk_streamk_reset(void* workspace, size_t workspace_bytes, void* stream);
 /* TEST HOOK: byte offsets, inside the workspace of ssdk_heads_bwd / ssdk_heads_bwd_ex, of the intermediates the ordered anchor-row backward
  * keeps for level `level` (fp32 mode): out[0..7] = ga (rows [type][B*H*W][Jpad]), T (rows [row][9*Cin]), aidx (int [type][B*H*W]: T row or -1),
  * apix (int [type][B*H*W]: pixel of row r), acounts (int[16]: rows per type), plan (int[34]: first T row per type, then first 128-row

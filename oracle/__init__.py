@@ -50,6 +50,11 @@ def max_threads():
     return lib().orc_max_threads()
 
 
+def set_threads(n):
+    """OpenMP threads of the oracle's parallel loops from now on (bench.py's cpu_baseline probes {16, 32, 64, 128})."""
+    lib().orc_set_threads(C.c_int(int(n)))
+
+
 def pack_gt(gt_list, stride=None):
     """list[B] of [G_i, >=6] -> (rows [sum G, stride] f32, offsets int32 [B+1])."""
     stride = stride or max([6] + [g.shape[1] for g in gt_list if g.size])

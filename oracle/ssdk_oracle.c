@@ -34,6 +34,15 @@ int orc_max_threads(void) {
     return 1;
 #endif
 }
+/* bench.py's cpu_baseline probes the thread count (an oversubscribed OpenMP pool made the oracle leg wander 16x between boxes) */
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 
 /* torch.max / torch.min propagate NaN */
 static inline float tmaxf(float a, float b) { return (a > b || a != a) ? a : b; }

@@ -72,6 +72,7 @@ _SIGNATURES = {
     'ssdk_heads_fwd_timeouts': (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     'ssdk_streamk_poisoned': (C.c_int, []),
     'ssdk_debug_streamk_fault': (C.c_int, [C.c_int, C.c_uint]),
+    'ssdk_streamk_reset': (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     'ssdk_box_to_corners': (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
     'ssdk_box_to_centroids': (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]),
     'ssdk_box_area': (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
@@ -290,6 +291,17 @@ def streamk_poisoned():
     """True once a stream-K launch of this process has given up on a parked partial tile (the sticky pinned-host word; no
     synchronisation): every later head GEMM on that workspace, eager or replayed from a HIP graph, stores NaN."""
     return bool(lib().ssdk_streamk_poisoned())
+
+
+def streamk_reset():
+    """Recovery after a stream-K timeout: clears every ssdk_heads_fwd workspace this process made and the sticky host word
+    (``ssdk_streamk_reset``; synchronises their streams).  The step that timed out is lost; later steps and replays are healthy again."""
+    import torch
+    for (dev, tag, stream), buf in list(_scratch.items()):
+        if tag != STREAMK_TAG:
+            continue
+        with torch.cuda.device(dev):
+            check(lib().ssdk_streamk_reset(C.c_void_p(buf.data_ptr()), buf.numel(), C.c_void_p(stream)), 'ssdk_streamk_reset')
 
 
 def streamk_timeouts():

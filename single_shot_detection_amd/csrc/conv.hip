@@ -3261,7 +3261,27 @@ extern "C" int ssdk_streamk_poisoned(void) {
     return (g_sk_host_err && *static_cast<volatile unsigned*>(g_sk_host_err) != 0u) ? 1 : 0;
 }
 
+// Recovery (a trainer that restarts from a checkpoint inside the process): clears the workspace's flags and timeout counter and the
+// process-wide sticky host word.  Synchronises the stream first: nothing of an earlier launch may still be polling or parking.
+// HIP graphs captured before the fault replay healthy launches again (the kernel reads the counter at entry).
+extern "C" int ssdk_streamk_reset(void* workspace, size_t workspace_bytes, void* stream) {
+    SSDK_REQUIRE(workspace && workspace_bytes >= ssdk_heads_fwd_workspace_bytes(), SSDK_E_WORKSPACE,
+                 "ssdk_streamk_reset: the workspace of ssdk_heads_fwd (ssdk_heads_fwd_workspace_bytes() bytes) is required");
+    SSDK_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    Carver c(workspace);
+    c.take<float>((size_t)(kStreamKWgs + 1) * (4 * kMaxTN * 4 * 64 * 4));
+    unsigned* flags = c.take<unsigned>((size_t)kStreamKWgs + 2);
+    SSDK_CHECK_HIP(zero_async(flags, ((size_t)kStreamKWgs + 2) * sizeof(unsigned), (hipStream_t)stream));
+    SSDK_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (g_sk_host_err) *static_cast<volatile unsigned*>(g_sk_host_err) = 0u;
+    return SSDK_OK;
+}
+
+// (fault injection is honoured only when the process asked for it: SSDK_ENABLE_FAULT_INJECTION=1 in the environment -- the two device
+// globals it sets are read by every stream-K launch)
 extern "C" int ssdk_debug_streamk_fault(int drop_workgroup, unsigned spin_limit) {
+    const char* en = getenv("SSDK_ENABLE_FAULT_INJECTION");
+    SSDK_REQUIRE(en && atoi(en) != 0, SSDK_E_UNSUPPORTED, "ssdk_debug_streamk_fault: fault injection is off (set SSDK_ENABLE_FAULT_INJECTION=1: tests only)");
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_sk_drop_wg), &drop_workgroup, sizeof(int));
     if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_sk_spin_limit), &spin_limit, sizeof(unsigned));
     SSDK_REQUIRE(e == hipSuccess, (int)e, "ssdk_debug_streamk_fault: %s", hipGetErrorString(e));

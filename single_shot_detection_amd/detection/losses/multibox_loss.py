@@ -102,7 +102,7 @@ class _MultiboxLossFn(torch.autograd.Function):
                    'ssdk_multibox_loss_bwd')
         if row_mask is not None:
             from ..modules import heads as heads_mod
-            heads_mod.gradient_row_hint = heads_mod.RowHint(dscores, dlocs, row_mask)
+            heads_mod.set_row_hint(dscores, dlocs, row_mask)
         return dscores, dlocs, None, None, None
 
 

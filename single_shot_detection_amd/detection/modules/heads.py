@@ -4,6 +4,8 @@ One autograd function covers every pyramid level: it launches one implicit-GEMM 
 into the concatenated ``scores [B, A*C]`` / ``locs [B, A*4]`` buffers (no permute / contiguous / cat), and its
 backward produces the source-map gradients, the weight gradients and the bias gradients per level.
 """
+import threading
+
 import torch
 
 from ... import _lib
@@ -60,14 +62,19 @@ class RowHint(object):
         self.mask = mask   # uint8 [B, A]: 0 = the anchor's dscores and dlocs rows are zeros
 
 
-gradient_row_hint = None
+_hint_slot = threading.local()   # per autograd thread (torch runs one per device): threads cannot consume one another's hint
 row_hints_taken = 0   # (tests / diagnostics: heads backward calls that ran with a producer's row mask)
+
+
+def set_row_hint(dscores, dlocs, mask):
+    """Called by the producer of the heads' upstream gradient inside its backward (MultiboxLoss): ``mask`` uint8 [B, A], 0 = the anchor's
+    rows of ``dscores`` / ``dlocs`` are zeros."""
+    _hint_slot.hint = RowHint(dscores, dlocs, mask)
 
 
 def take_row_hint(dscores, dlocs):
     """The row mask for exactly these gradient tensors in this backward pass, or None; the hint is consumed either way."""
-    global gradient_row_hint
-    h, gradient_row_hint = gradient_row_hint, None
+    h, _hint_slot.hint = getattr(_hint_slot, 'hint', None), None
     if h is None or dscores is None or dlocs is None or h.task != torch._C._current_graph_task_id():
         return None
     if h.key != (dscores.data_ptr(), dscores._version, tuple(dscores.shape), dlocs.data_ptr(), dlocs._version, tuple(dlocs.shape)):
@@ -244,7 +251,7 @@ class _HeadsShared(object):
     """What the parts of one split heads call share: the output rows while the forward pass runs (dropped once the join has handed them
     on: the join node's outputs would otherwise keep the autograd graph alive through this object), and in the backward pass the
     gradient rows the join received."""
-    __slots__ = ('scores', 'locs', 's_tot', 'l_tot', 'dscores', 'dlocs', 'join_event', 'join_stream', 'pending', 'first_done', 'order', 'row_mask')
+    __slots__ = ('scores', 'locs', 's_tot', 'l_tot', 'dscores', 'dlocs', 'join_event', 'join_stream', 'pending', 'first_done', 'order', 'row_mask', 'parts_left')
 
     def __init__(self, scores, locs):
         self.scores, self.locs = scores, locs
@@ -254,6 +261,7 @@ class _HeadsShared(object):
         self.first_done = None   # backward: event behind the part that ran first (order = True: the other part waits for it)
         self.order = False
         self.row_mask = None     # backward: the gradient producer's row mask (take_row_hint), for every part
+        self.parts_left = 0      # backward: parts that have not run yet in this pass (the last one drops the gradient rows)
 
 
 class _HeadsPartFn(torch.autograd.Function):
@@ -292,6 +300,9 @@ class _HeadsPartFn(torch.autograd.Function):
         if sh.order and sh.first_done is None:
             sh.first_done = torch.cuda.Event()
             sh.first_done.record(cur)
+        sh.parts_left -= 1
+        if sh.parts_left <= 0:   # the gradient rows (88 MB at SSD-300, batch 32) are not held until the graph is freed
+            sh.dscores = sh.dlocs = sh.row_mask = None
         return (None, None, None, None) + tuple(out)
 
 
@@ -315,6 +326,8 @@ class _HeadsJoinFn(torch.autograd.Function):
         sh = ctx.shared
         s_shape, l_shape, dev = ctx.meta
         sh.row_mask = take_row_hint(dscores, dlocs)
+        sh.first_done = None      # (a second backward pass through a retained graph orders its parts on its OWN event)
+        sh.parts_left = ctx.n
         sh.dscores = torch.zeros(s_shape, dtype=torch.float32, device=dev) if dscores is None else dscores.float().contiguous()
         sh.dlocs = torch.zeros(l_shape, dtype=torch.float32, device=dev) if dlocs is None else dlocs.float().contiguous()
         sh.join_stream = torch.cuda.current_stream()

@@ -328,6 +328,22 @@ def _transposed_weights_of(weight, stride):
     return ent[3]
 
 
+def _forget_all_transposed_weights(*_args, **_kwargs):
+    """Global optimizer-step post hook: EVERY prepared layout is dropped when any optimizer has stepped.  An entry normally lives from
+    ``prepare_weight_transposes`` to the backward pass of the same step, which forgets it; but a forward pass without a backward pass, or a
+    backward pass that raised, leaves it behind, and a fused optimizer step changes the weights without bumping ``_version`` -- a later
+    forward pass that does not prepare again would then multiply with the old step's weights (advisor, round 4)."""
+    _wt_cache.clear()
+
+
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg
+    _reg(_forget_all_transposed_weights)
+    del _reg
+except ImportError:   # (an older torch: the per-backward forgetting and the version / data_ptr key are what is left)
+    pass
+
+
 def _forget_transposed_weights(weight):
     """A prepared layout serves ONE backward pass (the one of the forward pass prepare_weight_transposes preceded): an optimizer step comes
     next, and a fused one leaves no trace in the parameter's version counter."""

@@ -64,6 +64,14 @@ def main():
         res['eager_raises'] = False
     except (ValueError, _lib.SsdkError):
         res['eager_raises'] = True
+    # recovery: ssdk_streamk_reset clears the workspace and the sticky word -- eager calls and the SAME captured graph are healthy again
+    _lib.streamk_reset()
+    res['poisoned_after_reset'] = _lib.streamk_poisoned()
+    res['timeouts_after_reset'] = _lib.streamk_timeouts()
+    out2 = g()
+    torch.cuda.synchronize()
+    res['replay_after_reset_equals_healthy'] = bool(torch.equal(out2, healthy))
+    res['eager_after_reset_equals_healthy'] = bool(torch.equal(step(), healthy))
     json.dump(res, open(out_path, 'w'))
 
 

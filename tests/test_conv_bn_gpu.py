@@ -684,6 +684,39 @@ def test_prepared_weight_transposes_follow_a_fused_optimizer_step():
         opt.step()   # (moves the weights by half their gradient: a stale layout is off by far more than the bound)
 
 
+def test_prepared_weight_transposes_do_not_survive_an_optimizer_step():
+    """Advisor (round 4): a prepared layout that no backward pass consumed (forward with grad enabled, then no backward) must not serve a
+    LATER step's backward pass once a fused optimizer step has changed the weights without bumping ``_version`` -- every optimizer step
+    drops all prepared layouts (ops._forget_all_transposed_weights); the next backward re-lays out its own weights."""
+    import torch.nn.functional as F
+    from single_shot_detection_amd import ops
+    from single_shot_detection_amd.bf.modules.conv import Conv2dBn
+    torch.manual_seed(5)
+    tail = torch.nn.Sequential(Conv2dBn(64, 32, kernel_size=1, bias=False, use_bn=False, activation_params=None)).cuda()
+    tail = tail.to(memory_format=torch.channels_last).train()
+    try:
+        opt = torch.optim.SGD(tail.parameters(), lr=0.5, fused=True)
+    except (TypeError, RuntimeError, ValueError):
+        pytest.skip('no fused SGD in this torch build')
+    x = torch.randn((2, 64, 9, 9), device='cuda').contiguous(memory_format=torch.channels_last)
+    xi = x.clone().requires_grad_(True)
+    tail(xi).sum().backward()                  # gives the weights a gradient
+    assert ops.prepare_weight_transposes(tail) == 1
+    tail(x.clone().requires_grad_(True))       # a forward pass with grad enabled and NO backward pass: the prepared layout stays behind
+    assert len(ops._wt_cache) == 1
+    opt.step()                                 # fused: the weights change, their version counter does not
+    assert len(ops._wt_cache) == 0
+    xi = x.clone().requires_grad_(True)
+    y = tail(xi)                               # (no prepare_weight_transposes in front of this forward pass)
+    g = torch.randn(y.shape, device='cuda')
+    y.backward(g)
+    w0 = tail[0].conv.weight.detach().cpu().contiguous()
+    xc = x.cpu().contiguous().requires_grad_(True)
+    F.conv2d(xc, w0).backward(g.cpu())
+    scale = float(xc.grad.abs().max())
+    assert float((xi.grad.cpu() - xc.grad).abs().max()) <= 2e-5 * scale
+
+
 @pytest.mark.parametrize('B,C,H', [(2, 1024, 64), (3, 40, 5), (1, 128, 17), (4, 256, 2), (2, 64, 1)])
 def test_global_avg_pool_and_sigmoid_gate_vs_torch(B, C, H):
     """ops.global_avg_pool / ops.sigmoid_gate (M2Det SFAM, bf/modules/features.py:290-298) against torch on shapes that exercise the

@@ -507,13 +507,20 @@ def test_streamk_timeout_is_loud_in_graph_replays(tmp_path):
     import sys
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'streamk_fault_worker.py')
     out = os.path.join(str(tmp_path), 'fault.json')
-    r = subprocess.run([sys.executable, worker, out], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, worker, out], capture_output=True, text=True, timeout=600, env=dict(os.environ, SSDK_ENABLE_FAULT_INJECTION='1'))
     assert r.returncode == 0, r.stderr[-2000:]
     res = json.load(open(out))
     assert res['healthy_finite'] and not res['healthy_poisoned']
     assert res['nan_in_faulted_replay'] > 0 and res['untouched_rows_equal'], res
     assert res['poisoned_after_fault'] and res['timeouts'] >= 1, res
     assert res['graphed_callable_raises'] and res['all_nan_in_later_replay'] and res['eager_raises'], res
+    # ssdk_streamk_reset: the process recovers without a restart (advisor, round 4)
+    assert not res['poisoned_after_reset'] and res['timeouts_after_reset'] == 0, res
+    assert res['replay_after_reset_equals_healthy'] and res['eager_after_reset_equals_healthy'], res
+    # ... and the fault hook itself is refused unless the process asked for fault injection
+    from single_shot_detection_amd import _lib
+    if not os.environ.get('SSDK_ENABLE_FAULT_INJECTION'):
+        assert _lib.lib().ssdk_debug_streamk_fault(-1, 0) == -3
 
 
 @pytest.mark.parametrize('levels,C,B,density', [(SSD300_LEVELS, 81, 2, 0.05), (SSD300_LEVELS, 21, 2, 1.0), ([(24, 7, 3), (40, 5, 5)], 7, 3, 0.4),
@@ -619,7 +626,7 @@ def test_heads_backward_with_a_row_mask_equals_the_full_scan(cfg_name, batch):
             @staticmethod
             def backward(ctx, g):
                 ds, dl = gs.clone(), gl.clone()
-                heads_mod.gradient_row_hint = heads_mod.RowHint(ds, dl, mask)
+                heads_mod.set_row_hint(ds, dl, mask)
                 return ds, dl
         got = torch.autograd.grad(Producer.apply(scores, locs), xs + params, retain_graph=True)
         assert heads_mod.row_hints_taken == taken + 1
@@ -636,7 +643,7 @@ def test_heads_backward_with_a_row_mask_equals_the_full_scan(cfg_name, batch):
         @staticmethod
         def backward(ctx, g):
             ds, dl = gs.clone(), gl.clone()
-            heads_mod.gradient_row_hint = heads_mod.RowHint(ds, dl, torch.zeros((batch, A), dtype=torch.uint8, device='cuda'))   # (an all-zero mask: taking it would lose everything)
+            heads_mod.set_row_hint(ds, dl, torch.zeros((batch, A), dtype=torch.uint8, device='cuda'))   # (an all-zero mask: taking it would lose everything)
             return ds, dl
     total = Producer2.apply(scores, locs) + 1e-3 * scores.sum()
     got = torch.autograd.grad(total, xs + params, retain_graph=True)
