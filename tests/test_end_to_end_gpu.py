@@ -58,7 +58,6 @@ def test_ssd300_step_fn_train_and_eval():
     for h in hooks:
         h.remove()
     scores, locs = prediction
-    priors = detector.generate_anchors(imgs.to(dev), [taps[32], taps[42]] + [None] * 0) if False else None
     assert scores.shape == (B, 8108 * 21) and locs.shape == (B, 8108 * 4)      # A = 8108
     assert np.isfinite(loss.item()) and abs(state['loss'] - loss.item()) < 1e-4
 
@@ -73,9 +72,20 @@ def test_ssd300_step_fn_train_and_eval():
     for src, head in zip(sources, detector.predictor.heads):
         ref_s.append(F.conv2d(src, head['score'].weight.detach().cpu().contiguous(), head['score'].bias.detach().cpu(), padding=1).permute(0, 2, 3, 1).reshape(B, -1))
         ref_l.append(F.conv2d(src, head['loc'].weight.detach().cpu().contiguous(), head['loc'].bias.detach().cpu(), padding=1).permute(0, 2, 3, 1).reshape(B, -1))
+    # The two levels fed by the backbone taps are ONE convolution away from the reference's inputs: held to the fp32 bound of a K = 9 * 512
+    # sum (2e-6 * sqrt(K), as tests/test_heads_gpu.py).  The four tail levels sit behind up to eight train-mode BatchNorms whose
+    # statistics are taken over B * H * W = 2 * (9^2 .. 1^2) rows: a last-bit difference in a convolution sum is divided by sqrt(var + eps)
+    # of as few as two values per channel (the 1 x 1 level), layer after layer -- rtol 1e-3 / atol 2e-3 is what that chain is held to here;
+    # block by block the same arithmetic is pinned to 2e-5 by tests/test_blocks_golden_gpu.py (reference-generated goldens).
+    n0 = [h * h * 4 * 21 for h in (37,)][0] + 18 * 18 * 6 * 21
+    l0 = 37 * 37 * 4 * 4 + 18 * 18 * 6 * 4
+    got_s, got_l = scores.cpu().numpy(), locs.cpu().numpy()
+    tight = 2e-6 * np.sqrt(9 * 512)
+    np.testing.assert_allclose(got_s[:, :n0], torch.cat(ref_s, 1).numpy()[:, :n0], rtol=1e-5, atol=tight * float(np.abs(torch.cat(ref_s, 1).numpy()[:, :n0]).max() + 1))
+    np.testing.assert_allclose(got_l[:, :l0], torch.cat(ref_l, 1).numpy()[:, :l0], rtol=1e-5, atol=tight * float(np.abs(torch.cat(ref_l, 1).numpy()[:, :l0]).max() + 1))
     ref_s, ref_l = torch.cat(ref_s, 1).numpy(), torch.cat(ref_l, 1).numpy()
-    np.testing.assert_allclose(scores.cpu().numpy(), ref_s, rtol=1e-3, atol=2e-3)
-    np.testing.assert_allclose(locs.cpu().numpy(), ref_l, rtol=1e-3, atol=2e-3)
+    np.testing.assert_allclose(got_s, ref_s, rtol=1e-3, atol=2e-3)
+    np.testing.assert_allclose(got_l, ref_l, rtol=1e-3, atol=2e-3)
 
     cfg = syn.CONFIGS['ssd_300_vgg16_voc']
     anchors = oracle.anchors(cfg['anchor'], 300, cfg['levels'])
@@ -92,16 +102,19 @@ def test_ssd300_step_fn_train_and_eval():
     # ---- eval phase: list of [K,6] detections, checked against the oracle on the same logits ---------------------
     detector.eval()
     with torch.no_grad():
+        # (freshly initialised score heads give 21 near-equal probabilities per anchor: thousands of candidates whose ORDER is decided by
+        # the last ulp of an exp(), and greedy NMS follows the order -- no checker can pin that.  Spread the logits like a trained head's.)
+        for h in detector.predictor.heads:
+            h['score'].weight.mul_(60.0)
         loss_e, dets, state = step_fn(1, 'eval', (imgs, gt), state)
         s_e, l_e, pri = detector(imgs.to(dev))
     assert np.array_equal(pri.cpu().numpy().view(np.uint32), anchors.view(np.uint32))
     ref = oracle.postprocess(s_e.cpu().numpy(), l_e.cpu().numpy(), anchors, softmax=True, nms_thr=0.45)
-    assert len(dets) == B
-    for d, r in zip(dets, ref):
-        assert d.shape[1] == 6 and abs(d.shape[0] - r.shape[0]) <= 1
-        n = min(d.shape[0], r.shape[0])
-        if n:
-            np.testing.assert_allclose(np.sort(d.cpu().numpy()[:n, 5]), np.sort(r[:n, 5]), rtol=1e-4, atol=1e-6)
+    assert len(dets) == B and all(d.shape[1] == 6 for d in dets)
+    # row by row (class ids exact, scores 1e-5 relative, boxes 1e-4), a row may differ only on a selection boundary: the strict checker of
+    # tests/test_postprocess_gpu.py
+    from test_postprocess_gpu import Boundaries, compare
+    compare(dets, ref, boundaries=Boundaries(s_e.cpu().numpy(), 21, True))
 
     # predict_single surface (detector_wrapper.py:49-65) without a preprocess pipeline
     wrapper.preprocess = None
@@ -385,14 +398,19 @@ def test_graphed_training_steps_match_eager_ones(cfg_name, batch):
     assert step.scratch_allocated_in_capture == 0   # (nor is the stream-K workspace's zero-fill a node of the graph)
     for _ in range(3):
         eager.train_step()
+    start = [q.detach().clone() for q in params(eager)]
     for k in range(4):
         loss_e = eager.train_step()
         loss_g = step()
         torch.cuda.synchronize()
         assert abs(float(loss_e.detach()) - float(loss_g.detach())) <= 2e-4 * abs(float(loss_e.detach())) + 1e-6, (k, float(loss_e.detach()), float(loss_g.detach()))
-        for p, q in zip(params(graphed), params(eager)):
+        for p, q, q0 in zip(params(graphed), params(eager), start):
+            # 0.2 % of the parameter's size, plus 5 % of how far these steps have moved it: the default mode's atomics (legacy heads,
+            # split-K tail) retire in another order in a replay, and a parameter of size 2e-4 (a bias that started at 0) is all update --
+            # seen once at 1.3 % of it; a dead or stale graph node is off by the whole update.  Bit-for-bit: the deterministic-mode test.
             scale = float(q.detach().abs().max()) + 1e-12
-            assert float((p.detach() - q.detach()).abs().max()) <= 2e-3 * scale, k
+            moved = float((q.detach() - q0).abs().max())
+            assert float((p.detach() - q.detach()).abs().max()) <= 2e-3 * scale + 5e-2 * moved, k
 
 
 def _hot_path_state(hp):
