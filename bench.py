@@ -525,6 +525,95 @@ def train_graph_legs(device, cases=(('ssd_300_vgg16_voc', 32), ('ssd_mb2_voc', 2
     return out
 
 
+def step_fn_legs(device, cases=(('ssd_300_vgg16_voc_c21', 21, 32), ('ssd_300_vgg16_voc', 81, 2)), reps=20):
+    """The product API itself: detection.init(...) -> step_fn(step, 'train', (imgs, ground truth), state), loss.backward(), SGD on the
+    predictor's head-side parameters -- eager, and with graph_hot_path=True (the libssdk part of the step replayed from two HIP graphs
+    behind the eager PyTorch backbone).  The stand-in VGG16-BN backbone is excluded from the hot-path figure by device events around the
+    segment's two replays (graphs.GraphedSegment.collect_timing: input copies + forward graph; upstream gradient + backward graph +
+    gradient hand-over); ``hot_ms`` = forward + backward + the fused SGD step on those parameters, to be read against
+    ``graph_replay_ms_per_step`` of the same configuration (the whole bench step captured as one graph, per_config / train_graph)."""
+    from single_shot_detection_amd.detection import init as det_init
+    out = []
+    for cfg_name, ncls, b in cases:
+        cfg = syn.CONFIGS[cfg_name if cfg_name in syn.CONFIGS else 'ssd_300_vgg16_voc']
+        model = {'base': {'name': 'torchvision_vgg16_bn', 'pretrained': False},
+                 'detector': {'num_classes': ncls, 'use_depthwise': False,
+                              'features': {'name': 'Features', 'out_layers': (32, 42), 'last_feature_layer': 42},
+                              'extras': {'layers': (('s', 512), ('s', 256), ('s', 256), ('s', 256))}},
+                 'anchor_generator': dict(cfg['anchor'])}
+        args = ({'xy_scale': 10.0, 'wh_scale': 5.0},
+                {'score_threshold': .01, 'max_total': 200, 'nms': {'max_per_class': 100, 'overlap_threshold': .45}, 'score_converter': 'SOFTMAX'},
+                {'classification_loss': {'name': 'CrossEntropyLoss'}, 'localization_loss': {'name': 'SmoothL1Loss'},
+                 'classification_weight': 1.0, 'localization_weight': 1.0},
+                {'name': 'hard_negative_mining', 'negative_per_positive_ratio': 3, 'min_negative_per_image': 5},
+                {'matched_threshold': 0.5, 'unmatched_threshold': 0.5})
+        imgs = torch.randn((b, 3, cfg['size'], cfg['size']), device=device)
+        gt = [torch.from_numpy(g) for g in syn.make_ground_truth(b, cfg['size'], ncls, seed=1)]
+        res = {'config': cfg_name, 'batch': b}
+        for graphed in (False, True):
+            torch.manual_seed(0)
+            wrapper, init_state, step_fn = det_init.init(device, model, *args, graph_hot_path=graphed)
+            det = wrapper.model
+            det.train()
+            hot_params = [p for n, p in det.predictor.named_parameters() if not n.startswith('features.')]
+            opt = torch.optim.SGD(hot_params, lr=1e-4, momentum=0.9, fused=True)
+            state = init_state()
+
+            def one(k):
+                opt.zero_grad(set_to_none=True)
+                det.zero_grad(set_to_none=True)
+                loss, _, st = step_fn(k, 'train', (imgs, gt), state)
+                loss.backward()
+                opt.step()
+            for k in range(4):
+                one(k)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(reps):
+                one(k)
+            torch.cuda.synchronize()
+            res['graphed_step_fn_ms' if graphed else 'eager_step_fn_ms'] = (time.perf_counter() - t0) / reps * 1e3
+            if graphed:
+                seg = next(iter(step_fn.hot_segments.values())).segment
+                seg.collect_timing = True
+                fwd, bwd, sgd = [], [], []
+                for k in range(reps):
+                    opt.zero_grad(set_to_none=True)
+                    det.zero_grad(set_to_none=True)
+                    loss, _, st = step_fn(k, 'train', (imgs, gt), state)
+                    loss.backward()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    opt.step()
+                    e1.record()
+                    f, w = seg.read_timing()
+                    e1.synchronize()
+                    fwd.append(f); bwd.append(w); sgd.append(e0.elapsed_time(e1))
+                res['hot_forward_ms'], res['hot_backward_ms'], res['hot_sgd_ms'] = (float(np.median(v)) for v in (fwd, bwd, sgd))
+                res['hot_ms'] = res['hot_forward_ms'] + res['hot_backward_ms'] + res['hot_sgd_ms']
+            del wrapper, step_fn, det, opt
+            torch.cuda.empty_cache()
+        # the bench's own step of the same configuration, captured whole
+        from single_shot_detection_amd.detection.target_assigner import PackedGroundTruth
+        from single_shot_detection_amd.graphs import GraphedCallable
+        hp = HotPath(cfg_name, b, device)
+        hp.gt = PackedGroundTruth.from_list(hp.gt, device)
+        g = GraphedCallable(hp.train_step, [])
+        for _ in range(3):
+            g()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            g()
+        torch.cuda.synchronize()
+        res['graph_replay_ms_per_step'] = (time.perf_counter() - t0) / reps * 1e3
+        res['hot_over_replay'] = res['hot_ms'] / res['graph_replay_ms_per_step']
+        out.append(res)
+        del hp, g
+        torch.cuda.empty_cache()
+    return out
+
+
 PEAK_BF16_MATRIX_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA (the 5 PF headline figure includes 2:1 sparsity)
 
 
@@ -731,6 +820,7 @@ def main():
                     help='N > 1: synchronise the pyramid tail\'s BatchNorm statistics over the ranks (detection/init.py:85 convert_syncbn_model); '
                          'default is local statistics, the documented local-BN mode of SURVEY.md 8e')
     ap.add_argument('--fast-mode-only', action='store_true', help='print only the fast_mode block (opt-in split-bf16 head GEMM), N = 1')
+    ap.add_argument('--step-fn-only', action='store_true', help='print only the step_fn block (detection.init with and without graph_hot_path), N = 1')
     ap.add_argument('--rendezvous-only', action='store_true',
                     help='ranks form the process group, all-reduce their rank numbers, rank 0 prints a JSON line; no GPU work (launcher test)')
     args = ap.parse_args()
@@ -777,6 +867,9 @@ def main():
 
     if args.fast_mode_only:
         print(json.dumps({'fast_mode': fast_mode_legs(device, args.config, args.batch)}), flush=True)
+        return
+    if args.step_fn_only:
+        print(json.dumps({'step_fn': step_fn_legs(device)}), flush=True)
         return
     hp = HotPath(args.config, args.batch, device)
     bn_modules = [m for m in (hp.extras, hp.tower, hp.neck) if m is not None]
@@ -906,6 +999,7 @@ def main():
             out['per_config'] = per_config_legs(device)
             out['serving'] = serving_legs(device)
             out['train_graph'] = train_graph_legs(device)
+            out['step_fn'] = step_fn_legs(device)
             out['fast_mode'] = fast_mode_legs(device)
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(hp)

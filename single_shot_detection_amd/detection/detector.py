@@ -32,6 +32,11 @@ class Predictor(nn.Module):
                 list of the source maps the loc heads ran on (for anchor generation, detector.py:74)
         """
         sources, x = self.features(img)
+        return self.forward_from_taps(list(sources), x)
+
+    def forward_from_taps(self, sources, x):
+        """Everything behind the backbone (detector.py:39-66): pyramid tail, optional predictor tower, heads.  ``sources``: the backbone's
+        tapped maps, ``x``: its last map (the tail's input).  This is the part ``detection.init(graph_hot_path=True)`` captures."""
         sources = list(sources)
         if self.training and len(self.extras):
             ops.prepare_weight_transposes(self.extras)   # one re-layout launch for the whole tail's backward instead of one per layer

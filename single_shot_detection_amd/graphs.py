@@ -69,3 +69,120 @@ def graphed_eval(detector, postprocessor, example_images, warmup=3):
             return postprocessor.postprocess_padded((scores, locs), priors)
     return GraphedCallable(step, [example_images], warmup=warmup)
 
+
+
+class GraphedSegment(object):
+    """A differentiable segment of a training step -- ``fn(*inputs) -> (loss, *aux)`` -- captured as TWO HIP graphs (forward; backward of
+    ``loss`` with respect to ``inputs`` and ``params``) and exposed as one autograd node, so that what sits in front of it (a PyTorch
+    backbone) stays eager while the segment costs the host two graph launches instead of ~90 kernel launches.
+
+    ``detection.init(..., graph_hot_path=True)`` puts the libssdk part of a training step in it: pyramid tail + heads forward, target
+    assignment, sampler + multibox loss, and their backward (detection/init.py:108-135 between the backbone and ``loss.backward()``).
+
+    * ``inputs``: example tensors (shapes are fixed); the call copies the real ones into static buffers (the backbone's taps: one device
+      copy per step), the gradients with respect to them are returned to autograd as the static buffers themselves.
+    * ``params``: their gradients are NOT routed through autograd: after the backward replay ``p.grad`` is set to the static gradient
+      buffer (or the buffer is added to an existing ``p.grad``) -- no copy, but the tensor is overwritten by the next step's backward,
+      and parameter hooks do not fire (not for ``distributed=True``).
+    * only ``loss`` (output 0) is differentiable; outputs are static buffers the next call overwrites.
+    * anything else the segment reads (ground truth, anchors) must live in static device buffers the caller refills between calls
+      (``target_assigner.PackedGroundTruth``)."""
+
+    def __init__(self, fn, inputs, params, warmup=2, defer_weight_gradients=True):
+        from . import _lib, ops
+        self.fn = fn
+        self.params = [p for p in params if p.requires_grad]
+        self.static_in = [x.detach().clone().requires_grad_(True) for x in inputs]
+        # ``defer_weight_gradients``: the weight gradients of the segment's single-input convolutions (the pyramid tail) are computed at the
+        # end of the captured backward pass in grouped launches (ops.defer_weight_gradients: 8 launches that each underfill the chip -> 1);
+        # they reach ``param.grad`` directly, which is where this class picks the static buffers up
+        held = [p.grad for p in self.params]
+        for p in self.params:
+            p.grad = None
+        current = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(current)
+        with torch.cuda.stream(side), ops.deferred_weight_gradients(bool(defer_weight_gradients)):
+            # warm-up on the capture stream: every per-stream workspace exists before the capture (see GraphedCallable)
+            for _ in range(warmup):
+                outs = fn(*self.static_in)
+                torch.autograd.grad(outs[0], self.static_in + self.params, allow_unused=True)
+                for p in self.params:
+                    p.grad = None
+            del outs
+        current.wait_stream(side)
+        before = set(_lib._scratch)
+        self.g_fwd, self.g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_fwd, stream=side):
+            self.static_out = tuple(fn(*self.static_in))
+        self.static_gloss = torch.ones_like(self.static_out[0])
+        with torch.cuda.graph(self.g_bwd, stream=side, pool=self.g_fwd.pool()), ops.deferred_weight_gradients(bool(defer_weight_gradients)):
+            grads = torch.autograd.grad(self.static_out[0], self.static_in + self.params, grad_outputs=self.static_gloss, allow_unused=True)
+        self.static_gin = grads[:len(self.static_in)]
+        gparam = list(grads[len(self.static_in):])
+        for i, p in enumerate(self.params):   # deferred gradients: written straight into a fresh p.grad by the captured flush
+            if gparam[i] is None and p.grad is not None:
+                gparam[i] = p.grad
+            p.grad = held[i]
+        self.static_gparam = tuple(gparam)
+        self.scratch_allocated_in_capture = len(set(_lib._scratch) - before)
+        self.stream = side
+        self._anchor = torch.zeros((1,), device=self.static_in[0].device if self.static_in else 'cuda', requires_grad=True)   # (the node exists even when no input requires a gradient)
+        self.collect_timing = False   # bench.py: events around the two replays (incl. the input copies / the gradient hand-over)
+        self._ev = None
+
+    def read_timing(self):
+        """(forward ms, backward ms) of the last call with ``collect_timing`` on; synchronises with its events."""
+        if not self._ev or len(self._ev) < 4:
+            return None
+        self._ev[3].synchronize()
+        return self._ev[0].elapsed_time(self._ev[1]), self._ev[2].elapsed_time(self._ev[3])
+
+    def __call__(self, *inputs):
+        assert len(inputs) == len(self.static_in)
+        return _SegmentFn.apply(self, self._anchor, *inputs)
+
+
+class _SegmentFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, seg, anchor, *inputs):
+        from . import _lib
+        if _lib.streamk_poisoned():
+            raise _lib.SsdkError('GraphedSegment: an earlier stream-K head GEMM of this process gave up waiting for a parked partial tile -- see _lib.streamk_timeouts()')
+        if seg.collect_timing:
+            seg._ev = [torch.cuda.Event(enable_timing=True)]
+            seg._ev[0].record()
+        for dst, src in zip(seg.static_in, inputs):
+            if dst.shape != src.shape or dst.dtype != src.dtype:
+                raise ValueError('GraphedSegment: captured for %s %s, called with %s %s' % (tuple(dst.shape), dst.dtype, tuple(src.shape), src.dtype))
+            dst.detach().copy_(src, non_blocking=True)
+        seg.g_fwd.replay()
+        if seg.collect_timing:
+            seg._ev.append(torch.cuda.Event(enable_timing=True))
+            seg._ev[1].record()
+        ctx.seg = seg
+        ctx.n_in = len(inputs)
+        outs = tuple(o.detach() for o in seg.static_out)
+        ctx.mark_non_differentiable(*outs[1:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, gloss, *_unused):
+        seg = ctx.seg
+        timed = seg.collect_timing and seg._ev is not None and len(seg._ev) == 2
+        if timed:
+            seg._ev.append(torch.cuda.Event(enable_timing=True))
+            seg._ev[2].record()
+        seg.static_gloss.copy_(gloss.reshape(seg.static_gloss.shape), non_blocking=True)
+        seg.g_bwd.replay()
+        if timed:   # (before the host-side hand-over below: it launches nothing unless a gradient is accumulated)
+            seg._ev.append(torch.cuda.Event(enable_timing=True))
+            seg._ev[3].record()
+        for p, g in zip(seg.params, seg.static_gparam):
+            if g is None:
+                continue
+            if p.grad is None:
+                p.grad = g.detach()
+            else:
+                p.grad.add_(g)
+        return (None, None) + tuple(None if g is None else g.detach() for g in seg.static_gin)

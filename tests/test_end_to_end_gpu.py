@@ -632,3 +632,71 @@ def test_split_heads_step_captures_into_a_hip_graph():
     # the split only re-orders launches: eager split steps follow the single-stream ones, and the replay is step 5
     assert all(abs(a - b) <= 2e-4 * abs(b) for a, b in zip(res['eager'], res['ref'][:2])), res
     assert abs(res['replay'] - res['ref'][4]) <= 2e-4 * abs(res['ref'][4]), res
+
+
+@pytest.mark.parametrize('model_name', ['ssd300', 'mb2'])
+def test_step_fn_with_graphed_hot_path_equals_the_eager_step_fn(model_name, request):
+    """detection.init(graph_hot_path=True): the libssdk part of the training step (pyramid tail + heads, target assignment, sampler + loss,
+    their backward) replayed from two HIP graphs behind an eager PyTorch backbone (detection/init.py:108-135).  Under ops.deterministic()
+    three steps with different images and ground truth give the same bits as the eager step_fn from the same state: losses, the running
+    means step_fn keeps, and every parameter after SGD -- the backbone's too (its gradients come through the segment's input gradients)."""
+    import copy
+    from single_shot_detection_amd import ops
+    dev = torch.device('cuda:0')
+    if model_name == 'ssd300':
+        model, size, B, ncls = MODEL, 300, 2, 21
+    else:
+        model = MB2
+        size, B, ncls = 300, 2, 21
+    args = ({'xy_scale': 10.0, 'wh_scale': 5.0},
+            {'score_threshold': .01, 'max_total': 200, 'nms': {'max_per_class': 100, 'overlap_threshold': .45}, 'score_converter': 'SOFTMAX'},
+            {'classification_loss': {'name': 'CrossEntropyLoss'}, 'localization_loss': {'name': 'SmoothL1Loss'},
+             'classification_weight': 1.0, 'localization_weight': 1.0},
+            {'name': 'hard_negative_mining', 'negative_per_positive_ratio': 3, 'min_negative_per_image': 5},
+            {'matched_threshold': 0.5, 'unmatched_threshold': 0.5})
+    # (the backbone is stock PyTorch-ROCm: its convolutions must pick the same algorithm in both models for a bit-for-bit comparison --
+    # what the reference asks of cuDNN on every GPU run, bf/training/env.py:74-76)
+    prev_flags = (torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark)
+    torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = True, False
+    request.addfinalizer(lambda: (setattr(torch.backends.cudnn, 'deterministic', prev_flags[0]), setattr(torch.backends.cudnn, 'benchmark', prev_flags[1])))
+    with ops.deterministic():
+        torch.manual_seed(11)
+        w_e, init_e, step_e = det_init.init(dev, copy.deepcopy(model), *copy.deepcopy(args))
+        w_g, init_g, step_g = det_init.init(dev, copy.deepcopy(model), *copy.deepcopy(args), graph_hot_path=True)
+        w_g.model.load_state_dict(w_e.model.state_dict())
+        with torch.no_grad():   # same taps from both backbones?  (checked first: everything below depends on it)
+            probe = torch.randn((B, 3, size, size), device=dev)
+            for _ in range(2):
+                te, tg = w_e.model.predictor.features(probe), w_g.model.predictor.features(probe)
+            assert all(torch.equal(a, b) for a, b in zip(te[0], tg[0])), 'the two PyTorch backbones do not agree bit for bit on this box'
+        opt_e = torch.optim.SGD(w_e.model.parameters(), lr=1e-3, momentum=0.9)
+        opt_g = torch.optim.SGD(w_g.model.parameters(), lr=1e-3, momentum=0.9)
+        w_e.model.train()
+        w_g.model.train()
+        st_e, st_g = init_e(), init_g()
+        rng = np.random.default_rng(31)
+        for k in range(3):
+            imgs = torch.from_numpy(rng.standard_normal((B, 3, size, size), dtype=np.float32))
+            gt = [torch.from_numpy(g) for g in syn.make_ground_truth(B, size, ncls, seed=40 + k)]
+            opt_e.zero_grad(set_to_none=True)
+            opt_g.zero_grad(set_to_none=True)
+            loss_e, pred_e, st_e = step_e(k, 'train', (imgs, gt), st_e)
+            loss_g, pred_g, st_g = step_g(k, 'train', (imgs, gt), st_g)
+            assert torch.equal(pred_e[0], pred_g[0]) and torch.equal(pred_e[1], pred_g[1]), (k, float((pred_e[0] - pred_g[0]).abs().max()), float((pred_e[1] - pred_g[1]).abs().max()))
+            assert float(loss_e.detach()) == float(loss_g.detach()), (k, float(loss_e.detach()), float(loss_g.detach()))
+            assert st_e == st_g, (k, st_e, st_g)
+            loss_e.backward()
+            loss_g.backward()
+            for (n, p), q in zip(w_e.model.named_parameters(), w_g.model.parameters()):
+                assert (p.grad is None) == (q.grad is None), n
+                if p.grad is not None:
+                    assert torch.equal(p.grad, q.grad), (k, n, float((p.grad - q.grad).abs().max()))
+            opt_e.step()
+            opt_g.step()
+        for (n, p), q in zip(w_e.model.named_parameters(), w_g.model.parameters()):
+            assert torch.equal(p, q), n
+        # the eval phase of the same step_fn stays eager
+        w_g.model.eval()
+        with torch.no_grad():
+            _, dets, _ = step_g(0, 'eval', (imgs, gt), init_g())
+        assert len(dets) == B
