@@ -55,6 +55,7 @@ EXTRAS = {'ssd_300_vgg16_voc': (('s', 512), ('s', 256), ('s', 256), ('s', 256)),
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
+ACHIEVABLE_HBM_GBS = 6300.0       # ... and what a streaming kernel reaches on it (same section)
 
 
 def measured_traffic(kernel_key):
@@ -407,10 +408,23 @@ def hbm_legs(device, cfg_name='ssd_300_vgg16_voc', batch=64):
     A, C, B = hp.anchors.shape[0], hp.C, batch
     legs = {}
 
-    def leg(name, us, nbytes, note):
+    # what a kernel boundary costs on this box: dependent one-element launches back to back (device time per launch)
+    one = torch.zeros((1,), device=device)
+
+    def chain():
+        for _ in range(20):
+            one.add_(1.0)
+    boundary_us = gpu_time_us(chain, inner=5) / 20.0
+
+    def leg(name, us, nbytes, note, launches):
+        # floor_us: the larger of (algorithmic bytes at the 6.3 TB/s a streaming kernel reaches on this part, MI355X_MICROARCH.md) and
+        # (the call's dependent launches x the measured boundary): says whether a leg is bandwidth-short or launch-bound
         gbs = nbytes / (us * 1e-6) / 1e9
+        bw_floor = nbytes / ACHIEVABLE_HBM_GBS / 1e9 * 1e6
         legs[name] = {'us': us, 'algorithmic_bytes': nbytes, 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS,
-                      'what': note}
+                      'launches': launches, 'floor_us': max(bw_floor, launches * boundary_us), 'bandwidth_floor_us': bw_floor,
+                      'launch_floor_us': launches * boundary_us, 'bound': 'launch' if launches * boundary_us > bw_floor else 'hbm',
+                      'of_floor': max(bw_floor, launches * boundary_us) / us, 'what': note}
 
     # T1-T3: IoU match + target encode, 41*A bytes per image (anchors 16*A read once per image + 24*A target + mask); ground truth packed once
     # (the packing is host work that runs ahead of the stream), the library call itself is what is timed
@@ -421,15 +435,19 @@ def hbm_legs(device, cfg_name='ssd_300_vgg16_voc', batch=64):
     ews = torch.empty((max(lib.ssdk_encode_ground_truth_workspace_bytes(B, total), 4096),), dtype=torch.uint8, device=device)
     leg('encode_ground_truth', gpu_time_us(lambda: _lib.check(lib.ssdk_encode_ground_truth(
         _lib.ptr(rows), 6, _lib.ptr(offs), B, total, _lib.ptr(hp.anchors), A, 0.5, 0.5, _lib.ptr(tgt), None, _lib.ptr(ews), ews.numel(),
-        _lib.current_stream()), 'encode')), 41.0 * A * B, 'ssdk_encode_ground_truth (IoU + matcher + target rows)')
+        _lib.current_stream()), 'encode')), 41.0 * A * B, 'ssdk_encode_ground_truth (IoU + matcher + target rows): gt_argmax_kernel + assign_kernel', 2)
     logits = torch.from_numpy(syn.make_logits(B, A, C, seed=2)).to(device)
     locs = torch.from_numpy(syn.make_locs(B, A, seed=3, scale=0.5)).to(device)
     trained = logits.clone().view(B, A, C)
-    trained[..., 0] += 6.0
+    if hp.cfg['score_converter'] == 'SOFTMAX':
+        trained[..., 0] += 6.0      # background logit + 6: ~5 % of the (anchor, class) pairs pass the threshold
+    else:
+        trained -= 6.25             # sigmoid scores: the same share of pairs passes (logit(0.01) = -4.6 is 1.65 sigma above the mean)
     trained = trained.view(B, -1)
-    for tag, sc in (('worst_case', logits), ('trained_like', trained)):
+    # launches: sample plan (long lists) select x 2, class bound, NMS head, image bound, NMS tail, merge; short lists: no sample pass, no class bound
+    for tag, sc, launches in (('worst_case', logits, 7), ('trained_like', trained, 5)):
         us = gpu_time_us(lambda: hp.post.postprocess_padded((sc, locs), hp.anchors), inner=5)
-        leg(f'postprocess_{tag}', us, 4.0 * A * (C + 4) * B, 'ssdk_postprocess: score convert + threshold + per-class top-100 + decode + NMS + top-200')
+        leg(f'postprocess_{tag}', us, 4.0 * A * (C + 4) * B, 'ssdk_postprocess: score convert + threshold + per-class top-100 + decode + NMS + top-200', launches)
         legs[f'postprocess_{tag}']['nms_candidates_per_image'] = float(hp.post.last_nms_candidates.sum().item()) / B
     # S1 + L1: sampler (reads the logits once), loss forward, loss backward (writes dscores + dlocs)
     target = hp.assigner.encode_ground_truth(hp.gt, hp.anchors)
@@ -437,9 +455,12 @@ def hbm_legs(device, cfg_name='ssd_300_vgg16_voc', batch=64):
     ws = smp.loss_workspace(B, A, C, device)
     mask = torch.empty((B, A), dtype=torch.uint8, device=device)
     cls_col = target[..., 4]
-    leg('hard_negative_mining', gpu_time_us(lambda: _lib.check(lib.ssdk_hard_negative_mining(
-        _lib.ptr(logits), cls_col.data_ptr(), 6, B, A, C, 3.0, 5, _lib.ptr(mask), _lib.ptr(ws), ws.numel(), _lib.current_stream()), 'hnm')),
-        4.0 * A * C * B, 'ssdk_hard_negative_mining: hnm_rows (log-sum-exp of every row) + hnm_select')
+    if hp.cfg['loss'] == 'ce_hnm':
+        leg('hard_negative_mining', gpu_time_us(lambda: _lib.check(lib.ssdk_hard_negative_mining(
+            _lib.ptr(logits), cls_col.data_ptr(), 6, B, A, C, 3.0, 5, _lib.ptr(mask), _lib.ptr(ws), ws.numel(), _lib.current_stream()), 'hnm')),
+            4.0 * A * C * B, 'ssdk_hard_negative_mining: hnm_rows (log-sum-exp of every row) + hnm_select', 2)
+    else:
+        mask.copy_((cls_col > 0).to(torch.uint8))   # naive_sampler: positives only (sampler.py:9-10)
     params = hp.criterion.loss_params()
     out3 = torch.empty((3,), dtype=torch.float32, device=device)
     tgt2 = target.clone()
@@ -448,14 +469,14 @@ def hbm_legs(device, cfg_name='ssd_300_vgg16_voc', batch=64):
     leg('multibox_loss_fwd', gpu_time_us(lambda: _lib.check(lib.ssdk_multibox_loss_fwd(
         ctypes.byref(params), _lib.ptr(logits), _lib.ptr(locs), _lib.ptr(hp.anchors), _lib.ptr(tgt2), _lib.ptr(mask), B, A, C, 1, _lib.ptr(out3),
         _lib.ptr(ws), ws.numel(), _lib.current_stream()), 'loss_fwd')), (24.0 + 16.0 + 1.0 + 16.0) * A * B,
-        'ssdk_multibox_loss_fwd: target rows + locs + mask in, encoded box columns out (classification term by gather on the sampled rows)')
+        'ssdk_multibox_loss_fwd: target rows + locs + mask in, encoded box columns out (classification term by gather on the sampled rows): loss_fwd_kernel + loss_finalize_kernel', 2)
     dsc, dlo = torch.empty_like(logits), torch.empty_like(locs)
     gout = torch.ones((2,), dtype=torch.float32, device=device)
     leg('multibox_loss_bwd', gpu_time_us(lambda: _lib.check(lib.ssdk_multibox_loss_bwd(
         ctypes.byref(params), _lib.ptr(logits), _lib.ptr(locs), _lib.ptr(hp.anchors), _lib.ptr(tgt2), _lib.ptr(mask), _lib.ptr(gout), B, A, C,
         _lib.ptr(dsc), _lib.ptr(dlo), _lib.ptr(ws), ws.numel(), _lib.current_stream()), 'loss_bwd')), (4.0 * C + 16.0) * A * B,
-        'ssdk_multibox_loss_bwd: writes dscores + dlocs in full')
-    return {'workload': f'{cfg_name} batch {batch}, A={A}, C={C}', 'legs': legs}
+        'ssdk_multibox_loss_bwd: writes dscores + dlocs in full', 1)
+    return {'workload': f'{cfg_name} batch {batch}, A={A}, C={C}', 'kernel_boundary_us': boundary_us, 'legs': legs}
 
 
 PER_CONFIG = (('ssd_300_vgg16_voc', 64), ('ssd_300_vgg16_voc_c21', 32), ('ssd_mb2_voc', 2), ('ssd_512_vgg16_coco', 16),
@@ -996,6 +1017,11 @@ def main():
             out['deterministic'] = deterministic_leg(hp, max(4, args.steps // 2))
             hp.set_training(False)
             out['roofline_hbm'] = hbm_legs(device)
+            torch.cuda.empty_cache()
+            # ... and at the largest single-GPU configuration (RetinaNet-500, batch 32: A = 47 961, 491 MB of logits, 63 MB of match
+            # traffic): where the legs stop being launch-bound
+            out['roofline_hbm_largest'] = hbm_legs(device, 'retina_rn50_500_coco', 32)
+            torch.cuda.empty_cache()
             out['per_config'] = per_config_legs(device)
             out['serving'] = serving_legs(device)
             out['train_graph'] = train_graph_legs(device)
