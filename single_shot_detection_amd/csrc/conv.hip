@@ -2363,6 +2363,43 @@ __global__ void __launch_bounds__(256) anchor_dx_kernel(DxGroup grp) {
     }
 }
 
+// ---- strided convolutions' data gradient without atomics: contribution rows + per-pixel sum --------------------------------------------
+// T[out pixel][tap * Cin + c] = dy[out pixel][:] . W[:, tap, c] is an ordinary 1 x 1 GEMM over the output pixels (no multiply is spent on
+// (pixel, tap) pairs that do not exist); dX[(y, x)][c] = the sum, in tap order, of the T rows of the output pixels a tap connects to (y, x):
+// yo = (y + pad - ky) / stride where that divides (at most ceil(k / stride)^2 of the k^2 taps).  Every dX pixel is written: no zero-fill.
+struct StridedDxJob { const float* T; float* dx; int B, hin, win, cin, ho, wo, ks, stride, pad, blk_begin; };
+struct StridedDxGroup { int count; StridedDxJob j[kMaxProblems]; };
+__global__ void __launch_bounds__(256) strided_dx_kernel(StridedDxGroup grp) {
+    int ji = 0;
+#pragma unroll 1
+    for (int i = 1; i < grp.count; ++i)
+        if ((int)blockIdx.x >= grp.j[i].blk_begin) ji = i;
+    const StridedDxJob& J = grp.j[ji];
+    const int c4n = J.cin / 4;
+    const long long total = (long long)J.B * J.hin * J.win * c4n;
+    const long long e = (long long)(blockIdx.x - J.blk_begin) * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int c4 = (int)(e % c4n);
+    const long long pix = e / c4n;
+    const int x = (int)(pix % J.win), y = (int)((pix / J.win) % J.hin), b = (int)(pix / ((long long)J.win * J.hin));
+    const long long K9 = (long long)J.ks * J.ks * J.cin;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ky = 0; ky < J.ks; ++ky) {
+        const int ty = y + J.pad - ky;
+        if (ty < 0 || ty % J.stride) continue;
+        const int yo = ty / J.stride;
+        if (yo >= J.ho) continue;
+        for (int kx = 0; kx < J.ks; ++kx) {
+            const int tx = x + J.pad - kx;
+            if (tx < 0 || tx % J.stride) continue;
+            const int xo = tx / J.stride;
+            if (xo >= J.wo) continue;
+            acc += *reinterpret_cast<const f32x4*>(J.T + (((long long)b * J.ho + yo) * J.wo + xo) * K9 + (long long)(ky * J.ks + kx) * J.cin + 4 * c4);
+        }
+    }
+    *reinterpret_cast<f32x4*>(J.dx + pix * J.cin + 4 * c4) = acc;
+}
+
 // Deterministic mode: out[e] (+)= sum_k src[k * stride + e], k = 0 .. n_src - 1 IN THAT ORDER (the partial tiles of a K-split weight
 // gradient, the per-workgroup column sums of a bias gradient): the fixed-order second half of what the atomics do in any order.
 struct ReduceJob {
@@ -4388,6 +4425,8 @@ static size_t conv2d_bwd_ws_bytes(const ssdk_conv_desc* descs, int n, int batch,
         const size_t wsz = (size_t)d.cin * d.ksize * d.ksize * (size_t)d.cout;
         total += align_up(wsz * sizeof(float), 256);
         if (fast) total += 2 * align_up((size_t)cdiv(d.cin, 32) * 32 * d.ksize * d.ksize * d.cout * sizeof(__bf16), 256);   // the two split planes of the mirrored kernel
+        if (d.dx && d.stride > 1 && d.ksize > 0 && batch > 0)   // the contribution rows of the strided data gradient [B * Hout * Wout][taps * Cin]
+            total += align_up((size_t)batch * out_dim(d.hin, d.ksize, d.stride, d.pad) * out_dim(d.win, d.ksize, d.stride, d.pad) * d.ksize * d.ksize * d.cin * sizeof(float), 256);
         if (deterministic() && batch > 0 && d.ksize > 0 && d.stride > 0) {   // K-split copies of dw, per-workgroup column sums of db
             if (d.dw) total += align_up((size_t)conv_wgrad_splits(d, batch) * wsz * sizeof(float), 256);
             if (d.db) total += align_up((size_t)kColsumBlocks * d.cout * sizeof(float), 256);
@@ -4418,10 +4457,17 @@ static int conv2d_bwd_impl(const ssdk_conv_desc* descs, int n, int batch, int ac
     SSDK_REQUIRE(workspace && workspace_bytes >= conv2d_bwd_ws_bytes(descs, n, batch, fast), SSDK_E_WORKSPACE, "ssdk_conv2d_bwd: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     Carver carve(workspace);
-    ConvProblem dgrad[kMaxProblems], scat[kMaxProblems], dgrad_strided[kMaxProblems];
+    ConvProblem dgrad[kMaxProblems], scat[kMaxProblems], rowsT[kMaxProblems];
+    StridedDxGroup sdg{};
+    int n_rowsT = 0, sd_blocks = 0;
+    // strided data gradients: contribution rows + sum pass (ordered, no zero-fill) in deterministic mode; otherwise the atomic scatter
+    // form, which measured 15-35 us faster per SSD-300 step (3.055 against 3.07-3.09 ms: the small maps' row GEMMs underfill the chip);
+    // SSDK_CONV_STRIDED_ORDERED=1 takes the ordered form everywhere (measurement knob).  Round 4's deterministic form -- the
+    // output-stationary gather GEMM with three of four (pixel, tap) pairs masked -- cost 760 us per step where this costs 190.
+    static const bool strided_scatter = getenv("SSDK_CONV_STRIDED_ORDERED") == nullptr;
     WgradGroup wg{};
     ZeroList zl{};
-    int n_dgrad = 0, n_scat = 0, n_wgrad = 0, n_dgrad_strided = 0;
+    int n_dgrad = 0, n_scat = 0, n_wgrad = 0;
     // Deterministic mode: no K split with atomics, strided data gradients in the output-stationary (gather) form instead of the
     // scatter form, weight gradients as K-split copies added in split order, bias gradients as two-stage column sums
     const bool det = deterministic();
@@ -4451,20 +4497,25 @@ static int conv2d_bwd_impl(const ssdk_conv_desc* descs, int n, int batch, int ac
             SSDK_REQUIRE(((uintptr_t)d.w_t & 15) == 0, SSDK_E_INVALID, "ssdk_conv2d_bwd: w_t must be 16-byte aligned");
             wd = const_cast<float*>(d.w_t);
         }
-        if (det && d.dx && d.stride != 1) {
-            // output stationary with a stride (igemm_fwd_kernel<.., MIRROR, STRIDED>): a dx pixel gathers the taps whose source
-            // (y + pad - ky) / stride exists; the weights in the stride-1 layout [cin][taps*cout] (a layout prepared for the scatter form is not used)
-            wd = wd_own;
-            hipLaunchKernelGGL(transpose_taps_kernel, dim3(cdiv(d.cout, 32), cdiv(d.cin, 32), taps), dim3(256), 0, s, d.w, (const float*)nullptr,
-                               d.cout, 0, d.cout, taps, d.cin, wd);
-            SSDK_CHECK_LAUNCH("transpose_taps_kernel");
+        float* const rows_t = (d.dx && d.stride > 1) ? carve.take<float>((size_t)batch * ho * wo * taps * d.cin) : nullptr;
+        if (d.dx && d.stride != 1 && (det || !strided_scatter)) {
+            // T = dy . W as a 1 x 1 GEMM over the output pixels (weights [tap][cin][cout]: rows tap * Cin + c, K = cout), then the sum pass
+            if (!have_wt) {
+                hipLaunchKernelGGL(transpose_tapmajor_kernel, dim3(cdiv(d.cout, 32), cdiv(d.cin, 32), taps), dim3(256), 0, s, d.w, (const float*)nullptr,
+                                   d.cout, 0, d.cout, taps, d.cin, wd);
+                SSDK_CHECK_LAUNCH("transpose_tapmajor_kernel");
+            }
             ConvProblem g{};
             g.a = d.dy; g.a_bstride = (long long)ho * wo * d.cout; g.a_pstride = d.cout; g.Cc = d.cout;
-            g.B = batch; g.Hout = d.hin; g.Wout = d.win; g.Hin = ho; g.Win = wo; g.ksize = d.ksize; g.stride = d.stride; g.pad = d.pad;
-            g.w0 = wd; g.n0 = d.cin; g.n1 = 0;
-            g.o0 = d.dx; g.ob0 = (long long)d.hin * d.win * d.cin; g.os0 = d.cin;
-            finish_problem(g);
-            dgrad_strided[n_dgrad_strided++] = g;
+            g.B = batch; g.Hout = ho; g.Wout = wo; g.Hin = ho; g.Win = wo; g.ksize = 1; g.stride = 1; g.pad = 0;
+            g.w0 = wd; g.n0 = taps * d.cin; g.n1 = 0;
+            g.o0 = rows_t; g.ob0 = (long long)ho * wo * taps * d.cin; g.os0 = taps * d.cin;
+            finish_problem(g);   // (k_splits stays 1 -- whole K chains: a split would add into T with atomics; launch_group may narrow the column blocks)
+            rowsT[n_rowsT++] = g;
+            StridedDxJob& J = sdg.j[sdg.count++];
+            J.T = rows_t; J.dx = d.dx; J.B = batch; J.hin = d.hin; J.win = d.win; J.cin = d.cin; J.ho = ho; J.wo = wo; J.ks = d.ksize; J.stride = d.stride; J.pad = d.pad;
+            J.blk_begin = sd_blocks;
+            sd_blocks += (int)(((long long)batch * d.hin * d.win * (d.cin / 4) + 255) / 256);
         } else if (d.dx && d.stride == 1) {
             // output stationary: rows are INPUT pixels, A = dy [ho*wo][cout] with mirrored taps, W = wd [cin][taps*cout]
             if (!have_wt) {
@@ -4582,9 +4633,11 @@ static int conv2d_bwd_impl(const ssdk_conv_desc* descs, int n, int batch, int ac
         rc = launch_group(scat, n_scat, false, s, false, true);
         if (rc) return rc;
     }
-    if (n_dgrad_strided) {
-        rc = launch_group(dgrad_strided, n_dgrad_strided, true, s);
+    if (n_rowsT) {
+        rc = launch_group(rowsT, n_rowsT, false, s, true);
         if (rc) return rc;
+        hipLaunchKernelGGL(strided_dx_kernel, dim3(sd_blocks), dim3(256), 0, s, sdg);
+        SSDK_CHECK_LAUNCH("strided_dx_kernel");
     }
     if (n_fdg) {   // (after the re-layout launches above: the split reads their output)
         rc = launch_fast_group(fdg, ffp, n_fdg, fsg, fsplit_blocks, s);
