@@ -1364,7 +1364,7 @@ typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
 // ROW32 (anchor rows: Npad = Jpad is 32 .. 128): MFMA q owns output rows n_begin + 32 q .. + 31 -- lane (r, h) reads dY[pixel][r + 32 q] with a
 // ds_read_b32 per q -- and only the ceil(rows / 32) MFMAs that have rows are issued (Jpad = 96: 3 of 4; 21-class heads, Jpad = 32: 1 of 4).
 // The default map (MFMA q owns rows 4 i + q: one ds_read_b128 feeds four MFMAs) always issues four.
-template <bool FAST, bool ROW32 = false>
+template <bool FAST, bool ROW32 = false, int NQ = 4>   // NQ (ROW32 only): MFMAs per K step that have output rows = Npad / 32, the same for every problem of the launch
 __device__ __forceinline__ void wgrad_dma_body(const WgradGroup& grp) {
     __shared__ __attribute__((aligned(1024))) float s_dy0[32 * 128];
     __shared__ __attribute__((aligned(1024))) float s_dy1[32 * 128];
@@ -1412,7 +1412,6 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradGroup& grp) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r32 = lane & 31, h = lane >> 5;
     const bool wave_live = wave < tn;
-    const int nq = ROW32 ? min(4, (g.Npad - n_begin + 31) / 32) : 4;   // MFMAs per K step that have output rows
 
     const __amdgpu_buffer_rsrc_t rsrc_dy = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(dy_p), 0, (int)g.dy_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(g.x), 0, (int)g.x_bytes, 0x00020000);
@@ -1478,18 +1477,17 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradGroup& grp) {
             const float* bx = (ST ? s_x1 : s_x0) + h * 128 + wave * 32 + r32;
             float av[2][4], bv[2];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) av[0][q] = q < nq ? ady[32 * q] : 0.0f;
+            for (int q = 0; q < NQ; ++q) av[0][q] = ady[32 * q];
             bv[0] = bx[0];
 #pragma unroll
             for (int k2 = 0; k2 < 16; ++k2) {
                 if (k2 + 1 < 16) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) av[(k2 + 1) & 1][q] = q < nq ? ady[(k2 + 1) * 256 + 32 * q] : 0.0f;
+                    for (int q = 0; q < NQ; ++q) av[(k2 + 1) & 1][q] = ady[(k2 + 1) * 256 + 32 * q];
                     bv[(k2 + 1) & 1] = bx[(k2 + 1) * 256];
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (q < nq) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k2 & 1][q], bv[k2 & 1], acc[q], 0, 0, 0);
+                for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k2 & 1][q], bv[k2 & 1], acc[q], 0, 0, 0);
             }
         }
         if (wave_live && !FAST && !ROW32) {
@@ -1568,7 +1566,7 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradGroup& grp) {
         const int nrow = n_begin + (ROW32 ? i : 4 * i);
         const long long nK = (long long)nrow * K;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < (ROW32 ? NQ : 4); ++q) {
             const int n = nrow + (ROW32 ? 32 * q : q);   // MFMA q, row i
             if (n >= N) continue;
             float* const dst = (n < n0 ? base0 : base1) + nK + (long long)(ROW32 ? 32 * q : q) * K;
@@ -1579,7 +1577,7 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradGroup& grp) {
 }
 __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_wgrad_dma_kernel(WgradGroup grp) { wgrad_dma_body<false>(grp); }
 __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_wgrad_bf16x3_kernel(WgradGroup grp) { wgrad_dma_body<true>(grp); }
-__global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_wgrad_rows_kernel(WgradGroup grp) { wgrad_dma_body<false, true>(grp); }
+template <int NQ> __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_wgrad_rows_kernel(WgradGroup grp) { wgrad_dma_body<false, true, NQ>(grp); }
 
 // ---- dY pack (+ bias gradient) --------------------------------------------------------------------------------------
 // out[m][n] (n < Npad) = n < n0 ? ds[b*sb + p*n0 + n] : (n < n0+n1 ? dl[b*lb + p*n1 + n-n0] : 0);  db += column sums
@@ -3634,7 +3632,28 @@ static int launch_wgrad(WgradGroup& wg, hipStream_t s, bool fast = false, bool r
     for (int i = 0; i < wg.count; ++i)
         SSDK_REQUIRE(dma || !(wg.p[i].ordered && !wg.p[i].det_stride) , SSDK_E_UNSUPPORTED, "launch_wgrad: ordered stores need the LDS-DMA kernel");
     if (dma && fast) hipLaunchKernelGGL(igemm_wgrad_bf16x3_kernel, dim3(wg.total_blocks), dim3(kConvThreads), 0, s, wg);
-    else if (dma && rows32) hipLaunchKernelGGL(igemm_wgrad_rows_kernel, dim3(wg.total_blocks), dim3(kConvThreads), 0, s, wg);
+    else if (dma && rows32) {
+        // one launch per row-matrix width (Npad / 32 MFMAs per K step, a compile-time count: no zero rows multiplied, no branches in the K loop);
+        // the levels of a model share their class count, so this is one launch
+        for (int nq = 1; nq <= 4; ++nq) {
+            WgradGroup sub{};
+            int begin = 0;
+            for (int i = 0; i < wg.count; ++i) {
+                if (cdiv(wg.p[i].Npad, 32) != nq) continue;
+                const int blocks = (i + 1 < wg.count ? wg.p[i + 1].block_begin : wg.total_blocks) - wg.p[i].block_begin;
+                WgradProblem& q = sub.p[sub.count++];
+                q = wg.p[i];
+                q.block_begin = begin;
+                begin += blocks;
+            }
+            if (!sub.count) continue;
+            sub.total_blocks = begin;
+            if (nq == 1) hipLaunchKernelGGL(igemm_wgrad_rows_kernel<1>, dim3(begin), dim3(kConvThreads), 0, s, sub);
+            else if (nq == 2) hipLaunchKernelGGL(igemm_wgrad_rows_kernel<2>, dim3(begin), dim3(kConvThreads), 0, s, sub);
+            else if (nq == 3) hipLaunchKernelGGL(igemm_wgrad_rows_kernel<3>, dim3(begin), dim3(kConvThreads), 0, s, sub);
+            else hipLaunchKernelGGL(igemm_wgrad_rows_kernel<4>, dim3(begin), dim3(kConvThreads), 0, s, sub);
+        }
+    }
     else if (dma) hipLaunchKernelGGL(igemm_wgrad_dma_kernel, dim3(wg.total_blocks), dim3(kConvThreads), 0, s, wg);
     else hipLaunchKernelGGL(igemm_wgrad_kernel, dim3(wg.total_blocks), dim3(kConvThreads), 0, s, wg);
     SSDK_CHECK_LAUNCH("igemm_wgrad_kernel");
@@ -3723,8 +3742,9 @@ static bool ordered_heads_ok(const ssdk_head_level* levels, int n_levels, int ba
 }
 // K splits of the anchor-row weight gradient of a level: a fixed function of the shapes (sized for 1 / 16 of the anchors of a type carrying a
 // gradient, ~64 slices of 32 rows per split, at most 8; every split stores a full copy of the level's weight gradient).  Measured on
-// SSD-300 / 81 classes, batch 32 (level 0: ~55 slices per type; kernel + reduction, us): 1 split 224 + 10, 2 splits 160 + 15, 3: 208 + 15,
-// 6: 173 + 20, 8: 179 + 22 (tools/r05_stats.sh with SSDK_ANCHOR_WGRAD_SLICES = 128 / 64 / 32 / 16 / 8)
+// SSD-300 / 81 classes, batch 32 (level 0: ~55 slices per type; kernel + reduction, us): 1 split 150 + 10, 2 splits 123 + 14, 3: 158 + 14,
+// 5: 163 + 15, 6: 141 + 21 (tools/r05_stats.sh with SSDK_ANCHOR_WGRAD_SLICES = 128 / 64 / 32 / 22 / 16; before the K loop lost its per-MFMA
+// `q < nq` branches -- the kernel is now instantiated per row-matrix width -- the same sweep read 224 / 160 / 208 / - / 173)
 static inline int anchor_wgrad_splits(const ssdk_head_level& lv, int batch) {
     const int slices = cdiv(cdiv(batch * lv.h * lv.w, 16), 32);
     static const int per = []() { const char* e = getenv("SSDK_ANCHOR_WGRAD_SLICES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 64; }();   // (measurement knob)
