@@ -236,6 +236,10 @@ int ssdk_decode_box(const float* locs, const float* priors, float* out, int batc
 
 size_t ssdk_postprocess_workspace_bytes(int batch, int num_anchors, int num_classes, int softmax, int max_per_class,
                                         int max_total);
+/* ... for a call with this soft_nms: soft-NMS without max_per_class (or above 256) keeps a decaying score per candidate and up to
+ * min(max_per_class, num_anchors) rows per class, which the size above (= soft_nms 0) does not hold. */
+size_t ssdk_postprocess_workspace_bytes_ex(int batch, int num_anchors, int num_classes, int softmax, int max_per_class,
+                                           int max_total, int soft_nms);
 
 /*
  * detection/postprocessor.py:24-78 Postprocessor.postprocess with bf/utils/box_utils.py:166-194 (nms wrapper:
@@ -243,8 +247,9 @@ size_t ssdk_postprocess_workspace_bytes(int batch, int num_anchors, int num_clas
  * soft-NMS of box_utils.py:145-163 with sigma = soft_sigma) fused.
  *   scores DEV [batch, A, C] logits; locs DEV [batch, A, 4]; priors DEV [A, 4]
  *   softmax != 0: F.softmax and drop column 0 (classes 1..C-1); else sigmoid (classes 1..C)
- *   max_per_class: 1..256, or <= 0 for None (every candidate of a class enters NMS, box_utils.py:186), or > 256 -- the last two hard NMS
- *   only, at most 131 072 anchors, a class then yields at most max_total rows (more can never reach the final top-max_total);
+ *   max_per_class: 1..256, or <= 0 for None (every candidate of a class enters NMS, box_utils.py:186), or > 256 -- the last two take
+ *   the greedy kernels (hard: post_nms_any_kernel, a class then yields at most max_total rows, more can never reach the final
+ *   top-max_total; soft: post_softnms_any_kernel, workspace from ssdk_postprocess_workspace_bytes_ex) and at most 131 072 anchors;
  *   max_total <= 0 means None
  *   out    DEV [batch, out_cap, 6] rows (x1, y1, x2, y2, class, score); counts DEV int32 [batch];
  *          out_cap >= (max_total > 0 ? max_total : ncls * max_per_class)   (max_per_class None: ncls * num_anchors)

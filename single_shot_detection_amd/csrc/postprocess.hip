@@ -715,6 +715,155 @@ __global__ void __launch_bounds__(kPostThreads) post_nms_any_kernel(const float4
     }
 }
 
+// Soft-NMS (bf/utils/box_utils.py:145-163) for any number of candidates: the greedy path's counterpart of the wave loop in post_nms_kernel.
+// One workgroup per (image, class); the decaying scores live in global memory (cur[k], one float per candidate of the list; -inf = not
+// among the max_per_class best, i.e. not in the array _soft_nms sees).  What the reference's positions decide is reproduced without
+// sorting the list: the array order is ascending anchor (boxes[mask], postprocessor.py:63) or, after box_utils.py:186's top-k,
+// descending (score, ascending anchor) -- the oracle's convention for the unordered top-k -- so
+//   * argmax's first maximum (:152; NaN ranks above everything) = the entry with the largest tie value among those holding the maximum,
+//     tie = ~anchor (no top-k) or the original key (top-k),
+//   * `mask.nonzero().sum()` (:151, the SUM OF INDICES) is zero when nothing is live or when the only live entry is position 0 = the entry
+//     with the largest tie value of all,
+// and the mask tested at the top of an iteration is the one taken after the previous pick and BEFORE its decay (:156 vs :158-160).
+// Rows leave in pick order with the ORIGINAL scores (:163), so a class may hand all of its entries to the merge (cap = array length).
+__global__ void __launch_bounds__(kPostThreads) post_softnms_any_kernel(const float4* __restrict__ boxes, int A, int ncls, int K, int cap, float score_thr,
+                                                                        float sigma, const u64* __restrict__ cand, const int* __restrict__ cand_count,
+                                                                        float* __restrict__ cur_all, float* __restrict__ pc_rows, float* __restrict__ pc_score,
+                                                                        int* __restrict__ pc_count, u64* __restrict__ nms_candidates) {
+    __shared__ unsigned s_hist[256];
+    __shared__ u64 s_misc[2];
+    __shared__ u64 s_r64[kPostThreads / kWave];
+    __shared__ int s_rlive[kPostThreads / kWave];
+    __shared__ int s_k0, s_pick;
+    const int pc = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    const int i = pc / ncls, c = pc % ncls;
+    const int n = min(cand_count[pc], A);
+    if (n == 0) {
+        if (tid == 0) pc_count[pc] = 0;
+        return;
+    }
+    const u64* keys = cand + (size_t)pc * A;
+    float* cur = cur_all + (size_t)pc * A;
+    const float4* ibox = boxes + (size_t)i * A;
+    const bool topk = K > 0 && n > K;
+    u64 prefix = 0;
+    if (topk) {   // box_utils.py:186-188: the K-th largest key (keys are distinct), as in post_nms_any_kernel
+        unsigned above = 0;
+        for (int shift = 56; shift >= 0; shift -= 8) {
+            for (int b = tid; b < 256; b += kPostThreads) s_hist[b] = 0;
+            __syncthreads();
+            for (int k = tid; k < n; k += kPostThreads) {
+                const u64 key = keys[k];
+                if (shift == 56 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&s_hist[(unsigned)(key >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid < kWave) {
+                int digit;
+                unsigned cum, h;
+                wave_find_digit(s_hist, above, (unsigned)K, &digit, &cum, &h);
+                if (tid == 0) { s_misc[0] = prefix | ((u64)digit << shift); s_misc[1] = cum; }
+            }
+            __syncthreads();
+            prefix = s_misc[0];
+            above = (unsigned)s_misc[1];
+            __syncthreads();
+        }
+    }
+    const int m = topk ? K : n;
+    auto tie_of = [&](u64 key) -> u64 { return topk ? key : (key & 0xFFFFFFFFull); };
+    auto block_max64 = [&](u64 v) -> u64 {
+        v = wave_allreduce(v, OpMaxU64());
+        if (lane == 0) s_r64[wave] = v;
+        __syncthreads();
+        u64 r = s_r64[0];
+        for (int w = 1; w < kPostThreads / kWave; ++w) r = s_r64[w] > r ? s_r64[w] : r;
+        __syncthreads();
+        return r;
+    };
+    // the array: cur = the scores, -inf outside; position 0 = the largest tie value; every entry starts live (the list only holds scores > threshold)
+    u64 t0 = 0;
+    for (int k = tid; k < n; k += kPostThreads) {
+        const u64 key = keys[k];
+        const bool in = key >= prefix;
+        cur[k] = in ? __uint_as_float((unsigned)(key >> 32)) : -INFINITY;
+        if (in) { const u64 t = tie_of(key); t0 = t > t0 ? t : t0; }
+    }
+    t0 = block_max64(t0);
+    for (int k = tid; k < n; k += kPostThreads)
+        if (keys[k] >= prefix && tie_of(keys[k]) == t0) s_k0 = k;
+    __threadfence_block();
+    __syncthreads();
+    const int k0 = s_k0;
+    int nlive = m, live0 = 1;   // the mask of :147
+    int np = 0;
+    for (int it = 0; it < m; ++it) {
+        if (nlive == 0 || (nlive == 1 && live0)) break;   // :151
+        // :152 argmax over the whole array: the largest value (NaN first), then the largest tie value among its holders
+        unsigned pmax = 0;
+        for (int k = tid; k < n; k += kPostThreads) {
+            const float v = cur[k];
+            if (v == -INFINITY) continue;
+            unsigned u = __float_as_uint(v);
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+            if (v != v) u = 0xFFFFFFFFu;
+            pmax = u > pmax ? u : pmax;
+        }
+        pmax = (unsigned)block_max64((u64)pmax);
+        u64 tb = 0;
+        for (int k = tid; k < n; k += kPostThreads) {
+            const float v = cur[k];
+            if (v == -INFINITY) continue;
+            unsigned u = __float_as_uint(v);
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+            if (v != v) u = 0xFFFFFFFFu;
+            if (u == pmax) { const u64 t = tie_of(keys[k]); tb = t > tb ? t : tb; }
+        }
+        tb = block_max64(tb);
+        for (int k = tid; k < n; k += kPostThreads)
+            if (cur[k] != -INFINITY && tie_of(keys[k]) == tb) { s_pick = k; cur[k] = 0.0f; }   // :153 (one thread: tie values are distinct)
+        __threadfence_block();
+        __syncthreads();
+        const int bk = s_pick;
+        const u64 bkey = keys[bk];
+        const float4 bb = ibox[min(0xFFFFFFFFu - (unsigned)(bkey & 0xFFFFFFFFull), (unsigned)(A - 1))];
+        const float ba = area4(bb.x, bb.y, bb.z, bb.w);
+        if (tid == 0 && np < cap) {   // :154, :163: pick order, original score
+            float* o = pc_rows + ((size_t)pc * cap + np) * 6;
+            o[0] = bb.x; o[1] = bb.y; o[2] = bb.z; o[3] = bb.w;
+            o[4] = (float)(c + 1);   // postprocessor.py:66
+            o[5] = __uint_as_float((unsigned)(bkey >> 32));
+            pc_score[(size_t)pc * cap + np] = o[5];
+        }
+        ++np;
+        // :156 the mask, then :158-160 the decay of the masked entries
+        int mylive = 0, my0 = 0;
+        for (int k = tid; k < n; k += kPostThreads) {
+            const float v = cur[k];
+            if (v > score_thr) {   // (false for -inf, NaN and the zeros of the picked ones)
+                ++mylive;
+                if (k == k0) my0 = 1;
+                const float4 bj = ibox[min(0xFFFFFFFFu - (unsigned)(keys[k] & 0xFFFFFFFFull), (unsigned)(A - 1))];
+                const float inter = area4(tmaxf(bb.x, bj.x), tmaxf(bb.y, bj.y), tminf(bb.z, bj.z), tminf(bb.w, bj.w));
+                const float iou = inter / (ba + area4(bj.x, bj.y, bj.z, bj.w) - inter);
+                cur[k] = v * expf(-(iou * iou / sigma));
+            }
+        }
+        mylive = wave_allreduce(mylive | (my0 << 24), OpAddI());   // (at most 2^17 live entries; one entry is position 0)
+        if (lane == 0) s_rlive[wave] = mylive;
+        __threadfence_block();
+        __syncthreads();
+        int tot = 0;
+        for (int w = 0; w < kPostThreads / kWave; ++w) tot += s_rlive[w];
+        nlive = tot & 0xFFFFFF;
+        live0 = tot >> 24;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        pc_count[pc] = min(np, cap);
+        if (nms_candidates) atomicAdd(nms_candidates + i, (u64)m);
+    }
+}
+
 // One workgroup of the select pass owns a run of `tiles_per_wg` consecutive tiles of one image AND a segment of every class list of
 // that image (capacity = its rows): a hit's slot is the class's running count inside the workgroup (an LDS atomic), so nothing is
 // reserved through global memory -- no returning global atomic sits on the critical path of a tile (it was 3-5 us of every tile's
@@ -1678,8 +1827,9 @@ struct PostWsAny {
     float* pc_score;
     int* pc_count;
     u64* merge_keys;
+    float* cur;   // soft-NMS only: the decaying scores, one per key of cand
 };
-static PostWsAny carve_post_any(void* ws, size_t B, size_t A, size_t ncls, size_t cap, size_t* total) {
+static PostWsAny carve_post_any(void* ws, size_t B, size_t A, size_t ncls, size_t cap, size_t* total, bool soft = false) {
     Carver c(ws);
     PostWsAny w;
     w.cand = c.take<u64>(B * ncls * A);
@@ -1689,17 +1839,24 @@ static PostWsAny carve_post_any(void* ws, size_t B, size_t A, size_t ncls, size_
     w.pc_score = c.take<float>(B * ncls * cap);
     w.pc_count = c.take<int>(B * ncls);
     w.merge_keys = c.take<u64>(B * ncls * cap);
+    w.cur = soft ? c.take<float>(B * ncls * A) : nullptr;
     if (total) *total = c.off;
     return w;
 }
 
-extern "C" size_t ssdk_postprocess_workspace_bytes(int batch, int num_anchors, int num_classes, int softmax, int max_per_class,
-                                                   int max_total) {
+// (soft-NMS hands rows out in pick order with the original scores: the max_total best of an image can sit anywhere in a class's picks, so
+// the per-class row capacity is the array length, not max_total)
+static inline long long any_cap_of(int num_anchors, int max_per_class, int max_total, bool soft) {
+    return soft ? any_cap(num_anchors, max_per_class, 0) : any_cap(num_anchors, max_per_class, max_total);
+}
+
+extern "C" size_t ssdk_postprocess_workspace_bytes_ex(int batch, int num_anchors, int num_classes, int softmax, int max_per_class,
+                                                      int max_total, int soft_nms) {
     if (batch <= 0 || num_anchors <= 0 || num_classes <= 0) return 0;
     const size_t ncls = (size_t)ncls_of(num_classes, softmax);
     if (max_per_class <= 0 || max_per_class > kMaxPerClass) {   // None (<= 0) or beyond the bit-matrix kernel: the greedy path
         size_t t = 0;
-        carve_post_any(nullptr, (size_t)batch, (size_t)num_anchors, ncls, (size_t)any_cap(num_anchors, max_per_class, max_total), &t);
+        carve_post_any(nullptr, (size_t)batch, (size_t)num_anchors, ncls, (size_t)any_cap_of(num_anchors, max_per_class, max_total, soft_nms != 0), &t, soft_nms != 0);
         return t;
     }
     size_t total = 0, total2 = 0;
@@ -1711,6 +1868,9 @@ extern "C" size_t ssdk_postprocess_workspace_bytes(int batch, int num_anchors, i
         total2 = t > total2 ? t : total2;
     }
     return total > total2 ? total : total2;   // (soft-NMS takes the general pipeline: the caller may ask for either)
+}
+extern "C" size_t ssdk_postprocess_workspace_bytes(int batch, int num_anchors, int num_classes, int softmax, int max_per_class, int max_total) {
+    return ssdk_postprocess_workspace_bytes_ex(batch, num_anchors, num_classes, softmax, max_per_class, max_total, 0);
 }
 
 static int postprocess_v2(const PostPlan& p, const float* scores, const float* locs, const float* priors, int batch, int num_anchors,
@@ -1812,16 +1972,15 @@ extern "C" int ssdk_postprocess(const float* scores, const float* locs, const fl
     SSDK_REQUIRE(scores && locs && priors && out && counts, SSDK_E_INVALID, "ssdk_postprocess: null pointer");
     SSDK_REQUIRE(((uintptr_t)locs & 15) == 0 && ((uintptr_t)priors & 15) == 0, SSDK_E_INVALID, "ssdk_postprocess: locs/priors must be 16-byte aligned");
     const bool any_k = max_per_class <= 0 || max_per_class > kMaxPerClass;   // None, or beyond the bit-matrix kernel
-    SSDK_REQUIRE(!(any_k && soft_nms), SSDK_E_UNSUPPORTED, "ssdk_postprocess: soft-NMS takes max_per_class in 1..%d (got %d)", kMaxPerClass, max_per_class);
     SSDK_REQUIRE(max_total <= kSortCap, SSDK_E_UNSUPPORTED, "ssdk_postprocess: max_total=%d > %d", max_total, kSortCap);
     SSDK_REQUIRE(!soft_nms || soft_sigma > 0.0f, SSDK_E_INVALID, "ssdk_postprocess: soft-NMS sigma must be > 0");
     const int ncls = ncls_of(num_classes, softmax);
-    const long long per_class_cap = any_k ? any_cap(num_anchors, max_per_class, max_total) : (max_per_class < num_anchors ? max_per_class : num_anchors);   // (a class never holds more rows than there are anchors)
+    const long long per_class_cap = any_k ? any_cap_of(num_anchors, max_per_class, max_total, soft_nms != 0) : (max_per_class < num_anchors ? max_per_class : num_anchors);   // (a class never holds more rows than there are anchors)
     SSDK_REQUIRE(out_cap >= (max_total > 0 ? max_total : 1), SSDK_E_INVALID, "ssdk_postprocess: out_cap=%d too small", out_cap);
     SSDK_REQUIRE(max_total > 0 || (long long)out_cap >= (long long)ncls * per_class_cap, SSDK_E_INVALID,
                  "ssdk_postprocess: out_cap=%d < ncls * rows per class with max_total=None", out_cap);
-    SSDK_REQUIRE(workspace && workspace_bytes >= ssdk_postprocess_workspace_bytes(batch, num_anchors, num_classes, softmax, max_per_class, max_total),
-                 SSDK_E_WORKSPACE, "ssdk_postprocess: workspace too small");
+    SSDK_REQUIRE(workspace && workspace_bytes >= ssdk_postprocess_workspace_bytes_ex(batch, num_anchors, num_classes, softmax, max_per_class, max_total, soft_nms),
+                 SSDK_E_WORKSPACE, "ssdk_postprocess: workspace too small (soft-NMS without max_per_class or above %d: size it with ssdk_postprocess_workspace_bytes_ex)", kMaxPerClass);
     SSDK_REQUIRE((long long)batch * ncls < 2147483647LL && batch <= 65535, SSDK_E_INVALID, "ssdk_postprocess: grid too large");
     hipStream_t s = (hipStream_t)stream;
     const PostPlan plan = make_plan(batch, num_anchors, num_classes, softmax, max_per_class, max_total, post_wants_sample_pass(max_per_class));
@@ -1833,7 +1992,8 @@ extern "C" int ssdk_postprocess(const float* scores, const float* locs, const fl
         SSDK_REQUIRE(num_anchors <= kAnyMaxAnchors, SSDK_E_UNSUPPORTED, "ssdk_postprocess: max_per_class=None / > %d takes at most %d anchors", kMaxPerClass,
                      kAnyMaxAnchors);
         const int cap = (int)per_class_cap;
-        PostWsAny w = carve_post_any(workspace, (size_t)batch, (size_t)num_anchors, (size_t)ncls, (size_t)cap, nullptr);
+        SSDK_REQUIRE((long long)batch * ncls * cap < (1LL << 40), SSDK_E_UNSUPPORTED, "ssdk_postprocess: %lld rows per class", (long long)cap);
+        PostWsAny w = carve_post_any(workspace, (size_t)batch, (size_t)num_anchors, (size_t)ncls, (size_t)cap, nullptr, soft_nms != 0);
         SSDK_CHECK_HIP(zero_async(w.cand_count, sizeof(int) * (size_t)batch * ncls, s));
         if (nms_candidates) SSDK_CHECK_HIP(zero_async(nms_candidates, sizeof(int64_t) * (size_t)batch, s));
         const int tiles = cdiv(num_anchors, kPostTileRows);
@@ -1847,10 +2007,17 @@ extern "C" int ssdk_postprocess(const float* scores, const float* locs, const fl
         hipLaunchKernelGGL(post_decode_kernel, dim3((unsigned)(cdiv((int)((total + 255) / 256), 1) < 4096 ? (total + 255) / 256 : 4096)), dim3(kPostThreads), 0, s,
                            (const float4*)locs, (const float4*)priors, num_anchors, total, xy_scale, wh_scale, w.boxes);
         SSDK_CHECK_LAUNCH("post_decode_kernel");
-        hipLaunchKernelGGL(post_nms_any_kernel, dim3(batch * ncls), dim3(kPostThreads), 0, s, (const float4*)w.boxes, num_anchors, ncls,
-                           max_per_class > 0 ? max_per_class : 0, cap, nms_threshold, w.cand, w.cand_count, w.pc_rows, w.pc_score, w.pc_count,
-                           (u64*)nms_candidates);
-        SSDK_CHECK_LAUNCH("post_nms_any_kernel");
+        if (soft_nms) {
+            hipLaunchKernelGGL(post_softnms_any_kernel, dim3(batch * ncls), dim3(kPostThreads), 0, s, (const float4*)w.boxes, num_anchors, ncls,
+                               max_per_class > 0 ? max_per_class : 0, cap, score_threshold, soft_sigma, w.cand, w.cand_count, w.cur, w.pc_rows, w.pc_score,
+                               w.pc_count, (u64*)nms_candidates);
+            SSDK_CHECK_LAUNCH("post_softnms_any_kernel");
+        } else {
+            hipLaunchKernelGGL(post_nms_any_kernel, dim3(batch * ncls), dim3(kPostThreads), 0, s, (const float4*)w.boxes, num_anchors, ncls,
+                               max_per_class > 0 ? max_per_class : 0, cap, nms_threshold, w.cand, w.cand_count, w.pc_rows, w.pc_score, w.pc_count,
+                               (u64*)nms_candidates);
+            SSDK_CHECK_LAUNCH("post_nms_any_kernel");
+        }
         hipLaunchKernelGGL(post_merge_kernel, dim3(batch), dim3(kPostThreads), sizeof(int) * (size_t)(ncls + 1), s, ncls, cap, max_total, w.pc_rows,
                            w.pc_count, w.merge_keys, out, out_cap, counts);
         SSDK_CHECK_LAUNCH("post_merge_kernel");

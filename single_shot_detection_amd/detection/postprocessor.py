@@ -15,8 +15,6 @@ class Postprocessor(object):
             raise ValueError(f'Wrong value for score_converter: {score_converter}')
         self.soft = bool(self.nms_args.get('soft', False))      # box_utils.py:166 `soft`, `sigma`
         self.sigma = float(self.nms_args.get('sigma', 0.5))
-        if self.nms_args.get('max_per_class') is None and self.soft:
-            raise NotImplementedError('soft-NMS takes max_per_class in 1..256 on the GPU path')
         self.last_nms_candidates = None
 
     def postprocess(self, prediction, priors):
@@ -54,7 +52,7 @@ class Postprocessor(object):
             raise ValueError('postprocess without max_total and without max_per_class would return up to '
                              f'{cap} rows per image: set max_total')
         dev = b_scores.device
-        need = lib.ssdk_postprocess_workspace_bytes(batch_size, num_priors, num_classes, softmax, max_per_class, max_total)
+        need = lib.ssdk_postprocess_workspace_bytes_ex(batch_size, num_priors, num_classes, softmax, max_per_class, max_total, int(self.soft))
         ws = _lib.scratch(need, dev, 'postprocess')   # lives for this call only
         out = torch.empty((batch_size, cap, 6), dtype=torch.float32, device=dev)
         counts = torch.empty((batch_size,), dtype=torch.int32, device=dev)

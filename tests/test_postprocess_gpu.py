@@ -180,11 +180,57 @@ def test_postprocess_ties_and_identical_boxes():
 def test_unsupported_options_raise():
     with pytest.raises(ValueError):
         Postprocessor(BoxCoder(10., 5.), 0.01, {'max_per_class': 100, 'overlap_threshold': .45}, 'TANH', 200)
-    with pytest.raises(NotImplementedError):   # soft-NMS without a per-class cap
-        Postprocessor(BoxCoder(10., 5.), 0.01, {'overlap_threshold': .45, 'soft': True}, 'SOFTMAX', 200)
-    p = Postprocessor(BoxCoder(10., 5.), 0.01, {'max_per_class': 1000, 'overlap_threshold': .45, 'soft': True}, 'SOFTMAX', 200)
-    with pytest.raises(ValueError):            # soft-NMS beyond the 256-box kernel
-        p.postprocess((torch.zeros((1, 8 * 3), device='cuda'), torch.zeros((1, 8 * 4), device='cuda')), torch.ones((8, 4), device='cuda'))
+    # soft-NMS without a per-class cap, or above the 256 boxes of the wave kernel, needs the workspace of ..._workspace_bytes_ex: the size of
+    # the plain query is refused, loudly
+    from single_shot_detection_amd import _lib
+    lib = _lib.lib()
+    B, A, Cn = 1, 600, 3
+    assert lib.ssdk_postprocess_workspace_bytes_ex(B, A, Cn, 1, 0, 200, 1) > lib.ssdk_postprocess_workspace_bytes(B, A, Cn, 1, 0, 200)
+    ws = torch.empty(lib.ssdk_postprocess_workspace_bytes(B, A, Cn, 1, 0, 200), dtype=torch.uint8, device='cuda')
+    z = lambda *shape, dt=torch.float32: torch.zeros(shape, dtype=dt, device='cuda')   # noqa: E731
+    sc, lc, pr, out, cnt = z(B, A * Cn), z(B, A * 4), z(A, 4), z(B, 200, 6), z(B, dt=torch.int32)
+    rc = lib.ssdk_postprocess(_lib.ptr(sc), _lib.ptr(lc), _lib.ptr(pr), B, A, Cn, 1, 0.01, 0, 0.45, 1, 0.5, 200, 10.0, 5.0, _lib.ptr(out), 200,
+                              _lib.ptr(cnt), None, _lib.ptr(ws), ws.numel(), _lib.current_stream())
+    assert rc != 0
+
+
+@pytest.mark.parametrize('variant', ['rand', 'trained'])
+def test_soft_nms_without_per_class_cap_vs_oracle(variant):
+    """_soft_nms (bf/utils/box_utils.py:145-163) behind nms(max_per_class=None) and behind a cap above the 256 boxes of the wave kernel
+    (:186-188): post_softnms_any_kernel against the oracle, with and without max_total; then a case where the top-k cuts (more candidates
+    than the cap), one where a class has a single candidate (position 0: the `mask.nonzero().sum()` quirk of :151 ends the loop before it
+    is picked), and degenerate boxes (0 / 0 in :158 turns a score NaN, which argmax then picks first)."""
+    cfg, g, logits, locs, softmax = inputs('ssd_mb2_voc', variant, batch=2, seeds=(71, 72))
+    anchors = torch.from_numpy(g['anchors']).cuda()
+    pred = (torch.from_numpy(logits).cuda(), torch.from_numpy(locs).cuda())
+    for mpc, mt in ((None, 200), (300, 200), (1000, None)):
+        nms = {'overlap_threshold': cfg['nms_thr'], 'soft': True, 'sigma': 0.5}
+        if mpc is not None:
+            nms['max_per_class'] = mpc
+        post = Postprocessor(BoxCoder(10.0, 5.0), score_threshold=0.01, nms=nms, score_converter=cfg['score_converter'], max_total=mt)
+        out = post.postprocess(pred, anchors)
+        ref, cand = oracle.postprocess(logits, locs, g['anchors'], softmax=softmax, max_per_class=mpc, nms_thr=cfg['nms_thr'], soft=True, sigma=0.5,
+                                       max_total=mt, return_cand=True)
+        compare(out, ref, boundaries=Boundaries(logits, cfg['num_classes'], softmax, 0.01, mpc, mt))
+        assert np.array_equal(post.last_nms_candidates.cpu().numpy(), cand)
+    A, Cn = 700, 4
+    rng = np.random.default_rng(13)
+    pri = np.concatenate([rng.uniform(20, 280, (A, 2)), rng.uniform(10, 80, (A, 2))], 1).astype(np.float32)
+    pri[5:9, 2:] = 0.0                                   # degenerate priors: zero-area boxes
+    lg = rng.standard_normal((2, A, Cn)).astype(np.float32)
+    lg[1, :, 3] = -30.0
+    lg[1, 17, 3] = 8.0                                   # class 3 of image 1: one candidate
+    lc = (rng.standard_normal((2, A * 4)) * 0.3).astype(np.float32)
+    lc.reshape(2, A, 4)[:, 5:9] = 0.0
+    lg = lg.reshape(2, -1)
+    for mpc, mt in ((300, None), (None, 150)):           # ~400 candidates per class at threshold 0.05: the first cap cuts
+        nms = {'overlap_threshold': 0.45, 'soft': True, 'sigma': 0.3}
+        if mpc is not None:
+            nms['max_per_class'] = mpc
+        post = Postprocessor(BoxCoder(10.0, 5.0), score_threshold=0.05, nms=nms, score_converter='SOFTMAX', max_total=mt)
+        out = post.postprocess((torch.from_numpy(lg).cuda(), torch.from_numpy(lc).cuda()), torch.from_numpy(pri).cuda())
+        ref = oracle.postprocess(lg, lc, pri, softmax=True, score_thr=0.05, max_per_class=mpc, nms_thr=0.45, soft=True, sigma=0.3, max_total=mt)
+        compare(out, ref, boundaries=Boundaries(lg, Cn, True, 0.05, mpc, mt))
 
 
 @pytest.mark.parametrize('variant', ['rand', 'trained'])
