@@ -174,9 +174,11 @@ int ssdk_naive_sampler(const float* target_classes, int class_stride, int batch,
 
 /*
  * Loss configuration of detection/losses/multibox_loss.py:11-33 (what the constructed loss objects carry).
- *   focal_alpha < 0 means None (SoftmaxFocalLoss only).  reduce_mean != 0: the focal losses divide by the number of
+ *   focal_alpha < 0 means None (SoftmaxFocalLoss only).  reduce_mean == 1: the focal losses divide by the number of
  *   sampled rows -- the reference's constructor drops reduction='sum' for classes whose __init__ takes **kwargs
- *   (bf/utils/misc_utils.py:22-29).  soft_epsilon: label smoothing of the soft-target losses.
+ *   (bf/utils/misc_utils.py:22-29).  reduce_mean == 2: out3 holds the plain sums, NOT divided by
+ *   max(1, #positives) -- a loss module of bf/modules/losses.py:34-106 on its own (forward(prediction, target) outside
+ *   MultiboxLoss).  soft_epsilon: label smoothing of the soft-target losses.
  */
 typedef struct ssdk_loss_params {
     int cls_kind;  /* SSDK_CLS_* */

@@ -566,9 +566,10 @@ __global__ void __launch_bounds__(256) loss_finalize_kernel(const float* __restr
     n2 = block_sum(n2, s_redi);
     if (threadIdx.x == 0) {
         const int npos = n0, nrows = n1, nposrows = n2;
-        const float divider = (float)(npos < 1 ? 1 : npos);  // multibox_loss.py:88
+        // reduce_mean == 2: the plain sums, not divided by the positives (the standalone modules of bf/modules/losses.py)
+        const float divider = reduce_mean == 2 ? 1.0f : (float)(npos < 1 ? 1 : npos);  // multibox_loss.py:88
         const bool focal = cls_kind == SSDK_CLS_SIGMOID_FOCAL || cls_kind == SSDK_CLS_SOFTMAX_FOCAL;
-        const float mean_div = (focal && reduce_mean) ? (float)nrows : 1.0f;
+        const float mean_div = (focal && reduce_mean == 1) ? (float)nrows : 1.0f;
         float scale = 1.0f;
         if (cls_kind == SSDK_CLS_CE_SOFT) scale = 1.0f / ((float)t / (float)nrows);       // losses.py:89 target.sum(-1).mean() ** -1
         if (cls_kind == SSDK_CLS_BCE_SOFT) scale = 1.0f / ((float)t / (float)nposrows);   // losses.py:102-103
@@ -798,6 +799,7 @@ static int check_loss_params(const char* fn, const ssdk_loss_params* q) {
     SSDK_REQUIRE(q->loc_kind == SSDK_LOC_SMOOTH_L1 || q->loc_kind == SSDK_LOC_GIOU, SSDK_E_INVALID, "%s: loc_kind=%d", fn, q->loc_kind);
     SSDK_REQUIRE(q->smooth_l1_beta > 0, SSDK_E_INVALID, "%s: beta must be > 0", fn);
     SSDK_REQUIRE(q->soft_epsilon >= 0.0f && q->soft_epsilon < 1.0f, SSDK_E_INVALID, "%s: epsilon outside [0, 1) (losses.py:15)", fn);
+    SSDK_REQUIRE(q->reduce_mean >= 0 && q->reduce_mean <= 2, SSDK_E_INVALID, "%s: reduce_mean=%d (0 sum, 1 mean, 2 sums not divided by the positives)", fn, q->reduce_mean);
     return SSDK_OK;
 }
 

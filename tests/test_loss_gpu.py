@@ -290,3 +290,66 @@ def test_extra_losses_vs_reference_golden(tag):
     np.testing.assert_allclose(l_t.grad.view(B, A, 4).cpu().numpy(), dense_from_rows(g[tag + '_dlocs_rows'], g[tag + '_dlocs_vals'], (B, A, 4)),
                                rtol=3e-4, atol=3e-7)
     assert bool(g[tag + '_target_mutated']) == (not np.array_equal(target.cpu().numpy(), g['target']))
+
+
+@pytest.mark.parametrize('tag', sorted(EXTRA))
+def test_loss_modules_on_their_own_vs_reference_golden(tag):
+    """bf/modules/losses.py:34-114 outside MultiboxLoss: forward(prediction, target) on the rows the reference's MultiboxLoss hands its
+    classification / localisation module (multibox_loss.py:59-86, rebuilt here from the golden sampled mask and target), against the
+    reference's class_loss / loc_loss of tests/golden/losses_extra.npz (x the divider of :88), and the gradient against its dscores."""
+    import os
+    from conftest import GOLDEN
+    from single_shot_detection_amd.bf.modules import losses
+    from single_shot_detection_amd.bf.utils import box_utils
+    g = np.load(os.path.join(GOLDEN, 'losses_extra.npz'))
+    smp_name, cl, ll, nc = EXTRA[tag]
+    anchors_np = load_golden('ssd_mb2_voc')['anchors']
+    B, A = 2, anchors_np.shape[0]
+    logits = torch.from_numpy(syn.make_logits(B, A, nc, seed=2)).cuda().view(B, A, nc)
+    locs = torch.from_numpy(syn.make_locs(B, A, seed=3, scale=0.5)).cuda().view(B, A, 4)
+    target = torch.from_numpy(g['target'].copy()).cuda()
+    mask = torch.from_numpy(np.unpackbits(g[tag + '_sampled_bits'], axis=1)[:, :A].astype(bool)).cuda()
+    cls = target[..., 4].long()
+    positive = (cls != 0) & (cls != -1)
+    divider = float(positive.sum().clamp(min=1))
+    values = g[tag + '_values']
+    if ll['name'] == 'GeneralizedIoULoss':
+        coder = BoxCoder(10.0, 5.0)
+        anchors = torch.from_numpy(anchors_np).cuda()
+        boxes = box_utils.to_corners(coder.decode_box(locs, anchors))
+        module = losses.GeneralizedIoULoss(reduction=str(g[tag + '_loc_reduction']))
+        got = module(boxes[positive].view(-1, 4), target[..., :4][positive].view(-1, 4))
+        np.testing.assert_allclose(got.item(), values[2] * divider, rtol=1e-5)
+        with pytest.raises(NotImplementedError):
+            module(boxes[positive].view(-1, 4).clone().requires_grad_(True), target[..., :4][positive].view(-1, 4))
+        return
+    kw = {k: v for k, v in cl.items() if k != 'name'}
+    Loss = getattr(losses, cl['name'])
+    reduction = str(g[tag + '_cls_reduction'])
+    module = Loss(reduction=reduction, ignore_index=-1, **kw) if cl['name'] == 'SoftmaxFocalLoss' else Loss(reduction=reduction, **kw)
+    scores = logits[mask].clone().requires_grad_(True)
+    t_cls, t_score = cls[mask], target[..., 5][mask]
+    if module.__class__.__dict__.get('MULTICLASS', False):           # multibox_loss.py:64-67
+        class_target = torch.zeros_like(scores)
+        m = (t_cls != 0) & (t_cls != -1)
+        class_target[m, t_cls[m] - 1] = t_score[m]
+    elif getattr(module, 'SOFT_TARGET', False):                      # :68-71
+        class_target = torch.zeros_like(scores)
+        m = t_cls != -1
+        class_target[m, t_cls[m]] = t_score[m]
+    else:                                                            # :73
+        class_target = t_cls.view(-1)
+    got = module(scores, class_target.detach())
+    np.testing.assert_allclose(got.item(), values[1] * divider, rtol=1e-5)
+    got.backward()
+    dense = torch.zeros((B, A, nc), device='cuda')
+    dense[mask] = scores.grad / divider
+    ref = dense_from_rows(g[tag + '_dscores_rows'], g[tag + '_dscores_vals'], (B, A, nc))
+    np.testing.assert_allclose(dense.cpu().numpy(), ref, rtol=3e-4, atol=3e-7)
+    with pytest.raises(NotImplementedError):
+        type(module)(reduction='none')(scores.detach(), class_target.detach())
+    if class_target.dim() == 2:
+        bad = class_target.detach().clone()
+        bad[0, :2] = 0.5
+        with pytest.raises(NotImplementedError):
+            module(scores.detach(), bad)
