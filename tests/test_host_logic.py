@@ -52,8 +52,8 @@ def test_postprocessor_constructor_surface():
     with pytest.raises(ValueError):
         Postprocessor(BoxCoder(10., 5.), 0.01, {'max_per_class': 100, 'overlap_threshold': .45}, 'TANH')
     Postprocessor(BoxCoder(10., 5.), 0.01, {'overlap_threshold': .45}, 'SOFTMAX')            # max_per_class=None: every candidate enters NMS
-    with pytest.raises(NotImplementedError):                                                  # ... but not with soft-NMS
-        Postprocessor(BoxCoder(10., 5.), 0.01, {'overlap_threshold': .45, 'soft': True}, 'SOFTMAX')
+    p = Postprocessor(BoxCoder(10., 5.), 0.01, {'overlap_threshold': .45, 'soft': True, 'sigma': 0.3}, 'SOFTMAX')   # ... with soft-NMS too (box_utils.py:166)
+    assert p.soft and p.sigma == 0.3
 
 
 def test_product_path_refuses_cpu_tensors():
