@@ -550,7 +550,7 @@ constexpr int kWaveK = 128;          // post_nms_wave_kernel: sorted slots (max_
 constexpr int kMergeSlots = 8192;    // post_merge2_kernel: ncls * max_per_class <= this (8 keys per thread)
 constexpr int kMergeCap = 256;       // survivors of the merge's radix narrowing (>= max_total)
 constexpr int kTauCache = 1024;      // post_tau_kernel: keys of one sample list kept in LDS (8 KB per wave)
-constexpr int kNmsCache = 512;       // post_nms_wave_kernel: keys of one list kept in LDS (4 KB per wave: 20 waves per CU still fit)
+constexpr int kNmsCache = 1024;      // post_nms_wave_kernel: keys of one list kept in LDS (8 KB per wave)
 
 // exp(d) for d <= 0 (NaN stays NaN, -inf -> 0): t = d*log2e, r = the rounding error of that product + d*log2e_lo,
 // exp2(t) * (1 + r*ln2).  v_exp_f32 is 1 ulp over its whole range; the library's expf adds range checks this call site does not need.
