@@ -430,6 +430,12 @@ size_t ssdk_conv2d_bwd_workspace_bytes(const ssdk_conv_desc* descs, int n, int b
  * same dw / db -- weights shared across levels -- are summed into it). */
 int ssdk_conv2d_bwd(const ssdk_conv_desc* descs, int n, int batch, int accumulate, void* workspace, size_t workspace_bytes,
                     void* stream);
+/* ... with the stream-K state of ssdk_heads_fwd / ssdk_conv2d_fwd_ws (ssdk_heads_fwd_workspace_bytes() bytes, zeroed once, kept between
+ * calls): with SSDK_CONV_STREAMK_BWD=1 in the environment a stride-1 data-gradient launch of a few rounds of tiles whose last round is
+ * partly filled (the RetinaNet towers) runs in stream-K form like the forward launch of the same layers (off by default: measured no
+ * faster).  Same results up to fp32 summation order inside a tile cut in two. */
+int ssdk_conv2d_bwd_sk(const ssdk_conv_desc* descs, int n, int batch, int accumulate, void* workspace, size_t workspace_bytes,
+                       void* sk_workspace, size_t sk_workspace_bytes, void* stream);
 /* ... with the stride-1 data gradients in fast mode (see ssdk_heads_bwd_fast above). */
 size_t ssdk_conv2d_bwd_fast_workspace_bytes(const ssdk_conv_desc* descs, int n, int batch);
 int ssdk_conv2d_bwd_fast(const ssdk_conv_desc* descs, int n, int batch, int accumulate, int terms, void* workspace, size_t workspace_bytes,

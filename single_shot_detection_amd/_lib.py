@@ -96,6 +96,7 @@ _SIGNATURES = {
     'ssdk_conv2d_fwd_ws': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     'ssdk_conv2d_bwd_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     'ssdk_conv2d_bwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'ssdk_conv2d_bwd_sk': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     'ssdk_conv2d_transpose_weights': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'ssdk_relu_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]),
     'ssdk_batchnorm_workspace_bytes': (C.c_size_t, [C.c_int]),

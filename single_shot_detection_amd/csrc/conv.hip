@@ -741,7 +741,7 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
         }
     }
     PHASE(2)
-    if (!MIRROR && !GENERIC && !SCATTER && WAVES == 4 && sk_mode) {
+    if (!GENERIC && !SCATTER && WAVES == 4 && sk_mode) {   // (forward and mirrored-tap backward-data: igemm_streamk_kernel<MIRROR>)
         // accumulator image: [wave][column tile j][e / 4][lane] float4 -- every store / load instruction moves 1 KB contiguous
         f32x4* img = reinterpret_cast<f32x4*>(sk_buf) + (size_t)wave * MAXTN * 4 * 64 + lane;
         if (sk_mode == 1) {
@@ -800,7 +800,7 @@ __device__ __forceinline__ void dma_tile(const ConvProblem& g, int pi, int m_til
             if (tid == 0 && poison == poison) __hip_atomic_store(sk_flag + part, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    if (!MIRROR && !GENERIC && !SCATTER && WAVES == 4 && sk_poisoned) {
+    if (!GENERIC && !SCATTER && WAVES == 4 && sk_poisoned) {
         // an EARLIER launch on this workspace lost a partner (igemm_streamk_kernel read the counter at entry): its flag may still be up,
         // and a launch replayed from a HIP graph carries the same epoch -- it would add that launch's stale partial tile without
         // noticing.  From the first loss on, every tile of every launch on the workspace is NaN.
@@ -858,11 +858,14 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? (BK == 16 ? 3 : SSDK_
     dma_tile<MIRROR, GENERIC, SCATTER, WAVES, BK, MAXTN>(g, pi, m_tile, n_block, ksp);
 }
 
-// Stream-K form of igemm_dma_kernel<false, false, false, 4> (see StreamK): `nwg` persistent workgroups, each walks its range of units.
+// Stream-K form of igemm_dma_kernel<MIRROR, false, false, 4> (see StreamK): `nwg` persistent workgroups, each walks its range of units.
+// MIRROR = true (round 5): the stride-1 backward-data launches -- the RetinaNet towers' grouped data gradient is 2 664 tiles on 512 slots
+// like its forward launch.
 // Order inside a problem: column block major, M tile minor, K slice innermost; and the workgroups of one XCD (round-robin placement: equal
 // blockIdx % 8) take NEIGHBOURING ranges, so that at any moment an XCD works inside one or two column blocks: their weight rows
 // (2.3 MB per block of the 37 x 37 level) stay in its 4 MB L2 -- with M-tile-major order and ranges dealt out in blockIdx order every
 // XCD needed all of a level's weights at once and FETCH_SIZE tripled.
+template <bool MIRROR>
 __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_streamk_kernel(ConvGroup grp, StreamK sk) {
     const int s = (sk.nwg % 8 == 0) ? (int)(blockIdx.x % 8) * (sk.nwg / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
     // boundary b of the range split, snapped down to a whole K slice of the tile it falls in (both neighbours compute the same value)
@@ -909,15 +912,15 @@ __global__ void __launch_bounds__(kConvThreads, SSDK_CONV_WAVES) igemm_streamk_k
         const int s1 = (int)min((long long)slices, (long long)slice + left);
         if (s1 <= slice) break;   // (cannot happen: boundaries are whole slices; a guard against walking on the spot)
         if (slice == 0 && s1 == slices) {
-            dma_tile<false, false, false, 4, kBK, kMaxTN>(g, pi, m_tile, n_block, 0, 0, 0, 0, nullptr, nullptr, 0u, nullptr, 1, nullptr, poisoned);
+            dma_tile<MIRROR, false, false, 4, kBK, kMaxTN>(g, pi, m_tile, n_block, 0, 0, 0, 0, nullptr, nullptr, 0u, nullptr, 1, nullptr, poisoned);
         } else if (slice > 0) {   // second K part of a tile whose first part closes the previous workgroup's range: park the partial sums
-            dma_tile<false, false, false, 4, kBK, kMaxTN>(g, pi, m_tile, n_block, 0, 1, slice, s1, my_buf, sk.flags + s, sk.epoch, sk.timeouts, 1, nullptr,
+            dma_tile<MIRROR, false, false, 4, kBK, kMaxTN>(g, pi, m_tile, n_block, 0, 1, slice, s1, my_buf, sk.flags + s, sk.epoch, sk.timeouts, 1, nullptr,
                                                           false, drop);
         } else {                  // first K part: the rest was computed by the following workgroup(s) right after launch
             const long long tile_end = u + (long long)slices * tn;
             int parts = 1;
             while (s + 1 + parts < sk.nwg && sk.total_units * (s + 1 + parts) / sk.nwg < tile_end) ++parts;
-            dma_tile<false, false, false, 4, kBK, kMaxTN>(g, pi, m_tile, n_block, 0, 2, 0, s1, next_buf, sk.flags + s + 1, sk.epoch, sk.timeouts,
+            dma_tile<MIRROR, false, false, 4, kBK, kMaxTN>(g, pi, m_tile, n_block, 0, 2, 0, s1, next_buf, sk.flags + s + 1, sk.epoch, sk.timeouts,
                                                           parts, sk.host_err, poisoned);
         }
         u += (long long)(s1 - slice) * tn;
@@ -2962,7 +2965,7 @@ static long long streamk_generic_min_range() {
     return v > 0 ? v : 6 * kMaxTN;
 }
 // would launch_group run these forward problems in stream-K form? (decided before the caller splits K: a split launch never does)
-static bool streamk_would_take(const ConvProblem* probs, int count, bool generic) {
+static bool streamk_would_take(const ConvProblem* probs, int count, bool generic, bool mirror = false) {
     // generic convolutions: OFF unless asked for (SSDK_CONV_STREAMK_GENERIC=1).  Measured on the SSD-300 tail at batch 32
     // (tools/r03_sk_sweep.sh): the 1 x 1 512 -> 256 layer 56 -> 92-115 us and the 3 x 3 / 2 256 -> 512 layer 85 -> 140 us with ranges of
     // 8 .. 32 units -- a launch of ONE round has no tail to even out, and every workgroup then parks and fixes up a 64 KB partial tile
@@ -2970,13 +2973,17 @@ static bool streamk_would_take(const ConvProblem* probs, int count, bool generic
     // slots -- the last, partly filled round is what stream-K evens out: 46.40 -> 45.94 ms per step); SSDK_CONV_STREAMK_GENERIC=1: every
     // generic launch that qualifies like a heads launch, =0: none
     static const int generic_mode = []() { const char* e = getenv("SSDK_CONV_STREAMK_GENERIC"); return !e ? -1 : (atoi(e) ? 1 : 0); }();
-    if (getenv("SSDK_CONV_NO_STREAMK") || (generic && generic_mode == 0)) return false;
+    // Round 5: the mirrored-tap data gradient can take it too (igemm_streamk_kernel<true>), but does not by default: on the RetinaNet towers'
+    // grouped launch (2 688 tiles on 512 slots, 8 launches per step) it measured 1 475 us per launch against 1 478 us for the whole-tile
+    // launch and 46.13 / 46.11 against 46.12 / 46.22 ms per step -- nothing to show for the spin-waits.  SSDK_CONV_STREAMK_BWD=1 turns it on.
+    static const bool bwd_on = []() { const char* e = getenv("SSDK_CONV_STREAMK_BWD"); return e && atoi(e) != 0; }();
+    if (getenv("SSDK_CONV_NO_STREAMK") || (generic && generic_mode == 0) || (mirror && !bwd_on)) return false;
     long long units = 0, blocks = 0;
     for (int i = 0; i < count; ++i) {
         const ConvProblem& g = probs[i];
         if (g.Cc % kBK || g.mode) return false;
         const int N = (g.n1 > 0 ? cdiv(g.n0, 8) * 8 : g.n0) + g.n1, tiles_n = cdiv(N, 32);
-        const int half = (!g.stats && half_tile_of(N) && !getenv("SSDK_CONV_NO_HALF_TILE")) ? 1 : 0;   // (as launch_group will set half_last)
+        const int half = (!mirror && !g.stats && half_tile_of(N) && !getenv("SSDK_CONV_NO_HALF_TILE")) ? 1 : 0;   // (as launch_group will set half_last)
         units += (long long)g.m_tiles * g.ksize * g.ksize * (g.Cc / kBK) * (2 * tiles_n - half);           // half-tile units, as StreamK counts
         blocks += (long long)cdiv(g.m_tiles, 8) * 8 * cdiv(tiles_n, kMaxTN);
     }
@@ -3114,7 +3121,7 @@ static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t 
         SSDK_CHECK_LAUNCH("build_vtab_kernel");
         grp.vtab = vtab;
         hipLaunchKernelGGL((igemm_dma_kernel<false, false, true, 4>), dim3(2048), dim3(kConvThreads), 0, s, grp);
-    } else if (dma && skws && !mirror && !scatter && !bk16 && !tn6 && !getenv("SSDK_CONV_NO_STREAMK")) {
+    } else if (dma && skws && !scatter && !bk16 && !tn6 && !getenv("SSDK_CONV_NO_STREAMK")) {
         // stream-K only where it pays: a launch of a few rounds of whole tiles (its last round is then a large share of the time), and
         // every range at least as long as the longest tile (a tile is cut at most once)
         StreamK sk{};
@@ -3144,7 +3151,10 @@ static int launch_group(ConvProblem* probs, int count, bool mirror, hipStream_t 
             sk.host_err = streamk_host_err_word(s);
             sk.epoch = __atomic_add_fetch(&g_streamk_epoch, 1u, __ATOMIC_RELAXED);
             if (sk.epoch == 0) sk.epoch = __atomic_add_fetch(&g_streamk_epoch, 1u, __ATOMIC_RELAXED);   // (0 is what a fresh workspace holds)
-            hipLaunchKernelGGL(igemm_streamk_kernel, dim3(sk.nwg), dim3(kConvThreads), 0, s, grp, sk);
+            if (mirror) hipLaunchKernelGGL(igemm_streamk_kernel<true>, dim3(sk.nwg), dim3(kConvThreads), 0, s, grp, sk);
+            else hipLaunchKernelGGL(igemm_streamk_kernel<false>, dim3(sk.nwg), dim3(kConvThreads), 0, s, grp, sk);
+        } else if (mirror) {
+            hipLaunchKernelGGL((igemm_dma_kernel<true, false, false, 4>), dim3(begin), dim3(kConvThreads), 0, s, grp);
         } else if (generic) {
             hipLaunchKernelGGL((igemm_dma_kernel<false, true, false, 4>), dim3(begin), dim3(kConvThreads), 0, s, grp);
         } else {
@@ -4460,10 +4470,14 @@ extern "C" size_t ssdk_conv2d_bwd_fast_workspace_bytes(const ssdk_conv_desc* des
 // dy: gradient w.r.t. the convolution output (AFTER any fused ReLU has been undone by the caller), [batch,hout,wout,cout]
 // with cout % 4 == 0.  dw / db are ACCUMULATED when `accumulate` != 0 (shared weights across levels), else overwritten.
 static int conv2d_bwd_impl(const ssdk_conv_desc* descs, int n, int batch, int accumulate, void* workspace, size_t workspace_bytes, void* stream,
-                           bool fast);
+                           bool fast, void* sk_workspace = nullptr, size_t sk_workspace_bytes = 0);
 extern "C" int ssdk_conv2d_bwd(const ssdk_conv_desc* descs, int n, int batch, int accumulate, void* workspace, size_t workspace_bytes,
                                void* stream) {
     return conv2d_bwd_impl(descs, n, batch, accumulate, workspace, workspace_bytes, stream, false);
+}
+extern "C" int ssdk_conv2d_bwd_sk(const ssdk_conv_desc* descs, int n, int batch, int accumulate, void* workspace, size_t workspace_bytes,
+                                  void* sk_workspace, size_t sk_workspace_bytes, void* stream) {
+    return conv2d_bwd_impl(descs, n, batch, accumulate, workspace, workspace_bytes, stream, false, sk_workspace, sk_workspace_bytes);
 }
 extern "C" int ssdk_conv2d_bwd_fast(const ssdk_conv_desc* descs, int n, int batch, int accumulate, int terms, void* workspace, size_t workspace_bytes,
                                     void* stream) {
@@ -4472,12 +4486,15 @@ extern "C" int ssdk_conv2d_bwd_fast(const ssdk_conv_desc* descs, int n, int batc
 }
 
 static int conv2d_bwd_impl(const ssdk_conv_desc* descs, int n, int batch, int accumulate, void* workspace, size_t workspace_bytes, void* stream,
-                           bool fast) {
+                           bool fast, void* sk_workspace, size_t sk_workspace_bytes) {
     SSDK_REQUIRE(descs && n > 0 && n <= kMaxProblems, SSDK_E_INVALID, "ssdk_conv2d_bwd: n=%d (1..%d)", n, kMaxProblems);
+    SSDK_REQUIRE(!sk_workspace || !g_sk_host_err || *static_cast<volatile unsigned*>(g_sk_host_err) == 0u, SSDK_E_STREAMK_TIMEOUT,
+                 "ssdk_conv2d_bwd: an earlier stream-K launch of this process gave up waiting for a parked partial tile -- see ssdk_heads_fwd_timeouts");
     SSDK_REQUIRE(workspace && workspace_bytes >= conv2d_bwd_ws_bytes(descs, n, batch, fast), SSDK_E_WORKSPACE, "ssdk_conv2d_bwd: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     Carver carve(workspace);
     ConvProblem dgrad[kMaxProblems], scat[kMaxProblems], rowsT[kMaxProblems];
+    int dgrad_desc[kMaxProblems];
     StridedDxGroup sdg{};
     int n_rowsT = 0, sd_blocks = 0;
     // strided data gradients: contribution rows + sum pass (ordered, no zero-fill) in deterministic mode; otherwise the atomic scatter
@@ -4572,7 +4589,7 @@ static int conv2d_bwd_impl(const ssdk_conv_desc* descs, int n, int batch, int ac
                 fsrc[n_fdg] = wd;
                 fdg[n_fdg++] = g;
             } else {
-                if (maybe_split_k(g)) zl.add(d.dx, (size_t)batch * d.hin * d.win * d.cin);   // (small maps: K = taps * cout is one long chain per tile)
+                dgrad_desc[n_dgrad] = i;   // (a K split of the small maps is decided below, once the launch is known not to take stream-K)
                 dgrad[n_dgrad++] = g;
             }
         } else if (d.dx) {
@@ -4615,6 +4632,14 @@ static int conv2d_bwd_impl(const ssdk_conv_desc* descs, int n, int batch, int ac
             if (!seen) zl.add(d.db, (size_t)d.cout);
         }
     }
+    // stride-1 data gradients: a few rounds of whole tiles whose last round is partly filled (the RetinaNet towers: 2 688 tiles on 512 slots)
+    // run in stream-K form, as the forward launch of the same layers -- with the caller's stream-K state (the workspace of ssdk_heads_fwd /
+    // ssdk_conv2d_fwd_ws); otherwise the small maps split K (one long chain per tile: K = taps * cout) with atomics into a zeroed dx
+    const bool dgrad_sk = n_dgrad && sk_workspace && sk_workspace_bytes >= ssdk_heads_fwd_workspace_bytes() && streamk_would_take(dgrad, n_dgrad, true, true);
+    for (int q = 0; q < n_dgrad && !dgrad_sk; ++q) {
+        const ssdk_conv_desc& d = descs[dgrad_desc[q]];
+        if (maybe_split_k(dgrad[q])) zl.add(d.dx, (size_t)batch * d.hin * d.win * d.cin);
+    }
     int rc = zl.launch(s);
     if (rc) return rc;
     ReduceList rl;
@@ -4646,7 +4671,15 @@ static int conv2d_bwd_impl(const ssdk_conv_desc* descs, int n, int batch, int ac
         SSDK_CHECK_LAUNCH("colsum_kernel");
     }
     if (n_dgrad) {
-        rc = launch_group(dgrad, n_dgrad, true, s);
+        StreamKWs sk{};
+        const bool use_sk = dgrad_sk;
+        if (use_sk) {
+            Carver c(sk_workspace);
+            sk.partial = c.take<float>((size_t)(kStreamKWgs + 1) * (4 * kMaxTN * 4 * 64 * 4));
+            sk.flags = c.take<unsigned>((size_t)kStreamKWgs + 2);
+            sk.nwg = kStreamKWgs;
+        }
+        rc = launch_group(dgrad, n_dgrad, true, s, use_sk, false, nullptr, use_sk ? &sk : nullptr);
         if (rc) return rc;
     }
     if (n_scat) {

@@ -146,7 +146,11 @@ def _conv2d_bwd(lib, arr, n, batch, device, stream):
     else:
         need = lib.ssdk_conv2d_bwd_workspace_bytes(arr, n, batch)
         ws = _lib.scratch(need, device, 'conv2d_bwd')
-        _lib.check(lib.ssdk_conv2d_bwd(arr, n, batch, 0, _dp(ws), ws.numel(), stream), 'ssdk_conv2d_bwd')
+        if _GENERIC_STREAMK:   # (the stride-1 data gradients of a tower take stream-K like its forward launch: same state, same rule)
+            sk = _lib.scratch(lib.ssdk_heads_fwd_workspace_bytes(), device, _lib.STREAMK_TAG, zeroed=True)
+            _lib.check(lib.ssdk_conv2d_bwd_sk(arr, n, batch, 0, _dp(ws), ws.numel(), _dp(sk), sk.numel(), stream), 'ssdk_conv2d_bwd')
+        else:
+            _lib.check(lib.ssdk_conv2d_bwd(arr, n, batch, 0, _dp(ws), ws.numel(), stream), 'ssdk_conv2d_bwd')
 
 
 class _GroupConvFn(torch.autograd.Function):

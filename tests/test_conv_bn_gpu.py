@@ -795,3 +795,24 @@ def test_sfam_over_pieces_vs_torch(B, n_pieces, Cp, sizes):
         del os.environ['SSDK_SFAM_CAT']
     for a, b in zip(outs + list(grads), outs2 + list(grads2)):
         assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+
+
+def test_streamk_data_gradient_equals_the_whole_tile_launch():
+    """ssdk_conv2d_bwd_sk with SSDK_CONV_STREAMK_BWD=1 (opt-in, read once per process: a child process): a stride-1 data gradient of a few
+    rounds of tiles whose last round is partly filled (576 row tiles x 2 column blocks = 1 152 tiles on 512 slots, the shape class of the
+    RetinaNet towers) runs as igemm_streamk_kernel<true>; same numbers as the whole-tile launch (SSDK_CONV_NO_STREAMK=1) up to the
+    summation order inside a tile cut in two, and as torch's own data gradient."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SSDK_CONV_STREAMK_BWD='1')
+    out = subprocess.run([sys.executable, os.path.join(repo, 'tests', 'streamk_bwd_worker.py')], cwd=repo, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.returncode, out.stderr[-2000:])
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res['timeouts'] == 0
+    assert res['differs']                       # (the two launches do differ: some tiles are summed in two parts)
+    assert res['max_vs_plain'] <= 1e-5          # (relative to the largest gradient: sums of 2 304 products, cut at another place)
+    assert res['dw_max_vs_plain'] <= 1e-4
+    assert res['max_vs_torch'] <= 2e-4          # (MIOpen's own algorithm: a looser bound)
