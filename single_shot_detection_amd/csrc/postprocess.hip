@@ -1161,7 +1161,22 @@ struct KeySpace {
     }
 };
 
+// The one-wave helpers below synchronise the wave with its own LDS traffic.  WG = true: the wave is the whole workgroup (__syncthreads, as
+// the kernels of one wave per (image, class) always did); WG = false: the wave is one of several in a workgroup that walk different lists
+// (post_finish_kernel) -- a workgroup barrier would wait for waves that never come, and a wave's own DS operations complete in order, so
+// a fence that keeps the compiler from moving LDS accesses across it is all that is needed.
+template <bool WG>
+__device__ __forceinline__ void post_sync() {
+    if (WG) {
+        __syncthreads();
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // builds s_pref from the per-lane counts (lane g = count of segment g) and returns the total; one wave
+template <bool WG = true>
 __device__ __forceinline__ int wave_prefix_to_lds(int mycnt, int nseg, int* s_pref) {
     const int lane = lane_id();
     int incl = mycnt;
@@ -1174,13 +1189,13 @@ __device__ __forceinline__ int wave_prefix_to_lds(int mycnt, int nseg, int* s_pr
     const int total = __shfl(incl, kWave - 1, kWave);
     if (lane == 0) s_pref[kWave] = total;
     if (lane >= nseg) s_pref[lane] = total;   // (so that s_pref[nseg] = total for any nseg <= 64)
-    __syncthreads();
+    post_sync<WG>();
     return total;
 }
 
 // All n keys into an LDS array with every fetch of the wave in flight at once (n <= cap): the radix passes and the collection then run
 // from LDS.  Fetching per pass made the launch as long as one wave's chain of dependent memory round trips (3 passes x 3 trips).
-template <int CAP>
+template <int CAP, bool WG = true>
 __device__ __forceinline__ void wave_cache_keys(const KeySpace& ks, u64* s_all) {
     const int lane = lane_id();
     u64 v[CAP / kWave];
@@ -1189,18 +1204,19 @@ __device__ __forceinline__ void wave_cache_keys(const KeySpace& ks, u64* s_all) 
 #pragma unroll
     for (int k = 0; k < CAP / kWave; ++k)
         if (k * kWave + lane < ks.n) s_all[k * kWave + lane] = v[k];
-    __syncthreads();
+    post_sync<WG>();
 }
 
 // Radix narrowing by one wave: the prefix such that at most `cap` and at least K of the keys are >= it (keys distinct).
 // s_all != NULL: the keys are in LDS (wave_cache_keys), else they are fetched through ks.
+template <bool WG = true>
 __device__ __forceinline__ u64 wave_radix_prefix(unsigned* s_hist, int K, int cap, const KeySpace& ks, const u64* s_all) {
     const int lane = lane_id();
     u64 prefix = 0;
     unsigned above = 0;
     for (int shift = 56; shift >= 0; shift -= 8) {
         for (int b = lane; b < 256; b += kWave) s_hist[b] = 0;
-        __syncthreads();
+        post_sync<WG>();
         for (int p0 = 0; p0 < ks.n; p0 += 2 * kWave) {   // two independent fetches per trip
             const int pa = p0 + lane, pb = p0 + kWave + lane;
             const u64 ka = s_all ? s_all[min(pa, ks.n - 1)] : ks.load(min(pa, ks.n - 1));
@@ -1208,13 +1224,13 @@ __device__ __forceinline__ u64 wave_radix_prefix(unsigned* s_hist, int K, int ca
             if (pa < ks.n && (shift == 56 || (ka >> (shift + 8)) == (prefix >> (shift + 8)))) atomicAdd(&s_hist[(unsigned)(ka >> shift) & 255u], 1u);
             if (pb < ks.n && (shift == 56 || (kb >> (shift + 8)) == (prefix >> (shift + 8)))) atomicAdd(&s_hist[(unsigned)(kb >> shift) & 255u], 1u);
         }
-        __syncthreads();
+        post_sync<WG>();
         int digit;
         unsigned cum, h;
         wave_find_digit(s_hist, above, (unsigned)K, &digit, &cum, &h);
         prefix |= (u64)digit << shift;
         above = cum;
-        __syncthreads();
+        post_sync<WG>();
         if (cum + h <= (unsigned)cap) break;
     }
     return prefix;
@@ -1336,28 +1352,50 @@ __device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f3
 // MODE 2 (tail): a class whose Khead-th score is below the bound is done; any other one repeats the NMS on its candidates at or above
 //         the bound (all of them when it is 0) and overwrites the head's rows.  Exact: a kept box below the bound cannot be among the
 //         max_total best, and a box's fate depends only on better boxes of its class.
-template <bool TIE_UP, int MODE>
-__global__ void __launch_bounds__(kWave) post_nms_wave_kernel(const float4* __restrict__ locs, const float4* __restrict__ priors, int A, int ncls,
-                                                              int K, double thr_mid, float xy_scale, float wh_scale, NmsSrc src,
-                                                              float* __restrict__ pc_rows, float* __restrict__ pc_score, int* __restrict__ pc_count,
-                                                              int* __restrict__ pc_m, int stop, int Khead, const unsigned* __restrict__ img_tau,
-                                                              unsigned* __restrict__ head_last) {
+// the LDS of one list's wave (the kernel of one wave per list declares them; post_finish_kernel hands every tail wave a slice of its own)
+struct NmsLds {
+    u64* s_keys;      // [kCap]
+    u64* s_sorted;    // [kCap]
+    unsigned* s_hist; // [256]
+    int* s_pref;      // [kWave + 1]
+    u64* s_cache;     // [kNmsCache]
+    int* s_hot;       // [kWave]
+};
+constexpr size_t kNmsLdsBytes = (size_t)kWaveK * 8 * 2 + 256 * 4 + (kWave + 1 + 3) * 4 + (size_t)kNmsCache * 8 + kWave * 4;   // (MODE 2: kCap = kWaveK)
+__device__ __forceinline__ NmsLds carve_nms_lds(unsigned char* base) {
+    NmsLds l;
+    l.s_cache = reinterpret_cast<u64*>(base);
+    l.s_keys = l.s_cache + kNmsCache;
+    l.s_sorted = l.s_keys + kWaveK;
+    l.s_hist = reinterpret_cast<unsigned*>(l.s_sorted + kWaveK);
+    l.s_pref = reinterpret_cast<int*>(l.s_hist + 256);
+    l.s_hot = l.s_pref + (kWave + 1 + 3);
+    return l;
+}
+
+// WG: see post_sync.  floor_in (MODE 2): the image's bound (post_img_tau_kernel's value).
+template <bool TIE_UP, int MODE, bool WG>
+__device__ __forceinline__ void nms_wave_body(const float4* __restrict__ locs, const float4* __restrict__ priors, int A, int ncls,
+                                              int K, double thr_mid, float xy_scale, float wh_scale, const NmsSrc& src,
+                                              float* __restrict__ pc_rows, float* __restrict__ pc_score, int* __restrict__ pc_count,
+                                              int* __restrict__ pc_m, int stop, int Khead, unsigned floor_in,
+                                              unsigned* __restrict__ head_last, int pc, const NmsLds& lds) {
     constexpr int kCap = MODE == 1 ? kWave : kWaveK;   // survivors of the radix narrowing (the head keeps one entry per lane)
-    __shared__ u64 s_keys[kCap];
-    __shared__ u64 s_sorted[kCap];
-    __shared__ unsigned s_hist[256];
-    __shared__ int s_pref[kWave + 1];
-    __shared__ u64 s_cache[kNmsCache];
-    const int pc = blockIdx.x, lane = threadIdx.x;
+    u64* const s_keys = lds.s_keys;
+    u64* const s_sorted = lds.s_sorted;
+    unsigned* const s_hist = lds.s_hist;
+    int* const s_pref = lds.s_pref;
+    u64* const s_cache = lds.s_cache;
+    int* const s_hot = lds.s_hot;
+    const int lane = lane_id();
     const int i = pc / ncls, c = pc % ncls;
     const int Kuse = MODE == 1 ? Khead : K;
     unsigned floor_bits = 0;
     if (MODE == 2) {
         const unsigned hl = head_last[pc];
-        floor_bits = img_tau[i];
+        floor_bits = floor_in;
         if (hl == 0u || hl <= floor_bits) return;   // (hl - 1 < floor: every further candidate of this class is below the bound)
     }
-    __shared__ int s_hot[kWave];
     const int mycnt = lane < src.nseg ? src.segcnt[(size_t)pc * src.nseg_all + src.seg0 + lane] : 0;
     const int myhot = lane < src.nseg ? src.seghot[(size_t)pc * src.nseg_all + src.seg0 + lane] : 0;
     const int ntop_all = src.top ? src.topcnt[pc] : 0, ntop_hot = src.top ? src.tophot[pc] : 0;
@@ -1377,10 +1415,10 @@ __global__ void __launch_bounds__(kWave) post_nms_wave_kernel(const float4* __re
     const bool hot_view = MODE == 1 && n_hot >= Khead && n_hot < n_all;
     if (hot_view) {
         ks.ntop = ntop_hot; ks.s_hot = nullptr;
-        ks.n = ntop_hot + wave_prefix_to_lds(myhot, src.nseg, s_pref);
+        ks.n = ntop_hot + wave_prefix_to_lds<WG>(myhot, src.nseg, s_pref);
     } else {
         ks.ntop = ntop_all; ks.s_hot = s_hot;
-        ks.n = ntop_all + wave_prefix_to_lds(mycnt, src.nseg, s_pref);
+        ks.n = ntop_all + wave_prefix_to_lds<WG>(mycnt, src.nseg, s_pref);
     }
     const int n = ks.n;
     if (n_all == 0) {
@@ -1396,20 +1434,20 @@ __global__ void __launch_bounds__(kWave) post_nms_wave_kernel(const float4* __re
     u64 prefix = 0;
     const u64* s_all = nullptr;
     if (n > kCap && n <= kNmsCache) {
-        wave_cache_keys<kNmsCache>(ks, s_cache);
+        wave_cache_keys<kNmsCache, WG>(ks, s_cache);
         s_all = s_cache;
     }
-    if (n > kCap) prefix = wave_radix_prefix(s_hist, Kuse, kCap, ks, s_all);
+    if (n > kCap) prefix = wave_radix_prefix<WG>(s_hist, Kuse, kCap, ks, s_all);
     s_keys[lane] = 0ull;
     if (MODE != 1) s_keys[lane + 64] = 0ull;
-    __syncthreads();
+    post_sync<WG>();
     const int cnt = wave_collect(ks, s_all, prefix, kCap, [&](int pos, u64 key) { s_keys[pos] = key; });
-    __syncthreads();
+    post_sync<WG>();
     // --- rank by counting (keys are distinct): rank = number of larger keys; s_sorted[rank] = key
     const u64 kA = s_keys[lane], kB = MODE != 1 ? s_keys[lane + 64] : 0ull;
     s_sorted[lane] = 0ull;
     if (MODE != 1) s_sorted[lane + 64] = 0ull;
-    __syncthreads();
+    post_sync<WG>();
     {
         int rA = 0, rB = 0;
         const int c4 = (cnt + 3) & ~3;
@@ -1421,7 +1459,7 @@ __global__ void __launch_bounds__(kWave) post_nms_wave_kernel(const float4* __re
         if (lane < cnt) s_sorted[rA] = kA;
         if (MODE != 1 && lane + 64 < cnt) s_sorted[rB] = kB;
     }
-    __syncthreads();
+    post_sync<WG>();
     int m = min(cnt, Kuse);   // box_utils.py:186-188
     if (MODE != 2 && lane == 0 && src.nall_out) src.nall_out[pc] = n_all;
     if (MODE == 1 && lane == 0) {
@@ -1499,22 +1537,42 @@ __global__ void __launch_bounds__(kWave) post_nms_wave_kernel(const float4* __re
     }
 }
 
+template <bool TIE_UP, int MODE>
+__global__ void __launch_bounds__(kWave) post_nms_wave_kernel(const float4* __restrict__ locs, const float4* __restrict__ priors, int A, int ncls,
+                                                              int K, double thr_mid, float xy_scale, float wh_scale, NmsSrc src,
+                                                              float* __restrict__ pc_rows, float* __restrict__ pc_score, int* __restrict__ pc_count,
+                                                              int* __restrict__ pc_m, int stop, int Khead, const unsigned* __restrict__ img_tau,
+                                                              unsigned* __restrict__ head_last) {
+    constexpr int kCap = MODE == 1 ? kWave : kWaveK;
+    __shared__ u64 s_keys[kCap];
+    __shared__ u64 s_sorted[kCap];
+    __shared__ unsigned s_hist[256];
+    __shared__ int s_pref[kWave + 1];
+    __shared__ u64 s_cache[kNmsCache];
+    __shared__ int s_hot[kWave];
+    NmsLds lds;
+    lds.s_keys = s_keys; lds.s_sorted = s_sorted; lds.s_hist = s_hist; lds.s_pref = s_pref; lds.s_cache = s_cache; lds.s_hot = s_hot;
+    const int pc = blockIdx.x;
+    nms_wave_body<TIE_UP, MODE, true>(locs, priors, A, ncls, K, thr_mid, xy_scale, wh_scale, src, pc_rows, pc_score, pc_count, pc_m, stop, Khead,
+                                      MODE == 2 ? img_tau[pc / ncls] : 0u, head_last, pc, lds);
+}
+
 // The max_total-th largest score among an image's kept head boxes (post_nms_wave_kernel MODE 1), as float bits rounded down to 16
 // significant bits; 0 when the image has
 // at most max_total of them (then nothing may be dropped: the merge concatenates when the total stays within max_total).
-constexpr int kImgTauPer = 24;   // values per thread: ncls * Khead <= 256 * 24
-__global__ void __launch_bounds__(256) post_img_tau_kernel(int ncls, int K, int Khead, int max_total, const float* __restrict__ pc_score,
-                                                           const int* __restrict__ pc_count, unsigned* __restrict__ img_tau) {
-    __shared__ unsigned s_hist[256];
-    __shared__ unsigned s_misc[2];
-    __shared__ int s_total;
-    const int i = blockIdx.x, tid = threadIdx.x;
+constexpr int kImgTauPer = 24;   // values per thread of a 256-thread workgroup: ncls * Khead <= 256 * 24
+// (THREADS threads of one workgroup, all of them; returns the bound to every thread)
+template <int THREADS>
+__device__ __forceinline__ unsigned img_tau_block(int i, int ncls, int K, int Khead, int max_total, const float* __restrict__ pc_score,
+                                                  const int* __restrict__ pc_count, unsigned* s_hist, unsigned* s_misc, int* s_total) {
+    constexpr int kPer = kImgTauPer * 256 / THREADS;
+    const int tid = threadIdx.x;
     const int slots = ncls * Khead;
-    unsigned v[kImgTauPer];   // score bits + 1; 0 = no row
+    unsigned v[kPer];   // score bits + 1; 0 = no row
     int mine = 0;
 #pragma unroll
-    for (int k = 0; k < kImgTauPer; ++k) {
-        const int s = tid + k * 256;
+    for (int k = 0; k < kPer; ++k) {
+        const int s = tid + k * THREADS;
         v[k] = 0u;
         if (s < slots) {   // (count and score fetched side by side: a slot past the count holds stale bits, never an invalid address)
             const int c = s / Khead, r = s - c * Khead;
@@ -1524,22 +1582,19 @@ __global__ void __launch_bounds__(256) post_img_tau_kernel(int ncls, int K, int 
             if (r < have) { v[k] = bits + 1u; ++mine; }
         }
     }
-    if (tid == 0) s_total = 0;
+    if (tid == 0) *s_total = 0;
     __syncthreads();
     struct AddI { __device__ __forceinline__ int operator()(int a, int b) const { return a + b; } };
     mine = wave_allreduce(mine, AddI());
-    if (lane_id() == 0) atomicAdd(&s_total, mine);
+    if (lane_id() == 0) atomicAdd(s_total, mine);
     __syncthreads();
-    if (s_total <= max_total) {
-        if (tid == 0) img_tau[i] = 0u;
-        return;
-    }
+    if (*s_total <= max_total) return 0u;
     unsigned prefix = 0, above = 0;
     for (int shift = 24; shift >= 16; shift -= 8) {   // the upper 16 bits of the value only: still a lower bound, half the passes
-        s_hist[tid] = 0;
+        for (int b = tid; b < 256; b += THREADS) s_hist[b] = 0;
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < kImgTauPer; ++k)
+        for (int k = 0; k < kPer; ++k)
             if (v[k] != 0u && (shift == 24 || (v[k] >> (shift + 8)) == (prefix >> (shift + 8)))) atomicAdd(&s_hist[(v[k] >> shift) & 255u], 1u);
         __syncthreads();
         if (tid < kWave) {
@@ -1553,21 +1608,37 @@ __global__ void __launch_bounds__(256) post_img_tau_kernel(int ncls, int K, int 
         above = s_misc[1];
         __syncthreads();
     }
-    if (tid == 0) img_tau[i] = prefix ? prefix - 1u : 0u;   // (prefix <= the max_total-th largest stored value, which is score bits + 1)
+    return prefix ? prefix - 1u : 0u;   // (prefix <= the max_total-th largest stored value, which is score bits + 1)
+}
+__global__ void __launch_bounds__(256) post_img_tau_kernel(int ncls, int K, int Khead, int max_total, const float* __restrict__ pc_score,
+                                                           const int* __restrict__ pc_count, unsigned* __restrict__ img_tau) {
+    __shared__ unsigned s_hist[256];
+    __shared__ unsigned s_misc[2];
+    __shared__ int s_total;
+    const unsigned tau = img_tau_block<256>(blockIdx.x, ncls, K, Khead, max_total, pc_score, pc_count, s_hist, s_misc, &s_total);
+    if (threadIdx.x == 0) img_tau[blockIdx.x] = tau;
 }
 
 // per-image merge with the image's keys in registers (ncls * K <= kMergeSlots)
-__global__ void __launch_bounds__(1024) post_merge2_kernel(int ncls, int K, int max_total, const float* __restrict__ pc_rows,
-                                                           const float* __restrict__ pc_score, const int* __restrict__ pc_count,
-                                                           const int* __restrict__ pc_m, float* __restrict__ out, int out_cap,
-                                                           int* __restrict__ counts, long long* __restrict__ nms_candidates,
-                                                           const int* __restrict__ pc_nall, unsigned* __restrict__ host_hint) {
-    __shared__ u64 s_keys[kMergeCap];
-    __shared__ unsigned s_hist[256];
-    __shared__ u64 s_misc[4];
-    __shared__ int s_n;
-    extern __shared__ int s_prefix[];  // [ncls + 1]
-    const int i = blockIdx.x, tid = threadIdx.x;
+struct MergeLds {
+    u64* s_keys;       // [kMergeCap]
+    unsigned* s_hist;  // [256]
+    u64* s_misc;       // [4]
+    int* s_n;
+    int* s_prefix;     // [ncls + 1]
+};
+// (the 1 024 threads of one workgroup, all of them, image i)
+__device__ __forceinline__ void merge_block(int i, int ncls, int K, int max_total, const float* __restrict__ pc_rows,
+                                            const float* __restrict__ pc_score, const int* __restrict__ pc_count,
+                                            const int* __restrict__ pc_m, float* __restrict__ out, int out_cap,
+                                            int* __restrict__ counts, long long* __restrict__ nms_candidates,
+                                            const int* __restrict__ pc_nall, unsigned* __restrict__ host_hint, const MergeLds& lds) {
+    u64* const s_keys = lds.s_keys;
+    unsigned* const s_hist = lds.s_hist;
+    u64* const s_misc = lds.s_misc;
+    int& s_n = *lds.s_n;
+    int* const s_prefix = lds.s_prefix;
+    const int tid = threadIdx.x;
     const int* cnt = pc_count + (size_t)i * ncls;
     if (tid < kWave) {
         const int per = (ncls + kWave - 1) / kWave;
@@ -1687,6 +1758,75 @@ __global__ void __launch_bounds__(1024) post_merge2_kernel(int ncls, int K, int 
         }
         if (tid == 0) counts[i] = nw;
     }
+}
+__global__ void __launch_bounds__(1024) post_merge2_kernel(int ncls, int K, int max_total, const float* __restrict__ pc_rows,
+                                                           const float* __restrict__ pc_score, const int* __restrict__ pc_count,
+                                                           const int* __restrict__ pc_m, float* __restrict__ out, int out_cap,
+                                                           int* __restrict__ counts, long long* __restrict__ nms_candidates,
+                                                           const int* __restrict__ pc_nall, unsigned* __restrict__ host_hint) {
+    __shared__ u64 s_keys[kMergeCap];
+    __shared__ unsigned s_hist[256];
+    __shared__ u64 s_misc[4];
+    __shared__ int s_n;
+    extern __shared__ int s_prefix[];  // [ncls + 1]
+    MergeLds lds;
+    lds.s_keys = s_keys; lds.s_hist = s_hist; lds.s_misc = s_misc; lds.s_n = &s_n; lds.s_prefix = s_prefix;
+    merge_block(blockIdx.x, ncls, K, max_total, pc_rows, pc_score, pc_count, pc_m, out, out_cap, counts, nms_candidates, pc_nall, host_hint, lds);
+}
+
+// Round 5: what follows the NMS heads of an image, in ONE workgroup of 1 024 threads per image instead of three launches (image bound:
+// 64 workgroups x 256 threads; tail: one wave per (image, class), nearly all of which found nothing to do; merge: 64 x 1 024):
+//   A. the image's bound (img_tau_block);
+//   B. the classes that must be redone above the bound (head_last > bound: a handful per image, often none) are listed, and eight waves
+//      take them one list each (nms_wave_body MODE 2 with the wave-level synchronisation, a slice of LDS each);
+//   C. the merge (merge_block), behind a workgroup barrier and an agent-scope fence -- the tail waves' rows were written through this
+//      CU's L1, which may still hold the head's version of the same lines from phase A.
+// An image with many classes to redo (more than eight) takes them in rounds of eight: correct, just slower than the chip-wide launch was.
+constexpr int kFinishTailWaves = 8;
+template <bool TIE_UP>
+__global__ void __launch_bounds__(1024) post_finish_kernel(const float4* __restrict__ locs, const float4* __restrict__ priors, int A, int ncls, int K,
+                                                           double thr_mid, float xy_scale, float wh_scale, NmsSrc src, float* __restrict__ pc_rows,
+                                                           float* __restrict__ pc_score, int* __restrict__ pc_count, int* __restrict__ pc_m, int Khead,
+                                                           int max_total, unsigned* __restrict__ img_tau, unsigned* __restrict__ head_last,
+                                                           float* __restrict__ out, int out_cap, int* __restrict__ counts,
+                                                           long long* __restrict__ nms_candidates, const int* __restrict__ pc_nall,
+                                                           unsigned* __restrict__ host_hint) {
+    __shared__ u64 s_keys[kMergeCap];
+    __shared__ unsigned s_hist[256];
+    __shared__ u64 s_misc[4];
+    __shared__ unsigned s_misc32[2];
+    __shared__ int s_n, s_total, s_nflag;
+    __shared__ unsigned s_tau;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // [kFinishTailWaves][kNmsLdsBytes], then s_flagged[ncls], then s_prefix[ncls + 1]
+    int* const s_flagged = reinterpret_cast<int*>(s_dyn + (size_t)kFinishTailWaves * kNmsLdsBytes);
+    int* const s_prefix = s_flagged + ncls;
+    const int i = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+    // A
+    const unsigned tau = img_tau_block<1024>(i, ncls, K, Khead, max_total, pc_score, pc_count, s_hist, s_misc32, &s_total);
+    if (tid == 0) { img_tau[i] = tau; s_nflag = 0; }
+    __syncthreads();
+    // B
+    for (int c = tid; c < ncls; c += 1024) {
+        const unsigned hl = head_last[(size_t)i * ncls + c];
+        if (hl != 0u && hl > tau) s_flagged[atomicAdd(&s_nflag, 1)] = c;
+    }
+    __syncthreads();
+    const int nflag = s_nflag;
+    if (wave < kFinishTailWaves && nflag) {
+        const NmsLds lds = carve_nms_lds(s_dyn + (size_t)wave * kNmsLdsBytes);
+        for (int f = wave; f < nflag; f += kFinishTailWaves)
+            nms_wave_body<TIE_UP, 2, false>(locs, priors, A, ncls, K, thr_mid, xy_scale, wh_scale, src, pc_rows, pc_score, pc_count, pc_m, 0, Khead, tau,
+                                            head_last, i * ncls + s_flagged[f], lds);
+    }
+    if (nflag) {   // (uniform)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    // C
+    MergeLds ml;
+    ml.s_keys = s_keys; ml.s_hist = s_hist; ml.s_misc = s_misc; ml.s_n = &s_n; ml.s_prefix = s_prefix;
+    merge_block(i, ncls, K, max_total, pc_rows, pc_score, pc_count, pc_m, out, out_cap, counts, nms_candidates, pc_nall, host_hint, ml);
 }
 
 }  // namespace ssdk
@@ -1943,7 +2083,27 @@ static int postprocess_v2(const PostPlan& p, const float* scores, const float* l
     hipLaunchKernelGGL((post_nms_wave_kernel<TIE, MODE>), dim3(npc), dim3(kWave), 0, s, (const float4*)locs, (const float4*)priors, num_anchors, \
                        ncls, max_per_class, thr_mid, xy_scale, wh_scale, src, w.pc_rows, w.pc_score, w.pc_count, w.pc_m, nms_stop, khead,      \
                        w.img_tau, w.head_last)
-    if (khead) {
+    if (khead && !getenv("SSDK_POST_NO_FOLD")) {
+        if (tie_up) SSDK_NMS(true, 1); else SSDK_NMS(false, 1);
+        SSDK_CHECK_LAUNCH("post_nms_wave_kernel (head)");
+        // the image's bound, the few classes to redo above it and the merge: one workgroup per image (post_finish_kernel)
+        const size_t dyn = (size_t)kFinishTailWaves * kNmsLdsBytes + sizeof(int) * (size_t)(2 * ncls + 1);
+        static bool attr_set[2] = {false, false};
+        if (!attr_set[tie_up]) {
+            if (tie_up) SSDK_CHECK_HIP(hipFuncSetAttribute((const void*)post_finish_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 8 * 1024)));
+            else SSDK_CHECK_HIP(hipFuncSetAttribute((const void*)post_finish_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 8 * 1024)));
+            attr_set[tie_up] = true;
+        }
+        SSDK_REQUIRE(dyn <= 160 * 1024 - 8 * 1024, SSDK_E_UNSUPPORTED, "ssdk_postprocess: %d classes need %zu bytes of LDS", ncls, dyn);
+#define SSDK_FINISH(TIE)                                                                                                                      \
+    hipLaunchKernelGGL((post_finish_kernel<TIE>), dim3(batch), dim3(1024), dyn, s, (const float4*)locs, (const float4*)priors, num_anchors, ncls, \
+                       max_per_class, thr_mid, xy_scale, wh_scale, src, w.pc_rows, w.pc_score, w.pc_count, w.pc_m, khead, max_total, w.img_tau,   \
+                       w.head_last, out, out_cap, counts, (long long*)nms_candidates, w.pc_nall, hint)
+        if (tie_up) SSDK_FINISH(true); else SSDK_FINISH(false);
+#undef SSDK_FINISH
+        SSDK_CHECK_LAUNCH("post_finish_kernel");
+        return SSDK_OK;
+    } else if (khead) {   // (SSDK_POST_NO_FOLD: the three launches of rounds 2-4, a measurement knob)
         if (tie_up) SSDK_NMS(true, 1); else SSDK_NMS(false, 1);
         SSDK_CHECK_LAUNCH("post_nms_wave_kernel (head)");
         hipLaunchKernelGGL(post_img_tau_kernel, dim3(batch), dim3(256), 0, s, ncls, max_per_class, khead, max_total, w.pc_score, w.pc_count,
