@@ -447,7 +447,6 @@ def hbm_legs(device, cfg_name='ssd_300_vgg16_voc', batch=64):
     # launches: sample plan (long lists) select x 2 + class bound, short lists select only; then the NMS head and the per-image finish
     # (image bound + the few classes to redo + merge: post_finish_kernel, round 5), or -- where the two-pass NMS does not apply
     # (postprocess.hip nms_head_size) -- one NMS launch and the merge
-    ncls_post = C - 1 if hp.cfg['score_converter'] == 'SOFTMAX' else C
     for tag, sc, launches in (('worst_case', logits, 5), ('trained_like', trained, 3)):
         us = gpu_time_us(lambda: hp.post.postprocess_padded((sc, locs), hp.anchors), inner=5)
         leg(f'postprocess_{tag}', us, 4.0 * A * (C + 4) * B, 'ssdk_postprocess: score convert + threshold + per-class top-100 + decode + NMS + top-200', launches)

@@ -302,3 +302,34 @@ def test_fewer_anchors_than_max_per_class_without_max_total():
     out = post.postprocess((torch.from_numpy(lg).cuda(), torch.from_numpy(lc).cuda()), torch.from_numpy(pri).cuda())
     ref = oracle.postprocess(lg, lc, pri, softmax=False, score_thr=0.01, max_per_class=64, nms_thr=0.5, max_total=None)
     compare(out, ref, boundaries=Boundaries(lg, C, False, 0.01, 64, None))
+
+
+def test_finish_kernel_redoes_more_classes_than_it_has_tail_waves():
+    """post_finish_kernel (image bound + classes to redo + merge in one workgroup per image): twelve classes of image 0 hold 40 candidates
+    each on near-identical boxes (NMS keeps one or two per class, so the image keeps far fewer than max_total boxes: no bound, and every
+    class with more candidates than the NMS head took is redone) -- more lists than the kernel's eight tail waves, taken in two rounds;
+    image 1 is an ordinary one.  Against the oracle, strictly."""
+    cfg, g, logits, locs, softmax = inputs('ssd_mb2_voc', 'trained', batch=2, seeds=(81, 82))
+    A, Cn = g['anchors'].shape[0], cfg['num_classes']
+    assert softmax
+    rng = np.random.default_rng(17)
+    lg = logits.reshape(2, A, Cn).copy()
+    lc = locs.reshape(2, A, 4).copy()
+    lg[0] = rng.standard_normal((A, Cn)).astype(np.float32)
+    lg[0, :, 0] += 14.0                                   # background everywhere ...
+    pri = g['anchors']                                     # centroid form (cx, cy, w, h)
+    chosen = rng.permutation(A)[:12 * 40].reshape(12, 40)
+    for k in range(12):                                    # ... except 40 anchors per class, all decoded onto (nearly) one box per class
+        box = np.array([60.0 + 15.0 * k, 80.0 + 10.0 * k, 50.0, 70.0], np.float32)
+        for a in chosen[k]:
+            b = box + rng.uniform(-0.5, 0.5, 4).astype(np.float32)
+            lc[0, a] = [(b[0] - pri[a, 0]) / pri[a, 2] * 10.0, (b[1] - pri[a, 1]) / pri[a, 3] * 10.0,
+                        np.log(b[2] / pri[a, 2]) * 5.0, np.log(b[3] / pri[a, 3]) * 5.0]
+            lg[0, a, 1 + k] = 18.0 + rng.uniform(0.0, 4.0)
+    lg, lc = lg.reshape(2, -1), lc.reshape(2, -1)
+    post = make_post(cfg)
+    out = post.postprocess((torch.from_numpy(lg).cuda(), torch.from_numpy(lc).cuda()), torch.from_numpy(g['anchors']).cuda())
+    ref, cand = oracle.postprocess(lg, lc, g['anchors'], softmax=True, nms_thr=cfg['nms_thr'], return_cand=True)
+    assert 12 <= ref[0].shape[0] <= 40
+    compare(out, ref, boundaries=Boundaries(lg, Cn, True))
+    assert np.array_equal(post.last_nms_candidates.cpu().numpy(), cand)
