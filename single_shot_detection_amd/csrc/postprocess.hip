@@ -1075,15 +1075,17 @@ __global__ void __launch_bounds__(kPostThreads) post_select2_kernel(SelArgs a) {
         // (every pair passes: the worst case, where the lanes are evenly loaded anyway) keeps the per-thread loop.
         const int lane = tid & 63, wave = tid >> 6;
         if (SOFTMAX && q == 0 && live) { s_rowmax[row] = row_max; s_rowsum[row] = sum; s_rowinv[row] = rinv; }
-        if (lane == 0) s_qn[wave] = 0;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+        // queue base = the survivors of the lanes below, total = the wave's: from the five bits of the per-lane count (<= 24), a ballot and a
+        // masked bit count each -- no LDS (a returning LDS atomic of 64 lanes on ONE address, behind a store and in front of a load, was
+        // three dependent LDS round trips per tile and wave)
         const int mycnt = __popc(bits);
-        int qbase = 0;
-        if (mycnt) qbase = atomicAdd(&s_qn[wave], mycnt);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        const int total = s_qn[wave];   // (this wave's own DS operations complete in order)
+        int qbase = 0, total = 0;
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+            const unsigned long long mk = __ballot((mycnt >> b) & 1);
+            qbase += (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u)) << b;
+            total += __popcll(mk) << b;
+        }
         if (total <= kSelQueue) {
             unsigned short* qw = s_queue + wave * kSelQueue;
             while (bits) {
