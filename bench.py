@@ -59,10 +59,10 @@ ACHIEVABLE_HBM_GBS = 6300.0       # ... and what a streaming kernel reaches on i
 
 
 def measured_traffic(kernel_key):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r04_pmc.json, else the previous
-    round's: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this command by tools/r04_measure.sh; FETCH_SIZE doubled per
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r05_pmc.json, else an earlier
+    round's: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this command by tools/r05_measure.sh; FETCH_SIZE doubled per
     the gfx950 correction in MI355X_MICROARCH.md, both in KiB).  None when no file holds this workload's kernel."""
-    for name in ('r04_pmc.json', 'r03_pmc.json'):
+    for name in ('r05_pmc.json', 'r04_pmc.json', 'r03_pmc.json'):
         try:
             d = json.load(open(os.path.join(REPO, 'profiles', name)))[kernel_key]
             return (2.0 * d['FETCH_SIZE_KiB'] + d['WRITE_SIZE_KiB']) * 1024.0

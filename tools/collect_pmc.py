@@ -15,7 +15,7 @@ KEYS = {   # json key suffix -> substring of the kernel name
     'anchor_dx': 'anchor_dx_kernel', 'gather_rows': 'gather_rows_kernel', 'anchor_plan': 'anchor_plan_kernel', 'reduce_partials': 'reduce_partials_kernel',
     'loss_bwd': 'loss_bwd_kernel', 'loss_fwd': 'loss_fwd_kernel', 'hnm_rows': 'hnm_rows_kernel', 'hnm_select': 'hnm_select_kernel',
     'pack_dy': 'pack_dy_kernel', 'assign': 'assign_kernel', 'gt_argmax': 'gt_argmax_kernel',
-    'post_select': 'post_select2_kernel', 'post_nms': 'post_nms_wave_kernel', 'post_merge': 'post_merge2_kernel', 'post_tau': 'post_tau_kernel',
+    'post_select': 'post_select2_kernel', 'post_nms': 'post_nms_wave_kernel', 'post_merge': 'post_merge2_kernel', 'post_tau': 'post_tau_kernel', 'post_finish': 'post_finish_kernel',
 }
 out_path, tag, dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
