@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SSDK_VERSION 113
+#define SSDK_VERSION 114
 
 #define SSDK_OK 0
 #define SSDK_E_INVALID (-1)   /* bad argument / shape */
@@ -81,9 +81,10 @@ int ssdk_nms(const float* boxes, const float* scores, int n, float overlap_thres
  * torch.backends.cudnn.deterministic = True / benchmark = False (bf/training/env.py:74-76).  Off, several kernels add fp32 partial
  * results with atomics in the order the hardware happens to retire them: split-K convolutions (forward too), the scatter form of the
  * data gradients, the K-split weight gradients, the bias-gradient column sums.  On, every fp32 sum is taken in an order fixed by the
- * launch: convolutions are not split over K with atomics (stream-K's parked partial tiles are already added in range order), data
- * gradients take the output-stationary (gather) form -- the heads' too: their sparse scatter forms are not used --, weight gradients
- * write one partial tile per K split and a second kernel adds the partials in split order, bias gradients likewise.  Same inputs ->
+ * launch: convolutions are not split over K with atomics (stream-K's parked partial tiles are already added in range order), the data
+ * gradient of a strided convolution is a row matrix of contributions plus a per-pixel sum in a fixed order, weight gradients write one
+ * partial tile per K split and a second kernel adds the partials in split order, bias gradients likewise.  (The heads' backward is the
+ * same in both modes since round 5: rows in pixel order, plain stores, ordered sums -- no atomics either way.)  Same inputs ->
  * the same bits, run to run and eager vs HIP-graph replay; the cost is reported by bench.py (per_config[*].deterministic_ms_per_step).
  * (The BatchNorm sums stay fp64 atomics over per-workgroup fp32 partials: such sums are exact -- hence order-independent -- unless the
  * partials span more than ~2^18 in magnitude.)  The workspace sizes of ssdk_heads_bwd / ssdk_conv2d_bwd depend on the mode: size and
