@@ -29,13 +29,21 @@ constexpr int kSegAnchors = 512;  // anchors swept by one wave of gt_argmax_kern
 // therefore no zero-fill launch in front (the first version folded (box, 512-anchor segment) partial results into a zeroed array with
 // atomicMax: a third launch, and a memset node costs as much as a small kernel).
 constexpr int kArgmaxThreads = 1024;   // (a box's sweep is a chain of dependent L2 round trips per thread: 8 anchors per thread at A = 8 108, not 32)
+// Round 5: large anchor sets (RetinaNet: 47 961 -- 47 anchors per thread, 21 us for 144 boxes on 144 CUs) are swept by `segs` workgroups
+// per box, each STORING the key of its anchor range (gt_best[g * segs + seg]); assign_kernel takes the maximum of a box's keys when it
+// loads the box -- still no atomics and nothing to zero, and the same key as one sweep would produce (largest IoU, then smallest anchor).
+constexpr int kArgmaxMaxSegs = 8;
+static inline int argmax_segs(int A) { const int s = (A + kArgmaxThreads * 12 - 1) / (kArgmaxThreads * 12); return s < 1 ? 1 : (s > kArgmaxMaxSegs ? kArgmaxMaxSegs : s); }
 __global__ void __launch_bounds__(kArgmaxThreads) gt_argmax_kernel(const float* __restrict__ gt_rows, int gt_stride,
-                                                                   const float4* __restrict__ anchors, int A,
+                                                                   const float4* __restrict__ anchors, int A_all,
                                                                    unsigned long long* __restrict__ gt_best, const int32_t* __restrict__ gt_off,
                                                                    int batch) {
     __shared__ unsigned long long s_key[kArgmaxThreads / kWave];
     const int g = blockIdx.x;
     if (g >= gt_off[batch]) return;   // (a row buffer of fixed capacity, e.g. inside a captured HIP graph: rows past the last image's are padding)
+    const int segs = gridDim.y, seg = blockIdx.y;
+    const int seg_len = (A_all + segs - 1) / segs;
+    const int a_begin = seg * seg_len, A = min(A_all, a_begin + seg_len);   // this workgroup's anchors: [a_begin, A)
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const float* r = gt_rows + (size_t)g * gt_stride;
     const float4 gb = make_float4(r[0], r[1], r[2], r[3]);
@@ -47,7 +55,7 @@ __global__ void __launch_bounds__(kArgmaxThreads) gt_argmax_kernel(const float* 
         const float v = iou_corner(gb, garea, c, area4(c.x, c.y, c.z, c.w));
         if (bi < 0 || v > best || (v != v && best == best)) { best = v; bi = a; }
     };
-    int a = threadIdx.x;
+    int a = a_begin + threadIdx.x;
     for (; a + 3 * kArgmaxThreads < A; a += 4 * kArgmaxThreads) {   // four loads in flight, taken in ascending anchor order (first-index ties)
         const float4 p0 = anchors[a], p1 = anchors[a + kArgmaxThreads], p2 = anchors[a + 2 * kArgmaxThreads], p3 = anchors[a + 3 * kArgmaxThreads];
         take(a, p0);
@@ -64,7 +72,7 @@ __global__ void __launch_bounds__(kArgmaxThreads) gt_argmax_kernel(const float* 
     if (threadIdx.x < kWave) {
         unsigned long long k = threadIdx.x < kArgmaxThreads / kWave ? s_key[threadIdx.x] : 0ull;
         k = wave_allreduce(k, OpMaxU64());
-        if (threadIdx.x == 0) gt_best[g] = k;
+        if (threadIdx.x == 0) gt_best[(size_t)g * segs + seg] = k;
     }
 }
 
@@ -72,7 +80,7 @@ __global__ void __launch_bounds__(kAssignThreads) assign_kernel(const float* __r
                                                                 const int32_t* __restrict__ gt_off,
                                                                 const float4* __restrict__ anchors, int A, float matched_thr,
                                                                 float unmatched_thr,
-                                                                const unsigned long long* __restrict__ gt_best,
+                                                                const unsigned long long* __restrict__ gt_best, int segs,
                                                                 float* __restrict__ target, int32_t* __restrict__ box_idx) {
     __shared__ float4 s_box[kGtChunk];
     __shared__ float s_area[kGtChunk];
@@ -101,7 +109,9 @@ __global__ void __launch_bounds__(kAssignThreads) assign_kernel(const float* __r
             const float4 gb = make_float4(r[0], r[1], r[2], r[3]);
             s_box[threadIdx.x] = gb;
             s_area[threadIdx.x] = area4(gb.x, gb.y, gb.z, gb.w);
-            s_best_anchor[threadIdx.x] = (int)(0xFFFFFFFFu - (unsigned)(gt_best[g] & 0xFFFFFFFFull));
+            unsigned long long key = gt_best[(size_t)g * segs];
+            for (int q = 1; q < segs; ++q) { const unsigned long long k2 = gt_best[(size_t)g * segs + q]; key = k2 > key ? k2 : key; }
+            s_best_anchor[threadIdx.x] = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
         }
         __syncthreads();
         for (int k = 0; k < n; ++k) {
@@ -223,7 +233,7 @@ extern "C" int ssdk_match_per_prediction(const float* weights, int num_boxes, in
 extern "C" size_t ssdk_encode_ground_truth_workspace_bytes(int batch, int total_gt) {
     (void)batch;
     Carver c(nullptr);
-    c.take<unsigned long long>((size_t)(total_gt > 0 ? total_gt : 1));
+    c.take<unsigned long long>((size_t)(total_gt > 0 ? total_gt : 1) * kArgmaxMaxSegs);
     return c.off;
 }
 
@@ -242,14 +252,15 @@ extern "C" int ssdk_encode_ground_truth(const float* gt_rows, int gt_stride, con
                  "ssdk_encode_ground_truth: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     Carver c(workspace);
-    unsigned long long* gt_best = c.take<unsigned long long>((size_t)(total_gt > 0 ? total_gt : 1));
+    unsigned long long* gt_best = c.take<unsigned long long>((size_t)(total_gt > 0 ? total_gt : 1) * kArgmaxMaxSegs);
+    const int segs = argmax_segs(num_anchors);
     if (total_gt > 0) {
-        hipLaunchKernelGGL(gt_argmax_kernel, dim3(total_gt), dim3(kArgmaxThreads), 0, s, gt_rows, gt_stride, (const float4*)anchors, num_anchors, gt_best, gt_offsets, batch);
+        hipLaunchKernelGGL(gt_argmax_kernel, dim3(total_gt, segs), dim3(kArgmaxThreads), 0, s, gt_rows, gt_stride, (const float4*)anchors, num_anchors, gt_best, gt_offsets, batch);
         SSDK_CHECK_LAUNCH("gt_argmax_kernel");
     }
     dim3 grid(cdiv(num_anchors, kAssignThreads), batch);
     hipLaunchKernelGGL(assign_kernel, grid, dim3(kAssignThreads), 0, s, gt_rows, gt_stride, gt_offsets, (const float4*)anchors,
-                       num_anchors, matched_threshold, unmatched_threshold, gt_best, target, box_idx);
+                       num_anchors, matched_threshold, unmatched_threshold, gt_best, segs, target, box_idx);
     SSDK_CHECK_LAUNCH("assign_kernel");
     return SSDK_OK;
 }

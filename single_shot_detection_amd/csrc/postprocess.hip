@@ -551,6 +551,9 @@ constexpr int kMergeSlots = 8192;    // post_merge2_kernel: ncls * max_per_class
 constexpr int kMergeCap = 256;       // survivors of the merge's radix narrowing (>= max_total)
 constexpr int kTauCache = 1024;      // post_tau_kernel: keys of one sample list kept in LDS (8 KB per wave)
 constexpr int kNmsCache = 1024;      // post_nms_wave_kernel: keys of one list kept in LDS (8 KB per wave)
+constexpr int kNmsCacheHead = 1024;  // ... by the head launch (MODE 1).  (640 keys -- 7.7 KB of LDS per one-wave workgroup, 20 per CU, the 5 120 lists of
+                                     // SSD-300 / 81 classes at batch 64 in ONE resident round instead of two -- measured 45.2 against 38.6 us: the lists
+                                     // above 640 keys then re-read memory per radix pass, which costs more than the second round)
 
 // exp(d) for d <= 0 (NaN stays NaN, -inf -> 0): t = d*log2e, r = the rounding error of that product + d*log2e_lo,
 // exp2(t) * (1 + r*ln2).  v_exp_f32 is 1 ulp over its whole range; the library's expf adds range checks this call site does not need.
@@ -1435,8 +1438,9 @@ __device__ __forceinline__ void nms_wave_body(const float4* __restrict__ locs, c
     // --- the (up to kCap) largest keys, unordered, into s_keys
     u64 prefix = 0;
     const u64* s_all = nullptr;
-    if (n > kCap && n <= kNmsCache) {
-        wave_cache_keys<kNmsCache, WG>(ks, s_cache);
+    constexpr int kCache = MODE == 1 ? kNmsCacheHead : kNmsCache;
+    if (n > kCap && n <= kCache) {
+        wave_cache_keys<kCache, WG>(ks, s_cache);
         s_all = s_cache;
     }
     if (n > kCap) prefix = wave_radix_prefix<WG>(s_hist, Kuse, kCap, ks, s_all);
@@ -1550,7 +1554,7 @@ __global__ void __launch_bounds__(kWave) post_nms_wave_kernel(const float4* __re
     __shared__ u64 s_sorted[kCap];
     __shared__ unsigned s_hist[256];
     __shared__ int s_pref[kWave + 1];
-    __shared__ u64 s_cache[kNmsCache];
+    __shared__ u64 s_cache[MODE == 1 ? kNmsCacheHead : kNmsCache];
     __shared__ int s_hot[kWave];
     NmsLds lds;
     lds.s_keys = s_keys; lds.s_sorted = s_sorted; lds.s_hist = s_hist; lds.s_pref = s_pref; lds.s_cache = s_cache; lds.s_hot = s_hot;
