@@ -832,8 +832,8 @@ def per_config_legs(device, steps=4, warmup=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=50)    # (50 x 3 ms: a timed region of 0.15 s; 20 steps after 3 warm-up steps read 2-3 % high on a cold box)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--config', default='ssd_300_vgg16_voc')
     ap.add_argument('--batch', type=int, default=32, help='per-GPU batch (weak scaling)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
