@@ -451,6 +451,21 @@ def hbm_legs(device, cfg_name='ssd_300_vgg16_voc', batch=64):
         us = gpu_time_us(lambda: hp.post.postprocess_padded((sc, locs), hp.anchors), inner=5)
         leg(f'postprocess_{tag}', us, 4.0 * A * (C + 4) * B, 'ssdk_postprocess: score convert + threshold + per-class top-100 + decode + NMS + top-200', launches)
         legs[f'postprocess_{tag}']['nms_candidates_per_image'] = float(hp.post.last_nms_candidates.sum().item()) / B
+    # the same trained-like statistics, but a DIFFERENT batch in every call (two batches taking turns): the per-class hot bound the
+    # postprocess carries from one call to the next (postprocess.hip HotState) then comes from other images than the ones it is used on
+    other = torch.from_numpy(syn.make_logits(B, A, C, seed=12)).to(device).view(B, A, C)
+    if hp.cfg['score_converter'] == 'SOFTMAX':
+        other[..., 0] += 6.0
+    else:
+        other -= 6.25
+    other = other.view(B, -1)
+    turn = [0]
+
+    def alternating():
+        turn[0] ^= 1
+        return hp.post.postprocess_padded((other if turn[0] else trained, locs), hp.anchors)
+    leg('postprocess_trained_like_alternating_batches', gpu_time_us(alternating, inner=6), 4.0 * A * (C + 4) * B,
+        'ssdk_postprocess on two different trained-like batches taking turns (the bound of one call was left by the other batch)', 3)
     # S1 + L1: sampler (reads the logits once), loss forward, loss backward (writes dscores + dlocs)
     target = hp.assigner.encode_ground_truth(hp.gt, hp.anchors)
     from single_shot_detection_amd.detection import sampler as smp

@@ -22,6 +22,7 @@
 #include <string.h>
 
 #include <type_traits>
+#include <mutex>
 
 #include "common.h"
 
@@ -885,6 +886,7 @@ struct SelArgs {
     int seg0;          // index of this pass's segment 0 among them
     const unsigned* tau;   // [B * ncls] score-bit lower bounds (0 = none) or NULL
     const unsigned* hotb;  // [B * ncls] score bits at or above which a key is HOT (NULL: every key is)
+    int hotb_per_image;    // != 0: hotb is indexed [image * ncls + class]; 0: [class] -- one bound per class for every image (HotState)
     u64* cand;         // [B * ncls][list_cap]
     int* segcnt;       // [B * ncls][nseg]  keys in the segment
     int* seghot;       // [B * ncls][nseg]  of which hot (filled from the segment's front; the cold ones from its back)
@@ -920,7 +922,7 @@ __global__ void __launch_bounds__(kPostThreads) post_select2_kernel(SelArgs a) {
         s_taub[c] = tb;
         s_ccnt[c] = 0;
         s_cold[c] = 0;
-        s_hotb[c] = a.hotb ? a.hotb[(size_t)i * ncls + c] : 0u;
+        s_hotb[c] = a.hotb ? a.hotb[(a.hotb_per_image ? (size_t)i * ncls : (size_t)0) + c] : 0u;
     }
     __syncthreads();
     float lvl_min = INFINITY;   // (every thread the same loop: ncls broadcast reads once per workgroup)
@@ -1384,7 +1386,7 @@ __device__ __forceinline__ void nms_wave_body(const float4* __restrict__ locs, c
                                               int K, double thr_mid, float xy_scale, float wh_scale, const NmsSrc& src,
                                               float* __restrict__ pc_rows, float* __restrict__ pc_score, int* __restrict__ pc_count,
                                               int* __restrict__ pc_m, int stop, int Khead, unsigned floor_in,
-                                              unsigned* __restrict__ head_last, int pc, const NmsLds& lds) {
+                                              unsigned* __restrict__ head_last, int pc, const NmsLds& lds, unsigned* __restrict__ hot_acc = nullptr) {
     constexpr int kCap = MODE == 1 ? kWave : kWaveK;   // survivors of the radix narrowing (the head keeps one entry per lane)
     u64* const s_keys = lds.s_keys;
     u64* const s_sorted = lds.s_sorted;
@@ -1471,6 +1473,8 @@ __device__ __forceinline__ void nms_wave_body(const float4* __restrict__ locs, c
     if (MODE == 1 && lane == 0) {
         pc_m[pc] = min(n_all, K);   // boxes that enter NMS in the reference, whatever part of the work the bound spares
         head_last[pc] = n_all > Khead ? (unsigned)(s_sorted[Khead - 1] >> 32) + 1u : 0u;
+        // the next call's hot bound of this class (HotState): the lowest Khead-th best score over the images that have that many
+        if (hot_acc && cnt >= Khead) atomicMin(hot_acc + c, (unsigned)(s_sorted[Khead - 1] >> 32));
     }
     if (MODE == 2 && floor_bits) {   // the sorted entries at or above the image's bound are a prefix
         const bool geA = lane < m && (unsigned)(s_sorted[lane] >> 32) >= floor_bits;
@@ -1548,7 +1552,7 @@ __global__ void __launch_bounds__(kWave) post_nms_wave_kernel(const float4* __re
                                                               int K, double thr_mid, float xy_scale, float wh_scale, NmsSrc src,
                                                               float* __restrict__ pc_rows, float* __restrict__ pc_score, int* __restrict__ pc_count,
                                                               int* __restrict__ pc_m, int stop, int Khead, const unsigned* __restrict__ img_tau,
-                                                              unsigned* __restrict__ head_last) {
+                                                              unsigned* __restrict__ head_last, unsigned* __restrict__ hot_acc) {
     constexpr int kCap = MODE == 1 ? kWave : kWaveK;
     __shared__ u64 s_keys[kCap];
     __shared__ u64 s_sorted[kCap];
@@ -1560,7 +1564,7 @@ __global__ void __launch_bounds__(kWave) post_nms_wave_kernel(const float4* __re
     lds.s_keys = s_keys; lds.s_sorted = s_sorted; lds.s_hist = s_hist; lds.s_pref = s_pref; lds.s_cache = s_cache; lds.s_hot = s_hot;
     const int pc = blockIdx.x;
     nms_wave_body<TIE_UP, MODE, true>(locs, priors, A, ncls, K, thr_mid, xy_scale, wh_scale, src, pc_rows, pc_score, pc_count, pc_m, stop, Khead,
-                                      MODE == 2 ? img_tau[pc / ncls] : 0u, head_last, pc, lds);
+                                      MODE == 2 ? img_tau[pc / ncls] : 0u, head_last, pc, lds, MODE == 1 ? hot_acc : nullptr);
 }
 
 // The max_total-th largest score among an image's kept head boxes (post_nms_wave_kernel MODE 1), as float bits rounded down to 16
@@ -1796,17 +1800,23 @@ __global__ void __launch_bounds__(1024) post_finish_kernel(const float4* __restr
                                                            int max_total, unsigned* __restrict__ img_tau, unsigned* __restrict__ head_last,
                                                            float* __restrict__ out, int out_cap, int* __restrict__ counts,
                                                            long long* __restrict__ nms_candidates, const int* __restrict__ pc_nall,
-                                                           unsigned* __restrict__ host_hint) {
+                                                           unsigned* __restrict__ host_hint, unsigned* __restrict__ hot_cur,
+                                                           unsigned* __restrict__ hot_acc) {
     __shared__ u64 s_keys[kMergeCap];
     __shared__ unsigned s_hist[256];
     __shared__ u64 s_misc[4];
     __shared__ unsigned s_misc32[2];
     __shared__ int s_n, s_total, s_nflag;
-    __shared__ unsigned s_tau;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // [kFinishTailWaves][kNmsLdsBytes], then s_flagged[ncls], then s_prefix[ncls + 1]
     int* const s_flagged = reinterpret_cast<int*>(s_dyn + (size_t)kFinishTailWaves * kNmsLdsBytes);
     int* const s_prefix = s_flagged + ncls;
     const int i = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+    // HotState: what the head launch accumulated becomes the next call's bound per class (a class no image had Khead candidates of: none)
+    if (i == 0 && hot_cur && tid < ncls) {
+        const unsigned v = hot_acc[tid];
+        hot_cur[tid] = v == 0xFFFFFFFFu ? 0u : v;
+        hot_acc[tid] = 0xFFFFFFFFu;
+    }
     // A
     const unsigned tau = img_tau_block<1024>(i, ncls, K, Khead, max_total, pc_score, pc_count, s_hist, s_misc32, &s_total);
     if (tid == 0) { img_tau[i] = tau; s_nflag = 0; }
@@ -1872,6 +1882,58 @@ static unsigned* post_hint_word(hipStream_t s) {
     }
     return g_post_hint;
 }
+// HotState (round 5): in the plan WITHOUT a sample pass nothing told the select pass which keys the NMS head will want, so a head wave
+// narrowed its whole list (~580 keys on trained-like scores, of which it takes 16).  Now every call leaves, per class, the lowest
+// Khead-th best score over its images (post_nms_wave_kernel MODE 1 -> atomicMin, rolled over by post_finish_kernel), and the NEXT call's
+// select pass files keys at or above it at the front of their segments ("hot"), as the sample plan's per-list bound does.  Exactness does
+// not depend on the value: a head wave takes the hot view only when it holds at least Khead keys (every cold key is below every hot one
+// of the same list, because one call uses one bound per class), else the whole list.  What depends on it is speed: on a stream of
+// similar batches the hot view holds a few dozen keys.  One state per (device, stream) -- calls on a stream are ordered, so the bound a
+// call reads is not written while it runs --, keyed by the call's shape; never created or re-keyed during stream capture.
+// SSDK_POST_NO_HOT_STATE: off.
+struct HotState {
+    unsigned* cur;   // [kSelMaxC] score bits (0: every key is hot)
+    unsigned* acc;   // [kSelMaxC] running minimum of this call (0xFFFFFFFF: nothing yet)
+    int dev;
+    hipStream_t stream;
+    int ncls, khead, K, softmax;
+    unsigned thr_bits;
+    bool used;
+};
+static HotState* hot_state_for(hipStream_t s, int ncls, int khead, int K, int softmax, float thr) {
+    static const bool off = getenv("SSDK_POST_NO_HOT_STATE") != nullptr;
+    static std::mutex mu;
+    static HotState tab[16];
+    if (off || ncls > kSelMaxC) return nullptr;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    const bool capturing = st != hipStreamCaptureStatusNone;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    unsigned thr_bits;
+    memcpy(&thr_bits, &thr, 4);
+    std::lock_guard<std::mutex> lock(mu);
+    HotState* slot = nullptr;
+    for (auto& t : tab)
+        if (t.used && t.dev == dev && t.stream == s) { slot = &t; break; }
+    if (slot && slot->ncls == ncls && slot->khead == khead && slot->K == K && slot->softmax == softmax && slot->thr_bits == thr_bits) return slot;
+    if (capturing) return nullptr;   // (no allocation, no re-keying inside a capture: that call runs without a bound)
+    if (!slot) {
+        for (auto& t : tab)
+            if (!t.used) { slot = &t; break; }
+        if (!slot) return nullptr;
+        void* p = nullptr;
+        if (hipMalloc(&p, sizeof(unsigned) * 2 * kSelMaxC) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        slot->cur = static_cast<unsigned*>(p);
+        slot->acc = slot->cur + kSelMaxC;
+        slot->dev = dev; slot->stream = s; slot->used = true;
+    }
+    if (hipMemsetAsync(slot->cur, 0, sizeof(unsigned) * kSelMaxC, s) != hipSuccess ||
+        hipMemsetAsync(slot->acc, 0xFF, sizeof(unsigned) * kSelMaxC, s) != hipSuccess) { (void)hipGetLastError(); slot->ncls = -1; return nullptr; }
+    slot->ncls = ncls; slot->khead = khead; slot->K = K; slot->softmax = softmax; slot->thr_bits = thr_bits;
+    return slot;
+}
+
 static bool post_wants_sample_pass(int K) {
     if (getenv("SSDK_POST_NO_SAMPLE")) return false;
     if (getenv("SSDK_POST_SAMPLE") || !g_post_hint) return true;
@@ -2030,7 +2092,7 @@ static int postprocess_v2(const PostPlan& p, const float* scores, const float* l
     const size_t lds = (align_up((size_t)kPostTileRows * Cp, 4) + 5 * (size_t)ncls + 3 * kPostTileRows + kPostThreads / kWave) * 4 + (size_t)(kPostThreads / kWave) * kSelQueue * 2;
     SelArgs a;
     a.scores = scores; a.A = num_anchors; a.C = num_classes; a.ncls = ncls; a.c_off = softmax ? 1 : 0; a.thr = score_threshold;
-    a.list_cap = p.list_cap; a.nseg = p.nseg; a.cand = w.cand; a.segcnt = w.segcnt; a.seghot = w.seghot; a.hotb = nullptr;
+    a.list_cap = p.list_cap; a.nseg = p.nseg; a.cand = w.cand; a.segcnt = w.segcnt; a.seghot = w.seghot; a.hotb = nullptr; a.hotb_per_image = 1;
     a.stop = getenv("SSDK_POST_STOP") ? atoi(getenv("SSDK_POST_STOP")) : 0;
     const int jneed = cdiv(num_classes, 4);
     const int khead_plan = (getenv("SSDK_NMS_STOP") && atoi(getenv("SSDK_NMS_STOP"))) ? 0 : nms_head_size(ncls, max_per_class, max_total);
@@ -2055,6 +2117,7 @@ static int postprocess_v2(const PostPlan& p, const float* scores, const float* l
         return SSDK_OK;
     };
     const int seg_off_main = p.Gs * p.Ts * kPostTileRows;
+    HotState* hot = nullptr;
     if (p.ns) {
         int rc = launch(1, p.ns, p.Gs, p.Ts, 0, 0, nullptr, nullptr);
         if (rc) return rc;
@@ -2067,7 +2130,11 @@ static int postprocess_v2(const PostPlan& p, const float* scores, const float* l
         rc = launch(2, p.tiles - p.ns, p.Gm, p.Tm, seg_off_main, p.Gs, w.tau, hot_rank ? w.hotb : nullptr);
         if (rc) return rc;
     } else {
-        const int rc = launch(0, p.tiles, p.Gm, p.Tm, 0, 0, nullptr, nullptr);
+        // no sample pass: the hot bound per class the previous call on this stream left (HotState), if any
+        if (khead_plan && !getenv("SSDK_POST_NO_FOLD") && !getenv("SSDK_POST_NO_HOT")) hot = hot_state_for(s, ncls, khead_plan, max_per_class, softmax, score_threshold);
+        a.hotb_per_image = 0;
+        const int rc = launch(0, p.tiles, p.Gm, p.Tm, 0, 0, nullptr, hot ? hot->cur : nullptr);
+        a.hotb_per_image = 1;
         if (rc) return rc;
     }
     if (a.stop > 0) return SSDK_OK;   // debug: timing of the select stages alone (outputs are not written)
@@ -2088,7 +2155,7 @@ static int postprocess_v2(const PostPlan& p, const float* scores, const float* l
 #define SSDK_NMS(TIE, MODE)                                                                                                                     \
     hipLaunchKernelGGL((post_nms_wave_kernel<TIE, MODE>), dim3(npc), dim3(kWave), 0, s, (const float4*)locs, (const float4*)priors, num_anchors, \
                        ncls, max_per_class, thr_mid, xy_scale, wh_scale, src, w.pc_rows, w.pc_score, w.pc_count, w.pc_m, nms_stop, khead,      \
-                       w.img_tau, w.head_last)
+                       w.img_tau, w.head_last, hot ? hot->acc : nullptr)
     if (khead && !getenv("SSDK_POST_NO_FOLD")) {
         if (tie_up) SSDK_NMS(true, 1); else SSDK_NMS(false, 1);
         SSDK_CHECK_LAUNCH("post_nms_wave_kernel (head)");
@@ -2104,7 +2171,8 @@ static int postprocess_v2(const PostPlan& p, const float* scores, const float* l
 #define SSDK_FINISH(TIE)                                                                                                                      \
     hipLaunchKernelGGL((post_finish_kernel<TIE>), dim3(batch), dim3(1024), dyn, s, (const float4*)locs, (const float4*)priors, num_anchors, ncls, \
                        max_per_class, thr_mid, xy_scale, wh_scale, src, w.pc_rows, w.pc_score, w.pc_count, w.pc_m, khead, max_total, w.img_tau,   \
-                       w.head_last, out, out_cap, counts, (long long*)nms_candidates, w.pc_nall, hint)
+                       w.head_last, out, out_cap, counts, (long long*)nms_candidates, w.pc_nall, hint, hot ? hot->cur : nullptr,          \
+                       hot ? hot->acc : nullptr)
         if (tie_up) SSDK_FINISH(true); else SSDK_FINISH(false);
 #undef SSDK_FINISH
         SSDK_CHECK_LAUNCH("post_finish_kernel");

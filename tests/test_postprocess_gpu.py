@@ -333,3 +333,27 @@ def test_finish_kernel_redoes_more_classes_than_it_has_tail_waves():
     assert 12 <= ref[0].shape[0] <= 40
     compare(out, ref, boundaries=Boundaries(lg, Cn, True))
     assert np.array_equal(post.last_nms_candidates.cpu().numpy(), cand)
+
+
+def test_hot_bound_left_by_another_batch_never_changes_results(monkeypatch):
+    """HotState (postprocess.hip): in the plan without a sample pass every call leaves a per-class score bound that the next call's select
+    pass files its keys by.  Whatever the bound -- left by the same batch, by a batch with much lower scores (the bound is then too low:
+    large hot sets) or much higher ones (too high: fewer hot keys than the head wants, the waves take the whole list) -- the detections
+    are the oracle's."""
+    monkeypatch.setenv('SSDK_POST_NO_SAMPLE', '1')
+    cfg, g, logits, locs, softmax = inputs('ssd_300_vgg16_voc', 'trained', batch=2, seeds=(91, 92))
+    A, Cn = g['anchors'].shape[0], cfg['num_classes']
+    assert softmax
+    anchors = torch.from_numpy(g['anchors']).cuda()
+    post = make_post(cfg)
+    base = logits.reshape(2, A, Cn)
+    variants = []
+    for shift in (0.0, 0.0, -2.5, 2.0, 0.0, -2.5):     # the class logits against the background
+        lg = base.copy()
+        lg[..., 1:] += np.float32(shift)
+        variants.append(lg.reshape(2, -1))
+    for lg in variants:
+        out = post.postprocess((torch.from_numpy(lg).cuda(), torch.from_numpy(locs).cuda()), anchors)
+        ref, cand = oracle.postprocess(lg, locs, g['anchors'], softmax=True, nms_thr=cfg['nms_thr'], return_cand=True)
+        compare(out, ref, boundaries=Boundaries(lg, Cn, True))
+        assert np.array_equal(post.last_nms_candidates.cpu().numpy(), cand)
