@@ -279,6 +279,11 @@ int ssdk_postprocess(const float* scores, const float* locs, const float* priors
  *   backward outputs (ssdk_heads_bwd only; NULL = skip): dx DEV [batch,H,W,Cin]; dw_score/dw_loc like the weights
  *            (both or neither); db_score/db_loc.  All are overwritten, not accumulated.
  */
+/* A level that is a SINGLE head (n_loc == 0: the score tower's or the loc tower's convolution of a SharedConvPredictor level, which run as
+ * two calls because they read different maps) cannot tell the library how many anchor types a pixel has; its caller may pass that count
+ * in locs_offset, which means nothing else for such a level (0 = unknown).  With it the sparse backward of ssdk_heads_bwd takes the
+ * ordered anchor-row form (rows of n_score / types columns) in both modes; without it the level falls back to round 4's forms, dense in
+ * deterministic mode. */
 typedef struct ssdk_head_level {
     const float* x;
     int h, w, cin;

@@ -1599,6 +1599,7 @@ struct PackLevel {
     // columns; every anchor with a gradient is one row [Jpad] of ga[k]: C scores, 4 locs, zero padding; apix = the rows' pixel ids,
     // acount = rows per type (both written by anchor_plan_kernel / anchor_fill_kernel)
     int nb, C, Jpad, cap;
+    int LQ;            // loc columns per anchor: 4, or 0 for a level that is a single head (SharedConvPredictor: score and loc towers apart)
     float* ga; const int* apix; const int* acount;
     const int* mode;   // the level's backward form as anchor_plan_kernel chose it (2 = anchor rows: `out` is not needed; else `ga` is not)
     // gather_rows_kernel STORES the column sums of chunk c of type k into dbp[(k * chunks_cap + c) * Jpad + j] (anchor_dbias_kernel adds
@@ -1789,11 +1790,11 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(PackGroup grp, const i
                 const int m = mrow[u] < 0 ? 0 : mrow[u];
                 const int b = m / L.HW, p = m - b * L.HW;
                 const float* srow = L.ds + (long long)b * grp.sb + ((long long)p * L.nb + k) * C;
-                const float* lrow = L.dl + (long long)b * grp.lb + ((long long)p * L.nb + k) * 4;
+                const float* lrow = L.LQ ? L.dl + (long long)b * grp.lb + ((long long)p * L.nb + k) * 4 : srow;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int j = lane + 64 * q;
-                    v[u][q] = (mrow[u] >= 0 && j < C + 4 && j < Jpad) ? (j < C ? srow[j] : lrow[j - C]) : 0.0f;
+                    v[u][q] = (mrow[u] >= 0 && j < C + L.LQ && j < Jpad) ? (j < C ? srow[j] : lrow[j - C]) : 0.0f;
                 }
             }
 #pragma unroll
@@ -1812,7 +1813,7 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(PackGroup grp, const i
 #pragma unroll
         for (int q = 0; q < 4; ++q) s_sum[wave][lane + 64 * q] = acc[q];
         __syncthreads();
-        for (int j = threadIdx.x; j < C + 4; j += 256) {
+        for (int j = threadIdx.x; j < C + L.LQ; j += 256) {
             const float t = s_sum[0][j] + s_sum[1][j] + s_sum[2][j] + s_sum[3][j];
             L.dbp[((long long)k * L.chunks_cap + c) * Jpad + j] = t;   // (stored, not added: anchor_dbias_kernel adds the chunks in order)
         }
@@ -2046,7 +2047,7 @@ __global__ void __launch_bounds__(kAnchorBlk) anchor_fill_kernel(AnchorGroup grp
 
 // Which anchors carry a gradient, from the gradient itself (callers without a row mask): out[(b * HW + p) * nb + k] = any of the C score
 // values or 4 box values of anchor (p, k) of image b is non-zero.  A wave per pixel row, lanes over the nb * (C + 4) columns.
-struct MaskLevel { const float* ds; const float* dl; unsigned char* out; int nb, C, HW, blk_begin; };
+struct MaskLevel { const float* ds; const float* dl; unsigned char* out; int nb, C, HW, blk_begin, LQ; };
 struct MaskGroup { int count, B; long long sb, lb; MaskLevel lv[kMaxProblems]; };
 constexpr int kMaskRows = 16;   // pixel rows per workgroup
 __global__ void __launch_bounds__(256) anchor_mask_kernel(MaskGroup grp) {
@@ -2056,7 +2057,7 @@ __global__ void __launch_bounds__(256) anchor_mask_kernel(MaskGroup grp) {
         if ((int)blockIdx.x >= grp.lv[i].blk_begin) pi = i;
     const MaskLevel& L = grp.lv[pi];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int M = grp.B * L.HW, n0 = L.nb * L.C, n1 = L.nb * 4;
+    const int M = grp.B * L.HW, n0 = L.nb * L.C, n1 = L.nb * L.LQ;
     const float inv_c = 1.0f / (float)L.C;
     const int m0 = (blockIdx.x - L.blk_begin) * kMaskRows;
 #pragma unroll 1
@@ -2065,7 +2066,7 @@ __global__ void __launch_bounds__(256) anchor_mask_kernel(MaskGroup grp) {
         if (m >= M) break;
         const int b = m / L.HW, p = m - b * L.HW;
         const float* srow = L.ds + (long long)b * grp.sb + (long long)p * n0;
-        const float* lrow = L.dl + (long long)b * grp.lb + (long long)p * n1;
+        const float* lrow = n1 ? L.dl + (long long)b * grp.lb + (long long)p * n1 : srow;
         unsigned mine = 0u;
         for (int n = lane; n < n0; n += kWave) {
             const int a = (int)(((float)n + 0.5f) * inv_c);   // n / C, exact for n < 2^20
@@ -2082,7 +2083,7 @@ __global__ void __launch_bounds__(256) anchor_mask_kernel(MaskGroup grp) {
 }
 
 // db of every (level, type): the column sums gather_rows_kernel stored per 32-row chunk, added in chunk order
-struct DbiasLevel { const float* part; float* db0; float* db1; int nb, C, Jpad, chunks_cap; };
+struct DbiasLevel { const float* part; float* db0; float* db1; int nb, C, Jpad, chunks_cap, LQ; };
 struct DbiasGroup { int count; const int* acounts; DbiasLevel lv[kMaxProblems]; };
 __global__ void __launch_bounds__(128) anchor_dbias_kernel(DbiasGroup grp) {
     const int li = blockIdx.x / kAT, k = blockIdx.x % kAT;
@@ -2091,7 +2092,7 @@ __global__ void __launch_bounds__(128) anchor_dbias_kernel(DbiasGroup grp) {
     if (k >= L.nb) return;
     const int chunks = (grp.acounts[li * kAT + k] + 31) / 32;
     const float* p = L.part + (long long)k * L.chunks_cap * L.Jpad;
-    for (int j = threadIdx.x; j < L.C + 4; j += blockDim.x) {
+    for (int j = threadIdx.x; j < L.C + L.LQ; j += blockDim.x) {
         float s = 0.0f;
         int c = 0;
         for (; c + 8 <= chunks; c += 8) {
@@ -2103,7 +2104,7 @@ __global__ void __launch_bounds__(128) anchor_dbias_kernel(DbiasGroup grp) {
         }
         for (; c < chunks; ++c) s += p[(long long)c * L.Jpad + j];
         if (j < L.C) { if (L.db0) L.db0[k * L.C + j] = s; }
-        else if (L.db1) L.db1[k * 4 + (j - L.C)] = s;
+        else if (L.db1) L.db1[k * L.LQ + (j - L.C)] = s;
     }
 }
 
@@ -2119,7 +2120,7 @@ __global__ void __launch_bounds__(128) anchor_dbias_kernel(DbiasGroup grp) {
 struct RowGemmLevel {
     const float* ga; const float* ws; const float* wl;
     float* T;
-    int nb, C, cap, K9, n_chunks;
+    int nb, C, cap, K9, n_chunks, LQ;
 };
 struct RowGemmGroup { int count; int* plan; const int* acounts; const float* zeros; int probe; RowGemmLevel lv[kMaxProblems]; };   // probe: measurement knob (1: T stores dropped)
 
@@ -2194,7 +2195,7 @@ __global__ void __launch_bounds__(256, KQ <= 3 ? 3 : 2) anchor_rowgemm_kernel(Ro
 #pragma unroll
         for (int i = 0; i < kPerWave; ++i) {
             const int j = 4 * (wave + 4 * i) + (lane >> 4);
-            src[i] = j < C ? L.ws + ((long long)k * C + j) * K9 : (j < C + 4 ? L.wl + ((long long)k * 4 + (j - C)) * K9 : nullptr);
+            src[i] = j < C ? L.ws + ((long long)k * C + j) * K9 : (j < C + L.LQ ? L.wl + ((long long)k * L.LQ + (j - C)) * K9 : nullptr);
         }
         // The LDS-DMA is issued from an asm statement (M0 = the piece's LDS address, saved and restored inside the statement:
         // cdna_hip_programming.md, "M0 ... is compiler-reserved"): as a builtin the compiler sees an LDS write in flight and puts
@@ -3204,12 +3205,17 @@ static int check_level(const char* fn, int batch, const ssdk_head_level& lv) {
 
 static inline int npad_of(const ssdk_head_level& lv) { return cdiv(lv.n_score + lv.n_loc, 32) * 32; }
 // anchor types per pixel (0: unknown -- no loc head, or a layout the anchor-granular backward does not cover)
+// A single head (n_loc == 0: the score tower's or the loc tower's convolution of a SharedConvPredictor level, detector.py:50-66) has no loc
+// part to read the count from: its caller may pass it in locs_offset (meaningless otherwise for such a level; 0 = unknown).
 static inline int anchor_types_of(const ssdk_head_level& lv) {
-    if (lv.n_loc <= 0 || lv.n_loc % 4) return 0;
-    const int nb = lv.n_loc / 4;
-    return (nb < kMaxAnchorTypes && lv.n_score % nb == 0 && lv.cin % kBK == 0) ? nb : 0;
+    if (lv.n_loc < 0 || lv.n_loc % 4) return 0;
+    const long long nb = lv.n_loc > 0 ? lv.n_loc / 4 : lv.locs_offset;
+    return (nb > 0 && nb < kMaxAnchorTypes && lv.n_score % nb == 0 && lv.cin % kBK == 0) ? (int)nb : 0;
 }
-static inline int jpad_of(const ssdk_head_level& lv) { return cdiv(lv.n_score / (lv.n_loc / 4) + 4, 32) * 32; }
+static inline int loc_cols_of(const ssdk_head_level& lv) { return lv.n_loc > 0 ? 4 : 0; }
+static inline int jpad_of(const ssdk_head_level& lv) {   // (only where anchor_types_of(lv) != 0)
+    return cdiv(lv.n_score / anchor_types_of(lv) + loc_cols_of(lv), 32) * 32;
+}
 
 extern "C" size_t ssdk_heads_fwd_workspace_bytes(void) {
     return align_up((size_t)(kStreamKWgs + 1) * (4 * kMaxTN * 4 * 64 * 4) * sizeof(float), 256) + align_up((size_t)(kStreamKWgs + 2) * sizeof(unsigned), 256);
@@ -3846,8 +3852,8 @@ static int heads_bwd_ordered(const ssdk_head_level* levels, int n_levels, int ba
         const ssdk_head_level& lv = levels[i];
         int rc = check_level("ssdk_heads_bwd", batch, lv);
         if (rc) return rc;
-        SSDK_REQUIRE(dlocs, SSDK_E_INVALID, "ssdk_heads_bwd: null dlocs");
-        const int nb = anchor_types_of(lv), C = lv.n_score / nb, hw = lv.h * lv.w;
+        SSDK_REQUIRE(dlocs || lv.n_loc == 0, SSDK_E_INVALID, "ssdk_heads_bwd: null dlocs");
+        const int nb = anchor_types_of(lv), C = lv.n_score / nb, hw = lv.h * lv.w, LQ = loc_cols_of(lv);
         AnchorLevel& L = ag.lv[i];
         L.nb = nb; L.HW = hw; L.cap = batch * hw;
         L.blk_begin = blk_begin; L.nblk = cdiv(L.cap, kAnchorBlk);
@@ -3855,14 +3861,15 @@ static int heads_bwd_ordered(const ssdk_head_level* levels, int n_levels, int ba
         L.blk = w.blk[i]; L.apix = w.apix[i]; L.aidx = w.aidx[i];
         L.tcap = (int)std::min<long long>(w.tcap[i], 0x7fffffff);
         L.items_per_tile = lv.dx ? cdiv(9 * lv.cin, kRgChunkCols) : 0;
-        const bool covered = row_mask && lv.scores_offset % C == 0 && lv.locs_offset == 4 * (lv.scores_offset / C) &&
+        // (a single head -- n_loc == 0 -- is covered when its columns start at a whole anchor: its locs_offset carries the anchor-type count)
+        const bool covered = row_mask && lv.scores_offset % C == 0 && (LQ == 0 || lv.locs_offset == 4 * (lv.scores_offset / C)) &&
                              lv.scores_offset / C + (long long)hw * nb <= num_anchors;
         if (covered && !getenv("SSDK_PACK_SCAN")) {
             L.rmask = row_mask; L.a_total = num_anchors; L.a_off = (int)(lv.scores_offset / C);
         } else {
             L.rmask = w.imask[i]; L.a_total = hw * nb; L.a_off = 0;
             MaskLevel& Q = mg.lv[mg.count++];
-            Q.ds = dscores + lv.scores_offset; Q.dl = dlocs + lv.locs_offset; Q.out = w.imask[i]; Q.nb = nb; Q.C = C; Q.HW = hw;
+            Q.ds = dscores + lv.scores_offset; Q.dl = LQ ? dlocs + lv.locs_offset : nullptr; Q.out = w.imask[i]; Q.nb = nb; Q.C = C; Q.HW = hw; Q.LQ = LQ;
             Q.blk_begin = mask_blocks;
             mask_blocks += cdiv(L.cap, kMaskRows);
         }
@@ -3888,7 +3895,8 @@ static int heads_bwd_ordered(const ssdk_head_level* levels, int n_levels, int ba
     for (int i = 0; i < n_levels; ++i) {
         const ssdk_head_level& lv = levels[i];
         PackLevel& L = pg.lv[i];
-        L.ds = dscores + lv.scores_offset; L.dl = dlocs + lv.locs_offset;
+        L.LQ = loc_cols_of(lv);
+        L.ds = dscores + lv.scores_offset; L.dl = L.LQ ? dlocs + lv.locs_offset : nullptr;
         L.n0 = lv.n_score; L.n1 = lv.n_loc; L.Npad = npad_of(lv); L.HW = lv.h * lv.w;
         L.out = w.dyp[i];
         L.nb = ag.lv[i].nb; L.C = lv.n_score / L.nb; L.Jpad = jpad_of(lv); L.cap = batch * L.HW;
@@ -3900,7 +3908,8 @@ static int heads_bwd_ordered(const ssdk_head_level* levels, int n_levels, int ba
         max_npad = std::max(max_npad, L.Npad);
         worst_chunks += (long long)L.nb * L.chunks_cap;
         DbiasLevel& D = dbg.lv[i];
-        D.part = w.dbp[i]; D.db0 = lv.db_score; D.db1 = lv.db_loc; D.nb = L.nb; D.C = L.C; D.Jpad = L.Jpad; D.chunks_cap = L.chunks_cap;
+        D.part = w.dbp[i]; D.db0 = lv.db_score; D.db1 = L.LQ ? lv.db_loc : nullptr; D.nb = L.nb; D.C = L.C; D.Jpad = L.Jpad; D.chunks_cap = L.chunks_cap;
+        D.LQ = L.LQ;
     }
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)std::min<long long>(worst_chunks, 1024)), dim3(256), 0, s, pg, w.gtab);
     SSDK_CHECK_LAUNCH("gather_rows_kernel");
@@ -3926,7 +3935,7 @@ static int heads_bwd_ordered(const ssdk_head_level* levels, int n_levels, int ba
         for (int i = 0; i < n_levels; ++i) {
             const ssdk_head_level& lv = levels[i];
             RowGemmLevel& R = rg.lv[i];
-            R.ga = w.ga[i]; R.ws = lv.w_score; R.wl = lv.w_loc; R.T = w.T[i];
+            R.ga = w.ga[i]; R.ws = lv.w_score; R.wl = lv.w_loc; R.T = w.T[i]; R.LQ = loc_cols_of(lv);
             R.nb = ag.lv[i].nb; R.C = lv.n_score / R.nb; R.cap = batch * lv.h * lv.w; R.K9 = 9 * lv.cin; R.n_chunks = cdiv(9 * lv.cin, kRgChunkCols);
             kq = std::max(kq, jpad_of(lv) / 32);
             if (!lv.dx) continue;
@@ -3937,7 +3946,7 @@ static int heads_bwd_ordered(const ssdk_head_level* levels, int n_levels, int ba
             dx_blocks += cdiv(R.cap, 4);
         }
         for (int i = 0; i < n_levels; ++i)
-            SSDK_REQUIRE(jpad_of(levels[i]) / 32 == kq, SSDK_E_UNSUPPORTED, "ssdk_heads_bwd: the levels' class counts differ (C + 4 rounded up to 32: %d vs %d)",
+            SSDK_REQUIRE(jpad_of(levels[i]) / 32 == kq, SSDK_E_UNSUPPORTED, "ssdk_heads_bwd: the levels' row widths differ (columns per anchor rounded up to 32: %d vs %d)",
                          jpad_of(levels[i]), kq * 32);
         if (any_dx) {
             // what is resident at once: 3 / 2 workgroups per CU (measured at 512 / 768 / 1 024 workgroups: 127 / 120 / 126 us)
@@ -4004,8 +4013,9 @@ static int heads_bwd_ordered(const ssdk_head_level* levels, int n_levels, int ba
     for (int i = 0; i < n_levels; ++i) {
         const ssdk_head_level& lv = levels[i];
         if (!lv.dw_score) continue;
-        SSDK_REQUIRE(lv.dw_loc, SSDK_E_INVALID, "ssdk_heads_bwd: dw_loc missing");
+        SSDK_REQUIRE(lv.dw_loc || lv.n_loc == 0, SSDK_E_INVALID, "ssdk_heads_bwd: dw_loc missing");
         const long long K9 = (long long)9 * lv.cin, N = lv.n_score + lv.n_loc;
+        const int LQ = loc_cols_of(lv);
         WgradProblem g = heads_wgrad_problem(lv, batch);
         g.dy = w.dyp[i];
         g.mode = w.mode + i; g.want_mode = 0;
@@ -4016,16 +4026,16 @@ static int heads_bwd_ordered(const ssdk_head_level* levels, int n_levels, int ba
         wd_.p[n_wgrad] = g;
         const int nb = ag.lv[i].nb, C = lv.n_score / nb, ks = w.anchor_splits[i];
         WgradProblem a = heads_wgrad_problem(lv, batch);
-        a.dy = w.ga[i]; a.Npad = jpad_of(lv); a.n0 = C; a.n1 = 4; a.n_tiles = 1;
+        a.dy = w.ga[i]; a.Npad = jpad_of(lv); a.n0 = C; a.n1 = LQ; a.n_tiles = 1;
         a.mode = w.mode + i; a.want_mode = 2;
         a.row_list = w.apix[i]; a.row_count = nullptr;
         a.seg_count = w.acounts + i * kAT; a.segs = nb; a.seg_cap = batch * lv.h * lv.w;
-        a.dw0_seg = (long long)C * K9; a.dw1_seg = (long long)4 * K9;
+        a.dw0_seg = (long long)C * K9; a.dw1_seg = (long long)LQ * K9;
         a.ordered = 1;
         if (ks > 1) {
-            a.dw0 = w.dw_part[i]; a.dw1 = w.dw_part[i] + (size_t)lv.n_score * K9; a.det_stride = N * K9;
+            a.dw0 = w.dw_part[i]; a.dw1 = LQ ? w.dw_part[i] + (size_t)lv.n_score * K9 : nullptr; a.det_stride = N * K9;
         } else {
-            a.dw0 = lv.dw_score; a.dw1 = lv.dw_loc; a.det_stride = 0;
+            a.dw0 = lv.dw_score; a.dw1 = LQ ? lv.dw_loc : nullptr; a.det_stride = 0;
         }
         wa_.p[n_wgrad] = a;
         idx_of[n_wgrad] = i;
@@ -4054,10 +4064,10 @@ static int heads_bwd_ordered(const ssdk_head_level* levels, int n_levels, int ba
             SSDK_REQUIRE(g.k_splits == w.dense_splits[i], SSDK_E_WORKSPACE, "ssdk_heads_bwd: the workspace was sized for another split rule");
             const int used = wgrad_used_splits(g);
             int rc = rl.add(lv.dw_score, w.dw_part[i], (long long)lv.n_score * K9, N * K9, used, 0, s, w.mode + i, 0);
-            if (!rc) rc = rl.add(lv.dw_loc, w.dw_part[i] + (size_t)lv.n_score * K9, (long long)lv.n_loc * K9, N * K9, used, 0, s, w.mode + i, 0);
+            if (!rc && lv.n_loc) rc = rl.add(lv.dw_loc, w.dw_part[i] + (size_t)lv.n_score * K9, (long long)lv.n_loc * K9, N * K9, used, 0, s, w.mode + i, 0);
             const int ks = w.anchor_splits[i];
             if (!rc && ks > 1) rc = rl.add(lv.dw_score, w.dw_part[i], (long long)lv.n_score * K9, N * K9, ks, 0, s, w.mode + i, 2);
-            if (!rc && ks > 1) rc = rl.add(lv.dw_loc, w.dw_part[i] + (size_t)lv.n_score * K9, (long long)lv.n_loc * K9, N * K9, ks, 0, s, w.mode + i, 2);
+            if (!rc && ks > 1 && lv.n_loc) rc = rl.add(lv.dw_loc, w.dw_part[i] + (size_t)lv.n_score * K9, (long long)lv.n_loc * K9, N * K9, ks, 0, s, w.mode + i, 2);
             if (rc) return rc;
         }
         const int rc = rl.launch(s);

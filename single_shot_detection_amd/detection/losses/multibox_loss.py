@@ -68,7 +68,7 @@ class _MultiboxLossFn(torch.autograd.Function):
         ctx.save_for_backward(scores, locs, anchors, target, mask, ws)
         ctx.module = module
         ctx.shape = (B, A, C)
-        ctx.sparse_rows = fn is _sampler.hard_negative_mining   # (the gradient rows of the anchors that were not sampled are zeros)
+        ctx.sparse_rows = fn is _sampler.hard_negative_mining or fn is _sampler.naive_sampler   # (the gradient rows of the anchors that were not sampled are zeros)
         ctx.mark_non_differentiable(mask)
         ctx.set_materialize_grads(False)   # (an output nobody differentiated arrives as None, not as a zero tensor made by a fill launch)
         return out3[0], out3[1], out3[2], mask   # loss = class_loss + loc_loss (summed by the kernel: multibox_loss.py:93), class_loss, loc_loss

@@ -110,7 +110,8 @@ def _level_array(levels, grads=None):
         a.x, a.h, a.w, a.cin = _dp(lv['x']), lv['H'], lv['W'], lv['cin']
         a.w_score, a.b_score, a.n_score = _dp(lv['ws']), _dp(lv['bs']), lv['ns']
         a.w_loc, a.b_loc, a.n_loc = _dp(lv['wl']), _dp(lv['bl']), lv['nl']
-        a.scores_offset, a.locs_offset = lv['s_off'], lv['l_off']
+        # (a single head -- no loc part -- carries its anchor-type count where the locs offset would be: include/ssdk.h ssdk_head_level)
+        a.scores_offset, a.locs_offset = lv['s_off'], (lv['l_off'] if lv['nl'] else int(lv.get('nb_hint') or 0))
         if grads is not None:
             gr = grads[i]
             a.dx, a.dw_score, a.db_score, a.dw_loc, a.db_loc = (_dp(gr['dx']), _dp(gr['dws']), _dp(gr['dbs']),
@@ -118,7 +119,7 @@ def _level_array(levels, grads=None):
     return arr
 
 
-def _parse_levels(args, s_off=0, l_off=0):
+def _parse_levels(args, s_off=0, l_off=0, nb_hints=None):
     """(x, w_score, b_score, w_loc, b_loc) * L -> level dicts (NHWC maps, [N,3,3,Cin] weights, offsets into one image's output row),
     the parameters themselves (their gradient-bucket slots are looked up in the backward), and the offsets behind the last level."""
     levels, sinks = [], []
@@ -132,7 +133,8 @@ def _parse_levels(args, s_off=0, l_off=0):
             raise ValueError(f'head {i}: weights {tuple(ws.shape)}/{tuple(wl.shape)} do not match Cin={cin}, 3x3')
         levels.append(dict(x=x, ws=ws, bs=None if bs is None else bs.float().contiguous(), wl=wl,
                            bl=None if bl is None else bl.float().contiguous(), B=B, cin=cin, H=H, W=W,
-                           ns=ws.shape[0], nl=wl.shape[0], s_off=s_off, l_off=l_off))
+                           ns=ws.shape[0], nl=wl.shape[0], s_off=s_off, l_off=l_off,
+                           nb_hint=(nb_hints[i] if nb_hints is not None else 0)))
         s_off += H * W * ws.shape[0]
         l_off += H * W * wl.shape[0]
     if any(lv['B'] != levels[0]['B'] for lv in levels):
@@ -217,12 +219,29 @@ def _launch_backward(ctx, dscores, dlocs, needs, s_tot, l_tot, row_mask=None):
     return out
 
 
+def peek_row_hint_one(d):
+    """Single-head calls (SharedConvPredictor: the score heads and the loc heads run as two calls): the producer's row mask when ``d`` is
+    either of the two gradient tensors it was set for.  Not consumed: the partner call wants it too; the next backward pass replaces it."""
+    h = getattr(_hint_slot, 'hint', None)
+    if h is None or d is None or h.task != torch._C._current_graph_task_id():
+        return None
+    k = (d.data_ptr(), d._version, tuple(d.shape))
+    if k != h.key[:3] and k != h.key[3:]:
+        return None
+    if h.mask.shape[0] != d.shape[0]:
+        return None
+    global row_hints_taken
+    row_hints_taken += 1
+    return h.mask
+
+
 class _HeadsFn(torch.autograd.Function):
-    """apply(x_0, ws_0, bs_0, wl_0, bl_0, x_1, ...) -> (scores [B, sum HW*nb*C], locs [B, sum HW*nb*4])"""
+    """apply(nb_hints, x_0, ws_0, bs_0, wl_0, bl_0, x_1, ...) -> (scores [B, sum HW*nb*C], locs [B, sum HW*nb*4]); nb_hints: None, or
+    for single-head levels (empty loc weights) the anchor types per pixel, which such a level cannot tell from its own shapes"""
 
     @staticmethod
-    def forward(ctx, *args):
-        levels, sinks, s_off, l_off = _parse_levels(args)
+    def forward(ctx, nb_hints, *args):
+        levels, sinks, s_off, l_off = _parse_levels(args, nb_hints=nb_hints)
         B, dev = levels[0]['B'], levels[0]['x'].device
         scores = torch.empty((B, s_off), dtype=torch.float32, device=dev)
         locs = torch.empty((B, l_off), dtype=torch.float32, device=dev)
@@ -235,10 +254,11 @@ class _HeadsFn(torch.autograd.Function):
     def backward(ctx, dscores, dlocs):
         s_tot, l_tot = ctx.totals
         B, dev = ctx.levels[0]['B'], ctx.saved_tensors[0].device
-        mask = take_row_hint(dscores, dlocs)
+        single = l_tot == 0 and all(lv.get('nb_hint') for lv in ctx.levels)
+        mask = peek_row_hint_one(dscores) if single else take_row_hint(dscores, dlocs)
         dscores = (torch.zeros((B, s_tot), dtype=torch.float32, device=dev) if dscores is None else dscores.float().contiguous())
         dlocs = (torch.zeros((B, l_tot), dtype=torch.float32, device=dev) if dlocs is None else dlocs.float().contiguous())
-        return tuple(_launch_backward(ctx, dscores, dlocs, ctx.needs_input_grad, s_tot, l_tot, mask))
+        return (None,) + tuple(_launch_backward(ctx, dscores, dlocs, ctx.needs_input_grad[1:], s_tot, l_tot, mask))
 
 
 # ---- the same heads as TWO independent autograd nodes (dependency split) -------------------------------------------------------------
@@ -404,7 +424,7 @@ def multi_level_heads(sources_score, sources_loc, heads):
         else:
             split.append(True)
     if not any(split):
-        return _HeadsFn.apply(*args)
+        return _HeadsFn.apply(None, *args)
     # separate towers: run score heads and loc heads as two passes with an empty partner
     s_args, l_args = [], []
     for head, xs, xl in zip(heads, sources_score, sources_loc):
@@ -412,6 +432,8 @@ def multi_level_heads(sources_score, sources_loc, heads):
         empty_w_l = head['loc'].weight.new_zeros((0,) + tuple(head['loc'].weight.shape[1:]))
         s_args += [xs, head['score'].weight, head['score'].bias, empty_w, None]
         l_args += [xl, head['loc'].weight, head['loc'].bias, empty_w_l, None]
-    scores, _ = _HeadsFn.apply(*s_args)
-    locs, _ = _HeadsFn.apply(*l_args)
+    # (anchor types per pixel: what the partner head would have told the library -- the ordered sparse backward needs it)
+    hints = tuple(head['loc'].weight.shape[0] // 4 for head in heads)
+    scores, _ = _HeadsFn.apply(hints, *s_args)
+    locs, _ = _HeadsFn.apply(hints, *l_args)
     return scores, locs

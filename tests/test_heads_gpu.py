@@ -748,3 +748,65 @@ def test_heads_backward_is_bitwise_reproducible_by_default(cfg_name, batch):
         again = torch.autograd.grad([scores, locs], xs + params, [gs, gl], retain_graph=True)
         for a, r in zip(again, first):
             assert torch.equal(a, r)
+
+
+@pytest.mark.parametrize('levels,C,B,density,det', [
+    ([(64, 16, 9), (64, 8, 9), (64, 4, 9)], 80, 2, 0.05, False),     # RetinaNet-like: 9 anchor types, 80 sigmoid classes, few anchors with a gradient
+    ([(64, 16, 9), (64, 8, 9), (64, 4, 9)], 80, 2, 0.05, True),      # ... the same kernels in deterministic mode
+    ([(64, 16, 9), (64, 8, 9)], 80, 2, 1.0, False),                   # every anchor: the rows do not fit T, the dense form on the device
+    ([(96, 9, 3), (32, 5, 6)], 7, 3, 0.3, False),                     # other widths (C = 7 -> 32 columns; loc rows of 4 -> 32)
+])
+def test_single_head_towers_backward_vs_torch_cpu_conv(levels, C, B, density, det, monkeypatch):
+    """multi_level_heads with DIFFERENT source maps for the score and the loc heads (SharedConvPredictor: two towers, detector.py:50-66):
+    two single-head calls, each without the partner head that tells the library how many anchor types a pixel has -- the count travels in
+    the level's locs_offset.  The ordered anchor-row backward (round 5) then covers them: data, weight and bias gradients of both towers'
+    heads against torch's CPU convolution, for sparse (anchor rows) and dense upstream gradients, default and deterministic mode."""
+    from single_shot_detection_amd import ops
+    monkeypatch.delenv('SSDK_HEADS_BWD_MODE', raising=False)
+    rng = np.random.default_rng(23)
+    weights, xs_np, xl_np = {}, [], []
+    for i, (cin, h, nb) in enumerate(levels):
+        xs_np.append(rng.standard_normal((B, cin, h, h), dtype=np.float32))
+        xl_np.append(rng.standard_normal((B, cin, h, h), dtype=np.float32))
+        for k, nout in (('score', nb * C), ('loc', nb * 4)):
+            weights[(k, i)] = (rng.standard_normal((nout, cin, 3, 3), dtype=np.float32) * np.float32(0.02),
+                               rng.standard_normal((nout,), dtype=np.float32) * np.float32(0.1))
+    xs_cpu = [torch.from_numpy(x).requires_grad_(True) for x in xs_np]
+    xl_cpu = [torch.from_numpy(x).requires_grad_(True) for x in xl_np]
+    ws_cpu = {k: (torch.from_numpy(w).requires_grad_(True), torch.from_numpy(b).requires_grad_(True)) for k, (w, b) in weights.items()}
+    s_ref = torch.cat([F.conv2d(x, *ws_cpu[('score', i)], padding=1).permute(0, 2, 3, 1).reshape(B, -1) for i, x in enumerate(xs_cpu)], 1)
+    l_ref = torch.cat([F.conv2d(x, *ws_cpu[('loc', i)], padding=1).permute(0, 2, 3, 1).reshape(B, -1) for i, x in enumerate(xl_cpu)], 1)
+    A = sum(h * h * nb for _, h, nb in levels)
+    keep = torch.from_numpy((rng.random((B, A)) < density).astype(np.float32))        # anchors that carry a gradient
+    gs = torch.from_numpy(rng.standard_normal((B, A, C), dtype=np.float32)) * keep[..., None]
+    gl = torch.from_numpy(rng.standard_normal((B, A, 4), dtype=np.float32)) * keep[..., None]
+    gs, gl = gs.reshape(B, -1), gl.reshape(B, -1)
+    ((s_ref * gs).sum() + (l_ref * gl).sum()).backward()
+
+    heads = build_heads(levels, C, weights)
+    xs = [torch.from_numpy(x).cuda().requires_grad_(True) for x in xs_np]
+    xl = [torch.from_numpy(x).cuda().requires_grad_(True) for x in xl_np]
+    with ops.deterministic(det):
+        scores, locs = multi_level_heads(xs, xl, heads)
+        tol = 2e-6 * np.sqrt(9 * max(l[0] for l in levels))
+        np.testing.assert_allclose(scores.detach().cpu().numpy(), s_ref.detach().numpy(), rtol=1e-5, atol=tol)
+        np.testing.assert_allclose(locs.detach().cpu().numpy(), l_ref.detach().numpy(), rtol=1e-5, atol=tol)
+        ((scores * gs.cuda()).sum() + (locs * gl.cuda()).sum()).backward()
+    for i in range(len(levels)):
+        np.testing.assert_allclose(xs[i].grad.cpu().numpy(), xs_cpu[i].grad.numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(xl[i].grad.cpu().numpy(), xl_cpu[i].grad.numpy(), rtol=1e-4, atol=1e-4)
+        for k in ('score', 'loc'):
+            wref, bref = ws_cpu[(k, i)]
+            scale = float(wref.grad.abs().max()) + 1e-6
+            np.testing.assert_allclose(heads[i][k].weight.grad.cpu().numpy(), wref.grad.numpy(), rtol=1e-4, atol=2e-5 * scale + 1e-5)
+            np.testing.assert_allclose(heads[i][k].bias.grad.cpu().numpy(), bref.grad.numpy(), rtol=1e-4, atol=1e-4)
+    # (the ordered pipeline took these calls: its layout query answers for single-head levels that carry the anchor-type count)
+    from single_shot_detection_amd import _lib
+    import ctypes
+    arr = (_lib.HeadLevel * 1)()
+    arr[0].h, arr[0].w, arr[0].cin, arr[0].n_score, arr[0].n_loc, arr[0].locs_offset = levels[0][1], levels[0][1], levels[0][0], levels[0][2] * C, 0, levels[0][2]
+    arr[0].x, arr[0].w_score = xs[0].data_ptr(), heads[0]['score'].weight.data_ptr()
+    out = (ctypes.c_ulonglong * 8)()
+    assert _lib.lib().ssdk_debug_heads_bwd_layout(arr, 1, B, 0, out) == 0
+    arr[0].locs_offset = 0
+    assert _lib.lib().ssdk_debug_heads_bwd_layout(arr, 1, B, 0, out) == -3
