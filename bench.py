@@ -723,8 +723,8 @@ def fast_mode_tower_leg(device, cfg_name='retina_rn50_500_coco', batch=32):
     # the whole training step: fp32 against forward + data gradients + weight gradients in the split-bf16 mode
     hp.set_training(True)
 
-    def step_ms(n=4):
-        for _ in range(2):
+    def step_ms(n=8):
+        for _ in range(3):
             hp.train_step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
