@@ -761,9 +761,13 @@ def test_single_head_towers_backward_vs_torch_cpu_conv(levels, C, B, density, de
     two single-head calls, each without the partner head that tells the library how many anchor types a pixel has -- the count travels in
     the level's locs_offset.  The ordered anchor-row backward (round 5) then covers them: data, weight and bias gradients of both towers'
     heads against torch's CPU convolution, for sparse (anchor rows) and dense upstream gradients, default and deterministic mode."""
-    from single_shot_detection_amd import ops
     monkeypatch.delenv('SSDK_HEADS_BWD_MODE', raising=False)
-    rng = np.random.default_rng(23)
+    _single_heads_vs_torch_cpu_conv(levels, C, B, density, det, check_layout=True)
+
+
+def _single_heads_vs_torch_cpu_conv(levels, C, B, density, det, seed=23, check_layout=False):
+    from single_shot_detection_amd import ops
+    rng = np.random.default_rng(seed)
     weights, xs_np, xl_np = {}, [], []
     for i, (cin, h, nb) in enumerate(levels):
         xs_np.append(rng.standard_normal((B, cin, h, h), dtype=np.float32))
@@ -800,6 +804,8 @@ def test_single_head_towers_backward_vs_torch_cpu_conv(levels, C, B, density, de
             scale = float(wref.grad.abs().max()) + 1e-6
             np.testing.assert_allclose(heads[i][k].weight.grad.cpu().numpy(), wref.grad.numpy(), rtol=1e-4, atol=2e-5 * scale + 1e-5)
             np.testing.assert_allclose(heads[i][k].bias.grad.cpu().numpy(), bref.grad.numpy(), rtol=1e-4, atol=1e-4)
+    if not check_layout:
+        return
     # (the ordered pipeline took these calls: its layout query answers for single-head levels that carry the anchor-type count)
     from single_shot_detection_amd import _lib
     import ctypes

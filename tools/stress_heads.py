@@ -1,6 +1,6 @@
 """Randomised differential check of the multi-level heads (forward, dense and sparse backward) against torch's fp32 CPU convolution:
 random level lists (channels incl. Cin % 32 != 0, map sizes 1 .. 40, anchor counts, class counts), batch sizes that hit the split-K,
-the multi-cut stream-K and the whole-tile forms, gradient densities and forced backward modes.   python3 tools/stress_heads.py [cases] [seed]"""
+the multi-cut stream-K and the whole-tile forms, gradient densities and forced backward modes; some cases as two single-head calls.   python3 tools/stress_heads.py [cases] [seed]"""
 import os
 import sys
 
@@ -9,7 +9,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
-from test_heads_gpu import _heads_vs_torch_cpu_conv  # noqa: E402
+from test_heads_gpu import _heads_vs_torch_cpu_conv, _single_heads_vs_torch_cpu_conv  # noqa: E402
 
 
 class Env(object):
@@ -40,7 +40,12 @@ for case in range(cases):
     density, mode = [(1.0, None), (0.05, None), (0.05, '1'), (0.05, '2'), (0.4, '0'), (0.4, '1'), (0.4, '2')][int(rng.integers(0, 7))]
     tag = dict(case=case, levels=levels, C=C, B=B, density=density, mode=mode)
     try:
-        _heads_vs_torch_cpu_conv(levels, C, B, density, mode, Env())
+        if mode is None and case % 4 == 3:   # every fourth unforced case as two single-head calls (score and loc towers apart: round 5)
+            tag['single_heads'] = True
+            os.environ.pop('SSDK_HEADS_BWD_MODE', None)
+            _single_heads_vs_torch_cpu_conv(levels, C, B, density, bool(case & 4), seed=case)
+        else:
+            _heads_vs_torch_cpu_conv(levels, C, B, density, mode, Env())
     except Exception as e:   # noqa: BLE001
         bad += 1
         print('FAIL', tag, type(e).__name__, str(e)[:400].replace('\n', ' | '), flush=True)
