@@ -1642,7 +1642,8 @@ __device__ __forceinline__ void merge_block(int i, int ncls, int K, int max_tota
                                             const float* __restrict__ pc_score, const int* __restrict__ pc_count,
                                             const int* __restrict__ pc_m, float* __restrict__ out, int out_cap,
                                             int* __restrict__ counts, long long* __restrict__ nms_candidates,
-                                            const int* __restrict__ pc_nall, unsigned* __restrict__ host_hint, const MergeLds& lds) {
+                                            const int* __restrict__ pc_nall, unsigned* __restrict__ host_hint, const MergeLds& lds,
+                                            unsigned floor_bits = 0u) {
     u64* const s_keys = lds.s_keys;
     unsigned* const s_hist = lds.s_hist;
     u64* const s_misc = lds.s_misc;
@@ -1714,7 +1715,23 @@ __device__ __forceinline__ void merge_block(int i, int ncls, int K, int max_tota
     }
     u64 prefix = 0;
     unsigned above = 0;
-    for (int shift = 56; shift >= 0; shift -= 8) {
+    bool narrowed = false;
+    if (floor_bits) {
+        // the image's bound (post_finish_kernel: a rigorous lower bound of the max_total-th final score) usually leaves fewer keys than the
+        // rank stage holds: then it IS the narrowing, and the radix passes (two or three trips of histogram + digit search) are skipped
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+        int mine_ge = 0;
+#pragma unroll
+        for (int k = 0; k < kMergeSlots / 1024; ++k) mine_ge += (key[k] != 0ull && (unsigned)(key[k] >> 32) >= floor_bits) ? 1 : 0;
+        mine_ge = wave_allreduce(mine_ge, OpAddI());
+        if (lane_id() == 0 && mine_ge) atomicAdd(&s_n, mine_ge);
+        __syncthreads();
+        narrowed = s_n >= max_total && s_n <= kMergeCap;   // (>= max_total always holds for a valid bound; tested, not assumed)
+        __syncthreads();
+        if (narrowed) prefix = (u64)floor_bits << 32;
+    }
+    for (int shift = 56; shift >= 0 && !narrowed; shift -= 8) {
         for (int b = tid; b < 256; b += 1024) s_hist[b] = 0;
         __syncthreads();
 #pragma unroll
@@ -1842,7 +1859,7 @@ __global__ void __launch_bounds__(1024) post_finish_kernel(const float4* __restr
     // C
     MergeLds ml;
     ml.s_keys = s_keys; ml.s_hist = s_hist; ml.s_misc = s_misc; ml.s_n = &s_n; ml.s_prefix = s_prefix;
-    merge_block(i, ncls, K, max_total, pc_rows, pc_score, pc_count, pc_m, out, out_cap, counts, nms_candidates, pc_nall, host_hint, ml);
+    merge_block(i, ncls, K, max_total, pc_rows, pc_score, pc_count, pc_m, out, out_cap, counts, nms_candidates, pc_nall, host_hint, ml, tau);
 }
 
 }  // namespace ssdk
