@@ -1818,7 +1818,7 @@ __global__ void __launch_bounds__(1024) post_finish_kernel(const float4* __restr
                                                            float* __restrict__ out, int out_cap, int* __restrict__ counts,
                                                            long long* __restrict__ nms_candidates, const int* __restrict__ pc_nall,
                                                            unsigned* __restrict__ host_hint, unsigned* __restrict__ hot_cur,
-                                                           unsigned* __restrict__ hot_acc) {
+                                                           unsigned* __restrict__ hot_acc, float hot_margin) {
     __shared__ u64 s_keys[kMergeCap];
     __shared__ unsigned s_hist[256];
     __shared__ u64 s_misc[4];
@@ -1831,7 +1831,9 @@ __global__ void __launch_bounds__(1024) post_finish_kernel(const float4* __restr
     // HotState: what the head launch accumulated becomes the next call's bound per class (a class no image had Khead candidates of: none)
     if (i == 0 && hot_cur && tid < ncls) {
         const unsigned v = hot_acc[tid];
-        hot_cur[tid] = v == 0xFFFFFFFFu ? 0u : v;
+        // (a margin below the minimum: on a DIFFERENT batch about one list in 65 would otherwise hold fewer than Khead keys at or above the
+        // bound and take its whole list -- the slow waves that then end the head launch; a lower bound only lengthens the hot views a little)
+        hot_cur[tid] = v == 0xFFFFFFFFu ? 0u : __float_as_uint(__uint_as_float(v) * hot_margin);
         hot_acc[tid] = 0xFFFFFFFFu;
     }
     // A
@@ -2178,6 +2180,7 @@ static int postprocess_v2(const PostPlan& p, const float* scores, const float* l
         SSDK_CHECK_LAUNCH("post_nms_wave_kernel (head)");
         // the image's bound, the few classes to redo above it and the merge: one workgroup per image (post_finish_kernel)
         const size_t dyn = (size_t)kFinishTailWaves * kNmsLdsBytes + sizeof(int) * (size_t)(2 * ncls + 1);
+        static const float hot_margin = []() { const char* e = getenv("SSDK_POST_HOT_MARGIN"); const float v = e ? (float)atof(e) : 0.0f; return v > 0.0f && v <= 1.0f ? v : 0.9f; }();   // (measurement knob; batch of 64, same batch / two batches taking turns, us: 1.0: 92 / 103, 0.9: 94 / 98, 0.8: 95 / 100, 0.7: 97 / 102, 0.5: 103 / 107)
         static bool attr_set[2] = {false, false};
         if (!attr_set[tie_up]) {
             if (tie_up) SSDK_CHECK_HIP(hipFuncSetAttribute((const void*)post_finish_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 8 * 1024)));
@@ -2189,7 +2192,7 @@ static int postprocess_v2(const PostPlan& p, const float* scores, const float* l
     hipLaunchKernelGGL((post_finish_kernel<TIE>), dim3(batch), dim3(1024), dyn, s, (const float4*)locs, (const float4*)priors, num_anchors, ncls, \
                        max_per_class, thr_mid, xy_scale, wh_scale, src, w.pc_rows, w.pc_score, w.pc_count, w.pc_m, khead, max_total, w.img_tau,   \
                        w.head_last, out, out_cap, counts, (long long*)nms_candidates, w.pc_nall, hint, hot ? hot->cur : nullptr,          \
-                       hot ? hot->acc : nullptr)
+                       hot ? hot->acc : nullptr, hot_margin)
         if (tie_up) SSDK_FINISH(true); else SSDK_FINISH(false);
 #undef SSDK_FINISH
         SSDK_CHECK_LAUNCH("post_finish_kernel");
