@@ -21,6 +21,7 @@ of the path); the four extras blocks derive the remaining levels.  Weak scaling:
 The postprocess (eval) leg is timed separately and reported as nms_boxes_per_sec / postprocess_images_per_sec.
 """
 import argparse
+import gc as _pygc
 import json
 import os
 import sys
@@ -380,12 +381,20 @@ def cpu_baseline(hp, probe_images=4):
                       f'({t_conv * 1e3:.1f} ms/img)'}
 
 
+def quiesce():
+    """Collect Python garbage NOW: main() switches the automatic collector off, so that a full collection (~100 ms with the synthetic inputs
+    and modules of a few configurations alive: one eager step of fast_mode_legs measured 109 ms, host and device, in the middle of ten
+    2.4 ms ones) never lands inside a timed region; every leg calls this before it starts timing."""
+    _pygc.collect()
+
+
 def gpu_time_us(fn, inner=10, reps=5):
     """Median device time of one ``fn()`` in microseconds: ``inner`` back-to-back calls between two events on the launch stream, behind
     ~1 ms of queued spin so that the host is ahead of the GPU when the first one starts (a 20 us call is otherwise timed as the
     host's enqueue rate)."""
     fn()
     torch.cuda.synchronize()
+    quiesce()
     out = []
     for _ in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -516,6 +525,7 @@ def serving_legs(device, cfg_name='ssd_300_vgg16_voc', batches=(1, 2, 8), reps=3
         def rate(fn):
             for _ in range(3):
                 fn()
+            quiesce()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(reps):
@@ -547,6 +557,7 @@ def train_graph_legs(device, cases=(('ssd_300_vgg16_voc', 32), ('ssd_mb2_voc', 2
         def ms(fn):
             for _ in range(3):
                 fn()
+            quiesce()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(reps):
@@ -605,6 +616,7 @@ def step_fn_legs(device, cases=(('ssd_300_vgg16_voc_c21', 21, 32), ('ssd_300_vgg
                 opt.step()
             for k in range(4):
                 one(k)
+            quiesce()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for k in range(reps):
@@ -639,6 +651,7 @@ def step_fn_legs(device, cases=(('ssd_300_vgg16_voc_c21', 21, 32), ('ssd_300_vgg
         g = GraphedCallable(hp.train_step, [])
         for _ in range(3):
             g()
+        quiesce()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
@@ -681,6 +694,7 @@ def fast_mode_legs(device, cfg_name='ssd_300_vgg16_voc', batch=32, steps=10):
     with heads_mod.fast_mode('bf16x3'):
         for _ in range(2):
             hp.train_step()
+        quiesce()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -726,6 +740,7 @@ def fast_mode_tower_leg(device, cfg_name='retina_rn50_500_coco', batch=32):
     def step_ms(n=8):
         for _ in range(3):
             hp.train_step()
+        quiesce()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n):
@@ -757,6 +772,7 @@ def graph_replay_leg(hp, device, n):
         hp.gt = PackedGroundTruth.from_list(hp.gt, device, capacity=sum(len(g) for g in hp.gt) + 7)
         step = GraphedCallable(hp.train_step, [], warmup=2)
         step()
+        quiesce()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n):
@@ -779,6 +795,7 @@ def deterministic_leg(hp, n):
         with ops.deterministic():
             for _ in range(2):
                 hp.train_step()
+            quiesce()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(n):
@@ -798,6 +815,7 @@ def per_config_legs(device, steps=4, warmup=2):
         hp = HotPath(name, batch, device)
         for _ in range(warmup):
             hp.train_step()
+        quiesce()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         hp.train_step()
@@ -806,8 +824,10 @@ def per_config_legs(device, steps=4, warmup=2):
         # generation-2 collection of the previous configs' garbage inside four timed steps read as 22 ms per step in one pass of round 3
         n = steps if time.perf_counter() - t0 > 5e-3 else 10 * steps
         gc.collect()
+        gc_was_on = gc.isenabled()   # (main() already runs with the collector off; a caller that imported this module may not)
         gc.disable()
         try:
+            quiesce()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(n):
@@ -815,7 +835,8 @@ def per_config_legs(device, steps=4, warmup=2):
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / n
         finally:
-            gc.enable()
+            if gc_was_on:
+                gc.enable()
         fwd_ms, fl_img = head_gemm_time(hp)
         tf = fl_img * batch / (fwd_ms * 1e-3) / 1e12
         sc, lo = hp.forward_heads()
@@ -903,6 +924,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    _pygc.disable()   # (see quiesce(): garbage is collected between the timed regions, never inside one)
     if args.fast_mode_only:
         print(json.dumps({'fast_mode': fast_mode_legs(device, args.config, args.batch)}), flush=True)
         return
@@ -924,6 +946,7 @@ def main():
     gc.collect()
     gc.disable()
     try:
+        quiesce()
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -931,7 +954,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
     finally:
-        gc.enable()
+        pass   # (the collector stays off for the rest of the run: quiesce() collects between the timed regions)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -948,6 +971,7 @@ def main():
     hp.set_training(False)
     for _ in range(2):
         hp.eval_step()
+    quiesce()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.eval_steps):
@@ -958,6 +982,7 @@ def main():
     # postprocess alone
     scores, locs = hp.forward_heads()
     scores, locs = scores.detach(), locs.detach()
+    quiesce()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.eval_steps):
@@ -974,6 +999,7 @@ def main():
     tl = tl.view(args.batch, -1)
     hp.post.postprocess_padded((tl, locs), hp.anchors)
     cand_tl = int(hp.post.last_nms_candidates.sum().item())
+    quiesce()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.eval_steps):
